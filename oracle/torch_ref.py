@@ -1,0 +1,177 @@
+"""Plain-PyTorch CPU restatement of the emulator path -- TEST INFRASTRUCTURE ONLY.
+
+Used by tests/ (autograd reference for the backward kernels, fp64 conditioning
+checks) and by bench.py's cpu_baseline leg (nn.LSTM on the host cores is what
+the reference itself executes on CPU).  The product package never imports it.
+
+Restates (paths relative to /root/reference):
+  rnn/models/models.py:432-608      RNN_autoreg.forward (current generation)
+  TorchScript code in rnn/v4_rnn*_wrapper*.pt  (legacy generation, batch-first)
+  rnn/models/models.py:273-339      postprocessing
+  rnn/save_wrapper_mem.py:411-545   wrapper preprocessing / packing
+  rnn/utils.py:182-295              current wrapper (model_wrapper)
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+
+class EmulatorRef(nn.Module):
+    def __init__(self, consts, weights, *, legacy, use_lstm=True, mp_mode=1, output_prune=False,
+                 snowhice_fix=False, qinput_prune=False, rh_prune=False, scrub_inf=False,
+                 scrub_out_nan=False, dtype=torch.float32):
+        super().__init__()
+        self.legacy, self.use_lstm, self.mp_mode = legacy, use_lstm, mp_mode
+        self.output_prune, self.snowhice_fix = output_prune, snowhice_fix
+        self.qinput_prune, self.rh_prune = qinput_prune, rh_prune
+        self.scrub_inf, self.scrub_out_nan = scrub_inf, scrub_out_nan
+        for k, v in consts.items():
+            self.register_buffer(k, torch.from_numpy(np.asarray(v)).to(dtype))
+        w = {k: torch.from_numpy(np.asarray(v)).to(dtype) for k, v in weights.items()}
+        self.nlev, self.nx = consts["xmean_lev"].shape
+        self.nx_sfc = consts["xmean_sca"].shape[0]
+        G = 4 if use_lstm else 3
+        self.nh1 = w["rnn1.weight_hh_l0"].shape[1]
+        self.nh2 = w["rnn2.weight_hh_l0"].shape[1]
+        self.nh_mem = w["mlp_latent.weight"].shape[0] if "mlp_latent.weight" in w else 0
+        self.ny = w["mlp_output.weight"].shape[0]
+        self.ny_sfc = w["mlp_surface_output.weight"].shape[0]
+
+        def lin(name):
+            W = w[name + ".weight"]
+            l = nn.Linear(W.shape[1], W.shape[0]).to(dtype)
+            l.weight.data.copy_(W)
+            l.bias.data.copy_(w[name + ".bias"])
+            return l
+
+        self.mlp_initial = lin("mlp_initial")
+        self.mlp_surface1 = lin("mlp_surface1")
+        if use_lstm:
+            self.mlp_surface2 = lin("mlp_surface2")
+        if not legacy:
+            self.mlp_toa1 = lin("mlp_toa1")
+            if use_lstm:
+                self.mlp_toa2 = lin("mlp_toa2")
+        rnn = nn.LSTM if use_lstm else nn.GRU
+        self.rnn1 = rnn(self.nh1 + self.nh_mem, self.nh1, batch_first=False).to(dtype)
+        self.rnn2 = rnn(self.nh1, self.nh2, batch_first=False).to(dtype)
+        for r, n in ((self.rnn1, "rnn1"), (self.rnn2, "rnn2")):
+            for p in ("weight_ih_l0", "weight_hh_l0", "bias_ih_l0", "bias_hh_l0"):
+                getattr(r, p).data.copy_(w[f"{n}.{p}"])
+        if self.nh_mem > 0:
+            self.mlp_latent = lin("mlp_latent")
+        self.mlp_output = lin("mlp_output")
+        self.mlp_surface_output = lin("mlp_surface_output")
+        assert self.rnn1.weight_hh_l0.shape[0] == G * self.nh1
+
+    # ---- normalised-space model ---------------------------------------
+    def model_forward(self, x_main_n, x_sfc_n, mem_in=None, hx2=None, cx2=None):
+        """x_main_n (B,L,nx).  mem: legacy (B,L,nm) sequence order; current (L,B,nm) level order.
+        Returns out (B,L,ny), out_sfc (B,ny_sfc), mem_out (same layout as mem_in)."""
+        x = x_main_n.transpose(0, 1)                                # (L,B,nx) level order
+        sp = x_sfc_n[:, 0:1] * self.xdiv_sca[0] + self.xmean_sca[0]  # (B,1)
+        pres = self.hyam.view(-1, 1, 1) * 100000.0 + sp.unsqueeze(0) * self.hybm.view(-1, 1, 1)
+        pres = torch.sqrt(pres) / 314.0
+        x = torch.cat((x, pres), dim=2)
+        x = torch.tanh(self.mlp_initial(x))                          # (L,B,nh1) level order
+        if self.nh_mem > 0:
+            if self.legacy:   # memory is given in sequence order (surface first), batch-first
+                x = torch.cat((torch.flip(x, [0]), mem_in.transpose(0, 1)), dim=2)
+            else:             # level order, seq-first; flip after concat
+                x = torch.flip(torch.cat((x, mem_in), dim=2), [0])
+        else:
+            x = torch.flip(x, [0])
+        hx = torch.tanh(self.mlp_surface1(x_sfc_n))
+        if self.use_lstm:
+            cx = self.mlp_surface2(x_sfc_n)
+            if self.legacy:
+                cx = torch.tanh(cx)
+            r1, _ = self.rnn1(x, (hx.unsqueeze(0), cx.unsqueeze(0)))
+        else:
+            r1, _ = self.rnn1(x, hx.unsqueeze(0))
+        r1 = torch.flip(r1, [0])
+        if not self.legacy:
+            toa = torch.cat((x_sfc_n[:, 1:2], x_sfc_n[:, 6:7]), dim=1)
+            hx2 = self.mlp_toa1(toa)
+            if self.use_lstm:
+                cx2 = self.mlp_toa2(toa)
+        if self.use_lstm:
+            r2, (last_h, _) = self.rnn2(r1, (hx2.unsqueeze(0), cx2.unsqueeze(0)))
+        else:
+            r2, last_h = self.rnn2(r1, hx2.unsqueeze(0))
+        if self.nh_mem > 0:
+            z = self.mlp_latent(r2)                                  # (L,B,nm) level order
+            mem_out = torch.flip(z, [0]).transpose(0, 1) if self.legacy else z
+        else:
+            z, mem_out = r2, None
+        out = self.mlp_output(z)
+        if self.output_prune:
+            mask = torch.ones_like(out)
+            mask[0:12, :, 1:] = 0.0
+            out = out * mask
+        out_sfc = self.mlp_surface_output(last_h.squeeze(0))
+        self._taps = (r1, r2)
+        return out.transpose(0, 1), out_sfc, mem_out
+
+    # ---- wrapper pieces ------------------------------------------------
+    def preprocess(self, x_main, x_sfc):
+        x_main = x_main.clone()
+        x_sfc = x_sfc.clone()
+        if self.snowhice_fix:
+            x_sfc = torch.where(x_sfc >= 1e10, torch.tensor(-1.0, dtype=x_sfc.dtype), x_sfc)
+        x_main[:, :, 2] = 1 - torch.exp(-x_main[:, :, 2] * self.lbd_qc)
+        x_main[:, :, 3] = 1 - torch.exp(-x_main[:, :, 3] * self.lbd_qi)
+        x_main = (x_main - self.xmean_lev) / self.xdiv_lev
+        x_sfc = (x_sfc - self.xmean_sca) / self.xdiv_sca
+        if self.qinput_prune:
+            x_main[:, 0:15, 2:3] = 0.0
+        if self.rh_prune:
+            x_main[:, :, 1] = torch.clamp(x_main[:, :, 1], 0, 1.2)
+        x_main = torch.where(torch.isnan(x_main), torch.zeros((), dtype=x_main.dtype), x_main)
+        if self.scrub_inf:
+            x_main = torch.where(torch.isinf(x_main), torch.zeros((), dtype=x_main.dtype), x_main)
+        return x_main, x_sfc
+
+    def postprocess(self, out, out_sfc, x_raw):
+        """models.py:273-339 (mp_mode 0 returns UN-denormalised outputs; mp_mode 1 -> 6 vars)."""
+        if self.mp_mode == 0:
+            return out, out_sfc
+        o = out / self.yscale_lev
+        os_ = out_sfc / self.yscale_sca
+        T_old, ql, qi = x_raw[:, :, 0:1], x_raw[:, :, 2:3], x_raw[:, :, 3:4]
+        T_new = T_old + o[:, :, 0:1] * 1200
+        lf = F.hardtanh((T_new - 253.16) * 0.05, 0.0, 1.0)
+        qn_new = (ql + qi) + o[:, :, 2:3] * 1200
+        dql = (lf * qn_new - ql) * 0.0008333333333333334
+        dqi = ((1 - lf) * qn_new - qi) * 0.0008333333333333334
+        return torch.cat((o[:, :, 0:2], dql, dqi, o[:, :, 3:]), dim=2), os_
+
+    def wrapper_forward(self, x_main, x_sfc, mem_in=None, hx2=None, cx2=None):
+        """Packed wrapper (save_wrapper.py:255-298, save_wrapper_mem.py:499-545)."""
+        B = x_main.shape[0]
+        xn, xs = self.preprocess(x_main, x_sfc)
+        out, out_sfc, mem_out = self.model_forward(xn, xs, mem_in, hx2, cx2)
+        o6, os_ = self.postprocess(out, out_sfc, x_main)
+        parts = [o6.transpose(1, 2).reshape(B, -1), os_]
+        if mem_out is not None:
+            parts.append(mem_out.reshape(B, -1))
+        y = torch.cat(parts, dim=1)
+        if self.scrub_out_nan:
+            y = torch.where(torch.isnan(y), torch.zeros((), dtype=y.dtype), y)
+        return y
+
+    def wrapper_forward_tuple(self, x_main, x_sfc, mem_in):
+        """rnn/utils.py:260-295 (forward_base, include_q_input False)."""
+        xn, xs = self.preprocess(x_main, x_sfc)
+        out, out_sfc, mem_out = self.model_forward(xn, xs, mem_in)
+        o, os_ = self.postprocess(out, out_sfc, x_main)
+        o = torch.where(torch.isnan(o), torch.zeros((), dtype=o.dtype), o)
+        return o, os_, mem_out
+
+
+def from_npz(path, **kw):
+    d = np.load(path)
+    consts = {k[2:]: d[k] for k in d.files if k.startswith("c.")}
+    weights = {k[2:]: d[k] for k in d.files if k.startswith("w.")}
+    return EmulatorRef(consts, weights, **kw)
