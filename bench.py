@@ -1,0 +1,176 @@
+#!/usr/bin/env python3
+"""bench.py -- grid-columns/s of the emulator forward on N MI355X GPUs (one process per GPU).
+
+    python bench.py --gpus 1 --steps 200 --warmup 20
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[1]): the v4 stateless wrapper (weights of
+rnn/v4_rnn_wrapper_constrained.pt, committed as data under tests/golden/), one 384-column batch
+of synthetic raw inputs per GPU per step, inputs resident in HBM.  Columns are independent, so
+ranks shard them with NO data-path collective (weak scaling: 384 columns per GPU).
+
+One JSON line on rank 0.  `roofline` is for the dominant kernel (the register-stationary
+recurrent kernel, two launches per step), timed with HIP events on the launch stream;
+`cpu_baseline` is the oracle's torch restatement (nn.LSTM on the host cores) on the same batch.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "tests", "golden")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+PEAK_FP32_TFLOPS = 157.3   # MI355X dense fp32 (vector == f32 MFMA), MI355X_MICROARCH.md
+WORKLOADS = {
+    # name: (model npz, columns per GPU, FLOP per column, HBM bytes per column)
+    "v4_stateless_384": ("v4_stateless", 384, 31.79e6, 5148),
+    "v4_memory_384": ("v4_memory", 384, 32.95e6, 12828),
+    "v4_memory_2700": ("v4_memory", 2700, 32.95e6, 12828),
+}
+
+
+def load_model(tag):
+    d = np.load(os.path.join(ROOT, "tests", "golden", f"{tag}_model.npz"))
+    consts = {k[2:]: d[k] for k in d.files if k.startswith("c.")}
+    weights = {k[2:]: d[k] for k in d.files if k.startswith("w.")}
+    return consts, weights
+
+
+def cpu_baseline(tag, consts, weights, xm, xs, mem, hx, cx, budget_s=12.0):
+    """The oracle's torch restatement (what the reference executes on CPU: ATen nn.LSTM/Linear)
+    timed on this host's cores on the SAME batch; bounded to ~budget_s seconds."""
+    from oracle import torch_ref
+    ref = torch_ref.EmulatorRef(consts, weights, legacy=True)
+    cores = torch.get_num_threads()
+    args = [torch.from_numpy(xm), torch.from_numpy(xs), None if mem is None else torch.from_numpy(mem),
+            torch.from_numpy(hx), torch.from_numpy(cx)]
+    with torch.no_grad():
+        for _ in range(2):
+            ref.wrapper_forward(*args)
+        t0 = time.perf_counter()
+        n = 0
+        while True:
+            ref.wrapper_forward(*args)
+            n += 1
+            el = time.perf_counter() - t0
+            if (el > budget_s and n >= 5) or n >= 400:
+                break
+    B = xm.shape[0]
+    return {"value": B * n / el, "unit": "grid-columns/s", "cores": cores, "kind": "port",
+            "sample": f"{n} forward calls of the same {B}-column batch through oracle/torch_ref.py "
+                      f"(torch {torch.__version__} CPU, {cores} threads), {el:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--workload", default="v4_stateless_384", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if a.gpus > 1 and world != a.gpus:
+        sys.exit(f"--gpus {a.gpus} needs torch.distributed.run with WORLD_SIZE={a.gpus} (got {world})")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    import climsim_amd
+    from synth import synth_inputs
+
+    tag, B, flop_col, bytes_col = WORKLOADS[a.workload]
+    consts, weights = load_model(tag)
+    model = climsim_amd.NewModel_constraint(consts, weights, max_batch=B)
+    stateful = model.stateful
+    # each rank owns its own shard of columns (different seed), resident in HBM
+    xm, xs = synth_inputs(consts, B, 9000 + rank)
+    rng = np.random.Generator(np.random.PCG64(100 + rank))
+    hx, cx = rng.standard_normal((2, B, 128)).astype(np.float32)
+    mem = np.zeros((B, 60, 16), np.float32) if stateful else None
+    d_xm, d_xs = torch.from_numpy(xm).cuda(), torch.from_numpy(xs).cuda()
+    d_hx, d_cx = torch.from_numpy(hx).cuda(), torch.from_numpy(cx).cuda()
+    d_mem = torch.from_numpy(mem).cuda() if stateful else None
+    out = torch.empty(B, model.emulator.packed_width, device="cuda")
+
+    def step():
+        nonlocal d_mem
+        y = model.emulator.forward_packed(d_xm, d_xs, d_mem, d_hx, d_cx, out=out)
+        if stateful:   # caller-owned state, fed back exactly like the reference harness
+            d_mem = y[:, 368:].reshape(B, 60, 16).contiguous()
+        return y
+
+    def fence():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    fence()
+    el = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([el], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = float(t.item())
+    value = world * B * a.steps / el
+
+    # ---- per-kernel durations (HIP events on the launch stream), same step loop -------------------
+    em = model.emulator
+    em.set_profiling(True)
+    em.reset_profile()
+    for _ in range(min(a.steps, 100)):
+        step()
+    prof, ncalls = em.get_profile()
+    em.set_profiling(False)
+    rec_ms = 0.5 * (prof["rec_rnn1"] + prof["rec_rnn2"])
+    rec_flop = B * 60 * 2.0 * 4 * 128 * 128          # algorithmic FLOP of one recurrent launch
+    achieved = rec_flop / (rec_ms * 1e-3) / 1e12 if rec_ms > 0 else 0.0
+
+    if rank == 0:
+        line = {
+            "metric": "grid-columns/sec emulator fwd",
+            "value": value, "unit": "grid-columns/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": 1e3 * el / a.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": a.workload, "columns_per_gpu": B, "nlev": 60,
+                       "wrapper": "stateless v4 (rnn/v4_rnn_wrapper_constrained.pt weights)" if not stateful
+                       else "stateful v4 memory wrapper", "parallelism": f"columns sharded x{world}, no collective"},
+            "roofline": {"bound": "mfma", "kernel": "rec_kernel<128,4> (one launch per LSTM, 2 per step)",
+                         "achieved": achieved, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / PEAK_FP32_TFLOPS, "traffic": None,
+                         "flop_per_launch": rec_flop, "avg_launch_ms": rec_ms,
+                         "note": "fp32 packed-FMA vector pipe; same 157.3 TF peak as f32 MFMA"},
+            "whole_path": {"flop_per_column": flop_col, "achieved_tflops": value / world * flop_col / 1e12,
+                           "frac_fp32_peak": value / world * flop_col / 1e12 / PEAK_FP32_TFLOPS,
+                           "hbm_bytes_per_column": bytes_col,
+                           "achieved_hbm_gbs": value / world * bytes_col / 1e9},
+            "kernel_ms": prof, "kernel_profile_calls": ncalls,
+        }
+        if not a.no_cpu_baseline and world == 1:
+            line["cpu_baseline"] = cpu_baseline(tag, consts, weights, xm, xs, mem, hx, cx)
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

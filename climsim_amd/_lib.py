@@ -1,0 +1,80 @@
+"""ctypes binding of libclimsim_amd.so (the C ABI in include/climsim_amd.h).
+
+The product path has NO CPU fallback: if the HIP library is missing or cannot be loaded the
+import of anything that computes raises, loudly.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libclimsim_amd.so")
+
+_F = ctypes.c_void_p   # device pointers travel as integers
+
+CONFIG_FIELDS = ["nlev", "nx", "nx_sfc", "ny", "ny_sfc", "nh1", "nh2", "nh_mem", "use_lstm", "legacy",
+                 "output_prune", "mp_mode", "snowhice_fix", "qinput_prune", "rh_prune", "scrub_inf",
+                 "scrub_out_nan"]
+PARAM_FIELDS = ["xmean_lev", "xdiv_lev", "xmean_sca", "xdiv_sca", "lbd_qc", "lbd_qi",
+                "yscale_lev", "yscale_sca", "hyam", "hybm",
+                "mlp_initial_w", "mlp_initial_b", "mlp_surface1_w", "mlp_surface1_b",
+                "mlp_surface2_w", "mlp_surface2_b", "mlp_toa1_w", "mlp_toa1_b", "mlp_toa2_w", "mlp_toa2_b",
+                "rnn1_w_ih", "rnn1_w_hh", "rnn1_b_ih", "rnn1_b_hh",
+                "rnn2_w_ih", "rnn2_w_hh", "rnn2_b_ih", "rnn2_b_hh",
+                "mlp_latent_w", "mlp_latent_b", "mlp_output_w", "mlp_output_b",
+                "mlp_surface_output_w", "mlp_surface_output_b"]
+
+# Every symbol include/climsim_amd.h declares (checked by tests/test_abi.py).
+SYMBOLS = ["csa_create", "csa_destroy", "csa_set_params", "csa_packed_width", "csa_max_batch",
+           "csa_forward_packed", "csa_forward_tuple", "csa_model_forward", "csa_tap_rnn1",
+           "csa_tap_rnn2", "csa_last_error", "csa_version", "csa_set_profiling", "csa_reset_profile",
+           "csa_get_profile", "csa_stage_name"]
+
+
+class CsaConfig(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_int32) for n in CONFIG_FIELDS]
+
+
+class CsaParams(ctypes.Structure):
+    _fields_ = [(n, ctypes.POINTER(ctypes.c_float)) for n in PARAM_FIELDS]
+
+
+_lib = None
+
+
+def lib():
+    """Load the HIP library; raises RuntimeError (never falls back) when it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} not found: build it with `python -m climsim_amd.build` "
+            "(hipcc --offload-arch=gfx950). climsim_amd has no CPU fallback.")
+    L = ctypes.CDLL(LIB_PATH)
+    H = ctypes.c_void_p
+    i = ctypes.c_int
+    L.csa_create.argtypes = [ctypes.POINTER(CsaConfig), ctypes.POINTER(CsaParams), i, ctypes.POINTER(H)]
+    L.csa_destroy.argtypes = [H]
+    L.csa_set_params.argtypes = [H, ctypes.POINTER(CsaParams)]
+    L.csa_packed_width.argtypes = [H]
+    L.csa_max_batch.argtypes = [H]
+    L.csa_forward_packed.argtypes = [H, i, _F, _F, _F, _F, _F, _F, ctypes.c_void_p]
+    L.csa_forward_tuple.argtypes = [H, i, _F, _F, _F, _F, _F, _F, ctypes.c_void_p]
+    L.csa_model_forward.argtypes = [H, i, _F, _F, _F, _F, _F, _F, _F, _F, ctypes.c_void_p]
+    L.csa_tap_rnn1.argtypes = [H]
+    L.csa_tap_rnn1.restype = ctypes.c_void_p
+    L.csa_tap_rnn2.argtypes = [H]
+    L.csa_tap_rnn2.restype = ctypes.c_void_p
+    L.csa_set_profiling.argtypes = [H, i]
+    L.csa_reset_profile.argtypes = [H]
+    L.csa_get_profile.argtypes = [H, ctypes.POINTER(ctypes.c_double), i, ctypes.POINTER(ctypes.c_long)]
+    L.csa_stage_name.argtypes = [i]
+    L.csa_stage_name.restype = ctypes.c_char_p
+    L.csa_last_error.restype = ctypes.c_char_p
+    L.csa_version.restype = ctypes.c_char_p
+    _lib = L
+    return L
+
+
+def last_error():
+    return lib().csa_last_error().decode()

@@ -1,0 +1,370 @@
+// api.hip -- C ABI of libclimsim_amd.so (include/climsim_amd.h): handle management, host-side
+// weight packing, and the launch sequence of one emulator call:
+//
+//   prep  ->  proj GEMM (W_ih1)  ->  rec (rnn1, upward)  ->  proj GEMM (W_ih2)  ->  rec (rnn2, downward)  ->  head
+//
+// All launches go to the caller's stream; nothing is allocated or synchronised inside a call.
+#include "common.h"
+#include <mutex>
+#include <string>
+#include <vector>
+#include <cstring>
+#include <cstdio>
+
+static thread_local std::string g_err;
+void csa_set_error(const char *what, hipError_t e)
+{
+    g_err = std::string(what) + ": " + hipGetErrorString(e);
+}
+void csa_set_error_msg(const char *msg) { g_err = msg; }
+extern "C" const char *csa_last_error(void) { return g_err.c_str(); }
+extern "C" const char *csa_version(void) { return "climsim_amd 0.1 (gfx950)"; }
+
+struct csa_emulator {
+    DevModel dm;
+    int max_batch;
+    std::vector<void *> owned;   // every device allocation
+    // scratch
+    float *X1, *P, *H1, *H2, *hc0;
+    // optional per-kernel timing (csa_set_profiling): events bracket the 6 launches of a call
+    bool profiling = false;
+    hipEvent_t ev[7] = {};
+    double acc_ms[6] = {};
+    long n_prof = 0;
+    bool pending = false;
+    // slots of device weight buffers that csa_set_params refreshes
+    struct Slot { float **dst; size_t n; };
+};
+
+namespace {
+
+struct Uploader {
+    csa_emulator *h;
+    int rc = CSA_OK;
+    float *alloc(size_t n)
+    {
+        void *p = nullptr;
+        if (hipMalloc(&p, sizeof(float) * (n ? n : 1)) != hipSuccess) { rc = CSA_ERR_NOMEM; return nullptr; }
+        h->owned.push_back(p);
+        return (float *)p;
+    }
+    const float *up(const float *host, size_t n)
+    {
+        float *d = alloc(n);
+        if (d && host && hipMemcpy(d, host, sizeof(float) * n, hipMemcpyHostToDevice) != hipSuccess) rc = CSA_ERR_HIP;
+        return d;
+    }
+    const float *up(const std::vector<float> &v) { return up(v.data(), v.size()); }
+};
+
+std::vector<float> transposed(const float *w, int O, int K)
+{
+    std::vector<float> t((size_t)O * K);
+    for (int o = 0; o < O; ++o)
+        for (int k = 0; k < K; ++k) t[(size_t)k * O + o] = w[(size_t)o * K + k];
+    return t;
+}
+
+// Input-projection weights with rows permuted to unit-major order n' = u*4 + g (GRU: 4th row 0),
+// and the bias that can be folded into the projection (b_ih + b_hh; GRU keeps b_hn apart).
+void pack_ih(int use_lstm, int nh, int K, const float *w_ih, const float *b_ih, const float *b_hh,
+             std::vector<float> &w, std::vector<float> &bias, std::vector<float> &bhn)
+{
+    const int G = use_lstm ? 4 : 3;
+    w.assign((size_t)4 * nh * K, 0.0f);
+    bias.assign((size_t)4 * nh, 0.0f);
+    bhn.assign((size_t)nh, 0.0f);
+    for (int u = 0; u < nh; ++u)
+        for (int g = 0; g < G; ++g) {
+            const int src = g * nh + u, dst = u * 4 + g;
+            memcpy(&w[(size_t)dst * K], &w_ih[(size_t)src * K], sizeof(float) * K);
+            if (!use_lstm && g == 2) { bias[dst] = b_ih[src]; bhn[u] = b_hh[src]; }
+            else bias[dst] = b_ih[src] + b_hh[src];
+        }
+}
+
+int check_cfg(const csa_config &c)
+{
+    if (c.nlev <= 0 || c.nx <= 0 || c.nx_sfc < 7 || c.ny <= 0 || c.ny_sfc <= 0 || c.nh1 <= 0 || c.nh2 <= 0 || c.nh_mem < 0) {
+        csa_set_error_msg("csa_create: bad sizes");
+        return CSA_ERR_ARG;
+    }
+    if (c.mp_mode != 0 && c.mp_mode != 1) {
+        csa_set_error_msg("csa_create: mp_mode -1/-2 not implemented by the HIP path");
+        return CSA_ERR_UNSUPPORTED;
+    }
+    if (c.mp_mode == 1 && c.ny != 5) {
+        csa_set_error_msg("csa_create: mp_mode 1 requires ny == 5 (models.py:216-217)");
+        return CSA_ERR_ARG;
+    }
+    if (!c.legacy && !c.use_lstm && false) return CSA_ERR_UNSUPPORTED;
+    return CSA_OK;
+}
+
+int upload_params(csa_emulator *h, const csa_params *p, bool first)
+{
+    // On refresh (training) the previously packed buffers are simply re-filled in place: the
+    // Uploader allocates on first use and the allocation order is deterministic.
+    (void)first;
+    const csa_config &c = h->dm.cfg;
+    DevModel &d = h->dm;
+    Uploader U{h};
+    const int L = c.nlev, nin1 = c.nh1 + c.nh_mem;
+    d.xmean_lev = U.up(p->xmean_lev, (size_t)L * c.nx);
+    d.xdiv_lev = U.up(p->xdiv_lev, (size_t)L * c.nx);
+    d.xmean_sca = U.up(p->xmean_sca, c.nx_sfc);
+    d.xdiv_sca = U.up(p->xdiv_sca, c.nx_sfc);
+    d.lbd_qc = U.up(p->lbd_qc, L);
+    d.lbd_qi = U.up(p->lbd_qi, L);
+    d.yscale_lev = U.up(p->yscale_lev, (size_t)L * c.ny);
+    d.yscale_sca = U.up(p->yscale_sca, c.ny_sfc);
+    d.hyam = U.up(p->hyam, L);
+    d.hybm = U.up(p->hybm, L);
+    d.init_wt = U.up(transposed(p->mlp_initial_w, c.nh1, c.nx + 1));
+    d.init_b = U.up(p->mlp_initial_b, c.nh1);
+    d.s1_wt = U.up(transposed(p->mlp_surface1_w, c.nh1, c.nx_sfc));
+    d.s1_b = U.up(p->mlp_surface1_b, c.nh1);
+    if (c.use_lstm) {
+        d.s2_wt = U.up(transposed(p->mlp_surface2_w, c.nh1, c.nx_sfc));
+        d.s2_b = U.up(p->mlp_surface2_b, c.nh1);
+    }
+    if (!c.legacy) {
+        d.toa1_wt = U.up(transposed(p->mlp_toa1_w, c.nh2, 2));
+        d.toa1_b = U.up(p->mlp_toa1_b, c.nh2);
+        if (c.use_lstm) {
+            d.toa2_wt = U.up(transposed(p->mlp_toa2_w, c.nh2, 2));
+            d.toa2_b = U.up(p->mlp_toa2_b, c.nh2);
+        }
+    }
+    std::vector<float> w, bias, bhn, packed;
+    pack_ih(c.use_lstm, c.nh1, nin1, p->rnn1_w_ih, p->rnn1_b_ih, p->rnn1_b_hh, w, bias, bhn);
+    d.wih1 = U.up(w); d.bias1 = U.up(bias); d.bhn1 = U.up(bhn);
+    pack_ih(c.use_lstm, c.nh2, c.nh1, p->rnn2_w_ih, p->rnn2_b_ih, p->rnn2_b_hh, w, bias, bhn);
+    d.wih2 = U.up(w); d.bias2 = U.up(bias); d.bhn2 = U.up(bhn);
+    packed.resize(rec_packed_floats(c.use_lstm, c.nh1));
+    rec_pack_weights(c.use_lstm, c.nh1, p->rnn1_w_hh, packed.data());
+    d.whh1p = U.up(packed);
+    packed.resize(rec_packed_floats(c.use_lstm, c.nh2));
+    rec_pack_weights(c.use_lstm, c.nh2, p->rnn2_w_hh, packed.data());
+    d.whh2p = U.up(packed);
+    if (c.nh_mem > 0) {
+        d.lat_wt = U.up(transposed(p->mlp_latent_w, c.nh_mem, c.nh2));
+        d.lat_b = U.up(p->mlp_latent_b, c.nh_mem);
+        d.out_w = U.up(p->mlp_output_w, (size_t)c.ny * c.nh_mem);
+    } else {
+        d.out_w = U.up(p->mlp_output_w, (size_t)c.ny * c.nh2);
+    }
+    d.out_b = U.up(p->mlp_output_b, c.ny);
+    d.sfo_w = U.up(p->mlp_surface_output_w, (size_t)c.ny_sfc * c.nh2);
+    d.sfo_b = U.up(p->mlp_surface_output_b, c.ny_sfc);
+    return U.rc;
+}
+
+bool params_complete(const csa_config &c, const csa_params *p)
+{
+    bool ok = p->xmean_lev && p->xdiv_lev && p->xmean_sca && p->xdiv_sca && p->lbd_qc && p->lbd_qi &&
+              p->yscale_lev && p->yscale_sca && p->hyam && p->hybm && p->mlp_initial_w && p->mlp_initial_b &&
+              p->mlp_surface1_w && p->mlp_surface1_b && p->rnn1_w_ih && p->rnn1_w_hh && p->rnn1_b_ih &&
+              p->rnn1_b_hh && p->rnn2_w_ih && p->rnn2_w_hh && p->rnn2_b_ih && p->rnn2_b_hh && p->mlp_output_w &&
+              p->mlp_output_b && p->mlp_surface_output_w && p->mlp_surface_output_b;
+    if (c.use_lstm) ok = ok && p->mlp_surface2_w && p->mlp_surface2_b;
+    if (!c.legacy) ok = ok && p->mlp_toa1_w && p->mlp_toa1_b && (!c.use_lstm || (p->mlp_toa2_w && p->mlp_toa2_b));
+    if (c.nh_mem > 0) ok = ok && p->mlp_latent_w && p->mlp_latent_b;
+    return ok;
+}
+
+void free_all(csa_emulator *h)
+{
+    for (void *p : h->owned) (void)hipFree(p);
+    h->owned.clear();
+}
+
+}  // namespace
+
+extern "C" int csa_create(const csa_config *cfg, const csa_params *hp, int max_batch, csa_emulator **out)
+{
+    if (!cfg || !hp || !out || max_batch <= 0) { csa_set_error_msg("csa_create: null argument"); return CSA_ERR_ARG; }
+    int rc = check_cfg(*cfg);
+    if (rc) return rc;
+    if (!params_complete(*cfg, hp)) { csa_set_error_msg("csa_create: missing parameter array"); return CSA_ERR_ARG; }
+    {
+        // the register-stationary recurrent kernel is instantiated for these hidden sizes only
+        const int ok1 = cfg->nh1 == 64 || cfg->nh1 == 96 || cfg->nh1 == 128;
+        const int ok2 = cfg->nh2 == 64 || cfg->nh2 == 96 || cfg->nh2 == 128;
+        if (!ok1 || !ok2) { csa_set_error_msg("csa_create: hidden size must be 64, 96 or 128"); return CSA_ERR_UNSUPPORTED; }
+    }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
+        csa_set_error_msg("csa_create: no HIP device (the product path has no CPU fallback)");
+        return CSA_ERR_HIP;
+    }
+    csa_emulator *h = new csa_emulator();
+    memset(&h->dm, 0, sizeof(h->dm));
+    h->dm.cfg = *cfg;
+    h->max_batch = max_batch;
+    rc = upload_params(h, hp, true);
+    if (rc == CSA_OK) {
+        Uploader U{h};
+        const size_t L = cfg->nlev, Bm = max_batch;
+        const size_t nhm = cfg->nh1 > cfg->nh2 ? cfg->nh1 : cfg->nh2;
+        h->X1 = U.alloc(L * Bm * (cfg->nh1 + cfg->nh_mem));
+        h->P = U.alloc(L * Bm * 4 * nhm);
+        h->H1 = U.alloc(L * Bm * cfg->nh1);
+        h->H2 = U.alloc(L * Bm * cfg->nh2);
+        h->hc0 = U.alloc(4 * Bm * nhm);
+        rc = U.rc;
+    }
+    if (rc != CSA_OK) {
+        free_all(h);
+        delete h;
+        if (g_err.empty()) csa_set_error_msg("csa_create: device allocation / upload failed");
+        return rc;
+    }
+    *out = h;
+    return CSA_OK;
+}
+
+extern "C" int csa_destroy(csa_emulator *h)
+{
+    if (!h) return CSA_ERR_ARG;
+    free_all(h);
+    for (int i = 0; i < 7; ++i) if (h->ev[i]) (void)hipEventDestroy(h->ev[i]);
+    delete h;
+    return CSA_OK;
+}
+
+extern "C" int csa_set_params(csa_emulator *h, const csa_params *hp)
+{
+    if (!h || !hp || !params_complete(h->dm.cfg, hp)) { csa_set_error_msg("csa_set_params: bad argument"); return CSA_ERR_ARG; }
+    // Rebuild all parameter buffers; scratch (the last five allocations) is kept.
+    std::vector<void *> scratch(h->owned.end() - 5, h->owned.end());
+    h->owned.resize(h->owned.size() - 5);
+    if (hipDeviceSynchronize() != hipSuccess) return CSA_ERR_HIP;
+    free_all(h);
+    int rc = upload_params(h, hp, false);
+    for (void *p : scratch) h->owned.push_back(p);
+    return rc;
+}
+
+extern "C" int csa_packed_width(const csa_emulator *h)
+{
+    if (!h) return CSA_ERR_ARG;
+    const csa_config &c = h->dm.cfg;
+    return 6 * c.nlev + c.ny_sfc + c.nlev * c.nh_mem;
+}
+extern "C" int csa_max_batch(const csa_emulator *h) { return h ? h->max_batch : CSA_ERR_ARG; }
+extern "C" const float *csa_tap_rnn1(const csa_emulator *h) { return h ? h->H1 : nullptr; }
+extern "C" const float *csa_tap_rnn2(const csa_emulator *h) { return h ? h->H2 : nullptr; }
+
+static const char *kStageNames[6] = {"prep", "proj_gemm_rnn1", "rec_rnn1", "proj_gemm_rnn2", "rec_rnn2", "head"};
+
+static void prof_collect(csa_emulator *h)
+{
+    if (!h->pending) return;
+    if (hipEventSynchronize(h->ev[6]) == hipSuccess) {
+        for (int i = 0; i < 6; ++i) {
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, h->ev[i], h->ev[i + 1]) == hipSuccess) h->acc_ms[i] += ms;
+        }
+        h->n_prof += 1;
+    }
+    h->pending = false;
+}
+
+extern "C" int csa_set_profiling(csa_emulator *h, int enable)
+{
+    if (!h) return CSA_ERR_ARG;
+    if (enable && !h->ev[0])
+        for (int i = 0; i < 7; ++i) CSA_HIP_CHECK(hipEventCreate(&h->ev[i]));
+    if (!enable) prof_collect(h);
+    h->profiling = enable != 0;
+    return CSA_OK;
+}
+
+extern "C" int csa_reset_profile(csa_emulator *h)
+{
+    if (!h) return CSA_ERR_ARG;
+    prof_collect(h);
+    for (int i = 0; i < 6; ++i) h->acc_ms[i] = 0.0;
+    h->n_prof = 0;
+    return CSA_OK;
+}
+
+extern "C" int csa_get_profile(csa_emulator *h, double *avg_ms, int n, long *calls)
+{
+    if (!h || !avg_ms || n < 6) return CSA_ERR_ARG;
+    prof_collect(h);
+    for (int i = 0; i < 6; ++i) avg_ms[i] = h->n_prof ? h->acc_ms[i] / (double)h->n_prof : 0.0;
+    if (calls) *calls = h->n_prof;
+    return CSA_OK;
+}
+
+extern "C" const char *csa_stage_name(int i) { return (i >= 0 && i < 6) ? kStageNames[i] : ""; }
+
+#define PROF_MARK(i)                                                 \
+    do {                                                             \
+        if (h->profiling) CSA_HIP_CHECK(hipEventRecord(h->ev[i], s)); \
+    } while (0)
+
+static int run_forward(csa_emulator *h, int B, int normalised, int mode,
+                       const float *x_main, const float *x_sfc, const float *mem_in,
+                       const float *hx2, const float *cx2,
+                       float *y0, float *y1, float *y2, hipStream_t s)
+{
+    const csa_config &c = h->dm.cfg;
+    if (B <= 0 || B > h->max_batch) { csa_set_error_msg("forward: B out of range (0 < B <= max_batch)"); return CSA_ERR_ARG; }
+    if (!x_main || !x_sfc || !y0) { csa_set_error_msg("forward: null tensor"); return CSA_ERR_ARG; }
+    if (c.nh_mem > 0 && !mem_in) { csa_set_error_msg("forward: rnn1_mem required (nh_mem > 0)"); return CSA_ERR_ARG; }
+    if (c.legacy && (!hx2 || (c.use_lstm && !cx2))) { csa_set_error_msg("forward: legacy generation needs explicit hx2/cx2 noise"); return CSA_ERR_ARG; }
+    const int L = c.nlev;
+    const size_t nhm = c.nh1 > c.nh2 ? c.nh1 : c.nh2;
+    int rc;
+    if (h->profiling) prof_collect(h);   // previous profiled call (host sync: profiling mode only)
+    PROF_MARK(0);
+    if ((rc = launch_prep(h->dm, B, normalised, x_main, x_sfc, mem_in, hx2, cx2, h->X1, h->hc0, s))) return rc;
+    PROF_MARK(1);
+    // rnn1: upward over the flipped sequence; hidden sequence stored back in level order
+    if ((rc = launch_proj_gemm(h->X1, h->dm.wih1, h->dm.bias1, h->P, L * B, 4 * c.nh1, c.nh1 + c.nh_mem, s))) return rc;
+    PROF_MARK(2);
+    if ((rc = launch_rec(c.use_lstm, c.nh1, h->dm.whh1p, h->dm.bhn1, h->P, h->hc0, h->hc0 + (size_t)B * nhm,
+                         h->H1, B, L, /*reverse_out=*/1, s))) return rc;
+    PROF_MARK(3);
+    // rnn2: downward in level order
+    if ((rc = launch_proj_gemm(h->H1, h->dm.wih2, h->dm.bias2, h->P, L * B, 4 * c.nh2, c.nh1, s))) return rc;
+    const float *h2 = c.legacy ? hx2 : h->hc0 + (size_t)2 * B * nhm;
+    const float *c2 = c.legacy ? cx2 : h->hc0 + (size_t)3 * B * nhm;
+    PROF_MARK(4);
+    if ((rc = launch_rec(c.use_lstm, c.nh2, h->dm.whh2p, h->dm.bhn2, h->P, h2, c2, h->H2, B, L, /*reverse_out=*/0, s))) return rc;
+    PROF_MARK(5);
+    rc = launch_head(h->dm, B, mode, h->H2, x_main, y0, y1, y2, s);
+    PROF_MARK(6);
+    if (h->profiling) h->pending = true;
+    return rc;
+}
+
+extern "C" int csa_forward_packed(csa_emulator *h, int B, const float *x_main, const float *x_sfc,
+                                  const float *mem_in, const float *hx2, const float *cx2, float *yout, void *stream)
+{
+    if (!h) return CSA_ERR_ARG;
+    if (h->dm.cfg.mp_mode != 1) { csa_set_error_msg("forward_packed: only the mp_mode 1 wrapper is packed (save_wrapper_mem.py:485-497)"); return CSA_ERR_UNSUPPORTED; }
+    if (h->dm.cfg.nh_mem > 0 && !h->dm.cfg.legacy) { csa_set_error_msg("forward_packed: the current generation uses the tuple wrapper"); return CSA_ERR_UNSUPPORTED; }
+    return run_forward(h, B, 0, HEAD_PACKED, x_main, x_sfc, mem_in, hx2, cx2, yout, nullptr, nullptr, (hipStream_t)stream);
+}
+
+extern "C" int csa_forward_tuple(csa_emulator *h, int B, const float *x_main, const float *x_sfc,
+                                 const float *mem_in, float *out_lev, float *out_sfc, float *mem_out, void *stream)
+{
+    if (!h) return CSA_ERR_ARG;
+    if (h->dm.cfg.legacy) { csa_set_error_msg("forward_tuple: current generation only"); return CSA_ERR_UNSUPPORTED; }
+    if (!out_sfc || (h->dm.cfg.nh_mem > 0 && !mem_out)) { csa_set_error_msg("forward_tuple: null output"); return CSA_ERR_ARG; }
+    return run_forward(h, B, 0, HEAD_TUPLE, x_main, x_sfc, mem_in, nullptr, nullptr, out_lev, out_sfc, mem_out, (hipStream_t)stream);
+}
+
+extern "C" int csa_model_forward(csa_emulator *h, int B, const float *x_main_n, const float *x_sfc_n,
+                                 const float *mem_in, const float *hx2, const float *cx2,
+                                 float *out, float *out_sfc, float *mem_out, void *stream)
+{
+    if (!h) return CSA_ERR_ARG;
+    if (!out_sfc || (h->dm.cfg.nh_mem > 0 && !mem_out)) { csa_set_error_msg("model_forward: null output"); return CSA_ERR_ARG; }
+    return run_forward(h, B, 1, HEAD_RAW, x_main_n, x_sfc_n, mem_in, hx2, cx2, out, out_sfc, mem_out, (hipStream_t)stream);
+}

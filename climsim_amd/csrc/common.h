@@ -1,0 +1,72 @@
+// Internal definitions shared by the HIP translation units of libclimsim_amd.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/climsim_amd.h"
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// Output modes of the head kernel.
+enum HeadMode { HEAD_PACKED = 0, HEAD_TUPLE = 1, HEAD_RAW = 2 };
+
+// Device-side view of one model (all pointers are device pointers).
+struct DevModel {
+    csa_config cfg;
+    // constants
+    const float *xmean_lev, *xdiv_lev, *xmean_sca, *xdiv_sca, *lbd_qc, *lbd_qi;
+    const float *yscale_lev, *yscale_sca, *hyam, *hybm;
+    // small MLPs, transposed to (in, out) so that thread j reads column j coalesced
+    const float *init_wt, *init_b;      // (nx+1, nh1)
+    const float *s1_wt, *s1_b;          // (nx_sfc, nh1)
+    const float *s2_wt, *s2_b;          // (nx_sfc, nh1)
+    const float *toa1_wt, *toa1_b;      // (2, nh2)
+    const float *toa2_wt, *toa2_b;      // (2, nh2)
+    // input projections: rows permuted to unit-major gate order n' = u*G + g
+    const float *wih1, *bias1;          // (G*nh1, nh1+nh_mem), (G*nh1)   bias = b_ih + b_hh (GRU: b_hn kept apart)
+    const float *wih2, *bias2;          // (G*nh2, nh1)
+    const float *bhn1, *bhn2;           // GRU only: b_hn (nh)
+    // recurrent weights packed for the register-stationary kernel (see rec.hip)
+    const float *whh1p, *whh2p;
+    // heads
+    const float *lat_wt, *lat_b;        // (nh2, nh_mem)
+    const float *out_w, *out_b;         // (ny, nh_mem or nh2) row-major
+    const float *sfo_w, *sfo_b;         // (ny_sfc, nh2) row-major
+};
+
+#define CSA_HIP_CHECK(expr)                                                        \
+    do {                                                                           \
+        hipError_t e_ = (expr);                                                    \
+        if (e_ != hipSuccess) {                                                    \
+            csa_set_error(#expr, e_);                                              \
+            return CSA_ERR_HIP;                                                    \
+        }                                                                          \
+    } while (0)
+
+void csa_set_error(const char *what, hipError_t e);
+void csa_set_error_msg(const char *msg);
+
+// ---- kernel launchers (each returns a csa_status) ---------------------------------------
+// prep.hip: normalise + pressure + mlp_initial + memory concat -> X1 (L,B,nh1+nh_mem) sequence
+// order; surface / TOA MLPs -> h0c0 (4,B,nh): [h0_rnn1, c0_rnn1, h0_rnn2, c0_rnn2].
+int launch_prep(const DevModel &m, int B, int normalised, const float *x_main, const float *x_sfc,
+                const float *mem_in, const float *hx2, const float *cx2,
+                float *X1, float *hc0, hipStream_t s);
+
+// gemm.hip: C(M,N) = A(M,K) * W(N,K)^T + bias(N), fp32 MFMA.
+int launch_proj_gemm(const float *A, const float *W, const float *bias, float *C,
+                     int M, int N, int K, hipStream_t s);
+
+// rec.hip: level-recurrent LSTM/GRU over L steps; P (L,B,G*nh) pre-activations in sequence
+// order, Hout (L,B,nh) written at level index (reverse ? L-1-t : t).
+int launch_rec(int use_lstm, int nh, const float *whh_packed, const float *bhn, const float *P,
+               const float *h0, const float *c0, float *Hout, int B, int L, int reverse_out,
+               hipStream_t s);
+size_t rec_packed_floats(int use_lstm, int nh);
+// host-side packer: W_hh (G*nh, nh) PyTorch layout -> register-stationary layout
+void rec_pack_weights(int use_lstm, int nh, const float *w_hh, float *packed);
+
+// head.hip: mlp_latent / mlp_output / surface head / de-normalisation / microphysics / packing
+int launch_head(const DevModel &m, int B, int mode, const float *H2, const float *x_main_raw,
+                float *y0, float *y1, float *y2, hipStream_t s);

@@ -1,0 +1,125 @@
+// prep.hip -- fused wrapper pre-processing + pressure feature + mlp_initial + memory concat
+// + surface/TOA initial-state MLPs.  One workgroup per grid column.
+//
+// Reference semantics (paths relative to the reference root):
+//   preprocessing      rnn/utils.py:182-217, rnn/save_wrapper_mem.py:411-457
+//   LayerPressure      rnn/layers.py:117-121 (sqrt(p)/314), call site rnn/models/models.py:446-453
+//   mlp_initial+tanh   rnn/models/models.py:457-458
+//   memory concat+flip rnn/models/models.py:461,478 (current); legacy artefacts concatenate the
+//                      memory AFTER the flip, i.e. it is indexed by sequence position
+//   mlp_surface1/2     rnn/models/models.py:485-491 (legacy: c0 = tanh(.))
+//   mlp_toa1/2         rnn/models/models.py:503-506
+//
+// HBM-bound elementwise kernel: reads 3.6 KB + 76 B (+3.8 KB memory) per column, writes the
+// rnn1 input rows X1 (L,B,nh1+nh_mem) in SEQUENCE order (t = 0 is the surface level).
+#include "common.h"
+
+#define PREP_THREADS 128
+#define PREP_MAX_NXP 32   // nx+1 upper bound held in registers
+
+__global__ __launch_bounds__(PREP_THREADS) void prep_kernel(
+    DevModel m, int B, int normalised,
+    const float *__restrict__ x_main, const float *__restrict__ x_sfc,
+    const float *__restrict__ mem_in, float *__restrict__ X1, float *__restrict__ hc0)
+{
+    extern __shared__ float smem[];
+    const int L = m.cfg.nlev, nx = m.cfg.nx, nxp = nx + 1, nxs = m.cfg.nx_sfc;
+    const int nh1 = m.cfg.nh1, nh2 = m.cfg.nh2, nm = m.cfg.nh_mem, nin1 = nh1 + nm;
+    const int nhm = nh1 > nh2 ? nh1 : nh2;
+    float *xl = smem;                 // (L, nxp)
+    float *xs = smem + L * nxp;       // (nxs)
+    const int b = blockIdx.x, tid = threadIdx.x;
+
+    // ---- surface inputs -----------------------------------------------------------------
+    for (int v = tid; v < nxs; v += PREP_THREADS) {
+        float x = x_sfc[(size_t)b * nxs + v];
+        if (!normalised) {
+            if (m.cfg.snowhice_fix && x >= 1e10f) x = -1.0f;
+            x = (x - m.xmean_sca[v]) / m.xdiv_sca[v];
+        }
+        xs[v] = x;
+    }
+    // ---- level inputs ---------------------------------------------------------------------
+    for (int idx = tid; idx < L * nx; idx += PREP_THREADS) {
+        const int l = idx / nx, v = idx - l * nx;
+        float x = x_main[(size_t)b * L * nx + idx];
+        if (!normalised) {
+            if (v == 2) x = 1.0f - expf(-x * m.lbd_qc[l]);
+            if (v == 3) x = 1.0f - expf(-x * m.lbd_qi[l]);
+            x = (x - m.xmean_lev[idx]) / m.xdiv_lev[idx];
+            if (m.cfg.qinput_prune && v == 2 && l < 15) x = 0.0f;
+            if (m.cfg.rh_prune && v == 1 && !isnan(x)) x = fminf(fmaxf(x, 0.0f), 1.2f);
+            if (isnan(x)) x = 0.0f;
+            if (m.cfg.scrub_inf && isinf(x)) x = 0.0f;
+        }
+        xl[l * nxp + v] = x;
+    }
+    __syncthreads();
+    {
+        const float sp = xs[0] * m.xdiv_sca[0] + m.xmean_sca[0];
+        for (int l = tid; l < L; l += PREP_THREADS) {
+            const float pres = m.hyam[l] * 100000.0f + sp * m.hybm[l];
+            xl[l * nxp + nx] = sqrtf(pres) / 314.0f;
+        }
+    }
+    __syncthreads();
+
+    // ---- initial states -------------------------------------------------------------------
+    for (int j = tid; j < nh1; j += PREP_THREADS) {
+        float a = m.s1_b[j];
+        for (int v = 0; v < nxs; ++v) a += m.s1_wt[v * nh1 + j] * xs[v];
+        hc0[((size_t)0 * B + b) * nhm + j] = tanhf(a);
+        if (m.cfg.use_lstm) {
+            float c = m.s2_b[j];
+            for (int v = 0; v < nxs; ++v) c += m.s2_wt[v * nh1 + j] * xs[v];
+            hc0[((size_t)1 * B + b) * nhm + j] = m.cfg.legacy ? tanhf(c) : c;
+        }
+    }
+    if (!m.cfg.legacy) {
+        const float t0 = xs[1], t1 = xs[6];
+        for (int j = tid; j < nh2; j += PREP_THREADS) {
+            hc0[((size_t)2 * B + b) * nhm + j] = m.toa1_b[j] + m.toa1_wt[j] * t0 + m.toa1_wt[nh2 + j] * t1;
+            if (m.cfg.use_lstm)
+                hc0[((size_t)3 * B + b) * nhm + j] = m.toa2_b[j] + m.toa2_wt[j] * t0 + m.toa2_wt[nh2 + j] * t1;
+        }
+    }
+
+    // ---- mlp_initial + tanh, written in sequence order -----------------------------------------
+    for (int j = tid; j < nh1; j += PREP_THREADS) {
+        float w[PREP_MAX_NXP];
+#pragma unroll
+        for (int v = 0; v < PREP_MAX_NXP; ++v) w[v] = v < nxp ? m.init_wt[v * nh1 + j] : 0.0f;
+        const float bj = m.init_b[j];
+        for (int t = 0; t < L; ++t) {
+            const float *xr = xl + (L - 1 - t) * nxp;
+            float a = bj;
+#pragma unroll
+            for (int v = 0; v < PREP_MAX_NXP; ++v)
+                if (v < nxp) a += w[v] * xr[v];
+            X1[((size_t)t * B + b) * nin1 + j] = tanhf(a);
+        }
+    }
+    // ---- memory concat ---------------------------------------------------------------------------
+    for (int idx = tid; idx < L * nm; idx += PREP_THREADS) {
+        const int t = idx / nm, k = idx - t * nm;
+        const float v = m.cfg.legacy ? mem_in[((size_t)b * L + t) * nm + k]
+                                     : mem_in[((size_t)(L - 1 - t) * B + b) * nm + k];
+        X1[((size_t)t * B + b) * nin1 + nh1 + k] = v;
+    }
+}
+
+int launch_prep(const DevModel &m, int B, int normalised, const float *x_main, const float *x_sfc,
+                const float *mem_in, const float *hx2, const float *cx2,
+                float *X1, float *hc0, hipStream_t s)
+{
+    (void)hx2; (void)cx2;
+    if (m.cfg.nx + 1 > PREP_MAX_NXP) {
+        csa_set_error_msg("prep: nx+1 exceeds PREP_MAX_NXP");
+        return CSA_ERR_UNSUPPORTED;
+    }
+    const size_t shm = sizeof(float) * ((size_t)m.cfg.nlev * (m.cfg.nx + 1) + m.cfg.nx_sfc);
+    hipLaunchKernelGGL(prep_kernel, dim3(B), dim3(PREP_THREADS), shm, s, m, B, normalised, x_main, x_sfc,
+                       mem_in, X1, hc0);
+    CSA_HIP_CHECK(hipGetLastError());
+    return CSA_OK;
+}

@@ -1,0 +1,119 @@
+/*
+ * climsim_amd.h -- C ABI of the MI355X-native per-column emulator path.
+ *
+ * This is the drop-in boundary for the reference's deployment wrappers
+ * (peterukk/ClimSim, paths relative to the reference root):
+ *
+ *   csa_forward_packed   replaces  TorchScript NewModel.forward
+ *                          stateless  rnn/save_wrapper.py:255-298      (x_main,x_sfc) -> (B,368)
+ *                          stateful   rnn/save_wrapper_mem.py:499-545  (x_main,x_sfc,rnn1_mem) -> (B,368+nlev*nh_mem)
+ *   csa_forward_tuple    replaces  model_wrapper.forward_base  rnn/utils.py:260-295
+ *                          (x_main0,x_sfc0,rnn1_mem) -> (out_lev (B,nlev,6), out_sfc (B,8), rnn1_mem (nlev,B,nh_mem))
+ *   csa_model_forward    replaces  RNN_autoreg.forward         rnn/models/models.py:432-608
+ *                          [x_main_norm, x_sfc_norm, rnn_mem] -> (out (B,nlev,ny), out_sfc (B,8), rnn_mem)
+ *
+ * Conventions: fp32, contiguous, batch-first, raw physical units in
+ * and out for the wrappers; inputs are never modified; ALL recurrent state (rnn1_mem) is owned
+ * by the caller and passed / returned on every call; the handle holds weights, constants and
+ * scratch only.  Every data pointer is a DEVICE pointer; `stream` is a hipStream_t (NULL =
+ * default stream).  Calls are asynchronous on `stream`, allocate nothing and are safe to
+ * capture into a hipGraph.  All functions return 0 on success or a negative csa_status; no
+ * exception crosses the boundary.  One call at a time per handle.
+ *
+ * The legacy generation (the shipped rnn/v4_rnn*_wrapper*.pt artefacts) draws
+ * hx2,cx2 = randn(B,nh) inside forward; here the draw is an explicit argument so that results
+ * are reproducible and checkable (the Python facade draws it with torch when not given).
+ */
+#ifndef CLIMSIM_AMD_H
+#define CLIMSIM_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+    CSA_OK = 0,
+    CSA_ERR_ARG = -1,          /* bad shape / null pointer / B out of range */
+    CSA_ERR_UNSUPPORTED = -2,  /* configuration not implemented by the HIP path */
+    CSA_ERR_HIP = -3,          /* HIP runtime error (see csa_last_error) */
+    CSA_ERR_NOMEM = -4
+} csa_status;
+
+typedef struct {
+    int32_t nlev, nx, nx_sfc, ny, ny_sfc;   /* 60, 15, 19, 5, 8 */
+    int32_t nh1, nh2, nh_mem;               /* 128, 128, 16 (nh_mem 0 = stateless model) */
+    int32_t use_lstm;        /* 1 LSTM, 0 GRU */
+    int32_t legacy;          /* 1: shipped-artefact generation; 0: current RNN_autoreg */
+    int32_t output_prune;    /* models.py:554-559 */
+    int32_t mp_mode;         /* 1: liq/ice diagnosed from T; 0: none */
+    int32_t snowhice_fix, qinput_prune, rh_prune, scrub_inf, scrub_out_nan;
+} csa_config;
+
+/* HOST pointers, PyTorch state_dict layout (out_features,in_features); copied by csa_create. */
+typedef struct {
+    const float *xmean_lev, *xdiv_lev, *xmean_sca, *xdiv_sca, *lbd_qc, *lbd_qi;
+    const float *yscale_lev, *yscale_sca, *hyam, *hybm;
+    const float *mlp_initial_w, *mlp_initial_b;
+    const float *mlp_surface1_w, *mlp_surface1_b, *mlp_surface2_w, *mlp_surface2_b;
+    const float *mlp_toa1_w, *mlp_toa1_b, *mlp_toa2_w, *mlp_toa2_b;
+    const float *rnn1_w_ih, *rnn1_w_hh, *rnn1_b_ih, *rnn1_b_hh;
+    const float *rnn2_w_ih, *rnn2_w_hh, *rnn2_b_ih, *rnn2_b_hh;
+    const float *mlp_latent_w, *mlp_latent_b, *mlp_output_w, *mlp_output_b;
+    const float *mlp_surface_output_w, *mlp_surface_output_b;
+} csa_params;
+
+typedef struct csa_emulator csa_emulator;
+
+/* Uploads/packs weights for the current HIP device and allocates scratch for up to
+ * max_batch columns per call. */
+int csa_create(const csa_config *cfg, const csa_params *host_params, int max_batch, csa_emulator **out);
+int csa_destroy(csa_emulator *h);
+
+/* Re-upload weights (training: after an optimiser step).  Host pointers, same layout. */
+int csa_set_params(csa_emulator *h, const csa_params *host_params);
+
+/* Width of one packed output row: 6*nlev + ny_sfc + nlev*nh_mem. */
+int csa_packed_width(const csa_emulator *h);
+int csa_max_batch(const csa_emulator *h);
+
+/* Packed wrappers.  mem_in NULL iff nh_mem == 0.  hx2/cx2 (B,nh2) required iff legacy. */
+int csa_forward_packed(csa_emulator *h, int B,
+                       const float *x_main, const float *x_sfc, const float *mem_in,
+                       const float *hx2, const float *cx2,
+                       float *yout, void *stream);
+
+/* Tuple wrapper of the current generation; mem_in/mem_out are (nlev,B,nh_mem). */
+int csa_forward_tuple(csa_emulator *h, int B,
+                      const float *x_main, const float *x_sfc, const float *mem_in,
+                      float *out_lev, float *out_sfc, float *mem_out, void *stream);
+
+/* Normalised-space model forward.  mem layout: legacy (B,nlev,nh_mem) sequence order,
+ * current (nlev,B,nh_mem) level order. */
+int csa_model_forward(csa_emulator *h, int B,
+                      const float *x_main_n, const float *x_sfc_n, const float *mem_in,
+                      const float *hx2, const float *cx2,
+                      float *out, float *out_sfc, float *mem_out, void *stream);
+
+/* Debug taps of the last call: rnn1 / rnn2 hidden sequences, (nlev,B,nh) level order. */
+const float *csa_tap_rnn1(const csa_emulator *h);
+const float *csa_tap_rnn2(const csa_emulator *h);
+
+/* Optional per-kernel timing with HIP events on the call's own stream (bench.py's roofline
+ * accounting).  While enabled, each forward records 7 events around its 6 launches and the NEXT
+ * call (or csa_get_profile) collects them, which synchronises the host with the previous call:
+ * measurement mode only.  Stages: prep, proj_gemm_rnn1, rec_rnn1, proj_gemm_rnn2, rec_rnn2, head. */
+int csa_set_profiling(csa_emulator *h, int enable);
+int csa_reset_profile(csa_emulator *h);
+int csa_get_profile(csa_emulator *h, double *avg_ms /* [6] */, int n, long *calls);
+const char *csa_stage_name(int i);
+
+const char *csa_last_error(void);
+const char *csa_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
