@@ -65,8 +65,9 @@ std::vector<float> transposed(const float *w, int O, int K)
     return t;
 }
 
-// Input-projection weights with rows permuted to unit-major order n' = u*4 + g (GRU: 4th row 0),
-// and the bias that can be folded into the projection (b_ih + b_hh; GRU keeps b_hn apart).
+// Input-projection weights with rows permuted to unit-major order n' = u*4 + pos.  LSTM: pos runs
+// over [i, g~, f, o] (the pair order the recurrent kernel's lane groups read); GRU: [r, z, n, 0].
+// The bias that can be folded into the projection is b_ih + b_hh (GRU keeps b_hn apart).
 void pack_ih(int use_lstm, int nh, int K, const float *w_ih, const float *b_ih, const float *b_hh,
              std::vector<float> &w, std::vector<float> &bias, std::vector<float> &bhn)
 {
@@ -76,7 +77,8 @@ void pack_ih(int use_lstm, int nh, int K, const float *w_ih, const float *b_ih, 
     bhn.assign((size_t)nh, 0.0f);
     for (int u = 0; u < nh; ++u)
         for (int g = 0; g < G; ++g) {
-            const int src = g * nh + u, dst = u * 4 + g;
+            static const int lstm_pos[4] = {0, 2, 1, 3};   // PyTorch i,f,g,o -> position in [i,g,f,o]
+            const int src = g * nh + u, dst = u * 4 + (use_lstm ? lstm_pos[g] : g);
             memcpy(&w[(size_t)dst * K], &w_ih[(size_t)src * K], sizeof(float) * K);
             if (!use_lstm && g == 2) { bias[dst] = b_ih[src]; bhn[u] = b_hh[src]; }
             else bias[dst] = b_ih[src] + b_hh[src];

@@ -55,6 +55,20 @@ __device__ __forceinline__ float quad_sum(float v)
     return v;
 }
 
+__device__ __forceinline__ float dpp_xor1(float v)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float dpp_xor2(float v)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));
+}
+
+// Workgroup barrier that waits for this wave's LDS traffic ONLY.  __syncthreads() also drains
+// vmcnt(0), i.e. it would stall every step on the global prefetch of P and on the h_t store
+// (measured: +475 ns per step); those stay in flight across the barrier here.
+#define LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+
 // acc(col0,col1) += w.x * h(col0,col1)   /   += w.y * h
 #define PK_FMA_LO(acc, w, h) asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[0,1,1]" : "+v"(acc) : "v"(w), "v"(h))
 #define PK_FMA_HI(acc, w, h) asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(acc) : "v"(w), "v"(h))
@@ -75,6 +89,9 @@ __global__ __launch_bounds__(NH * 4, 2) void rec_kernel(
     __shared__ __attribute__((aligned(16))) float hbuf[2][4 * CH];
 
     const int tid = threadIdx.x, u = tid >> 2, p = tid & 3, col = p & 1;
+#ifdef REC_EXP_CLOCK
+    const unsigned long long clk0 = __builtin_readcyclecounter(), rt0 = wall_clock64();
+#endif
     int b = 2 * blockIdx.x + col;
     const bool valid = b < B;
     if (!valid) b = B - 1;              // odd tail: the spare column recomputes a real one, writes nothing
@@ -101,21 +118,38 @@ __global__ __launch_bounds__(NH * 4, 2) void rec_kernel(
     constexpr int PS = G == 4 ? 4 : 4;               // P row stride per unit (GRU rows padded to 4)
     const float *Pb = P + (size_t)b * (PS * NH) + u * PS;
     const size_t Pstep = (size_t)B * (PS * NH);
+    // input projections are prefetched two steps ahead (they do not depend on the recurrence)
     f32x4 pre = *(const f32x4 *)Pb;
+    f32x4 pre1 = L > 1 ? *(const f32x4 *)(Pb + Pstep) : pre;
     __syncthreads();
 
     for (int t = 0; t < L; ++t) {
         const int cur = t & 1;
-        // prefetch next step's input projection (independent of the recurrence)
-        f32x4 pre_next = pre;
-        if (t + 1 < L) pre_next = *(const f32x4 *)(Pb + (size_t)(t + 1) * Pstep);
+        // h_{t-1} is stored one step late, just ahead of the prefetch: by the time the register
+        // rotation at the bottom of the loop needs this step's prefetch (an in-order vmcnt wait)
+        // both have long completed, so no step ever stalls on global memory.
+#ifndef REC_EXP_NO_GLOBAL
+        if (t > 0 && writer) {
+            const int lvl = reverse_out ? L - t : t - 1;
+            Hout[((size_t)lvl * B + b) * NH + u] = h;
+        }
+#endif
+        f32x4 pre2 = pre1;
+#ifndef REC_EXP_NO_GLOBAL
+        if (t + 2 < L) pre2 = *(const f32x4 *)(Pb + (size_t)(t + 2) * Pstep);
+#endif
 
         f32x2 acc[G];
 #pragma unroll
         for (int g = 0; g < G; ++g) acc[g] = f32x2{0.0f, 0.0f};
         const f32x4 *hp = (const f32x4 *)&hbuf[cur][p * CH];
+#ifdef REC_EXP_NO_FMA
+#pragma unroll
+        for (int j = 0; j < 1; ++j) {
+#else
 #pragma unroll
         for (int j = 0; j < KC / 2; ++j) {
+#endif
             const f32x4 hv = hp[j];
             const f32x2 ha = {hv.x, hv.y}, hb = {hv.z, hv.w};   // (k,col0|col1), (k+1,col0|col1)
 #pragma unroll
@@ -129,6 +163,10 @@ __global__ __launch_bounds__(NH * 4, 2) void rec_kernel(
             const float sx = quad_sum(acc[g].x), sy = quad_sum(acc[g].y);
             s[g] = col ? sy : sx;
         }
+#ifdef REC_EXP_NO_GATES
+        h = 0.25f * (pre.x + s[0]) + 0.01f * (pre.y + s[1] + pre.z + s[2] + pre.w + s[G - 1]);
+        h = fminf(fmaxf(h, -1.0f), 1.0f);
+#else
         if (G == 4) {
             const float ig = sigmoid_f(pre.x + s[0]);
             const float fg = sigmoid_f(pre.y + s[1]);
@@ -142,13 +180,143 @@ __global__ __launch_bounds__(NH * 4, 2) void rec_kernel(
             const float n = tanh_f(pre.z + r * (s[2] + bn));
             h = (1.0f - z) * n + z * h;
         }
+#endif
         if (p < 2) hbuf[cur ^ 1][hslot] = h;
-        if (writer) {
-            const int lvl = reverse_out ? L - 1 - t : t;
-            Hout[((size_t)lvl * B + b) * NH + u] = h;
+        pre = pre1;
+        pre1 = pre2;
+        LDS_BARRIER();
+    }
+    if (writer) {
+        const int lvl = reverse_out ? 0 : L - 1;
+        Hout[((size_t)lvl * B + b) * NH + u] = h;
+    }
+#ifdef REC_EXP_CLOCK
+    if (tid == 0 && blockIdx.x == 0) {   // diagnostic build only: shader cycles and 100 MHz ticks of block 0
+        Hout[0] = (float)(__builtin_readcyclecounter() - clk0);
+        Hout[1] = (float)(wall_clock64() - rt0);
+    }
+#endif
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// LSTM kernel, second generation: same register-stationary / two-columns-per-CU layout, with the
+// serial part of every step (everything that is not the 128 packed FMAs) cut down:
+//   * h_{t-1} is kept in LDS twice, as (col0,col1) and as (col1,col0) pairs; odd k-quarters read
+//     the swapped copy, so in every lane accumulator.x is "my column" (col = p&1).  The k-quarter
+//     sum then becomes a reduce-SCATTER of 6 DPP adds (was an all-reduce of 16): after
+//     r = acc.x + xor1(acc.y) and f = r[s] + xor2(r[s+2]) lane p holds the two gates of ITS group
+//     (p<2: i,g~; p>=2: f,o) for ITS column.  Which gate sits in which accumulator slot differs per
+//     lane group and is decided by the host packer (slots = [i,g,f,o] for p<2, [f,o,i,g] for p>=2),
+//     so no select is needed anywhere.
+//   * two activations per lane instead of five (slot 0 is always a sigmoid, slot 1 is tanh or
+//     sigmoid through per-lane constants), one DPP transfer of i*g~ to the lane that owns c_t.
+//   * no register rotation of the prefetched projections (time loop unrolled x2), so the compiler
+//     never waits on a just-issued global load or store inside the recurrence.
+// P rows are laid out [i, g~, f, o] per unit (see pack_ih in api.hip): lane reads one 8-byte pair.
+template <int NH>
+__global__ __launch_bounds__(NH * 4, 2) void lstm_rec2_kernel(
+    const f32x4 *__restrict__ Wp4, const float *__restrict__ P,
+    const float *__restrict__ h0, const float *__restrict__ c0, float *__restrict__ Hout,
+    int B, int L, int reverse_out)
+{
+    constexpr int NT = NH * 4;
+    constexpr int KC = NH / 4;
+    constexpr int CH = 2 * KC + 4;      // floats per k-quarter, padded by one 16-B slot
+    constexpr int CPY = 4 * CH;         // floats per copy
+    static_assert(KC % 4 == 0, "nh must be a multiple of 16");
+    __shared__ __attribute__((aligned(16))) float hbuf[2][2 * CPY];
+
+    const int tid = threadIdx.x, u = tid >> 2, p = tid & 3, col = p & 1, grp = p >> 1;
+#ifdef REC_EXP_CLOCK
+    const unsigned long long clk0 = __builtin_readcyclecounter(), rt0 = wall_clock64();
+#endif
+    int b = 2 * blockIdx.x + col;
+    const bool valid = b < B;
+    if (!valid) b = B - 1;
+    const bool owner = grp == 1;                 // lanes p>=2 own c_t / h_t of (u, col)
+
+    f32x2 w[4][KC / 2];
+#pragma unroll
+    for (int i = 0; i < KC; ++i) {
+        const f32x4 v = Wp4[(size_t)i * NT + tid];
+        const int s = (4 * i) / KC, kk = (4 * i) % KC;
+        w[s][kk / 2] = f32x2{v.x, v.y};
+        w[s][kk / 2 + 1] = f32x2{v.z, v.w};
+    }
+    // slot-1 activation: tanh for the (i,g~) lanes, sigmoid for the (f,o) lanes
+    const float k1 = grp ? -1.44269504088896341f : -2.88539008177792681f;
+    const float a1 = grp ? 1.0f : 2.0f, c1 = grp ? 0.0f : -1.0f;
+
+    float h = h0[(size_t)b * NH + u];
+    float c = c0[(size_t)b * NH + u];
+    const int slotN = 2 * u + col + 4 * (u / KC);
+    const int slotS = CPY + 2 * u + (1 - col) + 4 * (u / KC);
+    if (owner) { hbuf[0][slotN] = h; hbuf[0][slotS] = h; }
+
+    const float *Pb = P + (size_t)b * (4 * NH) + u * 4 + grp * 2;
+    const size_t Pstep = (size_t)B * (4 * NH);
+    const int rdoff = col * CPY + p * CH;
+    f32x2 preA = *(const f32x2 *)Pb, preB = preA;
+    __syncthreads();
+
+#define LSTM2_STEP(T, CUR, NXT)                                                                    \
+    {                                                                                              \
+        const int t_ = (T);                                                                        \
+        if (t_ + 1 < L) NXT = *(const f32x2 *)(Pb + (size_t)(t_ + 1) * Pstep);                     \
+        const f32x4 *hp = (const f32x4 *)&hbuf[t_ & 1][rdoff];                                     \
+        f32x4 hv[KC / 2];                                                                          \
+        _Pragma("unroll") for (int j = 0; j < KC / 2; ++j) hv[j] = hp[j];                          \
+        f32x2 acc[4] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};                           \
+        _Pragma("unroll") for (int j = 0; j < KC / 2; ++j) {                                       \
+            const f32x2 ha = {hv[j].x, hv[j].y}, hb = {hv[j].z, hv[j].w};                          \
+            _Pragma("unroll") for (int s = 0; s < 4; ++s) PK_FMA_LO(acc[s], w[s][j], ha);          \
+            _Pragma("unroll") for (int s = 0; s < 4; ++s) PK_FMA_HI(acc[s], w[s][j], hb);          \
+        }                                                                                          \
+        float r[4];                                                                                \
+        _Pragma("unroll") for (int s = 0; s < 4; ++s) r[s] = acc[s].x + dpp_xor1(acc[s].y);        \
+        const float v0 = r[0] + dpp_xor2(r[2]) + CUR.x;                                            \
+        const float v1 = r[1] + dpp_xor2(r[3]) + CUR.y;                                            \
+        const float g0 = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504088896341f * v0)); \
+        const float g1 = a1 * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(k1 * v1)) + c1;  \
+        const float ig = dpp_xor2(g0 * g1);           /* sigma(i)*tanh(g~) arrives at the (f,o) lane */ \
+        c = g0 * c + ig;                                                                           \
+        const float th = 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-2.88539008177792681f * c)) - 1.0f; \
+        h = g1 * th;                                                                               \
+        if (owner) {                                                                               \
+            hbuf[(t_ & 1) ^ 1][slotN] = h;                                                         \
+            hbuf[(t_ & 1) ^ 1][slotS] = h;                                                         \
+            if (valid) Hout[((size_t)(reverse_out ? L - 1 - t_ : t_) * B + b) * NH + u] = h;       \
+        }                                                                                          \
+        LDS_BARRIER();                                                                             \
+    }
+
+    for (int t = 0; t < L; t += 2) {
+        LSTM2_STEP(t, preA, preB)
+        if (t + 1 < L) LSTM2_STEP(t + 1, preB, preA)
+    }
+#undef LSTM2_STEP
+#ifdef REC_EXP_CLOCK
+    if (tid == 0 && blockIdx.x == 0) {
+        Hout[0] = (float)(__builtin_readcyclecounter() - clk0);
+        Hout[1] = (float)(wall_clock64() - rt0);
+    }
+#endif
+}
+
+// slot -> PyTorch gate index (i,f,g,o = 0,1,2,3) for lane groups p<2 and p>=2
+static const int kLstm2Slot[2][4] = {{0, 2, 1, 3}, {1, 3, 0, 2}};
+
+static void lstm2_pack_weights(int nh, const float *w_hh, float *packed)
+{
+    const int NT = nh * 4, KC = nh / 4;
+    for (int tid = 0; tid < NT; ++tid) {
+        const int u = tid >> 2, p = tid & 3, grp = p >> 1;
+        for (int idx = 0; idx < 4 * KC; ++idx) {
+            const int s = idx / KC, kk = idx % KC, g = kLstm2Slot[grp][s];
+            const int i = idx / 4, e = idx % 4;
+            packed[((size_t)i * NT + tid) * 4 + e] = w_hh[(size_t)(g * nh + u) * nh + p * KC + kk];
         }
-        pre = pre_next;
-        __syncthreads();
     }
 }
 
@@ -156,6 +324,7 @@ size_t rec_packed_floats(int use_lstm, int nh) { return (size_t)(use_lstm ? 4 : 
 
 void rec_pack_weights(int use_lstm, int nh, const float *w_hh, float *packed)
 {
+    if (use_lstm) { lstm2_pack_weights(nh, w_hh, packed); return; }
     const int G = use_lstm ? 4 : 3, NT = nh * 4, KC = nh / 4;
     for (int tid = 0; tid < NT; ++tid) {
         const int u = tid >> 2, p = tid & 3;
@@ -173,7 +342,7 @@ static int launch_rec_nh(int use_lstm, const float *whh, const float *bhn, const
 {
     const dim3 grid((B + 1) / 2), block(NH * 4);
     if (use_lstm)
-        hipLaunchKernelGGL((rec_kernel<NH, 4>), grid, block, 0, s, (const f32x4 *)whh, bhn, P, h0, c0, Hout, B, L,
+        hipLaunchKernelGGL((lstm_rec2_kernel<NH>), grid, block, 0, s, (const f32x4 *)whh, P, h0, c0, Hout, B, L,
                            reverse_out);
     else
         hipLaunchKernelGGL((rec_kernel<NH, 3>), grid, block, 0, s, (const f32x4 *)whh, bhn, P, h0, c0, Hout, B, L,
