@@ -260,21 +260,36 @@ __global__ __launch_bounds__(NH * 4, 2) void lstm_rec2_kernel(
     f32x2 preA = *(const f32x2 *)Pb, preB = preA;
     __syncthreads();
 
+    // P(t+1) is fetched with an asm global_load at the top of step t and first touched behind an
+    // explicit vmcnt(1) ("everything but the newest VMEM op") just before the gates of step t+1,
+    // a whole step later; the h_t store of the previous step is older still.  hipcc inserts no
+    // waits for loads issued inside asm, so nothing in the recurrence ever stalls on global
+    // memory; the "+v" operand of the wait orders the consumers behind it.  The LDS reads of
+    // h_{t-1} are left to the compiler (two ds_read_b128 in flight per wave).  Measured with the
+    // in-kernel stamps of the REC_EXP_STAMP build: hand-pipelining them 4 deep changes nothing and
+    // issuing all sixteen up front costs +170 cycles per step; the FMA phase is bound by the
+    // LDS->VGPR return traffic (16 KB per wave per step) competing with the packed FMAs, not by
+    // read latency: 1234 cycles per step with h in registers vs ~1650 with h from LDS
+    // (tools/valu_bench.hip).
 #define LSTM2_STEP(T, CUR, NXT)                                                                    \
     {                                                                                              \
         const int t_ = (T);                                                                        \
-        if (t_ + 1 < L) NXT = *(const f32x2 *)(Pb + (size_t)(t_ + 1) * Pstep);                     \
+        if (t_ + 1 < L) {                                                                          \
+            const float *pn = Pb + (size_t)(t_ + 1) * Pstep;                                       \
+            asm volatile("global_load_dwordx2 %0, %1, off" : "=&v"(NXT) : "v"(pn) : "memory");     \
+        }                                                                                          \
         const f32x4 *hp = (const f32x4 *)&hbuf[t_ & 1][rdoff];                                     \
-        f32x4 hv[KC / 2];                                                                          \
-        _Pragma("unroll") for (int j = 0; j < KC / 2; ++j) hv[j] = hp[j];                          \
         f32x2 acc[4] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};                           \
         _Pragma("unroll") for (int j = 0; j < KC / 2; ++j) {                                       \
-            const f32x2 ha = {hv[j].x, hv[j].y}, hb = {hv[j].z, hv[j].w};                          \
+            const f32x4 hv = hp[j];                                                                \
+            const f32x2 ha = {hv.x, hv.y}, hb = {hv.z, hv.w};                                      \
             _Pragma("unroll") for (int s = 0; s < 4; ++s) PK_FMA_LO(acc[s], w[s][j], ha);          \
             _Pragma("unroll") for (int s = 0; s < 4; ++s) PK_FMA_HI(acc[s], w[s][j], hb);          \
         }                                                                                          \
+        STAMP(1, acc[0])                                                                           \
         float r[4];                                                                                \
         _Pragma("unroll") for (int s = 0; s < 4; ++s) r[s] = acc[s].x + dpp_xor1(acc[s].y);        \
+        if (t_ > 0) asm volatile("s_waitcnt vmcnt(1)" : "+v"(CUR));                                \
         const float v0 = r[0] + dpp_xor2(r[2]) + CUR.x;                                            \
         const float v1 = r[1] + dpp_xor2(r[3]) + CUR.y;                                            \
         const float g0 = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504088896341f * v0)); \
@@ -283,23 +298,48 @@ __global__ __launch_bounds__(NH * 4, 2) void lstm_rec2_kernel(
         c = g0 * c + ig;                                                                           \
         const float th = 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-2.88539008177792681f * c)) - 1.0f; \
         h = g1 * th;                                                                               \
+        STAMP(2, h)                                                                                \
         if (owner) {                                                                               \
             hbuf[(t_ & 1) ^ 1][slotN] = h;                                                         \
             hbuf[(t_ & 1) ^ 1][slotS] = h;                                                         \
             if (valid) Hout[((size_t)(reverse_out ? L - 1 - t_ : t_) * B + b) * NH + u] = h;       \
         }                                                                                          \
         LDS_BARRIER();                                                                             \
+        STAMP(0, h)                                                                                \
     }
+
+#ifdef REC_EXP_STAMP
+    // diagnostic build only: per-phase shader-cycle sums of one wave (phase k ends at stamp k)
+    unsigned long long st_last = __builtin_readcyclecounter(), st_sum[3] = {0, 0, 0};
+#define STAMP(K, DEP)                                                                              \
+    {                                                                                              \
+        asm volatile("" : "+v"(DEP));                                                              \
+        __builtin_amdgcn_sched_barrier(0);                                                         \
+        const unsigned long long now_ = __builtin_readcyclecounter();                              \
+        __builtin_amdgcn_sched_barrier(0);                                                         \
+        st_sum[K] += now_ - st_last;                                                               \
+        st_last = now_;                                                                            \
+    }
+#else
+#define STAMP(K, DEP)
+#endif
 
     for (int t = 0; t < L; t += 2) {
         LSTM2_STEP(t, preA, preB)
         if (t + 1 < L) LSTM2_STEP(t + 1, preB, preA)
     }
 #undef LSTM2_STEP
+#undef STAMP
 #ifdef REC_EXP_CLOCK
     if (tid == 0 && blockIdx.x == 0) {
         Hout[0] = (float)(__builtin_readcyclecounter() - clk0);
         Hout[1] = (float)(wall_clock64() - rt0);
+    }
+#endif
+#ifdef REC_EXP_STAMP
+    if ((tid & 63) == 0 && blockIdx.x == 0) {
+        float *dbg = Hout + 8 + (tid >> 6) * 4;
+        dbg[0] = (float)st_sum[1]; dbg[1] = (float)st_sum[2]; dbg[2] = (float)st_sum[0];
     }
 #endif
 }

@@ -38,6 +38,11 @@ int main(int argc, char **argv)
 #ifdef REC_EXP_CLOCK
     printf("block0: %.0f shader cycles, %.0f ticks(100MHz) -> %.3f GHz, %.1f cycles/step\n", H[0], H[1], H[0] / H[1] * 0.1, H[0] / L);
 #endif
+#ifdef REC_EXP_STAMP
+    for (int wv = 0; wv < 8; ++wv)
+        printf("wave %d: cycles/step  fma(read+fma) %.0f  gates %.0f  write+barrier %.0f\n", wv, H[8 + wv * 4] / L,
+               H[9 + wv * 4] / L, H[10 + wv * 4] / L);
+#endif
     printf("B=%d  %.2f us/launch  %.1f ns/step  %.2f TFLOP/s  checksum %.6f\n", B, us, 1e3 * us / L,
            (double)B * L * 2 * 4 * nh * nh / (us * 1e-6) / 1e12, cs);
     return 0;
