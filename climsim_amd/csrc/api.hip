@@ -155,6 +155,7 @@ int upload_params(csa_emulator *h, const csa_params *p, bool first)
         d.out_w = U.up(p->mlp_output_w, (size_t)c.ny * c.nh_mem);
     } else {
         d.out_w = U.up(p->mlp_output_w, (size_t)c.ny * c.nh2);
+        d.out_wt = U.up(transposed(p->mlp_output_w, c.ny, c.nh2));
     }
     d.out_b = U.up(p->mlp_output_b, c.ny);
     d.sfo_w = U.up(p->mlp_surface_output_w, (size_t)c.ny_sfc * c.nh2);

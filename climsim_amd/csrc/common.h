@@ -32,6 +32,7 @@ struct DevModel {
     // heads
     const float *lat_wt, *lat_b;        // (nh2, nh_mem)
     const float *out_w, *out_b;         // (ny, nh_mem or nh2) row-major
+    const float *out_wt;                // (nh2, ny) transposed copy, stateless model only
     const float *sfo_w, *sfo_b;         // (ny_sfc, nh2) row-major
 };
 

@@ -13,62 +13,88 @@
 
 #define HEAD_THREADS 256
 
+// First stage of the head: Z(l, j) = b1[j] + sum_k H2(l, k) * W1t(k, j), j < n1, where (W1t, n1) is
+// mlp_latent (n1 = nh_mem) for the memory models or mlp_output itself (n1 = ny) for the stateless
+// one.  Thread (lg, j): j = tid % n1p, lg = tid / n1p, n1p = n1 rounded up to a power of two;
+// it keeps column j of W1t in registers (NH2 VGPRs) and walks levels lg, lg + G, ...; the hidden
+// rows come from LDS as float4 broadcasts.
+template <int NH2>
 __global__ __launch_bounds__(HEAD_THREADS) void head_kernel(
     DevModel m, int B, int mode, const float *__restrict__ H2, const float *__restrict__ x_raw,
     float *__restrict__ y0, float *__restrict__ y1, float *__restrict__ y2)
 {
-    extern __shared__ float smem[];
+    extern __shared__ __attribute__((aligned(16))) float smem[];
     const int L = m.cfg.nlev, nx = m.cfg.nx, ny = m.cfg.ny, nys = m.cfg.ny_sfc;
-    const int nh2 = m.cfg.nh2, nm = m.cfg.nh_mem, ldh = nh2 + 1;
-    float *hs = smem;                       // (L, nh2+1)
+    const int nm = m.cfg.nh_mem;
+    constexpr int ldh = NH2 + 4;            // float4-aligned rows, 16-B skew between rows
+    float *hs = smem;                       // (L, ldh)
     float *zs = hs + L * ldh;               // (L, nm)
     float *os = zs + L * (nm > 0 ? nm : 1); // (L, ny)
     const int b = blockIdx.x, tid = threadIdx.x;
     const bool legacy = m.cfg.legacy != 0;
+    const int W = 6 * L + nys + L * nm;     // packed row width
 
-    for (int idx = tid; idx < L * nh2; idx += HEAD_THREADS) {
-        const int l = idx / nh2, k = idx - l * nh2;
-        hs[l * ldh + k] = H2[((size_t)l * B + b) * nh2 + k];
+    for (int idx = tid; idx < L * (NH2 / 4); idx += HEAD_THREADS) {
+        const int l = idx / (NH2 / 4), k4 = idx - l * (NH2 / 4);
+        *(f32x4 *)&hs[l * ldh + 4 * k4] = *(const f32x4 *)&H2[((size_t)l * B + b) * NH2 + 4 * k4];
+    }
+    const int n1 = nm > 0 ? nm : ny;
+    int n1p = 1;
+    while (n1p < n1) n1p <<= 1;
+    const int j = tid & (n1p - 1), lg = tid / n1p, G = HEAD_THREADS / n1p;
+    const float *w1t = nm > 0 ? m.lat_wt : m.out_wt;   // (NH2, n1)
+    float wreg[NH2];
+    float b1 = 0.0f;
+    if (j < n1) {
+#pragma unroll
+        for (int k = 0; k < NH2; ++k) wreg[k] = w1t[k * n1 + j];
+        b1 = nm > 0 ? m.lat_b[j] : m.out_b[j];
     }
     __syncthreads();
 
-    // ---- latent memory -----------------------------------------------------------------------
-    if (nm > 0) {
-        float *mem_out = mode == HEAD_PACKED ? y0 + (size_t)b * (6 * L + nys + L * nm) + 6 * L + nys
-                                             : y2;
-        for (int idx = tid; idx < L * nm; idx += HEAD_THREADS) {
-            const int l = idx / nm, j = idx - l * nm;
-            float a = m.lat_b[j];
-            const float *hr = hs + l * ldh;
-            for (int k = 0; k < nh2; ++k) a += hr[k] * m.lat_wt[k * nm + j];
-            zs[idx] = a;
-            float v = a;
-            if (mode == HEAD_PACKED) {
-                if (m.cfg.scrub_out_nan && isnan(v)) v = 0.0f;
-                // packed rows carry the model's memory block verbatim: legacy (L,nm) in sequence order
-                mem_out[(legacy ? (L - 1 - l) : l) * nm + j] = v;
-            } else if (legacy) {
-                mem_out[((size_t)b * L + (L - 1 - l)) * nm + j] = v;
-            } else {
-                mem_out[((size_t)l * B + b) * nm + j] = v;
+    if (j < n1) {
+        float *mem_out = mode == HEAD_PACKED ? y0 + (size_t)b * W + 6 * L + nys : y2;
+        for (int l = lg; l < L; l += G) {
+            const f32x4 *hr = (const f32x4 *)(hs + l * ldh);
+            float a0 = b1, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
+#pragma unroll
+            for (int k4 = 0; k4 < NH2 / 4; ++k4) {
+                const f32x4 hv = hr[k4];
+                a0 += hv.x * wreg[4 * k4];
+                a1 += hv.y * wreg[4 * k4 + 1];
+                a2 += hv.z * wreg[4 * k4 + 2];
+                a3 += hv.w * wreg[4 * k4 + 3];
             }
+            const float a = (a0 + a1) + (a2 + a3);
+            if (nm > 0) {
+                zs[l * nm + j] = a;
+                float v = a;
+                if (mode == HEAD_PACKED) {
+                    if (m.cfg.scrub_out_nan && isnan(v)) v = 0.0f;
+                    // packed rows carry the model's memory block verbatim: legacy (L,nm), sequence order
+                    mem_out[(legacy ? (L - 1 - l) : l) * nm + j] = v;
+                } else if (legacy) {
+                    mem_out[((size_t)b * L + (L - 1 - l)) * nm + j] = v;
+                } else {
+                    mem_out[((size_t)l * B + b) * nm + j] = v;
+                }
+            } else {
+                os[l * ny + j] = (m.cfg.output_prune && l < 12 && j >= 1) ? 0.0f : a;
+            }
+        }
+    }
+    __syncthreads();
+    // ---- second stage for the memory models: out = mlp_output(latent) ---------------------------
+    if (nm > 0) {
+        for (int idx = tid; idx < L * ny; idx += HEAD_THREADS) {
+            const int l = idx / ny, v = idx - l * ny;
+            float a = m.out_b[v];
+            for (int q = 0; q < nm; ++q) a += zs[l * nm + q] * m.out_w[v * nm + q];
+            if (m.cfg.output_prune && l < 12 && v >= 1) a = 0.0f;
+            os[idx] = a;
         }
         __syncthreads();
     }
-    // ---- level outputs (normalised) -----------------------------------------------------------
-    for (int idx = tid; idx < L * ny; idx += HEAD_THREADS) {
-        const int l = idx / ny, v = idx - l * ny;
-        float a = m.out_b[v];
-        if (nm > 0) {
-            for (int j = 0; j < nm; ++j) a += zs[l * nm + j] * m.out_w[v * nm + j];
-        } else {
-            const float *hr = hs + l * ldh;
-            for (int k = 0; k < nh2; ++k) a += hr[k] * m.out_w[v * nh2 + k];
-        }
-        if (m.cfg.output_prune && l < 12 && v >= 1) a = 0.0f;
-        os[idx] = a;
-    }
-    __syncthreads();
 
     // ---- de-normalise, microphysics, pack -------------------------------------------------------
     const bool post = (mode != HEAD_RAW) && m.cfg.mp_mode == 1;
@@ -97,7 +123,7 @@ __global__ __launch_bounds__(HEAD_THREADS) void head_kernel(
             const float dqi = ((1.0f - lf) * qn_new - qi) * 0.0008333333333333334f;
             float vals[6] = {dT, dqv, dql, dqi, du, dv};
             if (mode == HEAD_PACKED) {
-                float *y = y0 + (size_t)b * (6 * L + nys + L * nm);
+                float *y = y0 + (size_t)b * W;
 #pragma unroll
                 for (int v = 0; v < 6; ++v) {
                     float val = vals[v];
@@ -111,18 +137,25 @@ __global__ __launch_bounds__(HEAD_THREADS) void head_kernel(
             }
         }
     }
-    // ---- surface outputs -------------------------------------------------------------------------
-    for (int v = tid; v < nys; v += HEAD_THREADS) {
-        float a = m.sfo_b[v];
-        const float *hr = hs + (L - 1) * ldh;     // last_h of the downward RNN
-        for (int k = 0; k < nh2; ++k) a += hr[k] * m.sfo_w[v * nh2 + k];
-        if (mode == HEAD_PACKED) {
-            a = a / m.yscale_sca[v];
-            if (m.cfg.scrub_out_nan && isnan(a)) a = 0.0f;
-            y0[(size_t)b * (6 * L + nys + L * nm) + 6 * L + v] = a;
-        } else {
-            if (mode == HEAD_TUPLE && m.cfg.mp_mode != 0) a = a / m.yscale_sca[v];
-            y1[(size_t)b * nys + v] = a;
+    // ---- surface outputs: one wave, 8 lanes per output ---------------------------------------------
+    if (tid < 64) {
+        const int v = tid >> 3, part = tid & 7;
+        float a = 0.0f;
+        if (v < nys) {
+            const float *hr = hs + (L - 1) * ldh;     // last_h of the downward RNN
+            for (int k = part; k < NH2; k += 8) a += hr[k] * m.sfo_w[v * NH2 + k];
+        }
+        a += __shfl_xor(a, 1); a += __shfl_xor(a, 2); a += __shfl_xor(a, 4);
+        if (v < nys && part == 0) {
+            a += m.sfo_b[v];
+            if (mode == HEAD_PACKED) {
+                a = a / m.yscale_sca[v];
+                if (m.cfg.scrub_out_nan && isnan(a)) a = 0.0f;
+                y0[(size_t)b * W + 6 * L + v] = a;
+            } else {
+                if (mode == HEAD_TUPLE && m.cfg.mp_mode != 0) a = a / m.yscale_sca[v];
+                y1[(size_t)b * nys + v] = a;
+            }
         }
     }
 }
@@ -131,12 +164,19 @@ int launch_head(const DevModel &m, int B, int mode, const float *H2, const float
                 float *y0, float *y1, float *y2, hipStream_t s)
 {
     const int L = m.cfg.nlev, nm = m.cfg.nh_mem;
-    const size_t shm = sizeof(float) * ((size_t)L * (m.cfg.nh2 + 1) + (size_t)L * (nm > 0 ? nm : 1) + (size_t)L * m.cfg.ny);
-    if (shm > 64 * 1024) {
-        csa_set_error_msg("head: LDS footprint exceeds 64 KB");
+    const size_t shm = sizeof(float) * ((size_t)L * (m.cfg.nh2 + 4) + (size_t)L * (nm > 0 ? nm : 1) + (size_t)L * m.cfg.ny);
+    if (shm > 64 * 1024 || m.cfg.ny_sfc > 8 || (nm > 0 ? nm : m.cfg.ny) > 32) {
+        csa_set_error_msg("head: unsupported sizes (LDS > 64 KB, ny_sfc > 8 or first-stage width > 32)");
         return CSA_ERR_UNSUPPORTED;
     }
-    hipLaunchKernelGGL(head_kernel, dim3(B), dim3(HEAD_THREADS), shm, s, m, B, mode, H2, x_main_raw, y0, y1, y2);
+    switch (m.cfg.nh2) {
+    case 64:  hipLaunchKernelGGL(head_kernel<64>, dim3(B), dim3(HEAD_THREADS), shm, s, m, B, mode, H2, x_main_raw, y0, y1, y2); break;
+    case 96:  hipLaunchKernelGGL(head_kernel<96>, dim3(B), dim3(HEAD_THREADS), shm, s, m, B, mode, H2, x_main_raw, y0, y1, y2); break;
+    case 128: hipLaunchKernelGGL(head_kernel<128>, dim3(B), dim3(HEAD_THREADS), shm, s, m, B, mode, H2, x_main_raw, y0, y1, y2); break;
+    default:
+        csa_set_error_msg("head: hidden size must be 64, 96 or 128");
+        return CSA_ERR_UNSUPPORTED;
+    }
     CSA_HIP_CHECK(hipGetLastError());
     return CSA_OK;
 }

@@ -16,6 +16,14 @@
 
 #define PREP_THREADS 128
 #define PREP_MAX_NXP 32   // nx+1 upper bound held in registers
+#define PREP_LSPLIT 4     // workgroups per column (each owns a contiguous slice of levels)
+
+// tanh for the mlp_initial activation: (1 - t)/(1 + t), t = exp(-2x); absolute error ~6e-8.
+__device__ __forceinline__ float prep_tanh(float x)
+{
+    const float t = fminf(__builtin_amdgcn_exp2f(-2.88539008177792681f * x), 1e30f);
+    return (1.0f - t) / (1.0f + t);
+}
 
 __global__ __launch_bounds__(PREP_THREADS) void prep_kernel(
     DevModel m, int B, int normalised,
@@ -26,9 +34,13 @@ __global__ __launch_bounds__(PREP_THREADS) void prep_kernel(
     const int L = m.cfg.nlev, nx = m.cfg.nx, nxp = nx + 1, nxs = m.cfg.nx_sfc;
     const int nh1 = m.cfg.nh1, nh2 = m.cfg.nh2, nm = m.cfg.nh_mem, nin1 = nh1 + nm;
     const int nhm = nh1 > nh2 ? nh1 : nh2;
-    float *xl = smem;                 // (L, nxp)
-    float *xs = smem + L * nxp;       // (nxs)
     const int b = blockIdx.x, tid = threadIdx.x;
+    // this workgroup's slice of levels [l0, l1)
+    const int lper = (L + PREP_LSPLIT - 1) / PREP_LSPLIT;
+    const int l0 = blockIdx.y * lper, l1 = min(L, l0 + lper), nl = l1 - l0;
+    float *xl = smem;                 // (lper, nxp)
+    float *xs = smem + lper * nxp;    // (nxs)
+    if (nl <= 0) return;
 
     // ---- surface inputs -----------------------------------------------------------------
     for (int v = tid; v < nxs; v += PREP_THREADS) {
@@ -39,71 +51,75 @@ __global__ __launch_bounds__(PREP_THREADS) void prep_kernel(
         }
         xs[v] = x;
     }
-    // ---- level inputs ---------------------------------------------------------------------
-    for (int idx = tid; idx < L * nx; idx += PREP_THREADS) {
-        const int l = idx / nx, v = idx - l * nx;
-        float x = x_main[(size_t)b * L * nx + idx];
+    // ---- level inputs of the slice ------------------------------------------------------------
+    for (int idx = tid; idx < nl * nx; idx += PREP_THREADS) {
+        const int ll = idx / nx, v = idx - ll * nx, l = l0 + ll, gi = l * nx + v;
+        float x = x_main[(size_t)b * L * nx + gi];
         if (!normalised) {
             if (v == 2) x = 1.0f - expf(-x * m.lbd_qc[l]);
             if (v == 3) x = 1.0f - expf(-x * m.lbd_qi[l]);
-            x = (x - m.xmean_lev[idx]) / m.xdiv_lev[idx];
+            x = (x - m.xmean_lev[gi]) / m.xdiv_lev[gi];
             if (m.cfg.qinput_prune && v == 2 && l < 15) x = 0.0f;
             if (m.cfg.rh_prune && v == 1 && !isnan(x)) x = fminf(fmaxf(x, 0.0f), 1.2f);
             if (isnan(x)) x = 0.0f;
             if (m.cfg.scrub_inf && isinf(x)) x = 0.0f;
         }
-        xl[l * nxp + v] = x;
+        xl[ll * nxp + v] = x;
     }
     __syncthreads();
     {
         const float sp = xs[0] * m.xdiv_sca[0] + m.xmean_sca[0];
-        for (int l = tid; l < L; l += PREP_THREADS) {
+        for (int ll = tid; ll < nl; ll += PREP_THREADS) {
+            const int l = l0 + ll;
             const float pres = m.hyam[l] * 100000.0f + sp * m.hybm[l];
-            xl[l * nxp + nx] = sqrtf(pres) / 314.0f;
+            xl[ll * nxp + nx] = sqrtf(pres) / 314.0f;
         }
     }
     __syncthreads();
 
-    // ---- initial states -------------------------------------------------------------------
-    for (int j = tid; j < nh1; j += PREP_THREADS) {
-        float a = m.s1_b[j];
-        for (int v = 0; v < nxs; ++v) a += m.s1_wt[v * nh1 + j] * xs[v];
-        hc0[((size_t)0 * B + b) * nhm + j] = tanhf(a);
-        if (m.cfg.use_lstm) {
-            float c = m.s2_b[j];
-            for (int v = 0; v < nxs; ++v) c += m.s2_wt[v * nh1 + j] * xs[v];
-            hc0[((size_t)1 * B + b) * nhm + j] = m.cfg.legacy ? tanhf(c) : c;
+    // ---- initial states (first slice only) ---------------------------------------------------
+    if (blockIdx.y == 0) {
+        for (int j = tid; j < nh1; j += PREP_THREADS) {
+            float a = m.s1_b[j];
+            for (int v = 0; v < nxs; ++v) a += m.s1_wt[v * nh1 + j] * xs[v];
+            hc0[((size_t)0 * B + b) * nhm + j] = tanhf(a);
+            if (m.cfg.use_lstm) {
+                float c = m.s2_b[j];
+                for (int v = 0; v < nxs; ++v) c += m.s2_wt[v * nh1 + j] * xs[v];
+                hc0[((size_t)1 * B + b) * nhm + j] = m.cfg.legacy ? tanhf(c) : c;
+            }
         }
-    }
-    if (!m.cfg.legacy) {
-        const float t0 = xs[1], t1 = xs[6];
-        for (int j = tid; j < nh2; j += PREP_THREADS) {
-            hc0[((size_t)2 * B + b) * nhm + j] = m.toa1_b[j] + m.toa1_wt[j] * t0 + m.toa1_wt[nh2 + j] * t1;
-            if (m.cfg.use_lstm)
-                hc0[((size_t)3 * B + b) * nhm + j] = m.toa2_b[j] + m.toa2_wt[j] * t0 + m.toa2_wt[nh2 + j] * t1;
+        if (!m.cfg.legacy) {
+            const float t0 = xs[1], t1 = xs[6];
+            for (int j = tid; j < nh2; j += PREP_THREADS) {
+                hc0[((size_t)2 * B + b) * nhm + j] = m.toa1_b[j] + m.toa1_wt[j] * t0 + m.toa1_wt[nh2 + j] * t1;
+                if (m.cfg.use_lstm)
+                    hc0[((size_t)3 * B + b) * nhm + j] = m.toa2_b[j] + m.toa2_wt[j] * t0 + m.toa2_wt[nh2 + j] * t1;
+            }
         }
     }
 
-    // ---- mlp_initial + tanh, written in sequence order -----------------------------------------
+    // ---- mlp_initial + tanh, written in sequence order (t = L-1-l) ------------------------------
     for (int j = tid; j < nh1; j += PREP_THREADS) {
         float w[PREP_MAX_NXP];
 #pragma unroll
         for (int v = 0; v < PREP_MAX_NXP; ++v) w[v] = v < nxp ? m.init_wt[v * nh1 + j] : 0.0f;
         const float bj = m.init_b[j];
-        for (int t = 0; t < L; ++t) {
-            const float *xr = xl + (L - 1 - t) * nxp;
+        for (int ll = 0; ll < nl; ++ll) {
+            const float *xr = xl + ll * nxp;
             float a = bj;
 #pragma unroll
             for (int v = 0; v < PREP_MAX_NXP; ++v)
                 if (v < nxp) a += w[v] * xr[v];
-            X1[((size_t)t * B + b) * nin1 + j] = tanhf(a);
+            const int t = L - 1 - (l0 + ll);
+            X1[((size_t)t * B + b) * nin1 + j] = prep_tanh(a);
         }
     }
-    // ---- memory concat ---------------------------------------------------------------------------
-    for (int idx = tid; idx < L * nm; idx += PREP_THREADS) {
-        const int t = idx / nm, k = idx - t * nm;
+    // ---- memory concat -------------------------------------------------------------------------
+    for (int idx = tid; idx < nl * nm; idx += PREP_THREADS) {
+        const int ll = idx / nm, k = idx - ll * nm, t = L - 1 - (l0 + ll);
         const float v = m.cfg.legacy ? mem_in[((size_t)b * L + t) * nm + k]
-                                     : mem_in[((size_t)(L - 1 - t) * B + b) * nm + k];
+                                     : mem_in[((size_t)(l0 + ll) * B + b) * nm + k];
         X1[((size_t)t * B + b) * nin1 + nh1 + k] = v;
     }
 }
@@ -117,9 +133,10 @@ int launch_prep(const DevModel &m, int B, int normalised, const float *x_main, c
         csa_set_error_msg("prep: nx+1 exceeds PREP_MAX_NXP");
         return CSA_ERR_UNSUPPORTED;
     }
-    const size_t shm = sizeof(float) * ((size_t)m.cfg.nlev * (m.cfg.nx + 1) + m.cfg.nx_sfc);
-    hipLaunchKernelGGL(prep_kernel, dim3(B), dim3(PREP_THREADS), shm, s, m, B, normalised, x_main, x_sfc,
-                       mem_in, X1, hc0);
+    const int lper = (m.cfg.nlev + PREP_LSPLIT - 1) / PREP_LSPLIT;
+    const size_t shm = sizeof(float) * ((size_t)lper * (m.cfg.nx + 1) + m.cfg.nx_sfc);
+    hipLaunchKernelGGL(prep_kernel, dim3(B, PREP_LSPLIT), dim3(PREP_THREADS), shm, s, m, B, normalised, x_main,
+                       x_sfc, mem_in, X1, hc0);
     CSA_HIP_CHECK(hipGetLastError());
     return CSA_OK;
 }

@@ -36,13 +36,9 @@ __device__ __forceinline__ float sigmoid_f(float x)
 __device__ __forceinline__ float tanh_f(float x)
 {
 #if CSA_FAST_GATES
-    // tanh(x) = 1 - 2/(exp(2x)+1); for |x| < 0.04 the cancellation would cost relative accuracy,
-    // so switch to the odd Taylor polynomial there (error < 1e-9 relative).
-    const float e = __builtin_amdgcn_exp2f(2.88539008177792681f * x);
-    const float big = 1.0f - 2.0f * __builtin_amdgcn_rcpf(e + 1.0f);
-    const float x2 = x * x;
-    const float small = x * (1.0f + x2 * (-0.333333333f + x2 * 0.133333333f));
-    return fabsf(x) < 0.04f ? small : big;
+    // tanh(x) = (1 - t)/(1 + t), t = exp(-2x): absolute error ~1 ulp of 1 for every x.
+    const float t = fminf(__builtin_amdgcn_exp2f(-2.88539008177792681f * x), 1e30f);
+    return (1.0f - t) * __builtin_amdgcn_rcpf(1.0f + t);
 #else
     return tanhf(x);
 #endif
@@ -244,9 +240,12 @@ __global__ __launch_bounds__(NH * 4, 2) void lstm_rec2_kernel(
         w[s][kk / 2] = f32x2{v.x, v.y};
         w[s][kk / 2 + 1] = f32x2{v.z, v.w};
     }
-    // slot-1 activation: tanh for the (i,g~) lanes, sigmoid for the (f,o) lanes
+    // slot-1 activation: tanh for the (i,g~) lanes, sigmoid for the (f,o) lanes, both written as
+    // (1 - nb*t) / (1 + t) with t = exp(-x) (sigmoid, nb = 0) or t = exp(-2x) (tanh, nb = 1).  The
+    // tanh numerator 1 - t keeps an absolute error of one ulp of 1 (6e-8) for every x, unlike
+    // 2*sigmoid(2x) - 1; t is clamped so that exp overflow gives -1, not NaN.
     const float k1 = grp ? -1.44269504088896341f : -2.88539008177792681f;
-    const float a1 = grp ? 1.0f : 2.0f, c1 = grp ? 0.0f : -1.0f;
+    const float nb1 = grp ? 0.0f : 1.0f;
 
     float h = h0[(size_t)b * NH + u];
     float c = c0[(size_t)b * NH + u];
@@ -293,10 +292,12 @@ __global__ __launch_bounds__(NH * 4, 2) void lstm_rec2_kernel(
         const float v0 = r[0] + dpp_xor2(r[2]) + CUR.x;                                            \
         const float v1 = r[1] + dpp_xor2(r[3]) + CUR.y;                                            \
         const float g0 = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504088896341f * v0)); \
-        const float g1 = a1 * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(k1 * v1)) + c1;  \
+        const float t1 = fminf(__builtin_amdgcn_exp2f(k1 * v1), 1e30f);                            \
+        const float g1 = (1.0f - nb1 * t1) * __builtin_amdgcn_rcpf(1.0f + t1);                     \
         const float ig = dpp_xor2(g0 * g1);           /* sigma(i)*tanh(g~) arrives at the (f,o) lane */ \
         c = g0 * c + ig;                                                                           \
-        const float th = 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-2.88539008177792681f * c)) - 1.0f; \
+        const float tc = fminf(__builtin_amdgcn_exp2f(-2.88539008177792681f * c), 1e30f);          \
+        const float th = (1.0f - tc) * __builtin_amdgcn_rcpf(1.0f + tc);                           \
         h = g1 * th;                                                                               \
         STAMP(2, h)                                                                                \
         if (owner) {                                                                               \
