@@ -9,7 +9,8 @@
 // (64 accumulator VGPRs), K consumed in chunks of 16 staged through LDS.  A and W are both
 // "row-major with k contiguous", so one staging routine serves both operands; rows are padded
 // to KC+1 floats so that the MFMA operand reads (lane = row, fixed k) are bank-conflict free.
-// Global loads for chunk c+1 are issued before the MFMAs of chunk c (register double buffer).
+// Global loads for chunk c+1 are issued before the MFMAs of chunk c and land in the other LDS
+// buffer after them (register + LDS double buffer, one barrier per chunk).
 #include "common.h"
 
 #define GB_M 128
@@ -20,13 +21,23 @@
 
 __global__ __launch_bounds__(GB_THREADS) void proj_gemm_kernel(
     const float *__restrict__ A, const float *__restrict__ W, const float *__restrict__ bias,
-    float *__restrict__ C, int M, int N, int K)
+    float *__restrict__ C, int M, int N, int K, int tiles_m, int tiles_n)
 {
-    __shared__ float As[GB_M * GB_LD];
-    __shared__ float Ws[GB_N * GB_LD];
+    // double-buffered LDS: chunk c+1 is written while chunk c is being multiplied -> one barrier
+    // per 16-deep K chunk (8 k-steps x 4 MFMA = 2048 MFMA cycles per wave between barriers)
+    __shared__ float As[2][GB_M * GB_LD];
+    __shared__ float Ws[2][GB_N * GB_LD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    const int m0 = blockIdx.x * GB_M, n0 = blockIdx.y * GB_N;
+    // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs, so give each XCD a
+    // contiguous run of tiles and walk N fastest inside it: the tiles_n blocks that share an A
+    // row-panel then sit on one XCD and re-read it from that XCD's L2 (speed only).
+    int bid = blockIdx.x;
+    {
+        const int nwg = tiles_m * tiles_n;
+        if (nwg % 8 == 0) bid = (bid & 7) * (nwg >> 3) + (bid >> 3);
+    }
+    const int m0 = (bid / tiles_n) * GB_M, n0 = (bid % tiles_n) * GB_N;
 
     // staging map: thread -> (row r, r+64; k quad kq)
     const int lr = tid >> 2, kq = (tid & 3) * 4;
@@ -39,11 +50,11 @@ __global__ __launch_bounds__(GB_THREADS) void proj_gemm_kernel(
             rw[i] = (col < N && k < K) ? *(const f32x4 *)(W + (size_t)col * K + k) : f32x4{0, 0, 0, 0};
         }
     };
-    auto sstore = [&]() {
+    auto sstore = [&](int buf) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            float *pa = As + (lr + 64 * i) * GB_LD + kq;
-            float *pw = Ws + (lr + 64 * i) * GB_LD + kq;
+            float *pa = As[buf] + (lr + 64 * i) * GB_LD + kq;
+            float *pw = Ws[buf] + (lr + 64 * i) * GB_LD + kq;
             pa[0] = ra[i].x; pa[1] = ra[i].y; pa[2] = ra[i].z; pa[3] = ra[i].w;
             pw[0] = rw[i].x; pw[1] = rw[i].y; pw[2] = rw[i].z; pw[3] = rw[i].w;
         }
@@ -61,35 +72,64 @@ __global__ __launch_bounds__(GB_THREADS) void proj_gemm_kernel(
     const int wrow = (wn * 64 + (lane & 31)) * GB_LD + (lane >> 5);
 
     gload(0);
-    for (int k0 = 0; k0 < K; k0 += GB_K) {
-        __syncthreads();            // previous chunk fully consumed
-        sstore();
-        __syncthreads();
-        if (k0 + GB_K < K) gload(k0 + GB_K);
+    sstore(0);
+    __syncthreads();
+    const int nchunk = (K + GB_K - 1) / GB_K;
+    for (int c = 0; c < nchunk; ++c) {
+        const int cur = c & 1;
+        if (c + 1 < nchunk) gload((c + 1) * GB_K);
+        const float *as = As[cur], *ws = Ws[cur];
 #pragma unroll
         for (int kk = 0; kk < GB_K / 2; ++kk) {
-            const float a0 = As[arow + kk * 2], a1 = As[arow + 32 * GB_LD + kk * 2];
-            const float b0 = Ws[wrow + kk * 2], b1 = Ws[wrow + 32 * GB_LD + kk * 2];
+            const float a0 = as[arow + kk * 2], a1 = as[arow + 32 * GB_LD + kk * 2];
+            const float b0 = ws[wrow + kk * 2], b1 = ws[wrow + 32 * GB_LD + kk * 2];
             acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
             acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
             acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
             acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
         }
+        if (c + 1 < nchunk) sstore(cur ^ 1);
+        __syncthreads();
     }
 
-    // epilogue: D[i][j] with j = lane&31 (column) and i = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+    // epilogue: D[i][j] with j = lane&31 (column) and i = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
+    // The bias is added to every accumulator BEFORE the first store: a load consumed between
+    // stores makes hipcc emit s_waitcnt vmcnt(0) there, which also waits for the stores already
+    // issued and serialises the whole 64-store epilogue (measured: +9 us per launch).
+    float bv[2];
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int col = n0 + wn * 64 + j * 32 + (lane & 31);
-        if (col >= N) continue;
-        const float bv = bias ? bias[col] : 0.0f;
+        bv[j] = (bias && col < N) ? bias[col] : 0.0f;
+    }
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+    for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                if (row < M) C[(size_t)row * N + col] = acc[i][j][r] + bv;
-            }
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] += bv[j];
+    const bool interior = (m0 + GB_M <= M) && (n0 + GB_N <= N);
+    if (interior) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            float *cp = C + (size_t)(m0 + wm * 64 + 4 * (lane >> 5)) * N + n0 + wn * 64 + j * 32 + (lane & 31);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    cp[(size_t)(i * 32 + (r & 3) + 8 * (r >> 2)) * N] = acc[i][j][r];
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = n0 + wn * 64 + j * 32 + (lane & 31);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    if (row < M && col < N) C[(size_t)row * N + col] = acc[i][j][r];
+                }
         }
     }
 }
@@ -101,8 +141,9 @@ int launch_proj_gemm(const float *A, const float *W, const float *bias, float *C
         csa_set_error_msg("proj_gemm: K must be a multiple of 4");
         return CSA_ERR_UNSUPPORTED;
     }
-    dim3 grid((M + GB_M - 1) / GB_M, (N + GB_N - 1) / GB_N);
-    hipLaunchKernelGGL(proj_gemm_kernel, grid, dim3(GB_THREADS), 0, s, A, W, bias, C, M, N, K);
+    const int tiles_m = (M + GB_M - 1) / GB_M, tiles_n = (N + GB_N - 1) / GB_N;
+    hipLaunchKernelGGL(proj_gemm_kernel, dim3(tiles_m * tiles_n), dim3(GB_THREADS), 0, s, A, W, bias, C, M, N, K,
+                       tiles_m, tiles_n);
     CSA_HIP_CHECK(hipGetLastError());
     return CSA_OK;
 }
