@@ -44,6 +44,24 @@ def load_model(tag):
     return consts, weights
 
 
+def pmc_traffic(workload, kernel_prefix="lstm_rec2_kernel"):
+    """HBM bytes per launch of the dominant kernel from the committed PMC summary
+    (profiles/*_<workload>_pmc.json, produced by tools/profile_r1.sh + tools/summarize_profiles.py from
+    separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command); None if absent."""
+    import glob
+    fs = sorted(glob.glob(os.path.join(ROOT, "profiles", f"*_{workload}_pmc.json")))
+    if not fs:
+        return None
+    try:
+        d = json.load(open(fs[-1]))
+        for k, v in d["kernels"].items():
+            if k.startswith(kernel_prefix):
+                return v["hbm_bytes"]
+    except Exception:
+        return None
+    return None
+
+
 def cpu_baseline(tag, consts, weights, xm, xs, mem, hx, cx, budget_s=12.0):
     """The oracle's torch restatement (what the reference executes on CPU: ATen nn.LSTM/Linear)
     timed on this host's cores on the SAME batch; bounded to ~budget_s seconds."""
@@ -142,10 +160,8 @@ def main():
         step()
     fence()
     el = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([el], device="cuda", dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        el = float(t.item())
+    from climsim_amd.sharding import max_over_ranks
+    el = max_over_ranks(el, device="cuda")     # whole-job time = the slowest rank's
     value = world * B * a.steps / el
 
     # ---- per-kernel durations (HIP events on the launch stream), same step loop -------------------
@@ -171,7 +187,9 @@ def main():
                        else "stateful v4 memory wrapper", "parallelism": f"columns sharded x{world}, no collective"},
             "roofline": {"bound": "mfma", "kernel": "rec_kernel<128,4> (one launch per LSTM, 2 per step)",
                          "achieved": achieved, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_FP32_TFLOPS, "traffic": None,
+                         "frac": achieved / PEAK_FP32_TFLOPS, "traffic": pmc_traffic(a.workload),
+                         "traffic_unit": "HBM bytes per launch (rocprofv3 PMC, profiles/)",
+                         "algorithmic_hbm_bytes_per_launch": B * 60 * (4 * 128 + 128) * 4.0,
                          "flop_per_launch": rec_flop, "avg_launch_ms": rec_ms,
                          "note": "fp32 packed-FMA vector pipe; same 157.3 TF peak as f32 MFMA"},
             "whole_path": {"flop_per_column": flop_col, "achieved_tflops": value / world * flop_col / 1e12,
