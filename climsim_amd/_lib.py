@@ -27,7 +27,10 @@ PARAM_FIELDS = ["xmean_lev", "xdiv_lev", "xmean_sca", "xdiv_sca", "lbd_qc", "lbd
 SYMBOLS = ["csa_create", "csa_destroy", "csa_set_params", "csa_packed_width", "csa_max_batch",
            "csa_forward_packed", "csa_forward_tuple", "csa_model_forward", "csa_tap_rnn1",
            "csa_tap_rnn2", "csa_last_error", "csa_version", "csa_set_profiling", "csa_reset_profile",
-           "csa_get_profile", "csa_stage_name"]
+           "csa_get_profile", "csa_stage_name",
+           "csa_train_create", "csa_train_destroy", "csa_train_num_params", "csa_train_num_tensors",
+           "csa_train_param_info", "csa_train_params", "csa_train_sync_params", "csa_train_forward",
+           "csa_train_backward", "csa_train_loss", "csa_train_adam"]
 
 
 class CsaConfig(ctypes.Structure):
@@ -70,6 +73,20 @@ def lib():
     L.csa_get_profile.argtypes = [H, ctypes.POINTER(ctypes.c_double), i, ctypes.POINTER(ctypes.c_long)]
     L.csa_stage_name.argtypes = [i]
     L.csa_stage_name.restype = ctypes.c_char_p
+    Fp = ctypes.POINTER(ctypes.c_float)
+    f = ctypes.c_float
+    L.csa_train_create.argtypes = [ctypes.POINTER(CsaConfig), ctypes.POINTER(CsaParams), Fp, Fp, i, i, ctypes.POINTER(H)]
+    L.csa_train_destroy.argtypes = [H]
+    L.csa_train_num_params.argtypes = [H]
+    L.csa_train_num_tensors.argtypes = [H]
+    L.csa_train_param_info.argtypes = [H, i, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(i), ctypes.POINTER(i), ctypes.POINTER(i)]
+    L.csa_train_params.argtypes = [H]
+    L.csa_train_params.restype = ctypes.c_void_p
+    L.csa_train_sync_params.argtypes = [H, ctypes.c_void_p]
+    L.csa_train_forward.argtypes = [H, i, i, _F, _F, _F, _F, _F, _F, ctypes.c_void_p]
+    L.csa_train_backward.argtypes = [H, i, i, _F, _F, _F, _F, _F, ctypes.c_void_p]
+    L.csa_train_loss.argtypes = [H, i, i, f, f] + [_F] * 11 + [ctypes.c_void_p]
+    L.csa_train_adam.argtypes = [H, _F, f, f, f, f, f, i, ctypes.c_void_p]
     L.csa_last_error.restype = ctypes.c_char_p
     L.csa_version.restype = ctypes.c_char_p
     _lib = L

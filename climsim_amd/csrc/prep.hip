@@ -28,7 +28,8 @@ __device__ __forceinline__ float prep_tanh(float x)
 __global__ __launch_bounds__(PREP_THREADS) void prep_kernel(
     DevModel m, int B, int normalised,
     const float *__restrict__ x_main, const float *__restrict__ x_sfc,
-    const float *__restrict__ mem_in, float *__restrict__ X1, float *__restrict__ hc0)
+    const float *__restrict__ mem_in, float *__restrict__ X1, float *__restrict__ hc0,
+    float *__restrict__ X16out, float *__restrict__ xs_out)
 {
     extern __shared__ float smem[];
     const int L = m.cfg.nlev, nx = m.cfg.nx, nxp = nx + 1, nxs = m.cfg.nx_sfc;
@@ -76,6 +77,12 @@ __global__ __launch_bounds__(PREP_THREADS) void prep_kernel(
         }
     }
     __syncthreads();
+    if (X16out) {   // training: keep what the backward of mlp_initial / the surface MLPs needs
+        for (int idx = tid; idx < nl * nxp; idx += PREP_THREADS)
+            X16out[((size_t)b * L + l0) * nxp + idx] = xl[idx];
+        if (blockIdx.y == 0)
+            for (int v = tid; v < nxs; v += PREP_THREADS) xs_out[(size_t)b * nxs + v] = xs[v];
+    }
 
     // ---- initial states (first slice only) ---------------------------------------------------
     if (blockIdx.y == 0) {
@@ -136,7 +143,22 @@ int launch_prep(const DevModel &m, int B, int normalised, const float *x_main, c
     const int lper = (m.cfg.nlev + PREP_LSPLIT - 1) / PREP_LSPLIT;
     const size_t shm = sizeof(float) * ((size_t)lper * (m.cfg.nx + 1) + m.cfg.nx_sfc);
     hipLaunchKernelGGL(prep_kernel, dim3(B, PREP_LSPLIT), dim3(PREP_THREADS), shm, s, m, B, normalised, x_main,
-                       x_sfc, mem_in, X1, hc0);
+                       x_sfc, mem_in, X1, hc0, (float *)nullptr, (float *)nullptr);
+    CSA_HIP_CHECK(hipGetLastError());
+    return CSA_OK;
+}
+
+int launch_prep_train(const DevModel &m, int B, int normalised, const float *x_main, const float *x_sfc,
+                      const float *mem_in, float *X1, float *hc0, float *X16, float *xs_n, hipStream_t s)
+{
+    if (m.cfg.nx + 1 > PREP_MAX_NXP) {
+        csa_set_error_msg("prep: nx+1 exceeds PREP_MAX_NXP");
+        return CSA_ERR_UNSUPPORTED;
+    }
+    const int lper = (m.cfg.nlev + PREP_LSPLIT - 1) / PREP_LSPLIT;
+    const size_t shm = sizeof(float) * ((size_t)lper * (m.cfg.nx + 1) + m.cfg.nx_sfc);
+    hipLaunchKernelGGL(prep_kernel, dim3(B, PREP_LSPLIT), dim3(PREP_THREADS), shm, s, m, B, normalised, x_main,
+                       x_sfc, mem_in, X1, hc0, X16, xs_n);
     CSA_HIP_CHECK(hipGetLastError());
     return CSA_OK;
 }

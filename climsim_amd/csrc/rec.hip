@@ -210,11 +210,14 @@ __global__ __launch_bounds__(NH * 4, 2) void rec_kernel(
 //   * no register rotation of the prefetched projections (time loop unrolled x2), so the compiler
 //     never waits on a just-issued global load or store inside the recurrence.
 // P rows are laid out [i, g~, f, o] per unit (see pack_ih in api.hip): lane reads one 8-byte pair.
-template <int NH>
+// TRAIN = true additionally saves what BPTT needs: the activated gates are written IN PLACE over
+// the pre-activations P(t,b,u,[i,g~,f,o]) they came from, c_t goes to Cseq (L+1 slots, slot 0 = c_init),
+// h_t also to Hseq (L+1 slots in SEQUENCE order, slot 0 = h_init; may alias Hout for the downward RNN).
+template <int NH, bool TRAIN>
 __global__ __launch_bounds__(NH * 4, 2) void lstm_rec2_kernel(
-    const f32x4 *__restrict__ Wp4, const float *__restrict__ P,
+    const f32x4 *__restrict__ Wp4, float *__restrict__ P,
     const float *__restrict__ h0, const float *__restrict__ c0, float *__restrict__ Hout,
-    int B, int L, int reverse_out)
+    int B, int L, int reverse_out, float *__restrict__ Hseq, float *__restrict__ Cseq)
 {
     constexpr int NT = NH * 4;
     constexpr int KC = NH / 4;
@@ -252,6 +255,10 @@ __global__ __launch_bounds__(NH * 4, 2) void lstm_rec2_kernel(
     const int slotN = 2 * u + col + 4 * (u / KC);
     const int slotS = CPY + 2 * u + (1 - col) + 4 * (u / KC);
     if (owner) { hbuf[0][slotN] = h; hbuf[0][slotS] = h; }
+    if (TRAIN && owner && valid) {
+        Hseq[(size_t)b * NH + u] = h;
+        Cseq[(size_t)b * NH + u] = c;
+    }
 
     const float *Pb = P + (size_t)b * (4 * NH) + u * 4 + grp * 2;
     const size_t Pstep = (size_t)B * (4 * NH);
@@ -304,7 +311,13 @@ __global__ __launch_bounds__(NH * 4, 2) void lstm_rec2_kernel(
             hbuf[(t_ & 1) ^ 1][slotN] = h;                                                         \
             hbuf[(t_ & 1) ^ 1][slotS] = h;                                                         \
             if (valid) Hout[((size_t)(reverse_out ? L - 1 - t_ : t_) * B + b) * NH + u] = h;       \
+            if (TRAIN && valid) {                                                                  \
+                Hseq[((size_t)(t_ + 1) * B + b) * NH + u] = h;                                     \
+                Cseq[((size_t)(t_ + 1) * B + b) * NH + u] = c;                                     \
+            }                                                                                      \
         }                                                                                          \
+        if (TRAIN && valid)                                                                        \
+            *(f32x2 *)(P + ((size_t)t_ * B + b) * (4 * NH) + u * 4 + grp * 2) = f32x2{g0, g1};     \
         LDS_BARRIER();                                                                             \
         STAMP(0, h)                                                                                \
     }
@@ -383,11 +396,27 @@ static int launch_rec_nh(int use_lstm, const float *whh, const float *bhn, const
 {
     const dim3 grid((B + 1) / 2), block(NH * 4);
     if (use_lstm)
-        hipLaunchKernelGGL((lstm_rec2_kernel<NH>), grid, block, 0, s, (const f32x4 *)whh, P, h0, c0, Hout, B, L,
-                           reverse_out);
+        hipLaunchKernelGGL((lstm_rec2_kernel<NH, false>), grid, block, 0, s, (const f32x4 *)whh, (float *)P, h0, c0, Hout,
+                           B, L, reverse_out, (float *)nullptr, (float *)nullptr);
     else
         hipLaunchKernelGGL((rec_kernel<NH, 3>), grid, block, 0, s, (const f32x4 *)whh, bhn, P, h0, c0, Hout, B, L,
                            reverse_out);
+    CSA_HIP_CHECK(hipGetLastError());
+    return CSA_OK;
+}
+
+int launch_rec_train(int nh, const float *whh_packed, float *P, const float *h0, const float *c0, float *Hout,
+                     int B, int L, int reverse_out, float *Hseq, float *Cseq, hipStream_t s)
+{
+    const dim3 grid((B + 1) / 2), block(nh * 4);
+    switch (nh) {
+    case 64:  hipLaunchKernelGGL((lstm_rec2_kernel<64, true>), grid, block, 0, s, (const f32x4 *)whh_packed, P, h0, c0, Hout, B, L, reverse_out, Hseq, Cseq); break;
+    case 96:  hipLaunchKernelGGL((lstm_rec2_kernel<96, true>), grid, block, 0, s, (const f32x4 *)whh_packed, P, h0, c0, Hout, B, L, reverse_out, Hseq, Cseq); break;
+    case 128: hipLaunchKernelGGL((lstm_rec2_kernel<128, true>), grid, block, 0, s, (const f32x4 *)whh_packed, P, h0, c0, Hout, B, L, reverse_out, Hseq, Cseq); break;
+    default:
+        csa_set_error_msg("rec(train): hidden size not supported (64, 96, 128)");
+        return CSA_ERR_UNSUPPORTED;
+    }
     CSA_HIP_CHECK(hipGetLastError());
     return CSA_OK;
 }

@@ -1,0 +1,400 @@
+// train_api.hip -- C ABI of the training step (current-generation LSTM with memory):
+//   csa_train_forward  : RNN_autoreg.forward in training mode, activations of time slot tau kept
+//   csa_train_backward : backward of that slot (BPTT over the 60 levels x 2 LSTMs), gradients
+//                        ACCUMULATED into one canonical flat fp32 buffer, d(mem_in) returned so the
+//                        caller chains the slots of a TBPTT window (rnn/utils.py:1098-1137,1200-1377)
+//   csa_train_loss     : huber + w_h*energy + w_w*water with its gradient (rnn/metrics.py)
+//   csa_train_adam     : torch.optim.Adam arithmetic on the flat parameters, then re-pack
+// Parameters live in ONE canonical flat device buffer in state_dict layout (csa_train_param_info);
+// every kernel-specific layout (permuted W_ih, register-stationary W_hh / W_hh^T, transposed MLPs)
+// is a device-side gather of it through index maps built once on the host -- by running the same
+// host packers as the inference handle on arrays whose values are their own indices.
+#include "common.h"
+#include "pack.h"
+#include "train.h"
+#include <algorithm>
+#include <string>
+#include <vector>
+
+namespace {
+
+struct PInfo { std::string name; int off, rows, cols; };
+
+struct Gather { float *dst; int *idx; int *idx2; int n; };
+
+struct Slot {   // saved activations of one time step of the window
+    float *X16, *xs, *X1, *GP1, *C1, *H1lev, *H1seq, *GP2, *C2, *H2, *Z, *hc0;
+};
+
+}  // namespace
+
+struct csa_trainer {
+    DevModel dm;
+    int max_batch, max_window, nparam;
+    std::vector<PInfo> info;
+    std::vector<void *> owned;
+    float *params, *adam_m, *adam_v;
+    float *hyai, *hybi;
+    std::vector<Gather> gathers;
+    float *wih1T, *wih2T, *whh1Tp, *whh2Tp;
+    // gradient scatter maps
+    int *map_wih1, *map_whh1, *map_b1a, *map_b1b, *map_wih2, *map_whh2, *map_b2a, *map_b2b, *map_head, *map_prep;
+    std::vector<Slot> slots;
+    // work buffers
+    float *dH2, *dH1, *dX1, *dhc1, *dhc2, *part, *samp, *ecoef, *sp;
+    size_t part_floats;
+    int nsplit;
+};
+
+namespace {
+
+template <typename T> T *dalloc(csa_trainer *h, size_t n, int &rc)
+{
+    void *p = nullptr;
+    if (hipMalloc(&p, sizeof(T) * (n ? n : 1)) != hipSuccess) { rc = CSA_ERR_NOMEM; return nullptr; }
+    h->owned.push_back(p);
+    return (T *)p;
+}
+int *upload_idx(csa_trainer *h, const std::vector<int> &v, int &rc)
+{
+    int *d = dalloc<int>(h, v.size(), rc);
+    if (d && hipMemcpy(d, v.data(), sizeof(int) * v.size(), hipMemcpyHostToDevice) != hipSuccess) rc = CSA_ERR_HIP;
+    return d;
+}
+// register a gather: device buffer `n` floats filled from the flat params through idx (and idx2)
+const float *add_gather(csa_trainer *h, const std::vector<int> &idx, const std::vector<int> *idx2, int &rc)
+{
+    Gather g;
+    g.n = (int)idx.size();
+    g.dst = dalloc<float>(h, idx.size(), rc);
+    g.idx = upload_idx(h, idx, rc);
+    g.idx2 = idx2 ? upload_idx(h, *idx2, rc) : nullptr;
+    h->gathers.push_back(g);
+    return g.dst;
+}
+std::vector<int> iota_off(int off, int n) { std::vector<int> v(n); for (int i = 0; i < n; ++i) v[i] = off + i; return v; }
+std::vector<int> transposed_idx(int off, int O, int K)   // (O,K) source -> (K,O) buffer
+{
+    std::vector<int> v((size_t)O * K);
+    for (int o = 0; o < O; ++o) for (int k = 0; k < K; ++k) v[(size_t)k * O + o] = off + o * K + k;
+    return v;
+}
+std::vector<int> to_int(const std::vector<float> &f, int off)
+{
+    std::vector<int> v(f.size());
+    for (size_t i = 0; i < f.size(); ++i) v[i] = off + (int)f[i];
+    return v;
+}
+std::vector<float> index_values(size_t n) { std::vector<float> v(n); for (size_t i = 0; i < n; ++i) v[i] = (float)i; return v; }
+
+int repack(csa_trainer *h, hipStream_t s)
+{
+    for (const Gather &g : h->gathers) {
+        int rc = launch_gather(g.dst, h->params, g.idx, g.idx2, g.n, s);
+        if (rc) return rc;
+    }
+    return CSA_OK;
+}
+
+}  // namespace
+
+extern "C" int csa_train_create(const csa_config *cfg, const csa_params *p, const float *hyai, const float *hybi,
+                                int max_batch, int max_window, csa_trainer **out)
+{
+    if (!cfg || !p || !hyai || !hybi || !out || max_batch <= 0 || max_window <= 0) { csa_set_error_msg("csa_train_create: bad argument"); return CSA_ERR_ARG; }
+    const csa_config &c = *cfg;
+    if (c.legacy || !c.use_lstm || c.nh_mem <= 0 || c.mp_mode != 1) {
+        csa_set_error_msg("csa_train_create: the HIP training step covers the current-generation LSTM with memory, mp_mode 1");
+        return CSA_ERR_UNSUPPORTED;
+    }
+    const bool ok = (c.nh1 == 64 || c.nh1 == 96 || c.nh1 == 128) && (c.nh2 == 64 || c.nh2 == 96 || c.nh2 == 128);
+    if (!ok) { csa_set_error_msg("csa_train_create: hidden size must be 64, 96 or 128"); return CSA_ERR_UNSUPPORTED; }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) { csa_set_error_msg("csa_train_create: no HIP device"); return CSA_ERR_HIP; }
+
+    csa_trainer *h = new csa_trainer();
+    memset(&h->dm, 0, sizeof(h->dm));
+    h->dm.cfg = c;
+    h->max_batch = max_batch;
+    h->max_window = max_window;
+    int rc = CSA_OK;
+    const int L = c.nlev, nxp = c.nx + 1, nxs = c.nx_sfc, nh1 = c.nh1, nh2 = c.nh2, nm = c.nh_mem, nin1 = nh1 + nm;
+    const int nhm = nh1 > nh2 ? nh1 : nh2;
+
+    // ---- canonical flat layout (state_dict order of rnn/models/models.py::RNN_autoreg) ----------
+    struct Src { const char *name; const float *ptr; int rows, cols; };
+    const Src srcs[] = {
+        {"mlp_toa1.weight", p->mlp_toa1_w, nh2, 2}, {"mlp_toa1.bias", p->mlp_toa1_b, nh2, 1},
+        {"mlp_toa2.weight", p->mlp_toa2_w, nh2, 2}, {"mlp_toa2.bias", p->mlp_toa2_b, nh2, 1},
+        {"mlp_initial.weight", p->mlp_initial_w, nh1, nxp}, {"mlp_initial.bias", p->mlp_initial_b, nh1, 1},
+        {"mlp_surface1.weight", p->mlp_surface1_w, nh1, nxs}, {"mlp_surface1.bias", p->mlp_surface1_b, nh1, 1},
+        {"mlp_surface2.weight", p->mlp_surface2_w, nh1, nxs}, {"mlp_surface2.bias", p->mlp_surface2_b, nh1, 1},
+        {"rnn1.weight_ih_l0", p->rnn1_w_ih, 4 * nh1, nin1}, {"rnn1.weight_hh_l0", p->rnn1_w_hh, 4 * nh1, nh1},
+        {"rnn1.bias_ih_l0", p->rnn1_b_ih, 4 * nh1, 1}, {"rnn1.bias_hh_l0", p->rnn1_b_hh, 4 * nh1, 1},
+        {"rnn2.weight_ih_l0", p->rnn2_w_ih, 4 * nh2, nh1}, {"rnn2.weight_hh_l0", p->rnn2_w_hh, 4 * nh2, nh2},
+        {"rnn2.bias_ih_l0", p->rnn2_b_ih, 4 * nh2, 1}, {"rnn2.bias_hh_l0", p->rnn2_b_hh, 4 * nh2, 1},
+        {"mlp_latent.weight", p->mlp_latent_w, nm, nh2}, {"mlp_latent.bias", p->mlp_latent_b, nm, 1},
+        {"mlp_output.weight", p->mlp_output_w, c.ny, nm}, {"mlp_output.bias", p->mlp_output_b, c.ny, 1},
+        {"mlp_surface_output.weight", p->mlp_surface_output_w, c.ny_sfc, nh2},
+        {"mlp_surface_output.bias", p->mlp_surface_output_b, c.ny_sfc, 1},
+    };
+    int off = 0;
+    std::vector<float> flat;
+    for (const Src &s : srcs) {
+        if (!s.ptr) { delete h; csa_set_error_msg("csa_train_create: missing parameter array"); return CSA_ERR_ARG; }
+        h->info.push_back({s.name, off, s.rows, s.cols});
+        flat.insert(flat.end(), s.ptr, s.ptr + (size_t)s.rows * s.cols);
+        off += s.rows * s.cols;
+    }
+    h->nparam = off;
+    auto O = [&](const char *n) { for (auto &i : h->info) if (i.name == n) return i.off; return -1; };
+    h->params = dalloc<float>(h, off, rc);
+    h->adam_m = dalloc<float>(h, off, rc);
+    h->adam_v = dalloc<float>(h, off, rc);
+    if (rc == CSA_OK) {
+        if (hipMemcpy(h->params, flat.data(), sizeof(float) * off, hipMemcpyHostToDevice) != hipSuccess) rc = CSA_ERR_HIP;
+        if (hipMemset(h->adam_m, 0, sizeof(float) * off) != hipSuccess) rc = CSA_ERR_HIP;
+        if (hipMemset(h->adam_v, 0, sizeof(float) * off) != hipSuccess) rc = CSA_ERR_HIP;
+    }
+    // constants
+    auto upc = [&](const float *src, size_t n) { float *d = dalloc<float>(h, n, rc); if (d && hipMemcpy(d, src, sizeof(float) * n, hipMemcpyHostToDevice) != hipSuccess) rc = CSA_ERR_HIP; return d; };
+    DevModel &d = h->dm;
+    d.xmean_lev = upc(p->xmean_lev, (size_t)L * c.nx); d.xdiv_lev = upc(p->xdiv_lev, (size_t)L * c.nx);
+    d.xmean_sca = upc(p->xmean_sca, nxs); d.xdiv_sca = upc(p->xdiv_sca, nxs);
+    d.lbd_qc = upc(p->lbd_qc, L); d.lbd_qi = upc(p->lbd_qi, L);
+    d.yscale_lev = upc(p->yscale_lev, (size_t)L * c.ny); d.yscale_sca = upc(p->yscale_sca, c.ny_sfc);
+    d.hyam = upc(p->hyam, L); d.hybm = upc(p->hybm, L);
+    h->hyai = upc(hyai, L + 1); h->hybi = upc(hybi, L + 1);
+
+    // ---- gathers: canonical flat -> kernel layouts -------------------------------------------------
+    d.toa1_wt = add_gather(h, transposed_idx(O("mlp_toa1.weight"), nh2, 2), nullptr, rc);
+    d.toa1_b = add_gather(h, iota_off(O("mlp_toa1.bias"), nh2), nullptr, rc);
+    d.toa2_wt = add_gather(h, transposed_idx(O("mlp_toa2.weight"), nh2, 2), nullptr, rc);
+    d.toa2_b = add_gather(h, iota_off(O("mlp_toa2.bias"), nh2), nullptr, rc);
+    d.init_wt = add_gather(h, transposed_idx(O("mlp_initial.weight"), nh1, nxp), nullptr, rc);
+    d.init_b = add_gather(h, iota_off(O("mlp_initial.bias"), nh1), nullptr, rc);
+    d.s1_wt = add_gather(h, transposed_idx(O("mlp_surface1.weight"), nh1, nxs), nullptr, rc);
+    d.s1_b = add_gather(h, iota_off(O("mlp_surface1.bias"), nh1), nullptr, rc);
+    d.s2_wt = add_gather(h, transposed_idx(O("mlp_surface2.weight"), nh1, nxs), nullptr, rc);
+    d.s2_b = add_gather(h, iota_off(O("mlp_surface2.bias"), nh1), nullptr, rc);
+    std::vector<int> rowmap1, rowmap2;   // permuted row n' -> PyTorch gate row, per LSTM
+    auto lstm_pack = [&](int nh, int K, int o_wih, int o_whh, int o_bih, int o_bhh, const float *&wih, const float *&bias,
+                         const float *&whhp, float *&whhTp, float *&wihT, std::vector<int> &rowmap) {
+        std::vector<float> w, b, bhn;
+        std::vector<float> iw = index_values((size_t)4 * nh * K), ib = index_values((size_t)4 * nh);
+        pack_ih(1, nh, K, iw.data(), ib.data(), ib.data(), w, b, bhn);      // b = 2*index (b_ih+b_hh of equal indices)
+        wih = add_gather(h, to_int(w, o_wih), nullptr, rc);
+        std::vector<int> b1(4 * nh), b2(4 * nh);
+        rowmap.resize(4 * nh);
+        for (int n = 0; n < 4 * nh; ++n) { rowmap[n] = (int)(b[n] * 0.5f); b1[n] = o_bih + rowmap[n]; b2[n] = o_bhh + rowmap[n]; }
+        bias = add_gather(h, b1, &b2, rc);
+        std::vector<float> ih = index_values((size_t)4 * nh * nh), pk(rec_packed_floats(1, nh));
+        rec_pack_weights(1, nh, ih.data(), pk.data());
+        whhp = add_gather(h, to_int(pk, o_whh), nullptr, rc);
+        std::vector<float> pkT(bwd_rec_packed_floats(nh));
+        bwd_rec_pack_weights(nh, ih.data(), pkT.data());
+        whhTp = (float *)add_gather(h, to_int(pkT, o_whh), nullptr, rc);
+        // W_ih^T in permuted-column order: (K rows, 4nh cols): [k][n'] = W_ih[rowmap[n']][k]
+        std::vector<int> t((size_t)K * 4 * nh);
+        for (int k = 0; k < K; ++k) for (int n = 0; n < 4 * nh; ++n) t[(size_t)k * 4 * nh + n] = o_wih + rowmap[n] * K + k;
+        wihT = (float *)add_gather(h, t, nullptr, rc);
+    };
+    lstm_pack(nh1, nin1, O("rnn1.weight_ih_l0"), O("rnn1.weight_hh_l0"), O("rnn1.bias_ih_l0"), O("rnn1.bias_hh_l0"),
+              d.wih1, d.bias1, d.whh1p, h->whh1Tp, h->wih1T, rowmap1);
+    lstm_pack(nh2, nh1, O("rnn2.weight_ih_l0"), O("rnn2.weight_hh_l0"), O("rnn2.bias_ih_l0"), O("rnn2.bias_hh_l0"),
+              d.wih2, d.bias2, d.whh2p, h->whh2Tp, h->wih2T, rowmap2);
+    d.lat_wt = add_gather(h, transposed_idx(O("mlp_latent.weight"), nm, nh2), nullptr, rc);
+    d.lat_b = add_gather(h, iota_off(O("mlp_latent.bias"), nm), nullptr, rc);
+    d.out_w = add_gather(h, iota_off(O("mlp_output.weight"), c.ny * nm), nullptr, rc);
+    d.out_b = add_gather(h, iota_off(O("mlp_output.bias"), c.ny), nullptr, rc);
+    d.sfo_w = add_gather(h, iota_off(O("mlp_surface_output.weight"), c.ny_sfc * nh2), nullptr, rc);
+    d.sfo_b = add_gather(h, iota_off(O("mlp_surface_output.bias"), c.ny_sfc), nullptr, rc);
+
+    // ---- gradient scatter maps -------------------------------------------------------------------------
+    auto wmap = [&](const std::vector<int> &rowmap, int K, int o) {
+        std::vector<int> v((size_t)rowmap.size() * K);
+        for (size_t n = 0; n < rowmap.size(); ++n) for (int k = 0; k < K; ++k) v[n * K + k] = o + rowmap[n] * K + k;
+        return v;
+    };
+    auto bmap = [&](const std::vector<int> &rowmap, int o) { std::vector<int> v(rowmap.size()); for (size_t n = 0; n < rowmap.size(); ++n) v[n] = o + rowmap[n]; return v; };
+    h->map_wih1 = upload_idx(h, wmap(rowmap1, nin1, O("rnn1.weight_ih_l0")), rc);
+    h->map_whh1 = upload_idx(h, wmap(rowmap1, nh1, O("rnn1.weight_hh_l0")), rc);
+    h->map_b1a = upload_idx(h, bmap(rowmap1, O("rnn1.bias_ih_l0")), rc);
+    h->map_b1b = upload_idx(h, bmap(rowmap1, O("rnn1.bias_hh_l0")), rc);
+    h->map_wih2 = upload_idx(h, wmap(rowmap2, nh1, O("rnn2.weight_ih_l0")), rc);
+    h->map_whh2 = upload_idx(h, wmap(rowmap2, nh2, O("rnn2.weight_hh_l0")), rc);
+    h->map_b2a = upload_idx(h, bmap(rowmap2, O("rnn2.bias_ih_l0")), rc);
+    h->map_b2b = upload_idx(h, bmap(rowmap2, O("rnn2.bias_hh_l0")), rc);
+    {   // head partial layout: [W_out | b_out | W_lat | b_lat | W_sfo | b_sfo]
+        std::vector<int> v;
+        auto app = [&](const char *n, int cnt) { const int o = O(n); for (int i = 0; i < cnt; ++i) v.push_back(o + i); };
+        app("mlp_output.weight", c.ny * nm); app("mlp_output.bias", c.ny);
+        app("mlp_latent.weight", nm * nh2); app("mlp_latent.bias", nm);
+        app("mlp_surface_output.weight", c.ny_sfc * nh2); app("mlp_surface_output.bias", c.ny_sfc);
+        h->map_head = upload_idx(h, v, rc);
+    }
+    {   // prep partial layout: [W_init | b_init | W_s1 | b_s1 | W_s2 | b_s2 | W_toa1 | b_toa1 | W_toa2 | b_toa2]
+        std::vector<int> v;
+        auto app = [&](const char *n, int cnt) { const int o = O(n); for (int i = 0; i < cnt; ++i) v.push_back(o + i); };
+        app("mlp_initial.weight", nh1 * nxp); app("mlp_initial.bias", nh1);
+        app("mlp_surface1.weight", nh1 * nxs); app("mlp_surface1.bias", nh1);
+        app("mlp_surface2.weight", nh1 * nxs); app("mlp_surface2.bias", nh1);
+        app("mlp_toa1.weight", nh2 * 2); app("mlp_toa1.bias", nh2);
+        app("mlp_toa2.weight", nh2 * 2); app("mlp_toa2.bias", nh2);
+        h->map_prep = upload_idx(h, v, rc);
+    }
+
+    // ---- activations per slot + work buffers ----------------------------------------------------------------
+    const size_t Bm = max_batch, LB = (size_t)L * Bm;
+    for (int t = 0; t < max_window && rc == CSA_OK; ++t) {
+        Slot s;
+        s.X16 = dalloc<float>(h, Bm * L * nxp, rc); s.xs = dalloc<float>(h, Bm * nxs, rc);
+        s.X1 = dalloc<float>(h, LB * nin1, rc);
+        s.GP1 = dalloc<float>(h, LB * 4 * nh1, rc); s.C1 = dalloc<float>(h, (LB + Bm) * nh1, rc);
+        s.H1lev = dalloc<float>(h, LB * nh1, rc); s.H1seq = dalloc<float>(h, (LB + Bm) * nh1, rc);
+        s.GP2 = dalloc<float>(h, LB * 4 * nh2, rc); s.C2 = dalloc<float>(h, (LB + Bm) * nh2, rc);
+        s.H2 = dalloc<float>(h, (LB + Bm) * nh2, rc);
+        s.Z = dalloc<float>(h, LB * nm, rc); s.hc0 = dalloc<float>(h, 4 * Bm * nhm, rc);
+        h->slots.push_back(s);
+    }
+    h->dH2 = dalloc<float>(h, LB * nh2, rc); h->dH1 = dalloc<float>(h, LB * nh1, rc);
+    h->dX1 = dalloc<float>(h, LB * nin1, rc);
+    h->dhc1 = dalloc<float>(h, 2 * Bm * nhm, rc); h->dhc2 = dalloc<float>(h, 2 * Bm * nhm, rc);
+    h->nsplit = 32;
+    size_t pf = (size_t)h->nsplit * 4 * nhm * (nin1 > nhm ? nin1 : nhm);
+    const size_t pcol = Bm * (size_t)std::max(head_bwd_partial_floats(c), prep_bwd_partial_floats(c));
+    h->part_floats = pf > pcol ? pf : pcol;
+    h->part = dalloc<float>(h, h->part_floats, rc);
+    h->samp = dalloc<float>(h, (size_t)max_window * Bm * 9, rc);
+    h->ecoef = dalloc<float>(h, Bm, rc);
+    h->sp = dalloc<float>(h, (size_t)max_window * Bm, rc);
+    if (rc == CSA_OK) rc = repack(h, 0);
+    if (rc == CSA_OK && hipDeviceSynchronize() != hipSuccess) rc = CSA_ERR_HIP;
+    if (rc != CSA_OK) {
+        for (void *q : h->owned) (void)hipFree(q);
+        delete h;
+        return rc;
+    }
+    *out = h;
+    return CSA_OK;
+}
+
+extern "C" int csa_train_destroy(csa_trainer *h)
+{
+    if (!h) return CSA_ERR_ARG;
+    for (void *q : h->owned) (void)hipFree(q);
+    delete h;
+    return CSA_OK;
+}
+extern "C" int csa_train_num_params(const csa_trainer *h) { return h ? h->nparam : CSA_ERR_ARG; }
+extern "C" int csa_train_num_tensors(const csa_trainer *h) { return h ? (int)h->info.size() : CSA_ERR_ARG; }
+extern "C" int csa_train_param_info(const csa_trainer *h, int i, const char **name, int *offset, int *rows, int *cols)
+{
+    if (!h || i < 0 || i >= (int)h->info.size()) return CSA_ERR_ARG;
+    if (name) *name = h->info[i].name.c_str();
+    if (offset) *offset = h->info[i].off;
+    if (rows) *rows = h->info[i].rows;
+    if (cols) *cols = h->info[i].cols;
+    return CSA_OK;
+}
+extern "C" float *csa_train_params(csa_trainer *h) { return h ? h->params : nullptr; }
+extern "C" int csa_train_sync_params(csa_trainer *h, void *stream) { return h ? repack(h, (hipStream_t)stream) : CSA_ERR_ARG; }
+
+extern "C" int csa_train_forward(csa_trainer *h, int slot, int B, const float *x_main_n, const float *x_sfc_n,
+                                 const float *mem_in, float *out, float *out_sfc, float *mem_out, void *stream)
+{
+    if (!h || slot < 0 || slot >= h->max_window || B <= 0 || B > h->max_batch || !x_main_n || !x_sfc_n || !mem_in || !out || !out_sfc || !mem_out) {
+        csa_set_error_msg("csa_train_forward: bad argument");
+        return CSA_ERR_ARG;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    const csa_config &c = h->dm.cfg;
+    const int L = c.nlev, nh1 = c.nh1, nh2 = c.nh2, nm = c.nh_mem, nhm = nh1 > nh2 ? nh1 : nh2;
+    Slot &S = h->slots[slot];
+    int rc;
+    if ((rc = launch_prep_train(h->dm, B, 1, x_main_n, x_sfc_n, mem_in, S.X1, S.hc0, S.X16, S.xs, s))) return rc;
+    if ((rc = launch_proj_gemm(S.X1, h->dm.wih1, h->dm.bias1, S.GP1, L * B, 4 * nh1, nh1 + nm, s))) return rc;
+    if ((rc = launch_rec_train(nh1, h->dm.whh1p, S.GP1, S.hc0, S.hc0 + (size_t)B * nhm, S.H1lev, B, L, 1, S.H1seq, S.C1, s))) return rc;
+    if ((rc = launch_proj_gemm(S.H1lev, h->dm.wih2, h->dm.bias2, S.GP2, L * B, 4 * nh2, nh1, s))) return rc;
+    // rnn2: level order == sequence order, so the hidden sequence itself carries the extra slot 0
+    if ((rc = launch_rec_train(nh2, h->dm.whh2p, S.GP2, S.hc0 + (size_t)2 * B * nhm, S.hc0 + (size_t)3 * B * nhm,
+                               S.H2 + (size_t)B * nh2, B, L, 0, S.H2, S.C2, s))) return rc;
+    if ((rc = launch_head(h->dm, B, HEAD_RAW, S.H2 + (size_t)B * nh2, x_main_n, out, out_sfc, S.Z, s))) return rc;
+    CSA_HIP_CHECK(hipMemcpyAsync(mem_out, S.Z, sizeof(float) * (size_t)L * B * nm, hipMemcpyDeviceToDevice, s));
+    return CSA_OK;
+}
+
+extern "C" int csa_train_backward(csa_trainer *h, int slot, int B, const float *d_out, const float *d_out_sfc,
+                                  const float *d_mem_out, float *d_mem_in, float *grads, void *stream)
+{
+    if (!h || slot < 0 || slot >= h->max_window || B <= 0 || B > h->max_batch || !d_out || !d_out_sfc || !grads) {
+        csa_set_error_msg("csa_train_backward: bad argument");
+        return CSA_ERR_ARG;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    const csa_config &c = h->dm.cfg;
+    const int L = c.nlev, nh1 = c.nh1, nh2 = c.nh2, nm = c.nh_mem, nin1 = nh1 + nm, M = L * B, ns = h->nsplit;
+    const int nhm = nh1 > nh2 ? nh1 : nh2;
+    Slot &S = h->slots[slot];
+    int rc;
+    // head
+    if ((rc = launch_head_bwd(h->dm, B, d_out, d_out_sfc, d_mem_out, S.Z, S.H2 + (size_t)B * nh2, h->dH2, h->part, s))) return rc;
+    if ((rc = launch_reduce_partials(h->part, B, head_bwd_partial_floats(c), h->map_head, nullptr, grads, s))) return rc;
+    // rnn2 (downward): BPTT, then input / weight gradients from dP2 (stored in place in GP2)
+    if ((rc = launch_bwd_rec(nh2, h->whh2Tp, S.GP2, S.C2, h->dH2, h->dhc2, h->dhc2 + (size_t)B * nhm, B, L, 0, s))) return rc;
+    if ((rc = launch_proj_gemm(S.GP2, h->wih2T, nullptr, h->dH1, M, nh1, 4 * nh2, s))) return rc;
+    if ((rc = launch_gemm_tn_partial(S.GP2, 4 * nh2, S.H1lev, nh1, h->part, M, 4 * nh2, nh1, ns, s))) return rc;
+    if ((rc = launch_reduce_partials(h->part, ns, 4 * nh2 * nh1, h->map_wih2, nullptr, grads, s))) return rc;
+    if ((rc = launch_gemm_tn_partial(S.GP2, 4 * nh2, S.H2, nh2, h->part, M, 4 * nh2, nh2, ns, s))) return rc;
+    if ((rc = launch_reduce_partials(h->part, ns, 4 * nh2 * nh2, h->map_whh2, nullptr, grads, s))) return rc;
+    if ((rc = launch_colsum_partial(S.GP2, h->part, M, 4 * nh2, ns, s))) return rc;
+    if ((rc = launch_reduce_partials(h->part, ns, 4 * nh2, h->map_b2a, h->map_b2b, grads, s))) return rc;
+    // rnn1 (upward): dH1 is in level order, the recurrence runs in sequence order
+    if ((rc = launch_bwd_rec(nh1, h->whh1Tp, S.GP1, S.C1, h->dH1, h->dhc1, h->dhc1 + (size_t)B * nhm, B, L, 1, s))) return rc;
+    if ((rc = launch_proj_gemm(S.GP1, h->wih1T, nullptr, h->dX1, M, nin1, 4 * nh1, s))) return rc;
+    if ((rc = launch_gemm_tn_partial(S.GP1, 4 * nh1, S.X1, nin1, h->part, M, 4 * nh1, nin1, ns, s))) return rc;
+    if ((rc = launch_reduce_partials(h->part, ns, 4 * nh1 * nin1, h->map_wih1, nullptr, grads, s))) return rc;
+    if ((rc = launch_gemm_tn_partial(S.GP1, 4 * nh1, S.H1seq, nh1, h->part, M, 4 * nh1, nh1, ns, s))) return rc;
+    if ((rc = launch_reduce_partials(h->part, ns, 4 * nh1 * nh1, h->map_whh1, nullptr, grads, s))) return rc;
+    if ((rc = launch_colsum_partial(S.GP1, h->part, M, 4 * nh1, ns, s))) return rc;
+    if ((rc = launch_reduce_partials(h->part, ns, 4 * nh1, h->map_b1a, h->map_b1b, grads, s))) return rc;
+    // mlp_initial / surface / TOA MLPs, gradient w.r.t. the incoming memory
+    if ((rc = launch_prep_bwd(h->dm, B, h->dX1, S.X1, S.X16, S.xs, S.hc0, h->dhc1, h->dhc2, d_mem_in, h->part, s))) return rc;
+    return launch_reduce_partials(h->part, B, prep_bwd_partial_floats(c), h->map_prep, nullptr, grads, s);
+}
+
+__global__ void sp_kernel(const float *__restrict__ xs, int nxs, float a, float bconst, float *__restrict__ sp, int n)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) sp[i] = xs[(size_t)i * nxs] * a + bconst;
+}
+
+extern "C" int csa_train_loss(csa_trainer *h, int B, int Tw, float w_h, float w_w,
+                              const float *pred, const float *pred_sfc, const float *tgt, const float *tgt_sfc,
+                              const float *yto, const float *yto_sfc, const float *x_raw, const float *x_sfc_n,
+                              float *scalars, float *d_pred, float *d_pred_sfc, void *stream)
+{
+    if (!h || B <= 0 || B > h->max_batch || Tw <= 0 || Tw > h->max_window || !pred || !pred_sfc || !tgt || !tgt_sfc || !yto || !yto_sfc || !x_raw || !x_sfc_n || !scalars) {
+        csa_set_error_msg("csa_train_loss: bad argument");
+        return CSA_ERR_ARG;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    const int N = B * Tw;
+    // surface pressure de-normalised from the normalised x_sfc (rnn/utils.py:1248); host copies of the two scalars
+    float a, bc;
+    CSA_HIP_CHECK(hipMemcpy(&a, h->dm.xdiv_sca, sizeof(float), hipMemcpyDeviceToHost));
+    CSA_HIP_CHECK(hipMemcpy(&bc, h->dm.xmean_sca, sizeof(float), hipMemcpyDeviceToHost));
+    hipLaunchKernelGGL(sp_kernel, dim3((N + 255) / 256), dim3(256), 0, s, x_sfc_n, h->dm.cfg.nx_sfc, a, bc, h->sp, N);
+    return launch_loss(h->dm, h->hyai, h->hybi, B, Tw, w_h, w_w, pred, pred_sfc, tgt, tgt_sfc, yto, yto_sfc, x_raw, h->sp,
+                       h->samp, h->ecoef, scalars, d_pred, d_pred_sfc, s);
+}
+
+extern "C" int csa_train_adam(csa_trainer *h, const float *grads, float lr, float beta1, float beta2, float eps,
+                              float weight_decay, int step, void *stream)
+{
+    if (!h || !grads || step <= 0) { csa_set_error_msg("csa_train_adam: bad argument"); return CSA_ERR_ARG; }
+    hipStream_t s = (hipStream_t)stream;
+    int rc = launch_adam(h->params, grads, h->adam_m, h->adam_v, h->nparam, lr, beta1, beta2, eps, step, weight_decay, s);
+    if (rc) return rc;
+    return repack(h, s);
+}

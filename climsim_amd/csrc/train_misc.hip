@@ -1,0 +1,538 @@
+// train_misc.hip -- the non-recurrent kernels of the training step:
+//   gemm_tn_partial : C_s(N1,N2) = sum over a slice of rows m of A[m][n1] * Bm[m][n2]   (weight gradients
+//                     dW_ih = dP^T X, dW_hh = dP^T H_prev; contraction over the L*B rows, split over workgroups)
+//   colsum_partial  : bias gradients  db[n] = sum_m dP[m][n]
+//   reduce_partials : deterministic sum of the per-slice partials, scattered (row permutation) and
+//                     ACCUMULATED into the canonical flat gradient buffer
+//   head_bwd / prep_bwd : backward of head.hip / prep.hip (per-column partial weight gradients)
+//   loss_* : huber + energy + water loss of rnn/metrics.py with its analytic gradient
+//   adam / gather : optimiser update on the canonical flat parameters, re-packing for the kernels
+#include "common.h"
+#include "train.h"
+
+// -------------------------------------------------------------------------------------------------
+// C_s = A_slice^T * B_slice on the fp32 matrix cores.  128x128 output tile per workgroup, 4 waves
+// (2x2) of 2x2 MFMA 32x32x2 tiles; both operands are staged [m][n] exactly as they sit in memory
+// (the contraction index m is the slow one), so the MFMA operand reads are lane-contiguous.
+#define TN_T 128
+#define TN_MK 16
+__global__ __launch_bounds__(256) void gemm_tn_partial_kernel(
+    const float *__restrict__ A, int lda, const float *__restrict__ Bm, int ldb, float *__restrict__ Cpart,
+    int M, int N1, int N2, int rows_per_split)
+{
+    __shared__ float As[TN_MK][TN_T];
+    __shared__ float Bs[TN_MK][TN_T];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
+    const int n10 = blockIdx.x * TN_T, n20 = blockIdx.y * TN_T, split = blockIdx.z;
+    const int m_begin = split * rows_per_split, m_end = min(M, m_begin + rows_per_split);
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+    // staging: 16 rows x 128 floats per operand = 512 float4, two per thread
+    const int sr = tid >> 5, sc = (tid & 31) * 4;
+    for (int m0 = m_begin; m0 < m_end; m0 += TN_MK) {
+        __syncthreads();
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int m = m0 + sr + 8 * h;
+            f32x4 va = {0, 0, 0, 0}, vb = {0, 0, 0, 0};
+            if (m < m_end) {
+                const float *pa = A + (size_t)m * lda + n10 + sc;
+                const float *pb = Bm + (size_t)m * ldb + n20 + sc;
+                if (n10 + sc + 3 < N1) va = *(const f32x4 *)pa;
+                else for (int e = 0; e < 4; ++e) if (n10 + sc + e < N1) va[e] = pa[e];
+                if (n20 + sc + 3 < N2) vb = *(const f32x4 *)pb;
+                else for (int e = 0; e < 4; ++e) if (n20 + sc + e < N2) vb[e] = pb[e];
+            }
+            *(f32x4 *)&As[sr + 8 * h][sc] = va;
+            *(f32x4 *)&Bs[sr + 8 * h][sc] = vb;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < TN_MK / 2; ++kk) {
+            const int kr = kk * 2 + (lane >> 5);
+            const float a0 = As[kr][wm * 64 + (lane & 31)], a1 = As[kr][wm * 64 + 32 + (lane & 31)];
+            const float b0 = Bs[kr][wn * 64 + (lane & 31)], b1 = Bs[kr][wn * 64 + 32 + (lane & 31)];
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+        }
+    }
+    float *C = Cpart + (size_t)split * N1 * N2;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int c2 = n20 + wn * 64 + j * 32 + (lane & 31);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int c1 = n10 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (c1 < N1 && c2 < N2) C[(size_t)c1 * N2 + c2] = acc[i][j][r];
+            }
+    }
+}
+
+int launch_gemm_tn_partial(const float *A, int lda, const float *Bm, int ldb, float *Cpart, int M, int N1, int N2,
+                           int nsplit, hipStream_t s)
+{
+    if ((lda % 4) || (ldb % 4)) { csa_set_error_msg("gemm_tn: leading dimensions must be multiples of 4"); return CSA_ERR_UNSUPPORTED; }
+    int rps = (M + nsplit - 1) / nsplit;
+    rps = (rps + TN_MK - 1) / TN_MK * TN_MK;
+    dim3 grid((N1 + TN_T - 1) / TN_T, (N2 + TN_T - 1) / TN_T, nsplit);
+    hipLaunchKernelGGL(gemm_tn_partial_kernel, grid, dim3(256), 0, s, A, lda, Bm, ldb, Cpart, M, N1, N2, rps);
+    CSA_HIP_CHECK(hipGetLastError());
+    return CSA_OK;
+}
+
+// partial column sums of a (M, N) matrix: part[s][n]
+__global__ void colsum_partial_kernel(const float *__restrict__ A, float *__restrict__ part, int M, int N, int rps)
+{
+    const int n = blockIdx.x * blockDim.x + threadIdx.x, s = blockIdx.y;
+    if (n >= N) return;
+    const int m0 = s * rps, m1 = min(M, m0 + rps);
+    float a = 0.0f;
+    for (int m = m0; m < m1; ++m) a += A[(size_t)m * N + n];
+    part[(size_t)s * N + n] = a;
+}
+int launch_colsum_partial(const float *A, float *part, int M, int N, int nsplit, hipStream_t s)
+{
+    const int rps = (M + nsplit - 1) / nsplit;
+    hipLaunchKernelGGL(colsum_partial_kernel, dim3((N + 255) / 256, nsplit), dim3(256), 0, s, A, part, M, N, rps);
+    CSA_HIP_CHECK(hipGetLastError());
+    return CSA_OK;
+}
+
+// grad[map ? map[i] : i] += sum_s part[s][i]   (map may send two sources to different targets only;
+// idx2, when given, receives the same sum as well: b_ih and b_hh share one gradient)
+__global__ void reduce_partials_kernel(const float *__restrict__ part, int nsplit, int n,
+                                       const int *__restrict__ map, const int *__restrict__ map2,
+                                       float *__restrict__ grad)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float a = 0.0f;
+    for (int s = 0; s < nsplit; ++s) a += part[(size_t)s * n + i];
+    const int d = map ? map[i] : i;
+    if (d >= 0) grad[d] += a;
+    if (map2) { const int d2 = map2[i]; if (d2 >= 0) grad[d2] += a; }
+}
+int launch_reduce_partials(const float *part, int nsplit, int n, const int *map, const int *map2, float *grad, hipStream_t s)
+{
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((n + 255) / 256), dim3(256), 0, s, part, nsplit, n, map, map2, grad);
+    CSA_HIP_CHECK(hipGetLastError());
+    return CSA_OK;
+}
+
+// -------------------------------------------------------------------------------------------------
+// head backward, one workgroup per column (current generation, memory model):
+//   d_out (B,L,ny) [+ prune mask], d_out_sfc (B,nys), d_mem_out (L,B,nm)  ->  dH2 (L,B,nh2),
+//   per-column partial gradients of mlp_output, mlp_latent, mlp_surface_output.
+// partial layout per column: [W_out ny*nm | b_out ny | W_lat nm*nh2 | b_lat nm | W_sfo nys*nh2 | b_sfo nys]
+__global__ __launch_bounds__(256) void head_bwd_kernel(
+    DevModel m, int B, const float *__restrict__ d_out, const float *__restrict__ d_out_sfc,
+    const float *__restrict__ d_mem_out, const float *__restrict__ Z, const float *__restrict__ H2,
+    float *__restrict__ dH2, float *__restrict__ part)
+{
+    extern __shared__ float smem[];
+    const int L = m.cfg.nlev, ny = m.cfg.ny, nys = m.cfg.ny_sfc, nm = m.cfg.nh_mem, nh2 = m.cfg.nh2;
+    float *dz = smem;                 // (L, nm)
+    float *zs = dz + L * nm;          // (L, nm)
+    float *dos = zs + L * nm;         // (L, ny)
+    float *hs = dos + L * ny;         // (L, nh2)
+    const int b = blockIdx.x, tid = threadIdx.x;
+    float *pp = part + (size_t)b * (ny * nm + ny + nm * nh2 + nm + nys * nh2 + nys);
+    for (int idx = tid; idx < L * ny; idx += 256) {
+        const int l = idx / ny, v = idx - l * ny;
+        float d = d_out[((size_t)b * L + l) * ny + v];
+        if (m.cfg.output_prune && l < 12 && v >= 1) d = 0.0f;
+        dos[idx] = d;
+    }
+    for (int idx = tid; idx < L * nm; idx += 256) {
+        const int l = idx / nm, j = idx - l * nm;
+        zs[idx] = Z[((size_t)l * B + b) * nm + j];
+    }
+    for (int idx = tid; idx < L * nh2; idx += 256) {
+        const int l = idx / nh2, k = idx - l * nh2;
+        hs[idx] = H2[((size_t)l * B + b) * nh2 + k];
+    }
+    __syncthreads();
+    // dz = W_out^T d_out + d_mem_out
+    for (int idx = tid; idx < L * nm; idx += 256) {
+        const int l = idx / nm, j = idx - l * nm;
+        float a = d_mem_out ? d_mem_out[((size_t)l * B + b) * nm + j] : 0.0f;
+        for (int v = 0; v < ny; ++v) a += dos[l * ny + v] * m.out_w[v * nm + j];
+        dz[idx] = a;
+    }
+    __syncthreads();
+    // dH2 = W_lat^T dz (+ W_sfo^T d_out_sfc on the last level)
+    for (int idx = tid; idx < L * nh2; idx += 256) {
+        const int l = idx / nh2, k = idx - l * nh2;
+        float a = 0.0f;
+        for (int j = 0; j < nm; ++j) a += dz[l * nm + j] * m.lat_wt[k * nm + j];
+        if (l == L - 1)
+            for (int v = 0; v < nys; ++v) a += d_out_sfc[(size_t)b * nys + v] * m.sfo_w[v * nh2 + k];
+        dH2[((size_t)l * B + b) * nh2 + k] = a;
+    }
+    // partial weight gradients of this column
+    float *p = pp;
+    for (int idx = tid; idx < ny * nm; idx += 256) {          // dW_out[v][j] = sum_l d_out[l][v] z[l][j]
+        const int v = idx / nm, j = idx - v * nm;
+        float a = 0.0f;
+        for (int l = 0; l < L; ++l) a += dos[l * ny + v] * zs[l * nm + j];
+        p[idx] = a;
+    }
+    p += ny * nm;
+    for (int v = tid; v < ny; v += 256) {
+        float a = 0.0f;
+        for (int l = 0; l < L; ++l) a += dos[l * ny + v];
+        p[v] = a;
+    }
+    p += ny;
+    for (int idx = tid; idx < nm * nh2; idx += 256) {         // dW_lat[j][k] = sum_l dz[l][j] h2[l][k]
+        const int j = idx / nh2, k = idx - j * nh2;
+        float a = 0.0f;
+        for (int l = 0; l < L; ++l) a += dz[l * nm + j] * hs[l * nh2 + k];
+        p[idx] = a;
+    }
+    p += nm * nh2;
+    for (int j = tid; j < nm; j += 256) {
+        float a = 0.0f;
+        for (int l = 0; l < L; ++l) a += dz[l * nm + j];
+        p[j] = a;
+    }
+    p += nm;
+    for (int idx = tid; idx < nys * nh2; idx += 256) {        // dW_sfo[v][k] = d_out_sfc[v] h2[L-1][k]
+        const int v = idx / nh2, k = idx - v * nh2;
+        p[idx] = d_out_sfc[(size_t)b * nys + v] * hs[(L - 1) * nh2 + k];
+    }
+    p += nys * nh2;
+    for (int v = tid; v < nys; v += 256) p[v] = d_out_sfc[(size_t)b * nys + v];
+}
+
+int head_bwd_partial_floats(const csa_config &c)
+{
+    return c.ny * c.nh_mem + c.ny + c.nh_mem * c.nh2 + c.nh_mem + c.ny_sfc * c.nh2 + c.ny_sfc;
+}
+int launch_head_bwd(const DevModel &m, int B, const float *d_out, const float *d_out_sfc, const float *d_mem_out,
+                    const float *Z, const float *H2, float *dH2, float *part, hipStream_t s)
+{
+    const csa_config &c = m.cfg;
+    if (c.nh_mem <= 0) { csa_set_error_msg("head_bwd: memory model required"); return CSA_ERR_UNSUPPORTED; }
+    const size_t shm = sizeof(float) * (size_t)c.nlev * (2 * c.nh_mem + c.ny + c.nh2);
+    hipLaunchKernelGGL(head_bwd_kernel, dim3(B), dim3(256), shm, s, m, B, d_out, d_out_sfc, d_mem_out, Z, H2, dH2, part);
+    CSA_HIP_CHECK(hipGetLastError());
+    return CSA_OK;
+}
+
+// -------------------------------------------------------------------------------------------------
+// prep backward, one workgroup per column:  dX1 (L,B,nh1+nm) sequence order  ->
+//   d_mem_in (L,B,nm) level order;  partial grads of mlp_initial (through tanh), mlp_surface1/2 (from
+//   d h0/c0 of rnn1), mlp_toa1/2 (from d h0/c0 of rnn2).
+// partial layout: [W_init nh1*nxp | b_init nh1 | W_s1 nh1*nxs | b_s1 nh1 | W_s2 nh1*nxs | b_s2 nh1 |
+//                  W_toa1 nh2*2 | b_toa1 nh2 | W_toa2 nh2*2 | b_toa2 nh2]
+__global__ __launch_bounds__(128) void prep_bwd_kernel(
+    DevModel m, int B, const float *__restrict__ dX1, const float *__restrict__ X1, const float *__restrict__ X16,
+    const float *__restrict__ xs_n, const float *__restrict__ hc0, const float *__restrict__ dhc1,
+    const float *__restrict__ dhc2, float *__restrict__ d_mem_in, float *__restrict__ part)
+{
+    extern __shared__ float smem[];
+    const int L = m.cfg.nlev, nxp = m.cfg.nx + 1, nxs = m.cfg.nx_sfc, nh1 = m.cfg.nh1, nh2 = m.cfg.nh2;
+    const int nm = m.cfg.nh_mem, nin1 = nh1 + nm, nhm = nh1 > nh2 ? nh1 : nh2;
+    float *x16 = smem;                 // (L, nxp) level order
+    float *xs = x16 + L * nxp;         // (nxs)
+    const int b = blockIdx.x, tid = threadIdx.x;
+    for (int idx = tid; idx < L * nxp; idx += 128) x16[idx] = X16[(size_t)b * L * nxp + idx];
+    for (int v = tid; v < nxs; v += 128) xs[v] = xs_n[(size_t)b * nxs + v];
+    __syncthreads();
+    float *p = part + (size_t)b * prep_bwd_partial_floats(m.cfg);
+    // mlp_initial: a = tanh(.) saved in X1; dA = dX1 * (1 - a^2)
+    for (int j = tid; j < nh1; j += 128) {
+        float gw[32];
+#pragma unroll
+        for (int v = 0; v < 32; ++v) gw[v] = 0.0f;
+        float gb = 0.0f;
+        for (int t = 0; t < L; ++t) {
+            const size_t r = ((size_t)t * B + b) * nin1 + j;
+            const float a = X1[r];
+            const float dA = dX1[r] * (1.0f - a * a);
+            const float *xr = x16 + (L - 1 - t) * nxp;
+            gb += dA;
+#pragma unroll
+            for (int v = 0; v < 32; ++v) if (v < nxp) gw[v] += dA * xr[v];
+        }
+#pragma unroll
+        for (int v = 0; v < 32; ++v) if (v < nxp) p[j * nxp + v] = gw[v];
+        p[nh1 * nxp + j] = gb;
+    }
+    p += nh1 * nxp + nh1;
+    // surface MLPs: h0 = tanh(W1 xs + b1) (saved in hc0 slot 0), c0 = W2 xs + b2
+    for (int j = tid; j < nh1; j += 128) {
+        const float h0 = hc0[((size_t)0 * B + b) * nhm + j];
+        const float d1 = dhc1[((size_t)0 * B + b) * nhm + j] * (1.0f - h0 * h0);
+        const float d2 = dhc1[((size_t)1 * B + b) * nhm + j];
+        for (int v = 0; v < nxs; ++v) {
+            p[j * nxs + v] = d1 * xs[v];
+            p[nh1 * nxs + nh1 + j * nxs + v] = d2 * xs[v];
+        }
+        p[nh1 * nxs + j] = d1;
+        p[2 * nh1 * nxs + nh1 + j] = d2;
+    }
+    p += 2 * (nh1 * nxs + nh1);
+    {
+        const float t0 = xs[1], t1 = xs[6];
+        for (int j = tid; j < nh2; j += 128) {
+            const float d1 = dhc2[((size_t)0 * B + b) * nhm + j], d2 = dhc2[((size_t)1 * B + b) * nhm + j];
+            p[j * 2] = d1 * t0; p[j * 2 + 1] = d1 * t1; p[nh2 * 2 + j] = d1;
+            p[nh2 * 3 + j * 2] = d2 * t0; p[nh2 * 3 + j * 2 + 1] = d2 * t1; p[nh2 * 5 + j] = d2;
+        }
+    }
+    // gradient w.r.t. the incoming memory (level order)
+    if (d_mem_in)
+        for (int idx = tid; idx < L * nm; idx += 128) {
+            const int t = idx / nm, k = idx - t * nm;
+            d_mem_in[((size_t)(L - 1 - t) * B + b) * nm + k] = dX1[((size_t)t * B + b) * nin1 + nh1 + k];
+        }
+}
+
+int launch_prep_bwd(const DevModel &m, int B, const float *dX1, const float *X1, const float *X16, const float *xs_n,
+                    const float *hc0, const float *dhc1, const float *dhc2, float *d_mem_in, float *part, hipStream_t s)
+{
+    const size_t shm = sizeof(float) * ((size_t)m.cfg.nlev * (m.cfg.nx + 1) + m.cfg.nx_sfc);
+    hipLaunchKernelGGL(prep_bwd_kernel, dim3(B), dim3(128), shm, s, m, B, dX1, X1, X16, xs_n, hc0, dhc1, dhc2, d_mem_in, part);
+    CSA_HIP_CHECK(hipGetLastError());
+    return CSA_OK;
+}
+
+// -------------------------------------------------------------------------------------------------
+// Loss of the reference trainer (rnn/utils.py:1203-1366 with rnn/metrics.py:142-163,193-315):
+//   loss = huber(pred, target) + w_h * energy_mse + w_w * water_mse
+// N = T_w*B samples ordered (tau, b).  Pass 1 (one workgroup per sample): huber partial sum and
+// the column integrals e_pred, e_true, w_pred, w_true.  Pass 2 (one workgroup): scalars and the
+// per-column window means.  Pass 3 (per sample): analytic gradient w.r.t. pred / pred_sfc.
+struct LossConsts { float cp, Lv, Ls, ginv_e, ginv_w; };
+__device__ __forceinline__ LossConsts loss_consts() { return {1004.0f, 2.5104e6f, 2.8440e6f, 0.1020408163f, 0.1019716213f}; }
+
+__device__ __forceinline__ void mp_post(float T, float ql, float qi, float dT, float dqn, float &dql, float &dqi, float &lf, float &qn_new, bool &inside)
+{
+    const float T_new = T + dT * 1200.0f;
+    const float raw = (T_new - 253.16f) * 0.05f;
+    inside = raw > 0.0f && raw < 1.0f;
+    lf = fminf(fmaxf(raw, 0.0f), 1.0f);
+    qn_new = (ql + qi) + dqn * 1200.0f;
+    dql = (lf * qn_new - ql) * 0.0008333333333333334f;
+    dqi = ((1.0f - lf) * qn_new - qi) * 0.0008333333333333334f;
+}
+
+__device__ __forceinline__ float block_sum(float v, float *red)
+{
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    const int w = threadIdx.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[w] = v;
+    __syncthreads();
+    float s = 0.0f;
+    for (int i = 0; i < (int)(blockDim.x >> 6); ++i) s += red[i];
+    return s;
+}
+
+// per-sample scalars: [huber_sum, sq_sum, abs_sum, e_pred, e_true, w_pred, w_true, prec_pred, prec_true]
+#define LOSS_NS 9
+__global__ __launch_bounds__(128) void loss_pass1_kernel(
+    DevModel m, const float *__restrict__ hyai, const float *__restrict__ hybi, int N,
+    const float *__restrict__ pred, const float *__restrict__ pred_sfc, const float *__restrict__ tgt,
+    const float *__restrict__ tgt_sfc, const float *__restrict__ yto, const float *__restrict__ yto_sfc,
+    const float *__restrict__ x_raw, const float *__restrict__ sp, float *__restrict__ samp)
+{
+    __shared__ float red[4];
+    const int L = m.cfg.nlev, ny = m.cfg.ny, nys = m.cfg.ny_sfc, nx = m.cfg.nx;
+    const int n = blockIdx.x, tid = threadIdx.x;
+    const LossConsts k = loss_consts();
+    float hub = 0.f, sq = 0.f, ab = 0.f, ep = 0.f, et = 0.f, wp = 0.f, wt = 0.f;
+    const int ne = L * ny + nys;
+    for (int i = tid; i < ne; i += 128) {
+        const float d = i < L * ny ? pred[(size_t)n * L * ny + i] - tgt[(size_t)n * L * ny + i]
+                                   : pred_sfc[(size_t)n * nys + i - L * ny] - tgt_sfc[(size_t)n * nys + i - L * ny];
+        const float ad = fabsf(d);
+        hub += ad < 1.0f ? 0.5f * d * d : ad - 0.5f;
+        sq += d * d; ab += ad;
+    }
+    const float spn = sp[n];
+    for (int l = tid; l < L; l += 128) {
+        const float *o = pred + ((size_t)n * L + l) * ny, *ys = m.yscale_lev + l * ny;
+        const float *xr = x_raw + ((size_t)n * L + l) * nx, *yt = yto + ((size_t)n * L + l) * 6;
+        float dql, dqi, lf, qn; bool in;
+        const float dT = o[0] / ys[0], dqv = o[1] / ys[1];
+        mp_post(xr[0], xr[2], xr[3], dT, o[2] / ys[2], dql, dqi, lf, qn, in);
+        const float dhyb = hybi[l + 1] - hybi[l], dhya = hyai[l + 1] - hyai[l];
+        const float th_e = k.ginv_e * (spn * dhyb + 100000.0f * dhya);
+        const float th_w = k.ginv_w * (spn * dhyb + 100000.0f * dhya);
+        ep += th_e * (dT * k.cp - dql * k.Lv - dqi * k.Ls);
+        et += th_e * (yt[0] * k.cp - yt[2] * k.Lv - yt[3] * k.Ls);
+        wp += th_w * ((dqv + dql) + dqi);
+        wt += th_w * ((yt[1] + yt[2]) + yt[3]);
+    }
+    hub = block_sum(hub, red); sq = block_sum(sq, red); ab = block_sum(ab, red);
+    ep = block_sum(ep, red); et = block_sum(et, red); wp = block_sum(wp, red); wt = block_sum(wt, red);
+    if (tid == 0) {
+        const float snow_p = 1000.0f * (pred_sfc[(size_t)n * nys + 2] / m.yscale_sca[2]);
+        const float prec_p = 1000.0f * (pred_sfc[(size_t)n * nys + 3] / m.yscale_sca[3]);
+        const float snow_t = 1000.0f * yto_sfc[(size_t)n * nys + 2], prec_t = 1000.0f * yto_sfc[(size_t)n * nys + 3];
+        float *s = samp + (size_t)n * LOSS_NS;
+        s[0] = hub; s[1] = sq; s[2] = ab;
+        s[3] = ep - (prec_p - snow_p) * k.Lv - snow_p * k.Ls;
+        s[4] = et - (prec_t - snow_t) * k.Lv - snow_t * k.Ls;
+        s[5] = wp + prec_p;            // lhs - rhs, rhs = -precip
+        s[6] = wt + prec_t;
+        s[7] = prec_p * 0.001f; s[8] = prec_t * 0.001f;
+    }
+}
+
+// scalars out: [loss, huber, mse, mae, energy, water, precip_sum_mse];  colcoef (B): d energy_mse / d e_pred per sample
+__global__ __launch_bounds__(256) void loss_pass2_kernel(
+    DevModel m, int B, int Tw, float w_h, float w_w, const float *__restrict__ samp,
+    float *__restrict__ scal, float *__restrict__ ecoef)
+{
+    __shared__ float red[4];
+    const int L = m.cfg.nlev, ny = m.cfg.ny, nys = m.cfg.ny_sfc, N = B * Tw, tid = threadIdx.x;
+    float hub = 0.f, sq = 0.f, ab = 0.f, wat = 0.f;
+    for (int n = tid; n < N; n += 256) {
+        const float *s = samp + (size_t)n * LOSS_NS;
+        hub += s[0]; sq += s[1]; ab += s[2];
+        const float d = s[5] - s[6];
+        wat += d * d;
+    }
+    float en = 0.f, pr = 0.f;
+    for (int b = tid; b < B; b += 256) {
+        float ep = 0.f, et = 0.f, pp = 0.f, pt = 0.f;
+        for (int t = 0; t < Tw; ++t) {
+            const float *s = samp + (size_t)(t * B + b) * LOSS_NS;
+            ep += s[3]; et += s[4]; pp += s[7]; pt += s[8];
+        }
+        const float d = ep / Tw - et / Tw;
+        en += d * d;
+        ecoef[b] = 2.0f * d / ((float)B * (float)Tw);
+        pr += (pt - pp) * (pt - pp);
+    }
+    hub = block_sum(hub, red); sq = block_sum(sq, red); ab = block_sum(ab, red); wat = block_sum(wat, red);
+    en = block_sum(en, red); pr = block_sum(pr, red);
+    if (tid == 0) {
+        const float ntot = (float)N * (float)(L * ny + nys);
+        scal[1] = hub / ntot; scal[2] = sq / ntot; scal[3] = ab / ntot;
+        scal[4] = en / B; scal[5] = wat / N; scal[6] = pr / B / ((float)Tw * (float)Tw);
+        scal[0] = scal[1] + w_h * scal[4] + w_w * scal[5];
+    }
+}
+
+__global__ __launch_bounds__(128) void loss_pass3_kernel(
+    DevModel m, const float *__restrict__ hyai, const float *__restrict__ hybi, int B, int Tw, float w_h, float w_w,
+    const float *__restrict__ pred, const float *__restrict__ pred_sfc, const float *__restrict__ tgt,
+    const float *__restrict__ tgt_sfc, const float *__restrict__ x_raw, const float *__restrict__ sp,
+    const float *__restrict__ samp, const float *__restrict__ ecoef, float *__restrict__ d_pred, float *__restrict__ d_pred_sfc)
+{
+    const int L = m.cfg.nlev, ny = m.cfg.ny, nys = m.cfg.ny_sfc, nx = m.cfg.nx, N = B * Tw;
+    const int n = blockIdx.x, tid = threadIdx.x, b = n % B;
+    const LossConsts k = loss_consts();
+    const float inv_ntot = 1.0f / ((float)N * (float)(L * ny + nys));
+    const float ce = w_h * ecoef[b];                                           // d loss / d e_pred[n]
+    const float cw = w_w * 2.0f * (samp[(size_t)n * LOSS_NS + 5] - samp[(size_t)n * LOSS_NS + 6]) / (float)N;  // d loss / d wdiff_pred[n]
+    const float spn = sp[n];
+    for (int l = tid; l < L; l += 128) {
+        const float *o = pred + ((size_t)n * L + l) * ny, *tg = tgt + ((size_t)n * L + l) * ny;
+        const float *ys = m.yscale_lev + l * ny, *xr = x_raw + ((size_t)n * L + l) * nx;
+        float g[8];
+        for (int v = 0; v < ny; ++v) {
+            const float d = o[v] - tg[v];
+            g[v] = fminf(fmaxf(d, -1.0f), 1.0f) * inv_ntot;
+        }
+        float dql, dqi, lf, qn; bool in;
+        mp_post(xr[0], xr[2], xr[3], o[0] / ys[0], o[2] / ys[2], dql, dqi, lf, qn, in);
+        const float dhyb = hybi[l + 1] - hybi[l], dhya = hyai[l + 1] - hyai[l];
+        const float th_e = k.ginv_e * (spn * dhyb + 100000.0f * dhya);
+        const float th_w = k.ginv_w * (spn * dhyb + 100000.0f * dhya);
+        // gradients w.r.t. the post-processed tendencies
+        const float g_dT = ce * th_e * k.cp;
+        const float g_dql = -ce * th_e * k.Lv + cw * th_w;
+        const float g_dqi = -ce * th_e * k.Ls + cw * th_w;
+        const float g_dqv = cw * th_w;
+        // chain through the microphysics partition: dql = (lf qn_new - ql)/1200, dqi = ((1-lf) qn_new - qi)/1200
+        const float dlf = in ? 0.05f * 1200.0f : 0.0f;                          // d lf / d dT
+        const float s1200 = 0.0008333333333333334f;
+        const float ddT = g_dT + (g_dql - g_dqi) * dlf * qn * s1200;
+        const float ddqn = (g_dql * lf + g_dqi * (1.0f - lf)) * 1200.0f * s1200;
+        g[0] += ddT / ys[0];
+        g[1] += g_dqv / ys[1];
+        g[2] += ddqn / ys[2];
+        float *dp = d_pred + ((size_t)n * L + l) * ny;
+        for (int v = 0; v < ny; ++v) dp[v] = g[v];
+    }
+    for (int v = tid; v < nys; v += 128) {
+        const float d = pred_sfc[(size_t)n * nys + v] - tgt_sfc[(size_t)n * nys + v];
+        float g = fminf(fmaxf(d, -1.0f), 1.0f) * inv_ntot;
+        // energy: - rain*Lv - snow*Ls with snow = 1000*sfc2, prec = 1000*sfc3; water: + prec
+        if (v == 2) g += ce * (1000.0f * (k.Lv - k.Ls)) / m.yscale_sca[2];
+        if (v == 3) g += (ce * (-1000.0f * k.Lv) + cw * 1000.0f) / m.yscale_sca[3];
+        d_pred_sfc[(size_t)n * nys + v] = g;
+    }
+}
+
+int launch_loss(const DevModel &m, const float *hyai, const float *hybi, int B, int Tw, float w_h, float w_w,
+                const float *pred, const float *pred_sfc, const float *tgt, const float *tgt_sfc, const float *yto,
+                const float *yto_sfc, const float *x_raw, const float *sp, float *samp, float *ecoef, float *scal,
+                float *d_pred, float *d_pred_sfc, hipStream_t s)
+{
+    if (m.cfg.mp_mode != 1 || m.cfg.ny > 8) { csa_set_error_msg("loss: mp_mode 1 only"); return CSA_ERR_UNSUPPORTED; }
+    const int N = B * Tw;
+    hipLaunchKernelGGL(loss_pass1_kernel, dim3(N), dim3(128), 0, s, m, hyai, hybi, N, pred, pred_sfc, tgt, tgt_sfc, yto, yto_sfc, x_raw, sp, samp);
+    hipLaunchKernelGGL(loss_pass2_kernel, dim3(1), dim3(256), 0, s, m, B, Tw, w_h, w_w, samp, scal, ecoef);
+    if (d_pred)
+        hipLaunchKernelGGL(loss_pass3_kernel, dim3(N), dim3(128), 0, s, m, hyai, hybi, B, Tw, w_h, w_w, pred, pred_sfc, tgt, tgt_sfc, x_raw, sp, samp, ecoef, d_pred, d_pred_sfc);
+    CSA_HIP_CHECK(hipGetLastError());
+    return CSA_OK;
+}
+
+// -------------------------------------------------------------------------------------------------
+__global__ void adam_kernel(float *__restrict__ p, const float *__restrict__ g, float *__restrict__ m1,
+                            float *__restrict__ m2, int n, float lr, float b1, float b2, float eps, float bc1, float bc2,
+                            float wd)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    // torch.optim.Adam (no amsgrad): m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2;
+    // p -= lr/bc1 * m / (sqrt(v)/sqrt(bc2) + eps)
+    float gi = g[i] + wd * p[i];
+    const float a = b1 * m1[i] + (1.0f - b1) * gi;
+    const float v = b2 * m2[i] + (1.0f - b2) * gi * gi;
+    m1[i] = a; m2[i] = v;
+    p[i] -= (lr / bc1) * a / (sqrtf(v) / sqrtf(bc2) + eps);
+}
+int launch_adam(float *p, const float *g, float *m1, float *m2, int n, float lr, float b1, float b2, float eps, int step,
+                float wd, hipStream_t s)
+{
+    const float bc1 = 1.0f - powf(b1, (float)step), bc2 = 1.0f - powf(b2, (float)step);
+    hipLaunchKernelGGL(adam_kernel, dim3((n + 255) / 256), dim3(256), 0, s, p, g, m1, m2, n, lr, b1, b2, eps, bc1, bc2, wd);
+    CSA_HIP_CHECK(hipGetLastError());
+    return CSA_OK;
+}
+
+// dst[i] = idx[i] >= 0 ? src[idx[i]] (+ src[idx2[i]] if idx2) : 0     (re-packing canonical -> kernel layouts)
+__global__ void gather_kernel(float *__restrict__ dst, const float *__restrict__ src, const int *__restrict__ idx,
+                              const int *__restrict__ idx2, int n)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int a = idx[i];
+    float v = a >= 0 ? src[a] : 0.0f;
+    if (idx2) { const int c = idx2[i]; if (c >= 0) v += src[c]; }
+    dst[i] = v;
+}
+int launch_gather(float *dst, const float *src, const int *idx, const int *idx2, int n, hipStream_t s)
+{
+    hipLaunchKernelGGL(gather_kernel, dim3((n + 255) / 256), dim3(256), 0, s, dst, src, idx, idx2, n);
+    CSA_HIP_CHECK(hipGetLastError());
+    return CSA_OK;
+}

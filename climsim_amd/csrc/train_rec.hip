@@ -1,0 +1,203 @@
+// train_rec.hip -- backward (BPTT over the 60 levels) of the level-recurrent LSTM.
+//
+// Reference: autograd through nn.LSTM in the TBPTT loop, rnn/utils.py:1098-1137 (forward with
+// graph) and :1366-1371 (loss.backward); cell arithmetic = PyTorch LSTM (gate order i,f,g,o).
+//
+// Same MI355X mapping as the forward kernel (rec.hip): W_hh^T (128 x 512 fp32 = 256 KB) stays in the
+// VGPRs of one 512-thread workgroup for all 60 steps, two columns advance per workgroup with
+// v_pk_fma_f32, one LDS-only barrier per step, no inter-workgroup traffic.
+//
+// Per step t = L-1 .. 0 and column:
+//   dh      = dH_ext[t] + W_hh^T dp[t+1]                      (recurrent matvec, 512 -> 128)
+//   do~     = dh * tanh(c_t) ;  dc = dh * o * (1 - tanh(c_t)^2) + dc_carry
+//   di~ = dc*g ; dg~ = dc*i ; df~ = dc*c_{t-1} ; dc_carry = dc*f
+//   dp[t]   = (di~ i(1-i), dg~ (1-g^2), df~ f(1-f), do~ o(1-o))   written IN PLACE over the saved gates
+// dp (L,B,4*nh), unit-major [i,g~,f,o], then feeds the weight-gradient and input-gradient GEMMs.
+//
+// Thread (og, rc): og = tid>>4 owns the four outputs k = 4*og..4*og+3, rc = tid&15 the 32 rows
+// r' = u*4+pos of chunk rc; 4*32 = 128 weights per lane.  The 16 row-chunks of an output sit in one
+// DPP row: quad reduce-scatter (6 adds, same slot/column-swap trick as the forward kernel) followed by a
+// two-step rotate all-reduce across the four quads.  Lane (og, q4, rcq<2) then owns the cell
+// (u = 4*og + 2*(q4>>1) + rcq, col = q4&1): it keeps dc_carry in a register and does the elementwise
+// gate gradient.
+#include "common.h"
+
+#define PK_FMA_LO(acc, w, h) asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[0,1,1]" : "+v"(acc) : "v"(w), "v"(h))
+#define PK_FMA_HI(acc, w, h) asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(acc) : "v"(w), "v"(h))
+#define LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+
+__device__ __forceinline__ float tanh_acc(float x)
+{
+    const float t = fminf(__builtin_amdgcn_exp2f(-2.88539008177792681f * x), 1e30f);
+    return (1.0f - t) * __builtin_amdgcn_rcpf(1.0f + t);
+}
+
+template <int NH>
+__global__ __launch_bounds__(NH * 4, 2) void lstm_bwd_rec_kernel(
+    const f32x4 *__restrict__ WTp4, float *__restrict__ GP, const float *__restrict__ Cseq,
+    const float *__restrict__ dH, float *__restrict__ dh0, float *__restrict__ dc0,
+    int B, int L, int rev)
+{
+    constexpr int NT = NH * 4;
+    constexpr int RC = NH / 4;          // rows per chunk (16 chunks cover the 4*NH rows)
+    constexpr int CH = 2 * RC + 4;      // floats per chunk incl. one 16-B pad slot
+    constexpr int CPY = 16 * CH;
+    static_assert(RC % 4 == 0, "nh must be a multiple of 16");
+    __shared__ __attribute__((aligned(16))) float dpbuf[2][2 * CPY];
+
+    const int tid = threadIdx.x, og = tid >> 4, rc = tid & 15, q4 = rc & 3, rcq = rc >> 2;
+    const int col = q4 & 1, grp = q4 >> 1;
+    int b = 2 * blockIdx.x + col;
+    const bool valid = b < B;
+    if (!valid) b = B - 1;
+    const bool cell = rcq < 2;                       // this lane owns one (u, col) cell
+    const int u = 4 * og + 2 * grp + (rcq & 1);
+
+    f32x2 w[4][RC / 2];
+#pragma unroll
+    for (int i = 0; i < RC; ++i) {
+        const f32x4 v = WTp4[(size_t)i * NT + tid];
+        const int s = (4 * i) / RC, kk = (4 * i) % RC;
+        w[s][kk / 2] = f32x2{v.x, v.y};
+        w[s][kk / 2 + 1] = f32x2{v.z, v.w};
+    }
+
+    // LDS slots of this cell's four dp rows r' = u*4 + pos (normal and column-swapped copy)
+    const int r0 = u * 4;
+    const int cslot = (r0 / RC) * CH + (r0 % RC) * 2;      // 4 consecutive rows never straddle a chunk
+    const int rdoff = col * CPY + rc * CH;
+
+    float dc_carry = 0.0f, dh_rec = 0.0f;
+    const size_t cidx = (size_t)b * NH + u;
+    const size_t cstep = (size_t)B * NH;
+
+    // operands of the elementwise part are fetched one step ahead (they do not depend on the
+    // recurrence): saved gates, c_t (c_{t-1} of this step is c_t of the next), external dh
+    f32x4 g4 = {0, 0, 0, 0}, g4n = {0, 0, 0, 0};
+    float c_t = 0.f, c_p = 0.f, c_pn = 0.f, dhe = 0.f, dhen = 0.f;
+    if (cell) {
+        const int t = L - 1;
+        g4 = *(const f32x4 *)(GP + ((size_t)t * B + b) * (4 * NH) + u * 4);
+        c_t = Cseq[(size_t)(t + 1) * cstep + cidx];
+        c_p = Cseq[(size_t)t * cstep + cidx];
+        dhe = dH[((size_t)(rev ? L - 1 - t : t) * B + b) * NH + u];
+    }
+
+    for (int t = L - 1; t >= 0; --t) {
+        const int cur = t & 1;
+        if (cell) {
+            if (t > 0) {
+                const int tn = t - 1;
+                g4n = *(const f32x4 *)(GP + ((size_t)tn * B + b) * (4 * NH) + u * 4);
+                c_pn = Cseq[(size_t)tn * cstep + cidx];
+                dhen = dH[((size_t)(rev ? L - 1 - tn : tn) * B + b) * NH + u];
+            }
+            const float dh = dhe + dh_rec;
+            const float tc = tanh_acc(c_t);
+            const float dc = dh * g4.w * (1.0f - tc * tc) + dc_carry;
+            f32x4 dp;
+            dp.x = dc * g4.y * g4.x * (1.0f - g4.x);             // i
+            dp.y = dc * g4.x * (1.0f - g4.y * g4.y);             // g~
+            dp.z = dc * c_p * g4.z * (1.0f - g4.z);              // f
+            dp.w = dh * tc * g4.w * (1.0f - g4.w);               // o
+            dc_carry = dc * g4.z;
+            if (valid) *(f32x4 *)(GP + ((size_t)t * B + b) * (4 * NH) + u * 4) = dp;
+            float *n = &dpbuf[cur][cslot + col], *sw = &dpbuf[cur][CPY + cslot + (1 - col)];
+            n[0] = dp.x; n[2] = dp.y; n[4] = dp.z; n[6] = dp.w;
+            sw[0] = dp.x; sw[2] = dp.y; sw[4] = dp.z; sw[6] = dp.w;
+        }
+        LDS_BARRIER();
+        if (t == 0) break;      // the matvec below would only produce dh for a step before the first
+
+        // recurrent matvec on dp[t]: feeds step t-1
+        f32x2 acc[4] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
+        const f32x4 *dpp = (const f32x4 *)&dpbuf[cur][rdoff];
+#pragma unroll
+        for (int j = 0; j < RC / 2; ++j) {
+            const f32x4 v = dpp[j];
+            const f32x2 va = {v.x, v.y}, vb = {v.z, v.w};
+#pragma unroll
+            for (int s = 0; s < 4; ++s) PK_FMA_LO(acc[s], w[s][j], va);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) PK_FMA_HI(acc[s], w[s][j], vb);
+        }
+        float r[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) r[s] = acc[s].x + dpp_mov<0xB1>(acc[s].y);     // xor 1
+        float v0 = r[0] + dpp_mov<0x4E>(r[2]);                                     // xor 2
+        float v1 = r[1] + dpp_mov<0x4E>(r[3]);
+        v0 += dpp_mov<0x124>(v0); v1 += dpp_mov<0x124>(v1);                        // row_ror:4
+        v0 += dpp_mov<0x128>(v0); v1 += dpp_mov<0x128>(v1);                        // row_ror:8
+        dh_rec = (rcq & 1) ? v1 : v0;
+        g4 = g4n; c_t = c_p; c_p = c_pn; dhe = dhen;
+    }
+    // gradient w.r.t. the initial state: dh_init = W_hh^T dp[0], dc_init = dc_carry
+    {
+        f32x2 acc[4] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
+        const f32x4 *dpp = (const f32x4 *)&dpbuf[0][rdoff];
+#pragma unroll
+        for (int j = 0; j < RC / 2; ++j) {
+            const f32x4 v = dpp[j];
+            const f32x2 va = {v.x, v.y}, vb = {v.z, v.w};
+#pragma unroll
+            for (int s = 0; s < 4; ++s) PK_FMA_LO(acc[s], w[s][j], va);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) PK_FMA_HI(acc[s], w[s][j], vb);
+        }
+        float r[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) r[s] = acc[s].x + dpp_mov<0xB1>(acc[s].y);
+        float v0 = r[0] + dpp_mov<0x4E>(r[2]);
+        float v1 = r[1] + dpp_mov<0x4E>(r[3]);
+        v0 += dpp_mov<0x124>(v0); v1 += dpp_mov<0x124>(v1);
+        v0 += dpp_mov<0x128>(v0); v1 += dpp_mov<0x128>(v1);
+        if (cell && valid) {
+            dh0[cidx] = (rcq & 1) ? v1 : v0;
+            dc0[cidx] = dc_carry;
+        }
+    }
+}
+
+// slot s of a lane with group grp accumulates output j = (s + 2*grp) % 4 of its quad of outputs
+// row order inside a chunk: r' = u*4 + pos, pos over [i, g~, f, o]  ->  PyTorch gate row
+static const int kPosGate[4] = {0, 2, 1, 3};
+
+size_t bwd_rec_packed_floats(int nh) { return (size_t)4 * nh * nh; }
+
+void bwd_rec_pack_weights(int nh, const float *w_hh, float *packed)
+{
+    const int NT = nh * 4, RC = nh / 4;
+    for (int tid = 0; tid < NT; ++tid) {
+        const int og = tid >> 4, rc = tid & 15, grp = (rc & 3) >> 1;
+        for (int idx = 0; idx < 4 * RC; ++idx) {
+            const int s = idx / RC, rr = idx % RC;
+            const int k = 4 * og + (s + 2 * grp) % 4;
+            const int rp = rc * RC + rr;                    // r' = u*4 + pos
+            const int uu = rp / 4, pos = rp % 4;
+            const int i = idx / 4, e = idx % 4;
+            packed[((size_t)i * NT + tid) * 4 + e] = w_hh[(size_t)(kPosGate[pos] * nh + uu) * nh + k];
+        }
+    }
+}
+
+int launch_bwd_rec(int nh, const float *wt_packed, float *GP, const float *Cseq, const float *dH,
+                   float *dh0, float *dc0, int B, int L, int rev, hipStream_t s)
+{
+    const dim3 grid((B + 1) / 2), block(nh * 4);
+    switch (nh) {
+    case 64:  hipLaunchKernelGGL((lstm_bwd_rec_kernel<64>), grid, block, 0, s, (const f32x4 *)wt_packed, GP, Cseq, dH, dh0, dc0, B, L, rev); break;
+    case 96:  hipLaunchKernelGGL((lstm_bwd_rec_kernel<96>), grid, block, 0, s, (const f32x4 *)wt_packed, GP, Cseq, dH, dh0, dc0, B, L, rev); break;
+    case 128: hipLaunchKernelGGL((lstm_bwd_rec_kernel<128>), grid, block, 0, s, (const f32x4 *)wt_packed, GP, Cseq, dH, dh0, dc0, B, L, rev); break;
+    default:
+        csa_set_error_msg("bwd_rec: hidden size not supported (64, 96, 128)");
+        return CSA_ERR_UNSUPPORTED;
+    }
+    CSA_HIP_CHECK(hipGetLastError());
+    return CSA_OK;
+}

@@ -110,6 +110,40 @@ int csa_reset_profile(csa_emulator *h);
 int csa_get_profile(csa_emulator *h, double *avg_ms /* [6] */, int n, long *calls);
 const char *csa_stage_name(int i);
 
+/* ---- training step (e) ---------------------------------------------
+ * Replaces, for the current-generation LSTM with memory (mp_mode 1):
+ *   model(inp_list) with autograd graph      rnn/utils.py:1098-1137   -> csa_train_forward (slot = step of the window)
+ *   lossf + energy/water metrics + backward  rnn/utils.py:1203-1371, rnn/metrics.py:142-315
+ *                                                                     -> csa_train_loss, csa_train_backward
+ *   optim.step() (torch.optim.Adam)          rnn/utils.py:1377        -> csa_train_adam
+ * Gradients accumulate into ONE caller-provided flat fp32 buffer in state_dict layout
+ * (csa_train_param_info), which is also the buffer the single RCCL all-reduce of a data-parallel
+ * step runs on.  The caller chains d_mem_in of slot tau into d_mem_out of slot tau-1 (TBPTT) and
+ * zeroes `grads` at the start of a window.  hyai/hybi (nlev+1) are the hybrid interface coefficients
+ * used by the energy / water closures. */
+typedef struct csa_trainer csa_trainer;
+int csa_train_create(const csa_config *cfg, const csa_params *host_params, const float *hyai, const float *hybi,
+                     int max_batch, int max_window, csa_trainer **out);
+int csa_train_destroy(csa_trainer *h);
+int csa_train_num_params(const csa_trainer *h);
+int csa_train_num_tensors(const csa_trainer *h);
+int csa_train_param_info(const csa_trainer *h, int i, const char **name, int *offset, int *rows, int *cols);
+float *csa_train_params(csa_trainer *h);                     /* device pointer, canonical flat parameters */
+int csa_train_sync_params(csa_trainer *h, void *stream);     /* re-pack after writing csa_train_params() */
+int csa_train_forward(csa_trainer *h, int slot, int B, const float *x_main_n, const float *x_sfc_n,
+                      const float *mem_in, float *out, float *out_sfc, float *mem_out, void *stream);
+int csa_train_backward(csa_trainer *h, int slot, int B, const float *d_out, const float *d_out_sfc,
+                       const float *d_mem_out /* nullable */, float *d_mem_in /* nullable */, float *grads, void *stream);
+/* pred/tgt (Tw*B,nlev,ny) normalised, *_sfc (Tw*B,ny_sfc); yto (Tw*B,nlev,6), yto_sfc physical targets;
+ * x_raw (Tw*B,nlev,nx) raw inputs; x_sfc_n (Tw*B,nx_sfc) normalised.  scalars (device, 7 floats):
+ * loss, huber, mse, mae, energy, water, precip_sum_mse.  d_pred/d_pred_sfc nullable (evaluation). */
+int csa_train_loss(csa_trainer *h, int B, int Tw, float w_energy, float w_water,
+                   const float *pred, const float *pred_sfc, const float *tgt, const float *tgt_sfc,
+                   const float *yto, const float *yto_sfc, const float *x_raw, const float *x_sfc_n,
+                   float *scalars, float *d_pred, float *d_pred_sfc, void *stream);
+int csa_train_adam(csa_trainer *h, const float *grads, float lr, float beta1, float beta2, float eps,
+                   float weight_decay, int step, void *stream);
+
 const char *csa_last_error(void);
 const char *csa_version(void);
 

@@ -175,3 +175,43 @@ def from_npz(path, **kw):
     consts = {k[2:]: d[k] for k in d.files if k.startswith("c.")}
     weights = {k[2:]: d[k] for k in d.files if k.startswith("w.")}
     return EmulatorRef(consts, weights, **kw)
+
+
+# ---- loss of the reference trainer (TEST INFRASTRUCTURE) --------------------------------------------
+def window_loss(ref, preds, preds_sfc, tgt, tgt_sfc, yto, yto_sfc, x_raw, x_sfc_n, hyai, hybi, Tw,
+                w_energy=6.0e-6, w_water=6.0e7):
+    """huber + w_energy*energy + w_water*water, restating rnn/utils.py:1203-1366 with
+    rnn/metrics.py:142-163 (metrics_flatten), :193-239 (energy), :241-315 (water), :184-190 (precip)."""
+    hyai = torch.as_tensor(hyai, dtype=preds.dtype)
+    hybi = torch.as_tensor(hybi, dtype=preds.dtype)
+    flat_p = torch.cat((preds.flatten(start_dim=1), preds_sfc), dim=1)
+    flat_t = torch.cat((tgt.flatten(start_dim=1), tgt_sfc), dim=1)
+    huber = F.smooth_l1_loss(flat_p, flat_t)
+    mse = torch.mean(torch.square(flat_p - flat_t))
+    mae = F.l1_loss(flat_p, flat_t)
+    ypo, ypo_sfc = ref.postprocess(preds, preds_sfc, x_raw)
+    sp = x_sfc_n[:, 0:1] * ref.xdiv_sca[0:1] + ref.xmean_sca[0:1]
+    dhyb = (hybi[1:61] - hybi[0:60]).view(1, -1)
+    dhya = (hyai[1:61] - hyai[0:60]).view(1, -1)
+
+    def energy(y, ysfc):
+        thick = 0.1020408163 * (sp * dhyb + 100000.0 * dhya)
+        snow = 1000 * ysfc[:, 2]
+        prec = 1000 * ysfc[:, 3]
+        rain = prec - snow
+        e = torch.sum(thick * (y[:, :, 0] * 1004.0 - y[:, :, 2] * 2.5104e6 - y[:, :, 3] * 2.8440e6), 1) \
+            - rain * 2.5104e6 - snow * 2.8440e6
+        return torch.mean(e.reshape(Tw, -1), dim=0)
+
+    def water(y, ysfc):
+        thick = 0.1019716213 * (sp * dhyb + 100000.0 * dhya)
+        lhs = torch.sum(thick * torch.sum(y[:, :, 1:4], dim=2), 1)
+        return lhs + ysfc[:, 3] * 1000.0
+
+    e_mse = torch.mean(torch.square(energy(ypo, ypo_sfc) - energy(yto, yto_sfc)))
+    w_mse = torch.mean(torch.square(water(ypo, ypo_sfc) - water(yto, yto_sfc)))
+    pt = torch.sum(yto_sfc[:, 3].reshape(Tw, -1), 0)
+    pp = torch.sum(ypo_sfc[:, 3].reshape(Tw, -1), 0)
+    precip = torch.mean(torch.square(pt - pp)) / (Tw ** 2)
+    loss = huber + w_energy * e_mse + w_water * w_mse
+    return loss, dict(loss=loss, huber=huber, mse=mse, mae=mae, energy=e_mse, water=w_mse, precip_sum_mse=precip)
