@@ -103,12 +103,62 @@ def cpu_baseline(tag, consts, weights, xm, xs, mem, hx, cx, budget_s=12.0):
                       f"(torch {torch.__version__} CPU, {cores} threads), {el:.1f} s"}
 
 
+def train_workload(a, rank, local_rank, world, dist):
+    """Optional workload (BASELINE.json configs[2]): one TBPTT optimiser step of the current-generation
+    LSTM (window T_w = 3, 384 columns per GPU): 3 forwards with saved activations, loss, 3 backwards,
+    ONE flat-buffer RCCL all-reduce, Adam.  Unit: column-timesteps/s."""
+    from climsim_amd.train import Trainer
+    from oracle import torch_ref          # cpu_baseline leg only (rank 0, N=1)
+    from synth import synth_inputs
+    consts, weights = load_model("cur_lstm128")
+    grid = np.load(os.path.join(ROOT, "tests", "golden", "grid_consts.npz"))
+    B, Tw = 384, 3
+    tr = Trainer(consts, weights, grid["hyai"], grid["hybi"], output_prune=True, max_batch=B, max_window=Tw)
+    xm, xs = synth_inputs(consts, B, 7000 + rank)
+    g = torch.Generator().manual_seed(rank)
+    xmt, xst = torch.from_numpy(xm), torch.from_numpy(xs)
+    xn = xmt.clone()
+    xn[:, :, 2] = 1 - torch.exp(-xn[:, :, 2] * torch.from_numpy(consts["lbd_qc"]))
+    xn[:, :, 3] = 1 - torch.exp(-xn[:, :, 3] * torch.from_numpy(consts["lbd_qi"]))
+    xn = torch.nan_to_num((xn - torch.from_numpy(consts["xmean_lev"])) / torch.from_numpy(consts["xdiv_lev"]), 0.0, 0.0, 0.0)
+    xsn = (xst - torch.from_numpy(consts["xmean_sca"])) / torch.from_numpy(consts["xdiv_sca"])
+    t5, t8 = torch.randn(B, 60, 5, generator=g), torch.randn(B, 8, generator=g)
+    y6 = torch.randn(B, 60, 6, generator=g) * 1e-5
+    y8 = torch.rand(B, 8, generator=g) * 1e-7
+    dv = lambda t: [t.contiguous().cuda()] * Tw
+    args = (dv(xn), dv(xsn), dv(xmt), dv(t5), dv(t8), dv(y6), dv(y8))
+    mem = torch.zeros(60, B, 16, device="cuda")
+
+    def fence():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+    for _ in range(a.warmup):
+        sc, mem, _ = tr.window_step(*args, mem, world_size=world, global_columns=B * world)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        sc, mem, _ = tr.window_step(*args, mem, world_size=world, global_columns=B * world)
+    fence()
+    from climsim_amd.sharding import max_over_ranks
+    el = max_over_ranks(time.perf_counter() - t0, device="cuda")
+    if rank == 0:
+        print(json.dumps({
+            "metric": "train-step column-timesteps/sec (TBPTT window 3)", "value": world * B * Tw * a.steps / el,
+            "unit": "column-timesteps/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": 1e3 * el / a.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": a.workload, "columns_per_gpu": B, "window": Tw, "model": "RNN_autoreg LSTM 128/128, nh_mem 16",
+                       "parallelism": f"columns sharded x{world}, one flat-gradient all-reduce per step"},
+            "loss": sc["loss"]}), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--workload", default="v4_stateless_384", choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default="v4_stateless_384", choices=sorted(WORKLOADS) + ["train_tbptt3_384"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     a = ap.parse_args()
 
@@ -126,6 +176,12 @@ def main():
     import climsim_amd
     from synth import synth_inputs
 
+    if a.workload == "train_tbptt3_384":
+        train_workload(a, rank, local_rank, world, dist)
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
     tag, B, flop_col, bytes_col = WORKLOADS[a.workload]
     consts, weights = load_model(tag)
     model = climsim_amd.NewModel_constraint(consts, weights, max_batch=B)

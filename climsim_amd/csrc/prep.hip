@@ -22,16 +22,19 @@
 __device__ __forceinline__ float prep_tanh(float x)
 {
     const float t = fminf(__builtin_amdgcn_exp2f(-2.88539008177792681f * x), 1e30f);
-    return (1.0f - t) / (1.0f + t);
+    return (1.0f - t) * __builtin_amdgcn_rcpf(1.0f + t);
 }
 
+// NXP = nx+1 padded to a multiple of 4 (16 for the v4 inputs): the level rows sit in LDS with that
+// stride so the mlp_initial dot product reads them as float4 broadcasts with no predication.
+template <int NXP>
 __global__ __launch_bounds__(PREP_THREADS) void prep_kernel(
     DevModel m, int B, int normalised,
     const float *__restrict__ x_main, const float *__restrict__ x_sfc,
     const float *__restrict__ mem_in, float *__restrict__ X1, float *__restrict__ hc0,
     float *__restrict__ X16out, float *__restrict__ xs_out)
 {
-    extern __shared__ float smem[];
+    extern __shared__ __attribute__((aligned(16))) float smem[];
     const int L = m.cfg.nlev, nx = m.cfg.nx, nxp = nx + 1, nxs = m.cfg.nx_sfc;
     const int nh1 = m.cfg.nh1, nh2 = m.cfg.nh2, nm = m.cfg.nh_mem, nin1 = nh1 + nm;
     const int nhm = nh1 > nh2 ? nh1 : nh2;
@@ -39,8 +42,8 @@ __global__ __launch_bounds__(PREP_THREADS) void prep_kernel(
     // this workgroup's slice of levels [l0, l1)
     const int lper = (L + PREP_LSPLIT - 1) / PREP_LSPLIT;
     const int l0 = blockIdx.y * lper, l1 = min(L, l0 + lper), nl = l1 - l0;
-    float *xl = smem;                 // (lper, nxp)
-    float *xs = smem + lper * nxp;    // (nxs)
+    float *xl = smem;                 // (lper, NXP), zero padded beyond nxp
+    float *xs = smem + lper * NXP;    // (nxs)
     if (nl <= 0) return;
 
     // ---- surface inputs -----------------------------------------------------------------
@@ -65,21 +68,24 @@ __global__ __launch_bounds__(PREP_THREADS) void prep_kernel(
             if (isnan(x)) x = 0.0f;
             if (m.cfg.scrub_inf && isinf(x)) x = 0.0f;
         }
-        xl[ll * nxp + v] = x;
+        xl[ll * NXP + v] = x;
     }
+    if (NXP > nxp)
+        for (int idx = tid; idx < nl * (NXP - nxp); idx += PREP_THREADS)
+            xl[(idx / (NXP - nxp)) * NXP + nxp + idx % (NXP - nxp)] = 0.0f;
     __syncthreads();
     {
         const float sp = xs[0] * m.xdiv_sca[0] + m.xmean_sca[0];
         for (int ll = tid; ll < nl; ll += PREP_THREADS) {
             const int l = l0 + ll;
             const float pres = m.hyam[l] * 100000.0f + sp * m.hybm[l];
-            xl[ll * nxp + nx] = sqrtf(pres) / 314.0f;
+            xl[ll * NXP + nx] = sqrtf(pres) / 314.0f;
         }
     }
     __syncthreads();
     if (X16out) {   // training: keep what the backward of mlp_initial / the surface MLPs needs
         for (int idx = tid; idx < nl * nxp; idx += PREP_THREADS)
-            X16out[((size_t)b * L + l0) * nxp + idx] = xl[idx];
+            X16out[((size_t)b * L + l0) * nxp + idx] = xl[(idx / nxp) * NXP + idx % nxp];
         if (blockIdx.y == 0)
             for (int v = tid; v < nxs; v += PREP_THREADS) xs_out[(size_t)b * nxs + v] = xs[v];
     }
@@ -108,18 +114,21 @@ __global__ __launch_bounds__(PREP_THREADS) void prep_kernel(
 
     // ---- mlp_initial + tanh, written in sequence order (t = L-1-l) ------------------------------
     for (int j = tid; j < nh1; j += PREP_THREADS) {
-        float w[PREP_MAX_NXP];
+        float w[NXP];
 #pragma unroll
-        for (int v = 0; v < PREP_MAX_NXP; ++v) w[v] = v < nxp ? m.init_wt[v * nh1 + j] : 0.0f;
+        for (int v = 0; v < NXP; ++v) w[v] = v < nxp ? m.init_wt[v * nh1 + j] : 0.0f;
         const float bj = m.init_b[j];
         for (int ll = 0; ll < nl; ++ll) {
-            const float *xr = xl + ll * nxp;
-            float a = bj;
+            const f32x4 *xr = (const f32x4 *)(xl + ll * NXP);
+            float a0 = bj, a1 = 0.0f;
 #pragma unroll
-            for (int v = 0; v < PREP_MAX_NXP; ++v)
-                if (v < nxp) a += w[v] * xr[v];
+            for (int q = 0; q < NXP / 4; ++q) {
+                const f32x4 xv = xr[q];
+                a0 += w[4 * q] * xv.x; a1 += w[4 * q + 1] * xv.y;
+                a0 += w[4 * q + 2] * xv.z; a1 += w[4 * q + 3] * xv.w;
+            }
             const int t = L - 1 - (l0 + ll);
-            X1[((size_t)t * B + b) * nin1 + j] = prep_tanh(a);
+            X1[((size_t)t * B + b) * nin1 + j] = prep_tanh(a0 + a1);
         }
     }
     // ---- memory concat -------------------------------------------------------------------------
@@ -131,6 +140,21 @@ __global__ __launch_bounds__(PREP_THREADS) void prep_kernel(
     }
 }
 
+static int launch_prep_impl(const DevModel &m, int B, int normalised, const float *x_main, const float *x_sfc,
+                            const float *mem_in, float *X1, float *hc0, float *X16, float *xs_n, hipStream_t s)
+{
+    const int lper = (m.cfg.nlev + PREP_LSPLIT - 1) / PREP_LSPLIT;
+    const int nxp = m.cfg.nx + 1, NXP = nxp <= 16 ? 16 : 32;
+    const size_t shm = sizeof(float) * ((size_t)lper * NXP + m.cfg.nx_sfc + 4);
+    const dim3 grid(B, PREP_LSPLIT), block(PREP_THREADS);
+    if (NXP == 16)
+        hipLaunchKernelGGL(prep_kernel<16>, grid, block, shm, s, m, B, normalised, x_main, x_sfc, mem_in, X1, hc0, X16, xs_n);
+    else
+        hipLaunchKernelGGL(prep_kernel<32>, grid, block, shm, s, m, B, normalised, x_main, x_sfc, mem_in, X1, hc0, X16, xs_n);
+    CSA_HIP_CHECK(hipGetLastError());
+    return CSA_OK;
+}
+
 int launch_prep(const DevModel &m, int B, int normalised, const float *x_main, const float *x_sfc,
                 const float *mem_in, const float *hx2, const float *cx2,
                 float *X1, float *hc0, hipStream_t s)
@@ -140,12 +164,7 @@ int launch_prep(const DevModel &m, int B, int normalised, const float *x_main, c
         csa_set_error_msg("prep: nx+1 exceeds PREP_MAX_NXP");
         return CSA_ERR_UNSUPPORTED;
     }
-    const int lper = (m.cfg.nlev + PREP_LSPLIT - 1) / PREP_LSPLIT;
-    const size_t shm = sizeof(float) * ((size_t)lper * (m.cfg.nx + 1) + m.cfg.nx_sfc);
-    hipLaunchKernelGGL(prep_kernel, dim3(B, PREP_LSPLIT), dim3(PREP_THREADS), shm, s, m, B, normalised, x_main,
-                       x_sfc, mem_in, X1, hc0, (float *)nullptr, (float *)nullptr);
-    CSA_HIP_CHECK(hipGetLastError());
-    return CSA_OK;
+    return launch_prep_impl(m, B, normalised, x_main, x_sfc, mem_in, X1, hc0, nullptr, nullptr, s);
 }
 
 int launch_prep_train(const DevModel &m, int B, int normalised, const float *x_main, const float *x_sfc,
@@ -155,10 +174,5 @@ int launch_prep_train(const DevModel &m, int B, int normalised, const float *x_m
         csa_set_error_msg("prep: nx+1 exceeds PREP_MAX_NXP");
         return CSA_ERR_UNSUPPORTED;
     }
-    const int lper = (m.cfg.nlev + PREP_LSPLIT - 1) / PREP_LSPLIT;
-    const size_t shm = sizeof(float) * ((size_t)lper * (m.cfg.nx + 1) + m.cfg.nx_sfc);
-    hipLaunchKernelGGL(prep_kernel, dim3(B, PREP_LSPLIT), dim3(PREP_THREADS), shm, s, m, B, normalised, x_main,
-                       x_sfc, mem_in, X1, hc0, X16, xs_n);
-    CSA_HIP_CHECK(hipGetLastError());
-    return CSA_OK;
+    return launch_prep_impl(m, B, normalised, x_main, x_sfc, mem_in, X1, hc0, X16, xs_n, s);
 }

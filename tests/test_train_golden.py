@@ -104,7 +104,9 @@ def test_hip_adam_matches_torch_adam():
         ptorch.grad = grad.clone()
         opt.step()
     p1 = tr.flat_params().cpu()
-    assert rel_err((p1 - p0).numpy(), (ptorch.detach() - p0).numpy()) <= 1e-5
+    # parameters are O(0.5): their fp32 ulp (3e-8) bounds how well the 3e-3 update can be resolved
+    assert rel_err(p1.numpy(), ptorch.detach().numpy()) <= 3e-7
+    assert rel_err((p1 - p0).numpy(), (ptorch.detach() - p0).numpy()) <= 1e-4
     # and the re-packed kernel layouts follow the update: forward still agrees with the oracle on the new weights
     sd = {k: v.cpu().numpy() for k, v in tr.state_dict().items()}
     ref = torch_ref.EmulatorRef(consts, sd, legacy=False, use_lstm=True, scrub_inf=True)
