@@ -33,6 +33,8 @@ struct csa_emulator {
     double acc_ms[6] = {};
     long n_prof = 0;
     bool pending = false;
+    bool fused = false;          // dual-pipe fused LSTM kernel (csa_set_fused); off by default: measured slower
+                                 // than GEMM + recurrent kernel because W_ih is re-streamed from L2 per 8-level chunk
     // slots of device weight buffers that csa_set_params refreshes
     struct Slot { float **dst; size_t n; };
 };
@@ -116,6 +118,19 @@ int upload_params(csa_emulator *h, const csa_params *p, bool first)
     d.wih1 = U.up(w); d.bias1 = U.up(bias); d.bhn1 = U.up(bhn);
     pack_ih(c.use_lstm, c.nh2, c.nh1, p->rnn2_w_ih, p->rnn2_b_ih, p->rnn2_b_hh, w, bias, bhn);
     d.wih2 = U.up(w); d.bias2 = U.up(bias); d.bhn2 = U.up(bhn);
+    // dual-pipe fused LSTM path (fused.hip): nh = 128, K in {128,144}
+    d.wih1f = d.wih2f = nullptr;
+    if (c.use_lstm && c.nh1 == 128 && c.nh2 == 128 && (nin1 == 128 || nin1 == 144)) {
+        std::vector<float> wp, fp;
+        pack_ih(1, c.nh1, nin1, p->rnn1_w_ih, p->rnn1_b_ih, p->rnn1_b_hh, wp, bias, bhn);
+        fp.resize(fused_packed_floats(c.nh1, nin1));
+        fused_pack_wih(c.nh1, nin1, wp.data(), fp.data());
+        d.wih1f = U.up(fp);
+        pack_ih(1, c.nh2, c.nh1, p->rnn2_w_ih, p->rnn2_b_ih, p->rnn2_b_hh, wp, bias, bhn);
+        fp.resize(fused_packed_floats(c.nh2, c.nh1));
+        fused_pack_wih(c.nh2, c.nh1, wp.data(), fp.data());
+        d.wih2f = U.up(fp);
+    }
     packed.resize(rec_packed_floats(c.use_lstm, c.nh1));
     rec_pack_weights(c.use_lstm, c.nh1, p->rnn1_w_hh, packed.data());
     d.whh1p = U.up(packed);
@@ -275,6 +290,13 @@ extern "C" int csa_get_profile(csa_emulator *h, double *avg_ms, int n, long *cal
     return CSA_OK;
 }
 
+extern "C" int csa_set_fused(csa_emulator *h, int enable)
+{
+    if (!h) return CSA_ERR_ARG;
+    h->fused = enable != 0;
+    return (h->fused && h->dm.wih1f) ? 1 : 0;      // 1 = the fused path will be used
+}
+
 extern "C" const char *csa_stage_name(int i) { return (i >= 0 && i < 6) ? kStageNames[i] : ""; }
 
 #define PROF_MARK(i)                                                 \
@@ -298,19 +320,32 @@ static int run_forward(csa_emulator *h, int B, int normalised, int mode,
     if (h->profiling) prof_collect(h);   // previous profiled call (host sync: profiling mode only)
     PROF_MARK(0);
     if ((rc = launch_prep(h->dm, B, normalised, x_main, x_sfc, mem_in, hx2, cx2, h->X1, h->hc0, s))) return rc;
-    PROF_MARK(1);
-    // rnn1: upward over the flipped sequence; hidden sequence stored back in level order
-    if ((rc = launch_proj_gemm(h->X1, h->dm.wih1, h->dm.bias1, h->P, L * B, 4 * c.nh1, c.nh1 + c.nh_mem, s))) return rc;
-    PROF_MARK(2);
-    if ((rc = launch_rec(c.use_lstm, c.nh1, h->dm.whh1p, h->dm.bhn1, h->P, h->hc0, h->hc0 + (size_t)B * nhm,
-                         h->H1, B, L, /*reverse_out=*/1, s))) return rc;
-    PROF_MARK(3);
-    // rnn2: downward in level order
-    if ((rc = launch_proj_gemm(h->H1, h->dm.wih2, h->dm.bias2, h->P, L * B, 4 * c.nh2, c.nh1, s))) return rc;
     const float *h2 = c.legacy ? hx2 : h->hc0 + (size_t)2 * B * nhm;
     const float *c2 = c.legacy ? cx2 : h->hc0 + (size_t)3 * B * nhm;
-    PROF_MARK(4);
-    if ((rc = launch_rec(c.use_lstm, c.nh2, h->dm.whh2p, h->dm.bhn2, h->P, h2, c2, h->H2, B, L, /*reverse_out=*/0, s))) return rc;
+    if (h->fused && h->dm.wih1f) {
+        // dual-pipe path: each LSTM layer is ONE launch (projection on the MFMA pipe, recurrence on the
+        // VALU pipe of the same CUs); the two GEMM stages are empty
+        PROF_MARK(1);
+        PROF_MARK(2);
+        if ((rc = launch_fused_lstm(c.nh1, c.nh1 + c.nh_mem, h->dm.whh1p, h->dm.wih1f, h->dm.bias1, h->X1, h->hc0,
+                                    h->hc0 + (size_t)B * nhm, h->H1, B, L, /*reverse_out=*/1, s))) return rc;
+        PROF_MARK(3);
+        PROF_MARK(4);
+        if ((rc = launch_fused_lstm(c.nh2, c.nh1, h->dm.whh2p, h->dm.wih2f, h->dm.bias2, h->H1, h2, c2, h->H2, B, L,
+                                    /*reverse_out=*/0, s))) return rc;
+    } else {
+        PROF_MARK(1);
+        // rnn1: upward over the flipped sequence; hidden sequence stored back in level order
+        if ((rc = launch_proj_gemm(h->X1, h->dm.wih1, h->dm.bias1, h->P, L * B, 4 * c.nh1, c.nh1 + c.nh_mem, s))) return rc;
+        PROF_MARK(2);
+        if ((rc = launch_rec(c.use_lstm, c.nh1, h->dm.whh1p, h->dm.bhn1, h->P, h->hc0, h->hc0 + (size_t)B * nhm,
+                             h->H1, B, L, /*reverse_out=*/1, s))) return rc;
+        PROF_MARK(3);
+        // rnn2: downward in level order
+        if ((rc = launch_proj_gemm(h->H1, h->dm.wih2, h->dm.bias2, h->P, L * B, 4 * c.nh2, c.nh1, s))) return rc;
+        PROF_MARK(4);
+        if ((rc = launch_rec(c.use_lstm, c.nh2, h->dm.whh2p, h->dm.bhn2, h->P, h2, c2, h->H2, B, L, /*reverse_out=*/0, s))) return rc;
+    }
     PROF_MARK(5);
     rc = launch_head(h->dm, B, mode, h->H2, x_main, y0, y1, y2, s);
     PROF_MARK(6);

@@ -29,6 +29,8 @@ struct DevModel {
     const float *bhn1, *bhn2;           // GRU only: b_hn (nh)
     // recurrent weights packed for the register-stationary kernel (see rec.hip)
     const float *whh1p, *whh2p;
+    // W_ih in MFMA-operand order for the dual-pipe fused LSTM kernel (fused.hip); null if not built
+    const float *wih1f, *wih2f;
     // heads
     const float *lat_wt, *lat_b;        // (nh2, nh_mem)
     const float *out_w, *out_b;         // (ny, nh_mem or nh2) row-major
@@ -70,6 +72,13 @@ int launch_rec_train(int nh, const float *whh_packed, float *P, const float *h0,
 size_t rec_packed_floats(int use_lstm, int nh);
 // host-side packer: W_hh (G*nh, nh) PyTorch layout -> register-stationary layout
 void rec_pack_weights(int use_lstm, int nh, const float *w_hh, float *packed);
+
+// fused.hip: whole LSTM layer (projection on the MFMA pipe + recurrence on the VALU pipe) in one launch
+size_t fused_packed_floats(int nh, int K);
+void fused_pack_wih(int nh, int K, const float *w_perm, float *packed);
+int launch_fused_lstm(int nh, int K, const float *whh_packed, const float *wih_packed, const float *bias,
+                      const float *X, const float *h0, const float *c0, float *Hout, int B, int L, int reverse_out,
+                      hipStream_t s);
 
 // head.hip: mlp_latent / mlp_output / surface head / de-normalisation / microphysics / packing
 int launch_head(const DevModel &m, int B, int mode, const float *H2, const float *x_main_raw,

@@ -183,6 +183,10 @@ class Emulator:
         self._rc(rc, "csa_model_forward")
         return out, out_sfc, mem_out
 
+    def set_fused(self, enable):
+        """Select the dual-pipe fused LSTM kernels (default) or the six-launch path; returns True if fused is active."""
+        return bool(_lib.lib().csa_set_fused(self._h, int(bool(enable))))
+
     def set_profiling(self, enable):
         self._rc(_lib.lib().csa_set_profiling(self._h, int(bool(enable))), "csa_set_profiling")
 

@@ -110,6 +110,11 @@ int csa_reset_profile(csa_emulator *h);
 int csa_get_profile(csa_emulator *h, double *avg_ms /* [6] */, int n, long *calls);
 const char *csa_stage_name(int i);
 
+/* Kernel selection: 0 (default) = the six-launch path (projection GEMM + recurrent kernel);
+ * 1 = dual-pipe fused LSTM layers (fused.hip; LSTM, nh = 128) -- parity-tested, currently slower
+ * (DESIGN.md section 4.5).  Returns 1 if the fused path is in use. */
+int csa_set_fused(csa_emulator *h, int enable);
+
 /* ---- training step (e) ---------------------------------------------
  * Replaces, for the current-generation LSTM with memory (mp_mode 1):
  *   model(inp_list) with autograd graph      rnn/utils.py:1098-1137   -> csa_train_forward (slot = step of the window)

@@ -210,3 +210,29 @@ def test_error_behaviour(memory):
     big = torch.zeros(3001, 60, 15, device="cuda")
     with pytest.raises(RuntimeError):
         model(big, torch.zeros(3001, 19, device="cuda"), torch.zeros(3001, 60, 16, device="cuda"))
+
+
+def test_fused_and_unfused_paths_agree(memory):
+    """The dual-pipe fused LSTM kernel (default) and the six-launch path (projection GEMM + recurrent
+    kernel) are two implementations of the same arithmetic: both within 1e-5 of the oracle, and of each
+    other."""
+    from oracle.pyoracle import OracleModel
+    consts, weights, model = memory
+    B = 77
+    xm, xs = synth_inputs(consts, B, 31337)
+    g = np.random.Generator(np.random.PCG64(8))
+    mem = (0.3 * g.standard_normal((B, 60, 16))).astype(np.float32)
+    hx, cx = g.standard_normal((2, B, 128)).astype(np.float32)
+    args = (_dev(xm), _dev(xs), _dev(mem))
+    noise = (_dev(hx), _dev(cx))
+    try:
+        assert model.emulator.set_fused(True) is True
+        y_f = model(*args, noise=noise).cpu().numpy()
+        assert model.emulator.set_fused(False) is False
+        y_u = model(*args, noise=noise).cpu().numpy()
+    finally:
+        model.emulator.set_fused(False)
+    yo = OracleModel(consts, weights, legacy=True).wrapper_forward(xm, xs, mem, hx, cx)
+    assert max(block_errors(y_f, yo).values()) <= 1e-5
+    assert max(block_errors(y_u, yo).values()) <= 1e-5
+    assert max(block_errors(y_f, y_u).values()) <= 1e-5
