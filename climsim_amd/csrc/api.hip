@@ -33,6 +33,11 @@ struct csa_emulator {
     double acc_ms[6] = {};
     long n_prof = 0;
     bool pending = false;
+    // level-split overlap (run_forward_overlap): side stream + events, second pre-activation buffer, cell state hand-over
+    bool overlap = false;        // off by default: measured slower (cross-queue event waits cost more than the GEMM time hidden)
+    hipStream_t side = nullptr;
+    hipEvent_t ov_ev[12] = {};
+    float *P2 = nullptr, *cstate = nullptr;
     bool fused = false;          // dual-pipe fused LSTM kernel (csa_set_fused); off by default: measured slower
                                  // than GEMM + recurrent kernel because W_ih is re-streamed from L2 per 8-level chunk
     // slots of device weight buffers that csa_set_params refreshes
@@ -203,7 +208,14 @@ extern "C" int csa_create(const csa_config *cfg, const csa_params *hp, int max_b
         h->H1 = U.alloc(L * Bm * cfg->nh1);
         h->H2 = U.alloc(L * Bm * cfg->nh2);
         h->hc0 = U.alloc(4 * Bm * nhm);
+        h->P2 = U.alloc(L * Bm * 4 * nhm);
+        h->cstate = U.alloc(Bm * nhm);
         rc = U.rc;
+        if (rc == CSA_OK) {
+            if (hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking) != hipSuccess) rc = CSA_ERR_HIP;
+            for (int i = 0; i < 12 && rc == CSA_OK; ++i)
+                if (hipEventCreateWithFlags(&h->ov_ev[i], hipEventDisableTiming) != hipSuccess) rc = CSA_ERR_HIP;
+        }
     }
     if (rc != CSA_OK) {
         free_all(h);
@@ -220,6 +232,8 @@ extern "C" int csa_destroy(csa_emulator *h)
     if (!h) return CSA_ERR_ARG;
     free_all(h);
     for (int i = 0; i < 7; ++i) if (h->ev[i]) (void)hipEventDestroy(h->ev[i]);
+    for (int i = 0; i < 12; ++i) if (h->ov_ev[i]) (void)hipEventDestroy(h->ov_ev[i]);
+    if (h->side) (void)hipStreamDestroy(h->side);
     delete h;
     return CSA_OK;
 }
@@ -227,9 +241,9 @@ extern "C" int csa_destroy(csa_emulator *h)
 extern "C" int csa_set_params(csa_emulator *h, const csa_params *hp)
 {
     if (!h || !hp || !params_complete(h->dm.cfg, hp)) { csa_set_error_msg("csa_set_params: bad argument"); return CSA_ERR_ARG; }
-    // Rebuild all parameter buffers; scratch (the last five allocations) is kept.
-    std::vector<void *> scratch(h->owned.end() - 5, h->owned.end());
-    h->owned.resize(h->owned.size() - 5);
+    // Rebuild all parameter buffers; scratch (the last seven allocations) is kept.
+    std::vector<void *> scratch(h->owned.end() - 7, h->owned.end());
+    h->owned.resize(h->owned.size() - 7);
     if (hipDeviceSynchronize() != hipSuccess) return CSA_ERR_HIP;
     free_all(h);
     int rc = upload_params(h, hp, false);
@@ -304,6 +318,70 @@ extern "C" const char *csa_stage_name(int i) { return (i >= 0 && i < 6) ? kStage
         if (h->profiling) CSA_HIP_CHECK(hipEventRecord(h->ev[i], s)); \
     } while (0)
 
+// Level-split overlap of the two LSTM layers (LSTM, nh = 128).  rnn1 runs as NS launches over
+// consecutive step ranges; on a side stream the projection GEMM of the NEXT piece (layer 1) and of the
+// levels the PREVIOUS piece has just produced (layer 2) run concurrently with the recurrence -- the
+// recurrent kernel occupies 2 of 3 wave slots worth of registers and none of the MFMA pipe, so the GEMM
+// workgroups co-reside on the same CUs.  Only launch-granular stream events are used (no in-kernel flags),
+// arithmetic and results are bit-identical to the sequential path.
+//   S: prep, GEMM1[0], rec1[0], (wait g1) rec1[1], ..., rec1[NS-1], GEMM2[NS-1], (wait T) rec2, head
+//   T: (wait prep) GEMM1[1..NS-1], then for i < NS-1: (wait rec1[i]) GEMM2[i]
+static int run_forward_overlap(csa_emulator *h, int B, int normalised, int mode,
+                               const float *x_main, const float *x_sfc, const float *mem_in,
+                               const float *hx2, const float *cx2, float *y0, float *y1, float *y2, hipStream_t S)
+{
+    const csa_config &c = h->dm.cfg;
+    const int L = c.nlev, nh = c.nh1, K1 = c.nh1 + c.nh_mem, NS = 3;
+    const size_t nhm = nh;
+    hipStream_t T = h->side;
+    int bnd[NS + 1];
+    for (int i = 0; i <= NS; ++i) bnd[i] = ((L * i / NS) + 1) & ~1;       // even piece boundaries
+    bnd[0] = 0; bnd[NS] = L;
+    hipEvent_t *ev = h->ov_ev;      // [0] prep done, [1..NS-1] g1[i], [4..4+NS-2] r1[i], [8] T done
+    int rc;
+    if ((rc = launch_prep(h->dm, B, normalised, x_main, x_sfc, mem_in, hx2, cx2, h->X1, h->hc0, S))) return rc;
+    CSA_HIP_CHECK(hipEventRecord(ev[0], S));
+    CSA_HIP_CHECK(hipStreamWaitEvent(T, ev[0], 0));
+    for (int i = 1; i < NS; ++i) {                               // T: layer-1 projection of the later pieces
+        const size_t r0 = (size_t)bnd[i] * B;
+        if ((rc = launch_proj_gemm(h->X1 + r0 * K1, h->dm.wih1, h->dm.bias1, h->P + r0 * 4 * nh, (bnd[i + 1] - bnd[i]) * B,
+                                   4 * nh, K1, T))) return rc;
+        CSA_HIP_CHECK(hipEventRecord(ev[i], T));
+    }
+    if ((rc = launch_proj_gemm(h->X1, h->dm.wih1, h->dm.bias1, h->P, bnd[1] * B, 4 * nh, K1, S))) return rc;
+    for (int i = 0; i < NS; ++i) {
+        if (i > 0) CSA_HIP_CHECK(hipStreamWaitEvent(S, ev[i], 0));
+        // state entering piece i: h of step bnd[i]-1 sits in H1 at level L - bnd[i]; c in cstate
+        const float *hin = i == 0 ? h->hc0 : h->H1 + (size_t)(L - bnd[i]) * B * nh;
+        const float *cin = i == 0 ? h->hc0 + (size_t)B * nhm : h->cstate;
+        if ((rc = launch_rec_range(nh, h->dm.whh1p, h->P, hin, cin, h->H1, B, L, /*reverse_out=*/1, bnd[i], bnd[i + 1],
+                                   i + 1 < NS ? h->cstate : nullptr, S))) return rc;
+        // levels produced by piece i: [L - bnd[i+1], L - bnd[i])
+        const size_t r0 = (size_t)(L - bnd[i + 1]) * B;
+        const int rows = (bnd[i + 1] - bnd[i]) * B;
+        if (i + 1 < NS) {
+            CSA_HIP_CHECK(hipEventRecord(ev[4 + i], S));
+            CSA_HIP_CHECK(hipStreamWaitEvent(T, ev[4 + i], 0));
+            if ((rc = launch_proj_gemm(h->H1 + r0 * nh, h->dm.wih2, h->dm.bias2, h->P2 + r0 * 4 * nh, rows, 4 * nh, nh, T))) return rc;
+        } else {
+            if ((rc = launch_proj_gemm(h->H1 + r0 * nh, h->dm.wih2, h->dm.bias2, h->P2 + r0 * 4 * nh, rows, 4 * nh, nh, S))) return rc;
+        }
+    }
+    CSA_HIP_CHECK(hipEventRecord(ev[8], T));
+    CSA_HIP_CHECK(hipStreamWaitEvent(S, ev[8], 0));
+    const float *h2 = c.legacy ? hx2 : h->hc0 + (size_t)2 * B * nhm;
+    const float *c2 = c.legacy ? cx2 : h->hc0 + (size_t)3 * B * nhm;
+    if ((rc = launch_rec(1, nh, h->dm.whh2p, nullptr, h->P2, h2, c2, h->H2, B, L, /*reverse_out=*/0, S))) return rc;
+    return launch_head(h->dm, B, mode, h->H2, x_main, y0, y1, y2, S);
+}
+
+extern "C" int csa_set_overlap(csa_emulator *h, int enable)
+{
+    if (!h) return CSA_ERR_ARG;
+    h->overlap = enable != 0;
+    return h->overlap ? 1 : 0;
+}
+
 static int run_forward(csa_emulator *h, int B, int normalised, int mode,
                        const float *x_main, const float *x_sfc, const float *mem_in,
                        const float *hx2, const float *cx2,
@@ -317,6 +395,8 @@ static int run_forward(csa_emulator *h, int B, int normalised, int mode,
     const int L = c.nlev;
     const size_t nhm = c.nh1 > c.nh2 ? c.nh1 : c.nh2;
     int rc;
+    if (h->overlap && !h->profiling && !h->fused && c.use_lstm && c.nh1 == 128 && c.nh2 == 128 && L >= 8)
+        return run_forward_overlap(h, B, normalised, mode, x_main, x_sfc, mem_in, hx2, cx2, y0, y1, y2, s);
     if (h->profiling) prof_collect(h);   // previous profiled call (host sync: profiling mode only)
     PROF_MARK(0);
     if ((rc = launch_prep(h->dm, B, normalised, x_main, x_sfc, mem_in, hx2, cx2, h->X1, h->hc0, s))) return rc;

@@ -217,8 +217,13 @@ template <int NH, bool TRAIN>
 __global__ __launch_bounds__(NH * 4, 2) void lstm_rec2_kernel(
     const f32x4 *__restrict__ Wp4, float *__restrict__ P,
     const float *__restrict__ h0, const float *__restrict__ c0, float *__restrict__ Hout,
-    int B, int L, int reverse_out, float *__restrict__ Hseq, float *__restrict__ Cseq)
+    int B, int L, int reverse_out, float *__restrict__ Hseq, float *__restrict__ Cseq,
+    int t_begin, int t_end, float *__restrict__ Cfin)
 {
+    // [t_begin, t_end) = the steps of this launch (t_begin even): a layer may be split into several
+    // launches so that the next layer's projection GEMM on the levels already produced runs concurrently
+    // on another stream (api.hip); h0/c0 then point at the state left by the previous piece and the
+    // final c_t goes to Cfin.
     constexpr int NT = NH * 4;
     constexpr int KC = NH / 4;
     constexpr int CH = 2 * KC + 4;      // floats per k-quarter, padded by one 16-B slot
@@ -263,7 +268,7 @@ __global__ __launch_bounds__(NH * 4, 2) void lstm_rec2_kernel(
     const float *Pb = P + (size_t)b * (4 * NH) + u * 4 + grp * 2;
     const size_t Pstep = (size_t)B * (4 * NH);
     const int rdoff = col * CPY + p * CH;
-    f32x2 preA = *(const f32x2 *)Pb, preB = preA;
+    f32x2 preA = *(const f32x2 *)(Pb + (size_t)t_begin * Pstep), preB = preA;
     __syncthreads();
 
     // P(t+1) is fetched with an asm global_load at the top of step t and first touched behind an
@@ -280,7 +285,7 @@ __global__ __launch_bounds__(NH * 4, 2) void lstm_rec2_kernel(
 #define LSTM2_STEP(T, CUR, NXT)                                                                    \
     {                                                                                              \
         const int t_ = (T);                                                                        \
-        if (t_ + 1 < L) {                                                                          \
+        if (t_ + 1 < t_end) {                                                                      \
             const float *pn = Pb + (size_t)(t_ + 1) * Pstep;                                       \
             asm volatile("global_load_dwordx2 %0, %1, off" : "=&v"(NXT) : "v"(pn) : "memory");     \
         }                                                                                          \
@@ -295,7 +300,7 @@ __global__ __launch_bounds__(NH * 4, 2) void lstm_rec2_kernel(
         STAMP(1, acc[0])                                                                           \
         float r[4];                                                                                \
         _Pragma("unroll") for (int s = 0; s < 4; ++s) r[s] = acc[s].x + dpp_xor1(acc[s].y);        \
-        if (t_ > 0) asm volatile("s_waitcnt vmcnt(1)" : "+v"(CUR));                                \
+        if (t_ > t_begin) asm volatile("s_waitcnt vmcnt(1)" : "+v"(CUR));                                \
         const float v0 = r[0] + dpp_xor2(r[2]) + CUR.x;                                            \
         const float v1 = r[1] + dpp_xor2(r[3]) + CUR.y;                                            \
         const float g0 = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504088896341f * v0)); \
@@ -338,10 +343,11 @@ __global__ __launch_bounds__(NH * 4, 2) void lstm_rec2_kernel(
 #define STAMP(K, DEP)
 #endif
 
-    for (int t = 0; t < L; t += 2) {
+    for (int t = t_begin; t < t_end; t += 2) {
         LSTM2_STEP(t, preA, preB)
-        if (t + 1 < L) LSTM2_STEP(t + 1, preB, preA)
+        if (t + 1 < t_end) LSTM2_STEP(t + 1, preB, preA)
     }
+    if (Cfin && owner && valid) Cfin[(size_t)b * NH + u] = c;
 #undef LSTM2_STEP
 #undef STAMP
 #ifdef REC_EXP_CLOCK
@@ -397,7 +403,7 @@ static int launch_rec_nh(int use_lstm, const float *whh, const float *bhn, const
     const dim3 grid((B + 1) / 2), block(NH * 4);
     if (use_lstm)
         hipLaunchKernelGGL((lstm_rec2_kernel<NH, false>), grid, block, 0, s, (const f32x4 *)whh, (float *)P, h0, c0, Hout,
-                           B, L, reverse_out, (float *)nullptr, (float *)nullptr);
+                           B, L, reverse_out, (float *)nullptr, (float *)nullptr, 0, L, (float *)nullptr);
     else
         hipLaunchKernelGGL((rec_kernel<NH, 3>), grid, block, 0, s, (const f32x4 *)whh, bhn, P, h0, c0, Hout, B, L,
                            reverse_out);
@@ -410,13 +416,24 @@ int launch_rec_train(int nh, const float *whh_packed, float *P, const float *h0,
 {
     const dim3 grid((B + 1) / 2), block(nh * 4);
     switch (nh) {
-    case 64:  hipLaunchKernelGGL((lstm_rec2_kernel<64, true>), grid, block, 0, s, (const f32x4 *)whh_packed, P, h0, c0, Hout, B, L, reverse_out, Hseq, Cseq); break;
-    case 96:  hipLaunchKernelGGL((lstm_rec2_kernel<96, true>), grid, block, 0, s, (const f32x4 *)whh_packed, P, h0, c0, Hout, B, L, reverse_out, Hseq, Cseq); break;
-    case 128: hipLaunchKernelGGL((lstm_rec2_kernel<128, true>), grid, block, 0, s, (const f32x4 *)whh_packed, P, h0, c0, Hout, B, L, reverse_out, Hseq, Cseq); break;
+    case 64:  hipLaunchKernelGGL((lstm_rec2_kernel<64, true>), grid, block, 0, s, (const f32x4 *)whh_packed, P, h0, c0, Hout, B, L, reverse_out, Hseq, Cseq, 0, L, (float *)nullptr); break;
+    case 96:  hipLaunchKernelGGL((lstm_rec2_kernel<96, true>), grid, block, 0, s, (const f32x4 *)whh_packed, P, h0, c0, Hout, B, L, reverse_out, Hseq, Cseq, 0, L, (float *)nullptr); break;
+    case 128: hipLaunchKernelGGL((lstm_rec2_kernel<128, true>), grid, block, 0, s, (const f32x4 *)whh_packed, P, h0, c0, Hout, B, L, reverse_out, Hseq, Cseq, 0, L, (float *)nullptr); break;
     default:
         csa_set_error_msg("rec(train): hidden size not supported (64, 96, 128)");
         return CSA_ERR_UNSUPPORTED;
     }
+    CSA_HIP_CHECK(hipGetLastError());
+    return CSA_OK;
+}
+
+// LSTM, steps [t0, t1) only (t0 even); final cell state to Cfin.  nh = 128 (the split path of api.hip).
+int launch_rec_range(int nh, const float *whh_packed, const float *P, const float *h0, const float *c0, float *Hout,
+                     int B, int L, int reverse_out, int t0, int t1, float *Cfin, hipStream_t s)
+{
+    if (nh != 128 || (t0 & 1)) { csa_set_error_msg("rec_range: nh = 128 and an even first step are required"); return CSA_ERR_UNSUPPORTED; }
+    hipLaunchKernelGGL((lstm_rec2_kernel<128, false>), dim3((B + 1) / 2), dim3(512), 0, s, (const f32x4 *)whh_packed,
+                       (float *)P, h0, c0, Hout, B, L, reverse_out, (float *)nullptr, (float *)nullptr, t0, t1, Cfin);
     CSA_HIP_CHECK(hipGetLastError());
     return CSA_OK;
 }

@@ -187,6 +187,10 @@ class Emulator:
         """Select the dual-pipe fused LSTM kernels (default) or the six-launch path; returns True if fused is active."""
         return bool(_lib.lib().csa_set_fused(self._h, int(bool(enable))))
 
+    def set_overlap(self, enable):
+        """Level-split overlap of projection GEMMs with the recurrence on a side stream (default on)."""
+        return bool(_lib.lib().csa_set_overlap(self._h, int(bool(enable))))
+
     def set_profiling(self, enable):
         self._rc(_lib.lib().csa_set_profiling(self._h, int(bool(enable))), "csa_set_profiling")
 

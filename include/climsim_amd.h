@@ -114,6 +114,11 @@ const char *csa_stage_name(int i);
  * 1 = dual-pipe fused LSTM layers (fused.hip; LSTM, nh = 128) -- parity-tested, currently slower
  * (DESIGN.md section 4.5).  Returns 1 if the fused path is in use. */
 int csa_set_fused(csa_emulator *h, int enable);
+/* 1 = level-split overlap: rnn1 runs in three launches and the projection GEMMs of the other pieces /
+ * of the next layer run concurrently on an internal side stream (same results, bit for bit);
+ * 0 (default) = strictly sequential six launches.  Measured on MI355X at 384 columns: 230 us vs 202 us
+ * (the cross-queue event waits cost more than the GEMM time they hide), so it is opt-in. */
+int csa_set_overlap(csa_emulator *h, int enable);
 
 /* ---- training step (e) ---------------------------------------------
  * Replaces, for the current-generation LSTM with memory (mp_mode 1):

@@ -236,3 +236,24 @@ def test_fused_and_unfused_paths_agree(memory):
     assert max(block_errors(y_f, yo).values()) <= 1e-5
     assert max(block_errors(y_u, yo).values()) <= 1e-5
     assert max(block_errors(y_f, y_u).values()) <= 1e-5
+
+
+def test_overlap_path_is_bit_identical_to_sequential(memory):
+    """The level-split overlap (rnn1 in three launches, GEMMs on a side stream) reorders launches only."""
+    consts, weights, model = memory
+    for B in (5, 384):
+        xm, xs = synth_inputs(consts, B, 777 + B)
+        g = np.random.Generator(np.random.PCG64(B))
+        mem = (0.3 * g.standard_normal((B, 60, 16))).astype(np.float32)
+        hx, cx = g.standard_normal((2, B, 128)).astype(np.float32)
+        args = (_dev(xm), _dev(xs), _dev(mem))
+        noise = (_dev(hx), _dev(cx))
+        try:
+            model.emulator.set_overlap(True)
+            ys = [model(*args, noise=noise).clone() for _ in range(3)]
+            model.emulator.set_overlap(False)
+            y_seq = model(*args, noise=noise)
+        finally:
+            model.emulator.set_overlap(False)
+        for y in ys:
+            assert torch.equal(y, y_seq)
