@@ -13,7 +13,7 @@ _F = ctypes.c_void_p   # device pointers travel as integers
 
 CONFIG_FIELDS = ["nlev", "nx", "nx_sfc", "ny", "ny_sfc", "nh1", "nh2", "nh_mem", "use_lstm", "legacy",
                  "output_prune", "mp_mode", "snowhice_fix", "qinput_prune", "rh_prune", "scrub_inf",
-                 "scrub_out_nan"]
+                 "scrub_out_nan", "q_input_mode"]
 PARAM_FIELDS = ["xmean_lev", "xdiv_lev", "xmean_sca", "xdiv_sca", "lbd_qc", "lbd_qi",
                 "yscale_lev", "yscale_sca", "hyam", "hybm",
                 "mlp_initial_w", "mlp_initial_b", "mlp_surface1_w", "mlp_surface1_b",
@@ -30,7 +30,8 @@ SYMBOLS = ["csa_create", "csa_destroy", "csa_set_params", "csa_packed_width", "c
            "csa_get_profile", "csa_stage_name", "csa_set_fused", "csa_set_overlap",
            "csa_train_create", "csa_train_destroy", "csa_train_num_params", "csa_train_num_tensors",
            "csa_train_param_info", "csa_train_params", "csa_train_sync_params", "csa_train_forward",
-           "csa_train_backward", "csa_train_loss", "csa_train_adam"]
+           "csa_train_backward", "csa_train_loss", "csa_train_adam",
+           "csa_mlp_create", "csa_mlp_destroy", "csa_mlp_forward"]
 
 
 class CsaConfig(ctypes.Structure):
@@ -89,6 +90,10 @@ def lib():
     L.csa_train_backward.argtypes = [H, i, i, _F, _F, _F, _F, _F, ctypes.c_void_p]
     L.csa_train_loss.argtypes = [H, i, i, f, f] + [_F] * 11 + [ctypes.c_void_p]
     L.csa_train_adam.argtypes = [H, _F, f, f, f, f, f, i, ctypes.c_void_p]
+    PP = ctypes.POINTER(ctypes.POINTER(ctypes.c_float))
+    L.csa_mlp_create.argtypes = [i, ctypes.POINTER(i), PP, PP, f, i, i, ctypes.POINTER(H)]
+    L.csa_mlp_destroy.argtypes = [H]
+    L.csa_mlp_forward.argtypes = [H, i, _F, _F, ctypes.c_void_p]
     L.csa_last_error.restype = ctypes.c_char_p
     L.csa_version.restype = ctypes.c_char_p
     _lib = L

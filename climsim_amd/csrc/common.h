@@ -61,6 +61,10 @@ int launch_prep(const DevModel &m, int B, int normalised, const float *x_main, c
 int launch_proj_gemm(const float *A, const float *W, const float *bias, float *C,
                      int M, int N, int K, hipStream_t s);
 
+// same GEMM with a fused activation epilogue (MLP baseline): act 0 none, 1 LeakyReLU(alpha), 2 split linear|ReLU head
+int launch_gemm_act(const float *A, const float *W, const float *bias, float *C, int M, int N, int K,
+                    int act, float alpha, int n_lin, hipStream_t s);
+
 // rec.hip: level-recurrent LSTM/GRU over L steps; P (L,B,G*nh) pre-activations in sequence
 // order, Hout (L,B,nh) written at level index (reverse ? L-1-t : t).
 int launch_rec(int use_lstm, int nh, const float *whh_packed, const float *bhn, const float *P,

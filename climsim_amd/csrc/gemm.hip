@@ -21,8 +21,10 @@
 
 __global__ __launch_bounds__(GB_THREADS) void proj_gemm_kernel(
     const float *__restrict__ A, const float *__restrict__ W, const float *__restrict__ bias,
-    float *__restrict__ C, int M, int N, int K, int tiles_m, int tiles_n)
+    float *__restrict__ C, int M, int N, int K, int tiles_m, int tiles_n, int act, float alpha, int n_lin)
 {
+    // act: 0 none; 1 LeakyReLU(alpha) on every column; 2 split head: columns < n_lin linear, the rest ReLU
+    // (the Keras MLP baseline's Dense(120,linear) || Dense(8,relu) output, step2_retrain.py:118-121)
     // double-buffered LDS: chunk c+1 is written while chunk c is being multiplied -> one barrier
     // per 16-deep K chunk (8 k-steps x 4 MFMA = 2048 MFMA cycles per wave between barriers)
     __shared__ float As[2][GB_M * GB_LD];
@@ -107,7 +109,12 @@ __global__ __launch_bounds__(GB_THREADS) void proj_gemm_kernel(
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] += bv[j];
+            for (int r = 0; r < 16; ++r) {
+                float v = acc[i][j][r] + bv[j];
+                if (act == 1) v = v > 0.0f ? v : alpha * v;
+                else if (act == 2 && n0 + wn * 64 + j * 32 + (lane & 31) >= n_lin) v = fmaxf(v, 0.0f);
+                acc[i][j][r] = v;
+            }
     const bool interior = (m0 + GB_M <= M) && (n0 + GB_N <= N);
     if (interior) {
 #pragma unroll
@@ -137,13 +144,19 @@ __global__ __launch_bounds__(GB_THREADS) void proj_gemm_kernel(
 int launch_proj_gemm(const float *A, const float *W, const float *bias, float *C,
                      int M, int N, int K, hipStream_t s)
 {
+    return launch_gemm_act(A, W, bias, C, M, N, K, 0, 0.0f, 0, s);
+}
+
+int launch_gemm_act(const float *A, const float *W, const float *bias, float *C, int M, int N, int K,
+                    int act, float alpha, int n_lin, hipStream_t s)
+{
     if (K % 4 != 0) {
         csa_set_error_msg("proj_gemm: K must be a multiple of 4");
         return CSA_ERR_UNSUPPORTED;
     }
     const int tiles_m = (M + GB_M - 1) / GB_M, tiles_n = (N + GB_N - 1) / GB_N;
     hipLaunchKernelGGL(proj_gemm_kernel, dim3(tiles_m * tiles_n), dim3(GB_THREADS), 0, s, A, W, bias, C, M, N, K,
-                       tiles_m, tiles_n);
+                       tiles_m, tiles_n, act, alpha, n_lin);
     CSA_HIP_CHECK(hipGetLastError());
     return CSA_OK;
 }

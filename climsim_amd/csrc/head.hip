@@ -111,7 +111,7 @@ __global__ __launch_bounds__(HEAD_THREADS) void head_kernel(
             }
         } else if (post) {
             const float *ys = m.yscale_lev + l * ny;
-            const float *xr = x_raw + ((size_t)b * L + l) * nx;
+            const float *xr = x_raw + ((size_t)b * L + l) * (nx - (m.cfg.q_input_mode == 1));
             const float dT = o[0] / ys[0], dqv = o[1] / ys[1], dqn = o[2] / ys[2];
             const float du = o[3] / ys[3], dv = o[4] / ys[4];
             const float T_old = xr[0], ql = xr[2], qi = xr[3];

@@ -25,6 +25,37 @@ __device__ __forceinline__ float prep_tanh(float x)
     return (1.0f - t) * __builtin_amdgcn_rcpf(1.0f + t);
 }
 
+// Specific humidity from relative humidity (rnn/utils.py:134-180, relative_to_specific_humidity_torch):
+// 8th-order Horner polynomials for the saturation vapour pressure over liquid / ice, blended by
+// omega = clamp((T-253.16)/20, 0, 1); q = rh * Rd*esat / (Rv*p).
+__device__ __forceinline__ float prep_polyval9(const float *a, float x)
+{
+    float o = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) o = o * x + a[i];
+    return o;
+}
+__device__ float prep_rh_to_q(float rh, float T, float p)
+{
+    const float a_liq[9] = {-0.976195544e-15f, -0.952447341e-13f, 0.640689451e-10f, 0.206739458e-7f, 0.302950461e-5f,
+                            0.264847430e-3f, 0.142986287e-1f, 0.443987641f, 6.11239921f};
+    const float a_ice[9] = {0.252751365e-14f, 0.146898966e-11f, 0.385852041e-9f, 0.602588177e-7f, 0.615021634e-5f,
+                            0.420895665e-3f, 0.188439774e-1f, 0.503160820f, 6.11147274f};
+    const float T0 = 273.16f;
+    const float eliq = 100.0f * prep_polyval9(a_liq, fmaxf(T - T0, -80.0f));
+    float eice;
+    if (T > 273.15f) eice = eliq;
+    else if (T > 185.0f) eice = 100.0f * prep_polyval9(a_ice, T - T0);
+    else {
+        const float tmp = fmaxf(T - T0, -100.0f);
+        eice = 100.0f * (0.00763685f + tmp * (0.000151069f + tmp * 7.48215e-07f));
+    }
+    float omega = (T - 253.16f) / 20.0f;
+    omega = fminf(fmaxf(omega, 0.0f), 1.0f);
+    const float esat = omega * eliq + (1.0f - omega) * eice;
+    return rh * ((287.0f * esat) / (461.0f * p));
+}
+
 // NXP = nx+1 padded to a multiple of 4 (16 for the v4 inputs): the level rows sit in LDS with that
 // stride so the mlp_initial dot product reads them as float4 broadcasts with no predication.
 template <int NXP>
@@ -58,7 +89,13 @@ __global__ __launch_bounds__(PREP_THREADS) void prep_kernel(
     // ---- level inputs of the slice ------------------------------------------------------------
     for (int idx = tid; idx < nl * nx; idx += PREP_THREADS) {
         const int ll = idx / nx, v = idx - ll * nx, l = l0 + ll, gi = l * nx + v;
-        float x = x_main[(size_t)b * L * nx + gi];
+        const int qmode = normalised ? 0 : m.cfg.q_input_mode, nxr = nx - (qmode == 1);
+        const float *xrow = x_main + ((size_t)b * L + l) * nxr;
+        float x = v < nxr ? xrow[v] : 0.0f;
+        if ((qmode == 1 && v == nxr) || (qmode == 2 && v == 1)) {
+            const float pres = m.hyam[l] * 100000.0f + x_sfc[(size_t)b * nxs] * m.hybm[l];   // RAW surface pressure
+            x = prep_rh_to_q(xrow[1], xrow[0], pres);
+        }
         if (!normalised) {
             if (v == 2) x = 1.0f - expf(-x * m.lbd_qc[l]);
             if (v == 3) x = 1.0f - expf(-x * m.lbd_qi[l]);

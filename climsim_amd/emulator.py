@@ -54,7 +54,7 @@ def _ptr(t):
 class Emulator:
     def __init__(self, consts, state_dict, *, legacy, use_lstm=True, mp_mode=1, output_prune=False,
                  snowhice_fix=False, qinput_prune=False, rh_prune=False, scrub_inf=False,
-                 scrub_out_nan=False, max_batch=4096, device=None):
+                 scrub_out_nan=False, q_input_mode=0, max_batch=4096, device=None):
         self._h = None
         L = _lib.lib()
         if not torch.cuda.is_available():
@@ -85,6 +85,7 @@ class Emulator:
         cfg.output_prune, cfg.mp_mode = int(output_prune), int(mp_mode)
         cfg.snowhice_fix, cfg.qinput_prune, cfg.rh_prune = int(snowhice_fix), int(qinput_prune), int(rh_prune)
         cfg.scrub_inf, cfg.scrub_out_nan = int(scrub_inf), int(scrub_out_nan)
+        cfg.q_input_mode = int(q_input_mode)
         self.cfg = cfg
         self.max_batch = int(max_batch)
         h = ctypes.c_void_p()
@@ -152,7 +153,7 @@ class Emulator:
     def forward_tuple(self, x_main, x_sfc, rnn1_mem):
         c = self.cfg
         B = x_main.shape[0]
-        x_main = _check(x_main, (B, c.nlev, c.nx), "x_main")
+        x_main = _check(x_main, (B, c.nlev, c.nx - (1 if c.q_input_mode == 1 else 0)), "x_main")
         x_sfc = _check(x_sfc, (B, c.nx_sfc), "x_sfc")
         rnn1_mem = _check(rnn1_mem, (c.nlev, B, c.nh_mem), "rnn1_mem")
         nyo = 6 if c.mp_mode != 0 else c.ny

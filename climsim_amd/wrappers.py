@@ -94,12 +94,17 @@ class model_wrapper(nn.Module):
     """
 
     def __init__(self, consts, state_dict, *, use_lstm=True, output_prune=False, mp_mode=1,
-                 qinput_prune=False, rh_prune=False, snowhice_fix=True, max_batch=4096):
+                 qinput_prune=False, rh_prune=False, snowhice_fix=True, rh_to_q=False, include_q_input=None,
+                 max_batch=4096):
         super().__init__()
+        nx = np.asarray(consts["xmean_lev"]).shape[1]
+        if include_q_input is None:          # rnn/utils.py:107-111: nx in [16, 21] means q was appended
+            include_q_input = nx in (16, 21)
+        q_mode = 1 if include_q_input else (2 if rh_to_q else 0)
         self.emulator = Emulator(consts, state_dict, legacy=False, use_lstm=use_lstm, mp_mode=mp_mode,
                                  output_prune=output_prune, snowhice_fix=snowhice_fix,
                                  qinput_prune=qinput_prune, rh_prune=rh_prune, scrub_inf=True,
-                                 max_batch=max_batch)
+                                 q_input_mode=q_mode, max_batch=max_batch)
         c = self.emulator.cfg
         self.nx, self.nmem, self.nlev_mem = c.nx, c.nh_mem, c.nlev
 

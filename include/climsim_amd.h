@@ -50,6 +50,9 @@ typedef struct {
     int32_t output_prune;    /* models.py:554-559 */
     int32_t mp_mode;         /* 1: liq/ice diagnosed from T; 0: none */
     int32_t snowhice_fix, qinput_prune, rh_prune, scrub_inf, scrub_out_nan;
+    int32_t q_input_mode;    /* rnn/utils.py:262-272: 0 none; 1 include_q_input: specific humidity from (RH,T,p) is
+                                appended as the LAST level input (nx counts it; raw x_main has nx-1 columns);
+                                2 rh_to_q: it replaces RH (input 1) */
 } csa_config;
 
 /* HOST pointers, PyTorch state_dict layout (out_features,in_features); copied by csa_create. */
@@ -153,6 +156,17 @@ int csa_train_loss(csa_trainer *h, int B, int Tw, float w_energy, float w_water,
                    float *scalars, float *d_pred, float *d_pred_sfc, void *stream);
 int csa_train_adam(csa_trainer *h, const float *grads, float lr, float beta1, float beta2, float eps,
                    float weight_decay, int step, void *stream);
+
+/* ---- offline MLP baseline ------------------------------------------------------
+ * baseline_models/MLP/training/HPO/baseline_v1/step2_retrain/step2_retrain.py:93-121: Dense stack with
+ * LeakyReLU(alpha) and a split Dense(n_lin, linear) || Dense(rest, relu) output.  weights[l] is (dims[l+1], dims[l])
+ * row-major (the transpose of the Keras kernel), HOST pointers; the two output Dense layers are stacked into one
+ * (n_lin + n_relu, dims[nlayers-1]) matrix. */
+typedef struct csa_mlp csa_mlp;
+int csa_mlp_create(int nlayers, const int *dims, const float *const *weights, const float *const *biases,
+                   float leaky_alpha, int n_lin_out, int max_batch, csa_mlp **out);
+int csa_mlp_destroy(csa_mlp *h);
+int csa_mlp_forward(csa_mlp *h, int B, const float *x, float *y, void *stream);
 
 const char *csa_last_error(void);
 const char *csa_version(void);

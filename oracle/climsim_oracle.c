@@ -202,16 +202,50 @@ int oracle_model_forward(const oracle_model *m, int B,
     return 0;
 }
 
+/* rnn/utils.py:134-180: saturation vapour pressure polynomials and RH -> specific humidity */
+static float polyval9(const float *a, float x)
+{
+    float o = 0.0f;
+    for (int i = 0; i < 9; ++i) o = o * x + a[i];
+    return o;
+}
+static float rh_to_q(float rh, float T, float p)
+{
+    static const float a_liq[9] = {-0.976195544e-15f, -0.952447341e-13f, 0.640689451e-10f, 0.206739458e-7f,
+                                   0.302950461e-5f, 0.264847430e-3f, 0.142986287e-1f, 0.443987641f, 6.11239921f};
+    static const float a_ice[9] = {0.252751365e-14f, 0.146898966e-11f, 0.385852041e-9f, 0.602588177e-7f,
+                                   0.615021634e-5f, 0.420895665e-3f, 0.188439774e-1f, 0.503160820f, 6.11147274f};
+    const float T0 = 273.16f;
+    float xl = T - T0; if (xl < -80.0f) xl = -80.0f;
+    const float eliq = 100.0f * polyval9(a_liq, xl);
+    float eice;
+    if (T > 273.15f) eice = eliq;
+    else if (T > 185.0f) eice = 100.0f * polyval9(a_ice, T - T0);
+    else {
+        float tmp = T - T0; if (tmp < -100.0f) tmp = -100.0f;
+        eice = 100.0f * (0.00763685f + tmp * (0.000151069f + tmp * 7.48215e-07f));
+    }
+    float omega = (T - 253.16f) / 20.0f;
+    omega = omega < 0.0f ? 0.0f : (omega > 1.0f ? 1.0f : omega);
+    const float esat = omega * eliq + (1.0f - omega) * eice;
+    return rh * ((287.0f * esat) / (461.0f * p));
+}
+
 int oracle_preprocess(const oracle_model *m, int B, const float *x_main, const float *x_sfc,
                       float *x_main_n, float *x_sfc_n)
 {
     const int L = m->nlev, nx = m->nx;
+    const int nxr = nx - (m->q_input_mode == 1);      /* columns of the raw input */
     for (int b = 0; b < B; ++b) {
         for (int l = 0; l < L; ++l) {
-            const float *xi = x_main + ((size_t)b * L + l) * nx;
+            const float *xi = x_main + ((size_t)b * L + l) * nxr;
             float *xo = x_main_n + ((size_t)b * L + l) * nx;
             for (int v = 0; v < nx; ++v) {
-                float x = xi[v];
+                float x = v < nxr ? xi[v] : 0.0f;
+                if ((m->q_input_mode == 1 && v == nxr) || (m->q_input_mode == 2 && v == 1)) {
+                    const float pres = m->hyam[l] * 100000.0f + x_sfc[(size_t)b * m->nx_sfc] * m->hybm[l];
+                    x = rh_to_q(xi[1], xi[0], pres);
+                }
                 if (v == 2) x = 1.0f - expf(-x * m->lbd_qc[l]);
                 if (v == 3) x = 1.0f - expf(-x * m->lbd_qi[l]);
                 x = (x - m->xmean_lev[l * nx + v]) / m->xdiv_lev[l * nx + v];
@@ -302,6 +336,7 @@ int oracle_wrapper_forward_tuple(const oracle_model *m, int B,
 {
     const int L = m->nlev, nx = m->nx, ny = m->ny;
     if (m->legacy) return -6;
+    const int nxr = nx - (m->q_input_mode == 1);
     float *xn = (float *)malloc(sizeof(float) * (size_t)B * L * nx);
     float *xsn = (float *)malloc(sizeof(float) * (size_t)B * m->nx_sfc);
     float *out = (float *)malloc(sizeof(float) * (size_t)B * L * ny);
@@ -318,7 +353,7 @@ int oracle_wrapper_forward_tuple(const oracle_model *m, int B,
                 for (int l = 0; l < L; ++l) {
                     const float *o = out + ((size_t)b * L + l) * ny;
                     const float *ys = m->yscale_lev + (size_t)l * ny;
-                    const float *xr = x_main + ((size_t)b * L + l) * nx;
+                    const float *xr = x_main + ((size_t)b * L + l) * nxr;
                     float *y = out_lev + ((size_t)b * L + l) * 6;
                     const float dT = o[0] / ys[0], dqn = o[2] / ys[2];
                     float dql, dqi;

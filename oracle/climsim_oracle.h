@@ -45,6 +45,7 @@ typedef struct {
     int rh_prune;       /* clamp x[:,:,1] to [0,1.2] */
     int scrub_inf;      /* Inf -> 0 after normalisation (current wrappers); legacy artefacts only scrub NaN */
     int scrub_out_nan;  /* NaN -> 0 on the packed output (save_wrapper_mem.py:539) */
+    int q_input_mode;   /* rnn/utils.py:262-272: 0 none, 1 append q from (RH,T,p) as last input, 2 replace RH by q */
     /* constants */
     const float *xmean_lev, *xdiv_lev;   /* (nlev,nx) */
     const float *xmean_sca, *xdiv_sca;   /* (nx_sfc) */

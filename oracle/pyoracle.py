@@ -16,7 +16,7 @@ _F = ctypes.POINTER(ctypes.c_float)
 
 _INT_FIELDS = ["nlev", "nx", "nx_sfc", "ny", "ny_sfc", "nh1", "nh2", "nh_mem",
                "use_lstm", "legacy", "output_prune", "mp_mode", "snowhice_fix",
-               "qinput_prune", "rh_prune", "scrub_inf", "scrub_out_nan"]
+               "qinput_prune", "rh_prune", "scrub_inf", "scrub_out_nan", "q_input_mode"]
 _CONST_FIELDS = ["xmean_lev", "xdiv_lev", "xmean_sca", "xdiv_sca", "lbd_qc", "lbd_qi",
                  "yscale_lev", "yscale_sca", "hyam", "hybm"]
 _W_FIELDS = ["mlp_initial_w", "mlp_initial_b", "mlp_surface1_w", "mlp_surface1_b",
@@ -89,7 +89,7 @@ class OracleModel:
 
     def __init__(self, consts, weights, *, legacy, use_lstm=True, nh_mem=None, mp_mode=1,
                  output_prune=False, snowhice_fix=False, qinput_prune=False, rh_prune=False,
-                 scrub_inf=False, scrub_out_nan=False):
+                 scrub_inf=False, scrub_out_nan=False, q_input_mode=0):
         self._keep = {}
         cm = _CModel()
         for k in _CONST_FIELDS:
@@ -121,6 +121,7 @@ class OracleModel:
         cm.rh_prune = int(rh_prune)
         cm.scrub_inf = int(scrub_inf)
         cm.scrub_out_nan = int(scrub_out_nan)
+        cm.q_input_mode = int(q_input_mode)
         self.cm = cm
 
     @classmethod
@@ -161,7 +162,7 @@ class OracleModel:
     def preprocess(self, x_main, x_sfc):
         B = x_main.shape[0]
         x_main, x_sfc = _c(x_main), _c(x_sfc)
-        xn = np.empty_like(x_main)
+        xn = np.empty((B, self.cm.nlev, self.cm.nx), np.float32)
         xs = np.empty_like(x_sfc)
         lib().oracle_preprocess(ctypes.byref(self.cm), B, _ptr(x_main), _ptr(x_sfc), _ptr(xn), _ptr(xs))
         return xn, xs

@@ -20,8 +20,9 @@ import torch.nn.functional as F
 class EmulatorRef(nn.Module):
     def __init__(self, consts, weights, *, legacy, use_lstm=True, mp_mode=1, output_prune=False,
                  snowhice_fix=False, qinput_prune=False, rh_prune=False, scrub_inf=False,
-                 scrub_out_nan=False, dtype=torch.float32):
+                 scrub_out_nan=False, q_input_mode=0, dtype=torch.float32):
         super().__init__()
+        self.q_input_mode = q_input_mode
         self.legacy, self.use_lstm, self.mp_mode = legacy, use_lstm, mp_mode
         self.output_prune, self.snowhice_fix = output_prune, snowhice_fix
         self.qinput_prune, self.rh_prune = qinput_prune, rh_prune
@@ -133,6 +134,40 @@ class EmulatorRef(nn.Module):
             x_main = torch.where(torch.isinf(x_main), torch.zeros((), dtype=x_main.dtype), x_main)
         return x_main, x_sfc
 
+    # ---- RH -> q (rnn/utils.py:134-180, 262-272) ------------------------------------------------------
+    @staticmethod
+    def _polyval(coeffs, x):
+        out = torch.zeros_like(x)
+        for c in coeffs:
+            out = out * x + c
+        return out
+
+    def rh_to_q(self, rh, temp, pressure):
+        a_liq = [-0.976195544e-15, -0.952447341e-13, 0.640689451e-10, 0.206739458e-7, 0.302950461e-5,
+                 0.264847430e-3, 0.142986287e-1, 0.443987641, 6.11239921]
+        a_ice = [0.252751365e-14, 0.146898966e-11, 0.385852041e-9, 0.602588177e-7, 0.615021634e-5,
+                 0.420895665e-3, 0.188439774e-1, 0.503160820, 6.11147274]
+        T0, T00 = 273.16, 253.16
+        eliq = 100.0 * self._polyval(a_liq, torch.clamp(temp - T0, min=-80.0))
+        b2 = 100.0 * self._polyval(a_ice, temp - T0)
+        tmp = torch.clamp(temp - T0, min=-100.0)
+        b3 = 100.0 * (0.00763685 + tmp * (0.000151069 + tmp * 7.48215e-07))
+        eice = torch.where(temp > 273.15, eliq, torch.where(temp > 185.0, b2, b3))
+        omega = torch.clamp((temp - T00) / (T0 - T00), min=0.0, max=1.0)
+        esat = omega * eliq + (1.0 - omega) * eice
+        return rh * ((287.0 * esat) / (461.0 * pressure))
+
+    def apply_q_input(self, x_main0, x_sfc0):
+        if self.q_input_mode == 0:
+            return x_main0
+        pres = self.hyam * 100000.0 + x_sfc0[:, 0:1] * self.hybm
+        q = self.rh_to_q(x_main0[:, :, 1], x_main0[:, :, 0], pres)
+        if self.q_input_mode == 1:
+            return torch.cat((x_main0, q.unsqueeze(2)), dim=2)
+        x = x_main0.clone()
+        x[:, :, 1] = q
+        return x
+
     def postprocess(self, out, out_sfc, x_raw):
         """models.py:273-339 (mp_mode 0 returns UN-denormalised outputs; mp_mode 1 -> 6 vars)."""
         if self.mp_mode == 0:
@@ -162,7 +197,8 @@ class EmulatorRef(nn.Module):
         return y
 
     def wrapper_forward_tuple(self, x_main, x_sfc, mem_in):
-        """rnn/utils.py:260-295 (forward_base, include_q_input False)."""
+        """rnn/utils.py:260-295 (forward_base)."""
+        x_main = self.apply_q_input(x_main, x_sfc)
         xn, xs = self.preprocess(x_main, x_sfc)
         out, out_sfc, mem_out = self.model_forward(xn, xs, mem_in)
         o, os_ = self.postprocess(out, out_sfc, x_main)
@@ -215,3 +251,19 @@ def window_loss(ref, preds, preds_sfc, tgt, tgt_sfc, yto, yto_sfc, x_raw, x_sfc_
     precip = torch.mean(torch.square(pt - pp)) / (Tw ** 2)
     loss = huber + w_energy * e_mse + w_water * w_mse
     return loss, dict(loss=loss, huber=huber, mse=mse, mae=mae, energy=e_mse, water=w_mse, precip_sum_mse=precip)
+
+
+# ---- Keras MLP baseline restated in torch (TEST INFRASTRUCTURE) ---------------------------------------
+def mlp_ref(x, weights, biases, leaky_alpha=0.15, n_lin_out=120):
+    """baseline_models/MLP/.../step2_retrain.py:93-121: Dense+LeakyReLU(0.15) stack, Dense(128)+LeakyReLU,
+    then Dense(120,linear) || Dense(8,relu).  weights[l]: (out,in) = transposed Keras kernels; the last entry
+    stacks the two output layers.  No reference weights/outputs exist in the repository (TF absent, .h5 in
+    .MISSING_LARGE_BLOBS): parity of this baseline is UNPINNED by reference artefacts."""
+    h = x
+    for l, (W, b) in enumerate(zip(weights, biases)):
+        h = F.linear(h, W, b)
+        if l + 1 < len(weights):
+            h = F.leaky_relu(h, leaky_alpha)
+        else:
+            h = torch.cat((h[:, :n_lin_out], F.relu(h[:, n_lin_out:])), dim=1)
+    return h
