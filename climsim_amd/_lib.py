@@ -31,7 +31,9 @@ SYMBOLS = ["csa_create", "csa_destroy", "csa_set_params", "csa_packed_width", "c
            "csa_train_create", "csa_train_destroy", "csa_train_num_params", "csa_train_num_tensors",
            "csa_train_param_info", "csa_train_params", "csa_train_sync_params", "csa_train_forward",
            "csa_train_backward", "csa_train_loss", "csa_train_adam",
-           "csa_mlp_create", "csa_mlp_destroy", "csa_mlp_forward"]
+           "csa_mlp_create", "csa_mlp_destroy", "csa_mlp_forward",
+           "csa_stoch_gru5_create", "csa_stoch_lstm4_create", "csa_stoch_destroy", "csa_stoch_gru5_forward",
+           "csa_stoch_lstm4_forward"]
 
 
 class CsaConfig(ctypes.Structure):
@@ -94,6 +96,11 @@ def lib():
     L.csa_mlp_create.argtypes = [i, ctypes.POINTER(i), PP, PP, f, i, i, ctypes.POINTER(H)]
     L.csa_mlp_destroy.argtypes = [H]
     L.csa_mlp_forward.argtypes = [H, i, _F, _F, ctypes.c_void_p]
+    L.csa_stoch_gru5_create.argtypes = [i, i, Fp, Fp, Fp, Fp, Fp, i, ctypes.POINTER(H)]
+    L.csa_stoch_lstm4_create.argtypes = [i, i, Fp, i, ctypes.POINTER(H)]
+    L.csa_stoch_destroy.argtypes = [H]
+    L.csa_stoch_gru5_forward.argtypes = [H, i, i, _F, _F, _F, _F, ctypes.c_void_p]
+    L.csa_stoch_lstm4_forward.argtypes = [H, i, i, _F, _F, _F, _F, _F, _F, _F, ctypes.c_void_p]
     L.csa_last_error.restype = ctypes.c_char_p
     L.csa_version.restype = ctypes.c_char_p
     _lib = L

@@ -168,6 +168,22 @@ int csa_mlp_create(int nlayers, const int *dims, const float *const *weights, co
 int csa_mlp_destroy(csa_mlp *h);
 int csa_mlp_forward(csa_mlp *h, int B, const float *x, float *y, void *stream);
 
+/* ---- stochastic recurrent layers ---------------------------------------------------
+ * MyStochasticGRULayer5  rnn/models_torch_kernels.py:834-891 (its GPU path = the repo's inline CUDA, :29-252)
+ * MyStochasticLSTMLayer4 rnn/models_torch_kernels.py:1474-1531
+ * Weights are HOST pointers in the reference's (in_features, out_features) layout; x is (T,B,nx) sequence-first,
+ * eps (T,B,H) is the N(0,1) draw the reference makes at the top of forward, passed explicitly.  max_rows >= T*B. */
+typedef struct csa_stoch csa_stoch;
+int csa_stoch_gru5_create(int nx, int nh, const float *weight_ih, const float *weight_zh, const float *weight_encoder,
+                          const float *bias_ih /* nullable */, const float *bias_zh /* nullable */, int max_rows,
+                          csa_stoch **out);
+int csa_stoch_lstm4_create(int nx, int nh, const float *weight_encoder, int max_rows, csa_stoch **out);
+int csa_stoch_destroy(csa_stoch *h);
+int csa_stoch_gru5_forward(csa_stoch *h, int T, int B, const float *x, const float *h0, const float *eps,
+                           float *out, void *stream);
+int csa_stoch_lstm4_forward(csa_stoch *h, int T, int B, const float *x, const float *h0, const float *c0,
+                            const float *eps, float *out, float *hT, float *cT, void *stream);
+
 const char *csa_last_error(void);
 const char *csa_version(void);
 

@@ -267,3 +267,41 @@ def mlp_ref(x, weights, biases, leaky_alpha=0.15, n_lin_out=120):
         else:
             h = torch.cat((h[:, :n_lin_out], F.relu(h[:, n_lin_out:])), dim=1)
     return h
+
+
+# ---- stochastic recurrent layers (TEST INFRASTRUCTURE) ------------------------------------------------
+def stoch_gru5_ref(x, h, eps, weight_ih, weight_zh, weight_encoder, bias_ih=None, bias_zh=None):
+    """rnn/models_torch_kernels.py:834-891 (MyStochasticGRULayer5, CPU branch) with explicit eps (T,B,H)."""
+    T, B, nx = x.shape
+    H = h.shape[1]
+    xr = x.reshape(T * B, nx) @ weight_ih
+    if bias_ih is not None:
+        xr = xr + bias_ih
+    r_all, zg_all, n_all = xr.view(T, B, 3 * H).chunk(3, dim=2)
+    outs = []
+    for t in range(T):
+        mean_, logvar = (h @ weight_encoder).chunk(2, 1)
+        z = mean_ + eps[t] * torch.exp(0.5 * logvar)
+        zr = z @ weight_zh
+        if bias_zh is not None:
+            zr = zr + bias_zh
+        z_r, z_z, z_n = zr.chunk(3, 1)
+        r = torch.sigmoid(r_all[t] + z_r)
+        zg = torch.sigmoid(zg_all[t] + z_z)
+        n = torch.tanh(n_all[t] + r * z_n)
+        h = n + zg * (h - n)
+        outs.append(h)
+    return torch.stack(outs)
+
+
+def stoch_lstm4_ref(x, h, c, eps, weight_encoder):
+    """rnn/models_torch_kernels.py:1474-1531 (MyStochasticLSTMLayer4) with explicit eps (T,B,H)."""
+    outs = []
+    for t in range(x.shape[0]):
+        yy = torch.cat((x[t], h), dim=1) @ weight_encoder
+        mean_, logvar_, i, f, g = yy.chunk(5, 1)
+        o = torch.sigmoid(mean_ + eps[t] * torch.exp(0.5 * logvar_))
+        c = torch.sigmoid(f) * c + torch.sigmoid(i) * torch.tanh(g)
+        h = o * torch.tanh(c)
+        outs.append(h)
+    return torch.stack(outs), (h, c)
