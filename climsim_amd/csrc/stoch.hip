@@ -25,6 +25,14 @@ __device__ __forceinline__ float sq_sum(float v)
     v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));
     return v;
 }
+// Quad sum of BOTH column components, then pick this lane's column.  Never write
+// `col ? sq_sum(a.y) : sq_sum(a.x)`: C++ evaluates only the selected operand, the divergent condition becomes
+// control flow, and the DPP adds then run with half the quad masked off (they read 0 from inactive lanes).
+__device__ __forceinline__ float sq_pick(f32x2 a, int col)
+{
+    const float sx = sq_sum(a.x), sy = sq_sum(a.y);
+    return col ? sy : sx;
+}
 __device__ __forceinline__ float s_sigmoid(float x)
 {
     return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504088896341f * x));
@@ -100,17 +108,17 @@ __global__ __launch_bounds__(NH * 4, 2) void stoch_gru5_kernel(
         // phase A: (mean, logvar) = h W_enc
         f32x2 a2[2] = {{0.f, 0.f}, {0.f, 0.f}};
         quarter_matvec<2, KC>(we, hbuf + p * CH, a2);
-        const float mean = col ? sq_sum(a2[0].y) : sq_sum(a2[0].x);
-        const float logv = col ? sq_sum(a2[1].y) : sq_sum(a2[1].x);
+        const float mean = sq_pick(a2[0], col);
+        const float logv = sq_pick(a2[1], col);
         const float z = mean + e * s_exp(0.5f * logv);
         if (p < 2) zbuf[slot] = z;
         LDS_BARRIER();
         // phase B: (z_r, z_z, z_n) = z W_zh (+ b_zh)
         f32x2 a3[3] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
         quarter_matvec<3, KC>(wz, zbuf + p * CH, a3);
-        const float z_r = (col ? sq_sum(a3[0].y) : sq_sum(a3[0].x)) + bz[0];
-        const float z_z = (col ? sq_sum(a3[1].y) : sq_sum(a3[1].x)) + bz[1];
-        const float z_n = (col ? sq_sum(a3[2].y) : sq_sum(a3[2].x)) + bz[2];
+        const float z_r = sq_pick(a3[0], col) + bz[0];
+        const float z_z = sq_pick(a3[1], col) + bz[1];
+        const float z_n = sq_pick(a3[2], col) + bz[2];
         const float r = s_sigmoid(xr + z_r);
         const float zg = s_sigmoid(xz + z_z);
         const float n = s_tanh(xn + r * z_n);
@@ -155,7 +163,7 @@ __global__ __launch_bounds__(NH * 4, 2) void stoch_lstm4_kernel(
         quarter_matvec<5, KC>(w, hbuf[t & 1] + p * CH, a);
         float s[5];
 #pragma unroll
-        for (int g = 0; g < 5; ++g) s[g] = (col ? sq_sum(a[g].y) : sq_sum(a[g].x)) + xp[g];
+        for (int g = 0; g < 5; ++g) s[g] = sq_pick(a[g], col) + xp[g];
         const float o = s_sigmoid(s[0] + e * s_exp(0.5f * s[1]));
         c = s_sigmoid(s[3]) * c + s_sigmoid(s[2]) * s_tanh(s[4]);
         h = o * s_tanh(c);
