@@ -32,6 +32,7 @@ SYMBOLS = ["csa_create", "csa_destroy", "csa_set_params", "csa_packed_width", "c
            "csa_train_param_info", "csa_train_params", "csa_train_sync_params", "csa_train_forward",
            "csa_train_backward", "csa_train_loss", "csa_train_adam",
            "csa_mlp_create", "csa_mlp_destroy", "csa_mlp_forward",
+           "csa_cnn_create", "csa_cnn_destroy", "csa_cnn_forward",
            "csa_stoch_gru5_create", "csa_stoch_lstm4_create", "csa_stoch_destroy", "csa_stoch_gru5_forward",
            "csa_stoch_lstm4_forward"]
 
@@ -96,6 +97,9 @@ def lib():
     L.csa_mlp_create.argtypes = [i, ctypes.POINTER(i), PP, PP, f, i, i, ctypes.POINTER(H)]
     L.csa_mlp_destroy.argtypes = [H]
     L.csa_mlp_forward.argtypes = [H, i, _F, _F, ctypes.c_void_p]
+    L.csa_cnn_create.argtypes = [i, i, i, i, i, i, PP, PP, i, ctypes.POINTER(H)]
+    L.csa_cnn_destroy.argtypes = [H]
+    L.csa_cnn_forward.argtypes = [H, i, _F, _F, ctypes.c_void_p]
     L.csa_stoch_gru5_create.argtypes = [i, i, Fp, Fp, Fp, Fp, Fp, i, ctypes.POINTER(H)]
     L.csa_stoch_lstm4_create.argtypes = [i, i, Fp, i, ctypes.POINTER(H)]
     L.csa_stoch_destroy.argtypes = [H]

@@ -65,6 +65,10 @@ int launch_proj_gemm(const float *A, const float *W, const float *bias, float *C
 int launch_gemm_act(const float *A, const float *W, const float *bias, float *C, int M, int N, int K,
                     int act, float alpha, int n_lin, hipStream_t s);
 
+// general form: leading dimensions, implicit-GEMM conv1d(k=3,'same') over (column, level) rows, C += mode, ELU
+int launch_gemm_ex(const float *A, const float *W, const float *bias, float *C, int M, int N, int K, int act, float alpha,
+                   int n_lin, int lda, int ldc, int conv_L, int conv_cin, int accumulate, hipStream_t s);
+
 // rec.hip: level-recurrent LSTM/GRU over L steps; P (L,B,G*nh) pre-activations in sequence
 // order, Hout (L,B,nh) written at level index (reverse ? L-1-t : t).
 int launch_rec(int use_lstm, int nh, const float *whh_packed, const float *bhn, const float *P,

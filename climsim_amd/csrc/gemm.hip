@@ -21,8 +21,16 @@
 
 __global__ __launch_bounds__(GB_THREADS) void proj_gemm_kernel(
     const float *__restrict__ A, const float *__restrict__ W, const float *__restrict__ bias,
-    float *__restrict__ C, int M, int N, int K, int tiles_m, int tiles_n, int act, float alpha, int n_lin)
+    float *__restrict__ C, int M, int N, int K, int tiles_m, int tiles_n, int act, float alpha, int n_lin,
+    int lda, int ldc, int conv_L, int conv_cin, int accumulate)
 {
+    // lda / ldc: leading dimensions of A and C (K and N for a plain GEMM).
+    // conv_L > 0: implicit-GEMM 1-D convolution, kernel 3, 'same' padding, over rows = (column, level) with
+    //   conv_L levels per column: A row r is the 3*cin contiguous floats [x(l-1), x(l), x(l+1)] starting at
+    //   A + (r-1)*lda (lda = cin), with the first / last third masked to zero on the first / last level
+    //   (baseline_models/CNN/training/hpo_train.py:165-177, Conv1D(..., padding="same")).
+    // accumulate: C += result (the 1x1 residual projection added onto the block output, :180-184).
+    // act 3: ELU (the pre-output Conv1D(10, 1, activation="elu"), :189-194).
     // act: 0 none; 1 LeakyReLU(alpha) on every column; 2 split head: columns < n_lin linear, the rest ReLU
     // (the Keras MLP baseline's Dense(120,linear) || Dense(8,relu) output, step2_retrain.py:118-121)
     // double-buffered LDS: chunk c+1 is written while chunk c is being multiplied -> one barrier
@@ -48,7 +56,13 @@ __global__ __launch_bounds__(GB_THREADS) void proj_gemm_kernel(
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int row = m0 + lr + 64 * i, col = n0 + lr + 64 * i, k = k0 + kq;
-            ra[i] = (row < M && k < K) ? *(const f32x4 *)(A + (size_t)row * K + k) : f32x4{0, 0, 0, 0};
+            bool ok = row < M && k < K;
+            if (conv_L > 0 && ok) {
+                const int l = row % conv_L;
+                ok = !((l == 0 && k < conv_cin) || (l == conv_L - 1 && k >= 2 * conv_cin));
+            }
+            const float *ap = conv_L > 0 ? A + ((long)row - 1) * lda + k : A + (size_t)row * lda + k;
+            ra[i] = ok ? *(const f32x4 *)ap : f32x4{0, 0, 0, 0};
             rw[i] = (col < N && k < K) ? *(const f32x4 *)(W + (size_t)col * K + k) : f32x4{0, 0, 0, 0};
         }
     };
@@ -113,18 +127,19 @@ __global__ __launch_bounds__(GB_THREADS) void proj_gemm_kernel(
                 float v = acc[i][j][r] + bv[j];
                 if (act == 1) v = v > 0.0f ? v : alpha * v;
                 else if (act == 2 && n0 + wn * 64 + j * 32 + (lane & 31) >= n_lin) v = fmaxf(v, 0.0f);
+                else if (act == 3) v = v > 0.0f ? v : expm1f(v);
                 acc[i][j][r] = v;
             }
-    const bool interior = (m0 + GB_M <= M) && (n0 + GB_N <= N);
+    const bool interior = (m0 + GB_M <= M) && (n0 + GB_N <= N) && !accumulate;
     if (interior) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            float *cp = C + (size_t)(m0 + wm * 64 + 4 * (lane >> 5)) * N + n0 + wn * 64 + j * 32 + (lane & 31);
+            float *cp = C + (size_t)(m0 + wm * 64 + 4 * (lane >> 5)) * ldc + n0 + wn * 64 + j * 32 + (lane & 31);
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
-                    cp[(size_t)(i * 32 + (r & 3) + 8 * (r >> 2)) * N] = acc[i][j][r];
+                    cp[(size_t)(i * 32 + (r & 3) + 8 * (r >> 2)) * ldc] = acc[i][j][r];
         }
     } else {
 #pragma unroll
@@ -135,7 +150,10 @@ __global__ __launch_bounds__(GB_THREADS) void proj_gemm_kernel(
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                    if (row < M && col < N) C[(size_t)row * N + col] = acc[i][j][r];
+                    if (row < M && col < N) {
+                        float *cp = C + (size_t)row * ldc + col;
+                        *cp = accumulate ? *cp + acc[i][j][r] : acc[i][j][r];
+                    }
                 }
         }
     }
@@ -150,13 +168,23 @@ int launch_proj_gemm(const float *A, const float *W, const float *bias, float *C
 int launch_gemm_act(const float *A, const float *W, const float *bias, float *C, int M, int N, int K,
                     int act, float alpha, int n_lin, hipStream_t s)
 {
+    return launch_gemm_ex(A, W, bias, C, M, N, K, act, alpha, n_lin, K, N, 0, 0, 0, s);
+}
+
+int launch_gemm_ex(const float *A, const float *W, const float *bias, float *C, int M, int N, int K, int act, float alpha,
+                   int n_lin, int lda, int ldc, int conv_L, int conv_cin, int accumulate, hipStream_t s)
+{
+    if ((lda % 4) || (conv_L > 0 && (conv_cin % 4 || K != 3 * conv_cin))) {
+        csa_set_error_msg("gemm_ex: lda and cin must be multiples of 4, K = 3*cin in conv mode");
+        return CSA_ERR_UNSUPPORTED;
+    }
     if (K % 4 != 0) {
         csa_set_error_msg("proj_gemm: K must be a multiple of 4");
         return CSA_ERR_UNSUPPORTED;
     }
     const int tiles_m = (M + GB_M - 1) / GB_M, tiles_n = (N + GB_N - 1) / GB_N;
     hipLaunchKernelGGL(proj_gemm_kernel, dim3(tiles_m * tiles_n), dim3(GB_THREADS), 0, s, A, W, bias, C, M, N, K,
-                       tiles_m, tiles_n, act, alpha, n_lin);
+                       tiles_m, tiles_n, act, alpha, n_lin, lda, ldc, conv_L, conv_cin, accumulate);
     CSA_HIP_CHECK(hipGetLastError());
     return CSA_OK;
 }

@@ -168,6 +168,17 @@ int csa_mlp_create(int nlayers, const int *dims, const float *const *weights, co
 int csa_mlp_destroy(csa_mlp *h);
 int csa_mlp_forward(csa_mlp *h, int B, const float *x, float *y, void *stream);
 
+/* ---- offline CNN baseline, forward --------------------------------------------------
+ * baseline_models/CNN/training/hpo_train.py:124-200: 12 residual blocks of two Conv1D(406,3,same)+ReLU plus a 1x1
+ * projection of the block input, Conv1D(10,1,elu), Dense(2,linear) || Dense(8,relu).  weights/biases: HOST
+ * pointers in PyTorch Conv1d layout (cout,cin,k), 3 per block (conv_a, conv_b, residual), then the pre-output
+ * 1x1 conv, then the two Dense layers stacked as one (cout,cout) matrix. */
+typedef struct csa_cnn csa_cnn;
+int csa_cnn_create(int depth, int nlev, int cin, int width, int cout, int n_lin, const float *const *weights,
+                   const float *const *biases, int max_batch, csa_cnn **out);
+int csa_cnn_destroy(csa_cnn *h);
+int csa_cnn_forward(csa_cnn *h, int B, const float *x, float *y, void *stream);
+
 /* ---- stochastic recurrent layers ---------------------------------------------------
  * MyStochasticGRULayer5  rnn/models_torch_kernels.py:834-891 (its GPU path = the repo's inline CUDA, :29-252)
  * MyStochasticLSTMLayer4 rnn/models_torch_kernels.py:1474-1531

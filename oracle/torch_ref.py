@@ -305,3 +305,22 @@ def stoch_lstm4_ref(x, h, c, eps, weight_encoder):
         h = o * torch.tanh(c)
         outs.append(h)
     return torch.stack(outs), (h, c)
+
+
+# ---- Keras CNN baseline restated in torch (TEST INFRASTRUCTURE) ---------------------------------------
+def cnn_ref(x, weights, biases, depth=12, n_lin=2):
+    """baseline_models/CNN/training/hpo_train.py:159-200 (inference: Dropout is identity).  x (B,L,6) channels-last;
+    weights in Conv1d layout (cout,cin,k): per block conv_a, conv_b, residual; then pre-output conv; then stacked
+    dense (cout,cout,1).  No reference weights ship (model/saved_model.pb has no variables): parity UNPINNED."""
+    h = x.transpose(1, 2)                      # (B, C, L)
+    prev = h
+    i = 0
+    for _ in range(depth):
+        h = F.relu(F.conv1d(prev, weights[i], biases[i], padding=1)); i += 1
+        h = F.relu(F.conv1d(h, weights[i], biases[i], padding=1)); i += 1
+        h = h + F.conv1d(prev, weights[i], biases[i]); i += 1
+        prev = h
+    h = F.elu(F.conv1d(h, weights[i], biases[i])); i += 1
+    h = F.conv1d(h, weights[i], biases[i])
+    h = torch.cat((h[:, :n_lin], F.relu(h[:, n_lin:])), dim=1)
+    return h.transpose(1, 2)
