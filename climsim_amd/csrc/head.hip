@@ -173,8 +173,9 @@ int launch_head(const DevModel &m, int B, int mode, const float *H2, const float
     case 64:  hipLaunchKernelGGL(head_kernel<64>, dim3(B), dim3(HEAD_THREADS), shm, s, m, B, mode, H2, x_main_raw, y0, y1, y2); break;
     case 96:  hipLaunchKernelGGL(head_kernel<96>, dim3(B), dim3(HEAD_THREADS), shm, s, m, B, mode, H2, x_main_raw, y0, y1, y2); break;
     case 128: hipLaunchKernelGGL(head_kernel<128>, dim3(B), dim3(HEAD_THREADS), shm, s, m, B, mode, H2, x_main_raw, y0, y1, y2); break;
+    case 144: hipLaunchKernelGGL(head_kernel<144>, dim3(B), dim3(HEAD_THREADS), shm, s, m, B, mode, H2, x_main_raw, y0, y1, y2); break;
     default:
-        csa_set_error_msg("head: hidden size must be 64, 96 or 128");
+        csa_set_error_msg("head: hidden size must be 64, 96, 128 or 144");
         return CSA_ERR_UNSUPPORTED;
     }
     CSA_HIP_CHECK(hipGetLastError());

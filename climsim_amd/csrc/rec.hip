@@ -213,8 +213,12 @@ __global__ __launch_bounds__(NH * 4, 2) void rec_kernel(
 // TRAIN = true additionally saves what BPTT needs: the activated gates are written IN PLACE over
 // the pre-activations P(t,b,u,[i,g~,f,o]) they came from, c_t goes to Cseq (L+1 slots, slot 0 = c_init),
 // h_t also to Hseq (L+1 slots in SEQUENCE order, slot 0 = h_init; may alias Hout for the downward RNN).
-template <int NH, bool TRAIN>
-__global__ __launch_bounds__(NH * 4, 2) void lstm_rec2_kernel(
+// NL4 > 0 (nh = 144, the reference's default config): 9 waves per workgroup put three waves on one SIMD, so
+// a wave may hold 168 VGPRs, not 256, and the 144 weights per lane no longer fit beside the working set.  The
+// last NL4 float4 of every slot's weight run then live in LDS instead (NL4*64 B per lane, read conflict-free
+// once per step); the other (KC/4 - NL4) float4 per slot stay register-stationary.
+template <int NH, bool TRAIN, int NL4 = 0>
+__global__ __launch_bounds__(NH * 4, (NH / 16 + 3) / 4) void lstm_rec2_kernel(
     const f32x4 *__restrict__ Wp4, float *__restrict__ P,
     const float *__restrict__ h0, const float *__restrict__ c0, float *__restrict__ Hout,
     int B, int L, int reverse_out, float *__restrict__ Hseq, float *__restrict__ Cseq,
@@ -229,7 +233,9 @@ __global__ __launch_bounds__(NH * 4, 2) void lstm_rec2_kernel(
     constexpr int CH = 2 * KC + 4;      // floats per k-quarter, padded by one 16-B slot
     constexpr int CPY = 4 * CH;         // floats per copy
     static_assert(KC % 4 == 0, "nh must be a multiple of 16");
+    constexpr int KR = KC / 2 - 2 * NL4; // weight pairs per slot kept in registers
     __shared__ __attribute__((aligned(16))) float hbuf[2][2 * CPY];
+    extern __shared__ f32x4 wlds[];      // NL4 > 0: 4*NL4*NT float4 of dynamic LDS
 
     const int tid = threadIdx.x, u = tid >> 2, p = tid & 3, col = p & 1, grp = p >> 1;
 #ifdef REC_EXP_CLOCK
@@ -240,13 +246,17 @@ __global__ __launch_bounds__(NH * 4, 2) void lstm_rec2_kernel(
     if (!valid) b = B - 1;
     const bool owner = grp == 1;                 // lanes p>=2 own c_t / h_t of (u, col)
 
-    f32x2 w[4][KC / 2];
+    f32x2 w[4][KR > 0 ? KR : 1];
 #pragma unroll
     for (int i = 0; i < KC; ++i) {
         const f32x4 v = Wp4[(size_t)i * NT + tid];
         const int s = (4 * i) / KC, kk = (4 * i) % KC;
-        w[s][kk / 2] = f32x2{v.x, v.y};
-        w[s][kk / 2 + 1] = f32x2{v.z, v.w};
+        if (kk / 2 < KR) {
+            w[s][kk / 2] = f32x2{v.x, v.y};
+            w[s][kk / 2 + 1] = f32x2{v.z, v.w};
+        } else {
+            wlds[(s * NL4 + (kk / 2 - KR) / 2) * NT + tid] = v;
+        }
     }
     // slot-1 activation: tanh for the (i,g~) lanes, sigmoid for the (f,o) lanes, both written as
     // (1 - nb*t) / (1 + t) with t = exp(-x) (sigmoid, nb = 0) or t = exp(-2x) (tanh, nb = 1).  The
@@ -291,11 +301,24 @@ __global__ __launch_bounds__(NH * 4, 2) void lstm_rec2_kernel(
         }                                                                                          \
         const f32x4 *hp = (const f32x4 *)&hbuf[t_ & 1][rdoff];                                     \
         f32x2 acc[4] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};                           \
-        _Pragma("unroll") for (int j = 0; j < KC / 2; ++j) {                                       \
+        _Pragma("unroll") for (int j = 0; j < KR; ++j) {                                           \
             const f32x4 hv = hp[j];                                                                \
             const f32x2 ha = {hv.x, hv.y}, hb = {hv.z, hv.w};                                      \
             _Pragma("unroll") for (int s = 0; s < 4; ++s) PK_FMA_LO(acc[s], w[s][j], ha);          \
             _Pragma("unroll") for (int s = 0; s < 4; ++s) PK_FMA_HI(acc[s], w[s][j], hb);          \
+        }                                                                                          \
+        _Pragma("unroll") for (int q = 0; q < NL4; ++q) {                                          \
+            const f32x4 h0v = hp[KR + 2 * q], h1v = hp[KR + 2 * q + 1];                            \
+            const f32x2 ha0 = {h0v.x, h0v.y}, hb0 = {h0v.z, h0v.w};                                \
+            const f32x2 ha1 = {h1v.x, h1v.y}, hb1 = {h1v.z, h1v.w};                                \
+            _Pragma("unroll") for (int s = 0; s < 4; ++s) {                                        \
+                const f32x4 wv = wlds[(s * NL4 + q) * NT + tid];                                   \
+                const f32x2 w0 = {wv.x, wv.y}, w1 = {wv.z, wv.w};                                  \
+                PK_FMA_LO(acc[s], w0, ha0);                                                        \
+                PK_FMA_HI(acc[s], w0, hb0);                                                        \
+                PK_FMA_LO(acc[s], w1, ha1);                                                        \
+                PK_FMA_HI(acc[s], w1, hb1);                                                        \
+            }                                                                                      \
         }                                                                                          \
         STAMP(1, acc[0])                                                                           \
         float r[4];                                                                                \
@@ -401,12 +424,27 @@ static int launch_rec_nh(int use_lstm, const float *whh, const float *bhn, const
                          const float *c0, float *Hout, int B, int L, int reverse_out, hipStream_t s)
 {
     const dim3 grid((B + 1) / 2), block(NH * 4);
-    if (use_lstm)
-        hipLaunchKernelGGL((lstm_rec2_kernel<NH, false>), grid, block, 0, s, (const f32x4 *)whh, (float *)P, h0, c0, Hout,
-                           B, L, reverse_out, (float *)nullptr, (float *)nullptr, 0, L, (float *)nullptr);
-    else
+    if (use_lstm) {
+        constexpr int NL4 = NH > 128 ? 2 : 0;
+        constexpr size_t shm = (size_t)4 * NL4 * NH * 4 * sizeof(f32x4);
+        auto kern = lstm_rec2_kernel<NH, false, NL4>;
+        if (shm > 0) {
+            static bool attr_set = false;   // per process; idempotent
+            if (!attr_set) {
+                CSA_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+                attr_set = true;
+            }
+        }
+        hipLaunchKernelGGL(kern, grid, block, shm, s, (const f32x4 *)whh, (float *)P,
+                           h0, c0, Hout, B, L, reverse_out, (float *)nullptr, (float *)nullptr, 0, L, (float *)nullptr);
+    }
+    else if constexpr (NH <= 128)
         hipLaunchKernelGGL((rec_kernel<NH, 3>), grid, block, 0, s, (const f32x4 *)whh, bhn, P, h0, c0, Hout, B, L,
                            reverse_out);
+    else {
+        csa_set_error_msg("rec: the GRU kernel supports hidden sizes 64, 96, 128");
+        return CSA_ERR_UNSUPPORTED;
+    }
     CSA_HIP_CHECK(hipGetLastError());
     return CSA_OK;
 }
@@ -445,8 +483,9 @@ int launch_rec(int use_lstm, int nh, const float *whh_packed, const float *bhn, 
     case 64:  return launch_rec_nh<64>(use_lstm, whh_packed, bhn, P, h0, c0, Hout, B, L, reverse_out, s);
     case 96:  return launch_rec_nh<96>(use_lstm, whh_packed, bhn, P, h0, c0, Hout, B, L, reverse_out, s);
     case 128: return launch_rec_nh<128>(use_lstm, whh_packed, bhn, P, h0, c0, Hout, B, L, reverse_out, s);
+    case 144: return launch_rec_nh<144>(use_lstm, whh_packed, bhn, P, h0, c0, Hout, B, L, reverse_out, s);
     default:
-        csa_set_error_msg("rec: hidden size not supported by the register-stationary kernel (64, 96, 128)");
+        csa_set_error_msg("rec: hidden size not supported by the register-stationary kernel (64, 96, 128, 144)");
         return CSA_ERR_UNSUPPORTED;
     }
 }

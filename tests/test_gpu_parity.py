@@ -83,7 +83,7 @@ def test_memory_wrapper_rollout_vs_golden(memory, B):
         mem = y[:, 368:].reshape(B, 60, 16).contiguous()
 
 
-@pytest.mark.parametrize("tag", ["cur_lstm128", "cur_gru128"])
+@pytest.mark.parametrize("tag", ["cur_lstm128", "cur_lstm144", "cur_gru128"])
 def test_current_generation_vs_reference_class(tag):
     import climsim_amd
     consts, weights, flags = load_npz_model(tag)
