@@ -13,7 +13,7 @@ _F = ctypes.c_void_p   # device pointers travel as integers
 
 CONFIG_FIELDS = ["nlev", "nx", "nx_sfc", "ny", "ny_sfc", "nh1", "nh2", "nh_mem", "use_lstm", "legacy",
                  "output_prune", "mp_mode", "snowhice_fix", "qinput_prune", "rh_prune", "scrub_inf",
-                 "scrub_out_nan", "q_input_mode"]
+                 "scrub_out_nan", "q_input_mode", "add_stochastic_layer"]
 PARAM_FIELDS = ["xmean_lev", "xdiv_lev", "xmean_sca", "xdiv_sca", "lbd_qc", "lbd_qi",
                 "yscale_lev", "yscale_sca", "hyam", "hybm",
                 "mlp_initial_w", "mlp_initial_b", "mlp_surface1_w", "mlp_surface1_b",
@@ -21,11 +21,13 @@ PARAM_FIELDS = ["xmean_lev", "xdiv_lev", "xmean_sca", "xdiv_sca", "lbd_qc", "lbd
                 "rnn1_w_ih", "rnn1_w_hh", "rnn1_b_ih", "rnn1_b_hh",
                 "rnn2_w_ih", "rnn2_w_hh", "rnn2_b_ih", "rnn2_b_hh",
                 "mlp_latent_w", "mlp_latent_b", "mlp_output_w", "mlp_output_b",
-                "mlp_surface_output_w", "mlp_surface_output_b"]
+                "mlp_surface_output_w", "mlp_surface_output_b",
+                "rnn0_w_ih", "rnn0_w_hh", "rnn0_b_ih", "rnn0_b_hh", "rnn2_weight_encoder"]
 
 # Every symbol include/climsim_amd.h declares (checked by tests/test_abi.py).
 SYMBOLS = ["csa_create", "csa_destroy", "csa_set_params", "csa_packed_width", "csa_max_batch",
-           "csa_forward_packed", "csa_forward_tuple", "csa_model_forward", "csa_tap_rnn1",
+           "csa_forward_packed", "csa_forward_tuple", "csa_model_forward", "csa_forward_tuple_noise",
+           "csa_model_forward_noise", "csa_tap_rnn1",
            "csa_tap_rnn2", "csa_last_error", "csa_version", "csa_set_profiling", "csa_reset_profile",
            "csa_get_profile", "csa_stage_name", "csa_set_fused", "csa_set_overlap",
            "csa_train_create", "csa_train_destroy", "csa_train_num_params", "csa_train_num_tensors",
@@ -68,6 +70,8 @@ def lib():
     L.csa_forward_packed.argtypes = [H, i, _F, _F, _F, _F, _F, _F, ctypes.c_void_p]
     L.csa_forward_tuple.argtypes = [H, i, _F, _F, _F, _F, _F, _F, ctypes.c_void_p]
     L.csa_model_forward.argtypes = [H, i, _F, _F, _F, _F, _F, _F, _F, _F, ctypes.c_void_p]
+    L.csa_forward_tuple_noise.argtypes = [H, i] + [_F] * 9 + [ctypes.c_void_p]
+    L.csa_model_forward_noise.argtypes = [H, i] + [_F] * 9 + [ctypes.c_void_p]
     L.csa_tap_rnn1.argtypes = [H]
     L.csa_tap_rnn1.restype = ctypes.c_void_p
     L.csa_tap_rnn2.argtypes = [H]

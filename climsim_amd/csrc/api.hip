@@ -27,6 +27,7 @@ struct csa_emulator {
     std::vector<void *> owned;   // every device allocation
     // scratch
     float *X1, *P, *H1, *H2, *hc0;
+    csa_stoch *stoch = nullptr;  // add_stochastic_layer: the MyStochasticLSTMLayer4 stage (stoch.hip)
     // optional per-kernel timing (csa_set_profiling): events bracket the 6 launches of a call
     bool profiling = false;
     hipEvent_t ev[7] = {};
@@ -71,15 +72,23 @@ int check_cfg(const csa_config &c)
         csa_set_error_msg("csa_create: bad sizes");
         return CSA_ERR_ARG;
     }
-    if (c.mp_mode != 0 && c.mp_mode != 1) {
-        csa_set_error_msg("csa_create: mp_mode -1/-2 not implemented by the HIP path");
-        return CSA_ERR_UNSUPPORTED;
+    if (c.mp_mode != 0 && c.mp_mode != 1 && c.mp_mode != -1 && c.mp_mode != -2) {
+        csa_set_error_msg("csa_create: mp_mode must be 0, 1, -1 or -2 (models.py:203-227)");
+        return CSA_ERR_ARG;
+    }
+    if (c.mp_mode < 0 && (c.ny != 6 || c.legacy)) {
+        csa_set_error_msg("csa_create: mp_mode -1/-2 are current-generation models with ny == 6");
+        return CSA_ERR_ARG;
     }
     if (c.mp_mode == 1 && c.ny != 5) {
         csa_set_error_msg("csa_create: mp_mode 1 requires ny == 5 (models.py:216-217)");
         return CSA_ERR_ARG;
     }
-    if (!c.legacy && !c.use_lstm && false) return CSA_ERR_UNSUPPORTED;
+    if (c.add_stochastic_layer && (c.legacy || !c.use_lstm || c.nh1 != c.nh2 || c.nh_mem <= 0)) {
+        // models.py:405-412 with use_lstm; the GRU flavour raises AttributeError upstream (mlp_toa2 missing)
+        csa_set_error_msg("csa_create: add_stochastic_layer needs the current-generation LSTM with memory and nh1 == nh2");
+        return CSA_ERR_UNSUPPORTED;
+    }
     return CSA_OK;
 }
 
@@ -118,14 +127,20 @@ int upload_params(csa_emulator *h, const csa_params *p, bool first)
             d.toa2_b = U.up(p->mlp_toa2_b, c.nh2);
         }
     }
+    // the two deterministic layers, in execution order: (rnn1, rnn2), or (rnn0, rnn1) for the stochastic variant
+    const bool st = c.add_stochastic_layer != 0;
+    const float *a_ih = st ? p->rnn0_w_ih : p->rnn1_w_ih, *a_hh = st ? p->rnn0_w_hh : p->rnn1_w_hh;
+    const float *a_bi = st ? p->rnn0_b_ih : p->rnn1_b_ih, *a_bh = st ? p->rnn0_b_hh : p->rnn1_b_hh;
+    const float *b_ih = st ? p->rnn1_w_ih : p->rnn2_w_ih, *b_hh = st ? p->rnn1_w_hh : p->rnn2_w_hh;
+    const float *b_bi = st ? p->rnn1_b_ih : p->rnn2_b_ih, *b_bh = st ? p->rnn1_b_hh : p->rnn2_b_hh;
     std::vector<float> w, bias, bhn, packed;
-    pack_ih(c.use_lstm, c.nh1, nin1, p->rnn1_w_ih, p->rnn1_b_ih, p->rnn1_b_hh, w, bias, bhn);
+    pack_ih(c.use_lstm, c.nh1, nin1, a_ih, a_bi, a_bh, w, bias, bhn);
     d.wih1 = U.up(w); d.bias1 = U.up(bias); d.bhn1 = U.up(bhn);
-    pack_ih(c.use_lstm, c.nh2, c.nh1, p->rnn2_w_ih, p->rnn2_b_ih, p->rnn2_b_hh, w, bias, bhn);
+    pack_ih(c.use_lstm, c.nh2, c.nh1, b_ih, b_bi, b_bh, w, bias, bhn);
     d.wih2 = U.up(w); d.bias2 = U.up(bias); d.bhn2 = U.up(bhn);
     // dual-pipe fused LSTM path (fused.hip): nh = 128, K in {128,144}
     d.wih1f = d.wih2f = nullptr;
-    if (c.use_lstm && c.nh1 == 128 && c.nh2 == 128 && (nin1 == 128 || nin1 == 144)) {
+    if (!st && c.use_lstm && c.nh1 == 128 && c.nh2 == 128 && (nin1 == 128 || nin1 == 144)) {
         std::vector<float> wp, fp;
         pack_ih(1, c.nh1, nin1, p->rnn1_w_ih, p->rnn1_b_ih, p->rnn1_b_hh, wp, bias, bhn);
         fp.resize(fused_packed_floats(c.nh1, nin1));
@@ -137,10 +152,10 @@ int upload_params(csa_emulator *h, const csa_params *p, bool first)
         d.wih2f = U.up(fp);
     }
     packed.resize(rec_packed_floats(c.use_lstm, c.nh1));
-    rec_pack_weights(c.use_lstm, c.nh1, p->rnn1_w_hh, packed.data());
+    rec_pack_weights(c.use_lstm, c.nh1, a_hh, packed.data());
     d.whh1p = U.up(packed);
     packed.resize(rec_packed_floats(c.use_lstm, c.nh2));
-    rec_pack_weights(c.use_lstm, c.nh2, p->rnn2_w_hh, packed.data());
+    rec_pack_weights(c.use_lstm, c.nh2, b_hh, packed.data());
     d.whh2p = U.up(packed);
     if (c.nh_mem > 0) {
         d.lat_wt = U.up(transposed(p->mlp_latent_w, c.nh_mem, c.nh2));
@@ -161,8 +176,10 @@ bool params_complete(const csa_config &c, const csa_params *p)
     bool ok = p->xmean_lev && p->xdiv_lev && p->xmean_sca && p->xdiv_sca && p->lbd_qc && p->lbd_qi &&
               p->yscale_lev && p->yscale_sca && p->hyam && p->hybm && p->mlp_initial_w && p->mlp_initial_b &&
               p->mlp_surface1_w && p->mlp_surface1_b && p->rnn1_w_ih && p->rnn1_w_hh && p->rnn1_b_ih &&
-              p->rnn1_b_hh && p->rnn2_w_ih && p->rnn2_w_hh && p->rnn2_b_ih && p->rnn2_b_hh && p->mlp_output_w &&
+              p->rnn1_b_hh && p->mlp_output_w &&
               p->mlp_output_b && p->mlp_surface_output_w && p->mlp_surface_output_b;
+    if (c.add_stochastic_layer) ok = ok && p->rnn0_w_ih && p->rnn0_w_hh && p->rnn0_b_ih && p->rnn0_b_hh && p->rnn2_weight_encoder;
+    else ok = ok && p->rnn2_w_ih && p->rnn2_w_hh && p->rnn2_b_ih && p->rnn2_b_hh;
     if (c.use_lstm) ok = ok && p->mlp_surface2_w && p->mlp_surface2_b;
     if (!c.legacy) ok = ok && p->mlp_toa1_w && p->mlp_toa1_b && (!c.use_lstm || (p->mlp_toa2_w && p->mlp_toa2_b));
     if (c.nh_mem > 0) ok = ok && p->mlp_latent_w && p->mlp_latent_b;
@@ -212,6 +229,8 @@ extern "C" int csa_create(const csa_config *cfg, const csa_params *hp, int max_b
         h->P2 = U.alloc(L * Bm * 4 * nhm);
         h->cstate = U.alloc(Bm * nhm);
         rc = U.rc;
+        if (rc == CSA_OK && cfg->add_stochastic_layer)
+            rc = csa_stoch_lstm4_create(cfg->nh1, cfg->nh2, hp->rnn2_weight_encoder, (int)(L * Bm), &h->stoch);
         if (rc == CSA_OK) {
             if (hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking) != hipSuccess) rc = CSA_ERR_HIP;
             for (int i = 0; i < 12 && rc == CSA_OK; ++i)
@@ -220,6 +239,7 @@ extern "C" int csa_create(const csa_config *cfg, const csa_params *hp, int max_b
     }
     if (rc != CSA_OK) {
         free_all(h);
+        if (h->stoch) (void)csa_stoch_destroy(h->stoch);
         delete h;
         if (g_err.empty()) csa_set_error_msg("csa_create: device allocation / upload failed");
         return rc;
@@ -232,6 +252,7 @@ extern "C" int csa_destroy(csa_emulator *h)
 {
     if (!h) return CSA_ERR_ARG;
     free_all(h);
+    if (h->stoch) (void)csa_stoch_destroy(h->stoch);
     for (int i = 0; i < 7; ++i) if (h->ev[i]) (void)hipEventDestroy(h->ev[i]);
     for (int i = 0; i < 12; ++i) if (h->ov_ev[i]) (void)hipEventDestroy(h->ov_ev[i]);
     if (h->side) (void)hipStreamDestroy(h->side);
@@ -242,6 +263,7 @@ extern "C" int csa_destroy(csa_emulator *h)
 extern "C" int csa_set_params(csa_emulator *h, const csa_params *hp)
 {
     if (!h || !hp || !params_complete(h->dm.cfg, hp)) { csa_set_error_msg("csa_set_params: bad argument"); return CSA_ERR_ARG; }
+    if (h->stoch) { csa_set_error_msg("csa_set_params: not available for the stochastic variant (re-create the handle)"); return CSA_ERR_UNSUPPORTED; }
     // Rebuild all parameter buffers; scratch (the last seven allocations) is kept.
     std::vector<void *> scratch(h->owned.end() - 7, h->owned.end());
     h->owned.resize(h->owned.size() - 7);
@@ -373,7 +395,7 @@ static int run_forward_overlap(csa_emulator *h, int B, int normalised, int mode,
     const float *h2 = c.legacy ? hx2 : h->hc0 + (size_t)2 * B * nhm;
     const float *c2 = c.legacy ? cx2 : h->hc0 + (size_t)3 * B * nhm;
     if ((rc = launch_rec(1, nh, h->dm.whh2p, nullptr, h->P2, h2, c2, h->H2, B, L, /*reverse_out=*/0, S))) return rc;
-    return launch_head(h->dm, B, mode, h->H2, x_main, y0, y1, y2, S);
+    return launch_head(h->dm, B, mode, h->H2, x_main, x_sfc, y0, y1, y2, S);
 }
 
 extern "C" int csa_set_overlap(csa_emulator *h, int enable)
@@ -383,12 +405,35 @@ extern "C" int csa_set_overlap(csa_emulator *h, int enable)
     return h->overlap ? 1 : 0;
 }
 
+// Stochastic variant: LSTM down (noise init) -> LSTM up (surface init) -> stochastic LSTM down (TOA init).
+// prep writes X1 in LEVEL order here (no flip), so the first recurrence runs downward and stores its hidden
+// sequence flipped (= the sequence order of the upward pass), the second stores level order again.
+static int run_forward_stoch(csa_emulator *h, int B, int normalised, int mode, const float *x_main, const float *x_sfc,
+                             const float *mem_in, const float *hx0, const float *cx0, const float *eps,
+                             float *y0, float *y1, float *y2, hipStream_t s)
+{
+    const csa_config &c = h->dm.cfg;
+    if (B <= 0 || B > h->max_batch) { csa_set_error_msg("forward: B out of range (0 < B <= max_batch)"); return CSA_ERR_ARG; }
+    if (!x_main || !x_sfc || !mem_in || !hx0 || !cx0 || !eps || !y0) { csa_set_error_msg("forward(noise): null tensor"); return CSA_ERR_ARG; }
+    const int L = c.nlev, nh = c.nh1;
+    int rc;
+    if ((rc = launch_prep(h->dm, B, normalised, x_main, x_sfc, mem_in, nullptr, nullptr, h->X1, h->hc0, s))) return rc;
+    if ((rc = launch_proj_gemm(h->X1, h->dm.wih1, h->dm.bias1, h->P, L * B, 4 * nh, nh + c.nh_mem, s))) return rc;
+    if ((rc = launch_rec(1, nh, h->dm.whh1p, nullptr, h->P, hx0, cx0, h->H1, B, L, /*reverse_out=*/1, s))) return rc;
+    if ((rc = launch_proj_gemm(h->H1, h->dm.wih2, h->dm.bias2, h->P, L * B, 4 * nh, nh, s))) return rc;
+    if ((rc = launch_rec(1, nh, h->dm.whh2p, nullptr, h->P, h->hc0, h->hc0 + (size_t)B * nh, h->H2, B, L, /*reverse_out=*/1, s))) return rc;
+    if ((rc = csa_stoch_lstm4_forward(h->stoch, L, B, h->H2, h->hc0 + (size_t)2 * B * nh, h->hc0 + (size_t)3 * B * nh, eps,
+                                      h->H1, nullptr, nullptr, s))) return rc;
+    return launch_head(h->dm, B, mode, h->H1, x_main, x_sfc, y0, y1, y2, s);
+}
+
 static int run_forward(csa_emulator *h, int B, int normalised, int mode,
                        const float *x_main, const float *x_sfc, const float *mem_in,
                        const float *hx2, const float *cx2,
                        float *y0, float *y1, float *y2, hipStream_t s)
 {
     const csa_config &c = h->dm.cfg;
+    if (c.add_stochastic_layer) { csa_set_error_msg("forward: the stochastic variant takes its noise explicitly (csa_*_noise entry points)"); return CSA_ERR_ARG; }
     if (B <= 0 || B > h->max_batch) { csa_set_error_msg("forward: B out of range (0 < B <= max_batch)"); return CSA_ERR_ARG; }
     if (!x_main || !x_sfc || !y0) { csa_set_error_msg("forward: null tensor"); return CSA_ERR_ARG; }
     if (c.nh_mem > 0 && !mem_in) { csa_set_error_msg("forward: rnn1_mem required (nh_mem > 0)"); return CSA_ERR_ARG; }
@@ -428,7 +473,7 @@ static int run_forward(csa_emulator *h, int B, int normalised, int mode,
         if ((rc = launch_rec(c.use_lstm, c.nh2, h->dm.whh2p, h->dm.bhn2, h->P, h2, c2, h->H2, B, L, /*reverse_out=*/0, s))) return rc;
     }
     PROF_MARK(5);
-    rc = launch_head(h->dm, B, mode, h->H2, x_main, y0, y1, y2, s);
+    rc = launch_head(h->dm, B, mode, h->H2, x_main, x_sfc, y0, y1, y2, s);
     PROF_MARK(6);
     if (h->profiling) h->pending = true;
     return rc;
@@ -450,6 +495,26 @@ extern "C" int csa_forward_tuple(csa_emulator *h, int B, const float *x_main, co
     if (h->dm.cfg.legacy) { csa_set_error_msg("forward_tuple: current generation only"); return CSA_ERR_UNSUPPORTED; }
     if (!out_sfc || (h->dm.cfg.nh_mem > 0 && !mem_out)) { csa_set_error_msg("forward_tuple: null output"); return CSA_ERR_ARG; }
     return run_forward(h, B, 0, HEAD_TUPLE, x_main, x_sfc, mem_in, nullptr, nullptr, out_lev, out_sfc, mem_out, (hipStream_t)stream);
+}
+
+extern "C" int csa_forward_tuple_noise(csa_emulator *h, int B, const float *x_main, const float *x_sfc, const float *mem_in,
+                                       const float *hx0, const float *cx0, const float *eps,
+                                       float *out_lev, float *out_sfc, float *mem_out, void *stream)
+{
+    if (!h) return CSA_ERR_ARG;
+    if (!h->stoch) { csa_set_error_msg("forward_tuple_noise: handle was not created with add_stochastic_layer"); return CSA_ERR_ARG; }
+    if (!out_sfc || !mem_out) { csa_set_error_msg("forward_tuple_noise: null output"); return CSA_ERR_ARG; }
+    return run_forward_stoch(h, B, 0, HEAD_TUPLE, x_main, x_sfc, mem_in, hx0, cx0, eps, out_lev, out_sfc, mem_out, (hipStream_t)stream);
+}
+
+extern "C" int csa_model_forward_noise(csa_emulator *h, int B, const float *x_main_n, const float *x_sfc_n, const float *mem_in,
+                                       const float *hx0, const float *cx0, const float *eps,
+                                       float *out, float *out_sfc, float *mem_out, void *stream)
+{
+    if (!h) return CSA_ERR_ARG;
+    if (!h->stoch) { csa_set_error_msg("model_forward_noise: handle was not created with add_stochastic_layer"); return CSA_ERR_ARG; }
+    if (!out_sfc || !mem_out) { csa_set_error_msg("model_forward_noise: null output"); return CSA_ERR_ARG; }
+    return run_forward_stoch(h, B, 1, HEAD_RAW, x_main_n, x_sfc_n, mem_in, hx0, cx0, eps, out, out_sfc, mem_out, (hipStream_t)stream);
 }
 
 extern "C" int csa_model_forward(csa_emulator *h, int B, const float *x_main_n, const float *x_sfc_n,

@@ -91,5 +91,5 @@ int launch_fused_lstm(int nh, int K, const float *whh_packed, const float *wih_p
                       hipStream_t s);
 
 // head.hip: mlp_latent / mlp_output / surface head / de-normalisation / microphysics / packing
-int launch_head(const DevModel &m, int B, int mode, const float *H2, const float *x_main_raw,
+int launch_head(const DevModel &m, int B, int mode, const float *H2, const float *x_main_raw, const float *x_sfc_raw,
                 float *y0, float *y1, float *y2, hipStream_t s);

@@ -2,7 +2,7 @@
 //
 // Reference semantics:
 //   mlp_latent / mlp_output / output_prune / mlp_surface_output   rnn/models/models.py:547-560
-//   de-normalisation + microphysics partition (mp_mode 1)          rnn/models/models.py:273-339,
+//   de-normalisation + microphysics partition (mp_mode 1,-1,-2)    rnn/models/models.py:273-339,
 //                                                                  rnn/save_wrapper_mem.py:470-483
 //   packing (B,368[+nlev*nh_mem]) and NaN scrub                    rnn/save_wrapper_mem.py:485-497,539
 //   tuple output + NaN scrub on out_lev                            rnn/utils.py:286-295
@@ -10,6 +10,7 @@
 // HBM-bound: reads the rnn2 hidden sequence of its column (L*nh2 floats) once into LDS and the
 // raw T/qliq/qice inputs, writes the packed row with level-contiguous (coalesced) stores.
 #include "common.h"
+#include "rh_to_q.h"
 
 #define HEAD_THREADS 256
 
@@ -21,7 +22,7 @@
 template <int NH2>
 __global__ __launch_bounds__(HEAD_THREADS) void head_kernel(
     DevModel m, int B, int mode, const float *__restrict__ H2, const float *__restrict__ x_raw,
-    float *__restrict__ y0, float *__restrict__ y1, float *__restrict__ y2)
+    const float *__restrict__ x_sfc_raw, float *__restrict__ y0, float *__restrict__ y1, float *__restrict__ y2)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int L = m.cfg.nlev, nx = m.cfg.nx, ny = m.cfg.ny, nys = m.cfg.ny_sfc;
@@ -97,7 +98,8 @@ __global__ __launch_bounds__(HEAD_THREADS) void head_kernel(
     }
 
     // ---- de-normalise, microphysics, pack -------------------------------------------------------
-    const bool post = (mode != HEAD_RAW) && m.cfg.mp_mode == 1;
+    const bool post = (mode != HEAD_RAW) && m.cfg.mp_mode != 0;
+    const int mp = m.cfg.mp_mode;
     for (int l = tid; l < L; l += HEAD_THREADS) {
         const float *o = os + l * ny;
         if (mode == HEAD_RAW || m.cfg.mp_mode == 0) {
@@ -111,13 +113,41 @@ __global__ __launch_bounds__(HEAD_THREADS) void head_kernel(
             }
         } else if (post) {
             const float *ys = m.yscale_lev + l * ny;
-            const float *xr = x_raw + ((size_t)b * L + l) * (nx - (m.cfg.q_input_mode == 1));
-            const float dT = o[0] / ys[0], dqv = o[1] / ys[1], dqn = o[2] / ys[2];
-            const float du = o[3] / ys[3], dv = o[4] / ys[4];
+            const int nxr = nx - (m.cfg.q_input_mode == 1);
+            const float *xr = x_raw + ((size_t)b * L + l) * nxr;
+            // mp_mode 1: [dT,dqv,dqn,du,dv]; -1: [dT,dqv,dqn,liq_frac,du,dv]; -2: [dT,dqtot,cld_frac,liq_frac,du,dv]
+            const int iu = mp == 1 ? 3 : 4;
+            const float dT = o[0] / ys[0];
+            float dqv = o[1] / ys[1], dqn = o[2] / ys[2];
+            const float du = o[iu] / ys[iu], dv = o[iu + 1] / ys[iu + 1];
             const float T_old = xr[0], ql = xr[2], qi = xr[3];
+            if (mp == -2) {
+                // models.py:286-301: total-water tendency + cloud fraction of total water -> dqv, dqn.
+                // q_old is the LAST raw level input (the appended specific humidity when include_q_input)
+                float qv_old;
+                if (m.cfg.q_input_mode == 1) {
+                    const float pres = m.hyam[l] * 100000.0f + x_sfc_raw[(size_t)b * m.cfg.nx_sfc] * m.hybm[l];
+                    qv_old = prep_rh_to_q(xr[1], xr[0], pres);
+                } else {
+                    qv_old = xr[nxr - 1];
+                }
+                float cf = dqn * dqn;
+                cf = cf * cf;
+                if (!isnan(cf)) cf = fminf(fmaxf(cf, 0.0f), 1.0f);
+                const float qn_old = ql + qi;
+                const float qtot_new = (qn_old + qv_old) + dqv * 1200.0f;
+                const float qv_new = (1.0f - cf) * qtot_new, qn_new2 = cf * qtot_new;
+                dqv = (qv_new - qv_old) * 0.0008333333333333334f;
+                dqn = (qn_new2 - qn_old) * 0.0008333333333333334f;
+            }
             const float T_new = T_old + dT * 1200.0f;
-            float lf = (T_new - 253.16f) * 0.05f;
-            if (!isnan(lf)) lf = fminf(fmaxf(lf, 0.0f), 1.0f);
+            float lf;
+            if (mp == 1) {
+                lf = (T_new - 253.16f) * 0.05f;
+                if (!isnan(lf)) lf = fminf(fmaxf(lf, 0.0f), 1.0f);
+            } else {
+                lf = o[3] / ys[3];      // models.py:319: the clamped value is overwritten by the raw prediction
+            }
             const float qn_new = (ql + qi) + dqn * 1200.0f;
             const float dql = (lf * qn_new - ql) * 0.0008333333333333334f;
             const float dqi = ((1.0f - lf) * qn_new - qi) * 0.0008333333333333334f;
@@ -161,7 +191,7 @@ __global__ __launch_bounds__(HEAD_THREADS) void head_kernel(
 }
 
 int launch_head(const DevModel &m, int B, int mode, const float *H2, const float *x_main_raw,
-                float *y0, float *y1, float *y2, hipStream_t s)
+                const float *x_sfc_raw, float *y0, float *y1, float *y2, hipStream_t s)
 {
     const int L = m.cfg.nlev, nm = m.cfg.nh_mem;
     const size_t shm = sizeof(float) * ((size_t)L * (m.cfg.nh2 + 4) + (size_t)L * (nm > 0 ? nm : 1) + (size_t)L * m.cfg.ny);
@@ -170,10 +200,10 @@ int launch_head(const DevModel &m, int B, int mode, const float *H2, const float
         return CSA_ERR_UNSUPPORTED;
     }
     switch (m.cfg.nh2) {
-    case 64:  hipLaunchKernelGGL(head_kernel<64>, dim3(B), dim3(HEAD_THREADS), shm, s, m, B, mode, H2, x_main_raw, y0, y1, y2); break;
-    case 96:  hipLaunchKernelGGL(head_kernel<96>, dim3(B), dim3(HEAD_THREADS), shm, s, m, B, mode, H2, x_main_raw, y0, y1, y2); break;
-    case 128: hipLaunchKernelGGL(head_kernel<128>, dim3(B), dim3(HEAD_THREADS), shm, s, m, B, mode, H2, x_main_raw, y0, y1, y2); break;
-    case 144: hipLaunchKernelGGL(head_kernel<144>, dim3(B), dim3(HEAD_THREADS), shm, s, m, B, mode, H2, x_main_raw, y0, y1, y2); break;
+    case 64:  hipLaunchKernelGGL(head_kernel<64>, dim3(B), dim3(HEAD_THREADS), shm, s, m, B, mode, H2, x_main_raw, x_sfc_raw, y0, y1, y2); break;
+    case 96:  hipLaunchKernelGGL(head_kernel<96>, dim3(B), dim3(HEAD_THREADS), shm, s, m, B, mode, H2, x_main_raw, x_sfc_raw, y0, y1, y2); break;
+    case 128: hipLaunchKernelGGL(head_kernel<128>, dim3(B), dim3(HEAD_THREADS), shm, s, m, B, mode, H2, x_main_raw, x_sfc_raw, y0, y1, y2); break;
+    case 144: hipLaunchKernelGGL(head_kernel<144>, dim3(B), dim3(HEAD_THREADS), shm, s, m, B, mode, H2, x_main_raw, x_sfc_raw, y0, y1, y2); break;
     default:
         csa_set_error_msg("head: hidden size must be 64, 96, 128 or 144");
         return CSA_ERR_UNSUPPORTED;

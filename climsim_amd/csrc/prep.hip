@@ -25,52 +25,7 @@ __device__ __forceinline__ float prep_tanh(float x)
     return (1.0f - t) * __builtin_amdgcn_rcpf(1.0f + t);
 }
 
-// Specific humidity from relative humidity (rnn/utils.py:134-180, relative_to_specific_humidity_torch):
-// 8th-order Horner polynomials for the saturation vapour pressure over liquid / ice, blended by
-// omega = clamp((T-253.16)/20, 0, 1); q = rh * Rd*esat / (Rv*p).
-// unfusable multiply / add (inline asm: hipcc contracts even __fmul_rn + __fadd_rn into v_fma)
-__device__ __forceinline__ float mul_nofma(float a, float b)
-{
-    float r;
-    asm("v_mul_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-    return r;
-}
-__device__ __forceinline__ float add_nofma(float a, float b)
-{
-    float r;
-    asm("v_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-    return r;
-}
-__device__ __forceinline__ float prep_polyval9(const float *a, float x)
-{
-    // separate multiply and add, exactly as torch evaluates `out * x + c` (contraction is switched off for
-    // these two functions): near -87 C the fp32 Horner sum cancels to 1e-6 of its terms, the reference's own
-    // value is then ~17 % from the exact polynomial and an FMA evaluation lands ~16 % away from the reference
-    float o = 0.0f;
-#pragma unroll
-    for (int i = 0; i < 9; ++i) o = add_nofma(mul_nofma(o, x), a[i]);
-    return o;
-}
-__device__ float prep_rh_to_q(float rh, float T, float p)
-{
-    const float a_liq[9] = {-0.976195544e-15f, -0.952447341e-13f, 0.640689451e-10f, 0.206739458e-7f, 0.302950461e-5f,
-                            0.264847430e-3f, 0.142986287e-1f, 0.443987641f, 6.11239921f};
-    const float a_ice[9] = {0.252751365e-14f, 0.146898966e-11f, 0.385852041e-9f, 0.602588177e-7f, 0.615021634e-5f,
-                            0.420895665e-3f, 0.188439774e-1f, 0.503160820f, 6.11147274f};
-    const float T0 = 273.16f;
-    const float eliq = 100.0f * prep_polyval9(a_liq, fmaxf(T - T0, -80.0f));
-    float eice;
-    if (T > 273.15f) eice = eliq;
-    else if (T > 185.0f) eice = 100.0f * prep_polyval9(a_ice, T - T0);
-    else {
-        const float tmp = fmaxf(T - T0, -100.0f);
-        eice = 100.0f * add_nofma(0.00763685f, mul_nofma(tmp, add_nofma(0.000151069f, mul_nofma(tmp, 7.48215e-07f))));
-    }
-    float omega = (T - 253.16f) / 20.0f;
-    omega = fminf(fmaxf(omega, 0.0f), 1.0f);
-    const float esat = add_nofma(mul_nofma(omega, eliq), mul_nofma(1.0f - omega, eice));
-    return rh * ((287.0f * esat) / (461.0f * p));
-}
+#include "rh_to_q.h"
 
 // NXP = nx+1 padded to a multiple of 4 (16 for the v4 inputs): the level rows sit in LDS with that
 // stride so the mlp_initial dot product reads them as float4 broadcasts with no predication.
@@ -180,13 +135,13 @@ __global__ __launch_bounds__(PREP_THREADS) void prep_kernel(
                 a0 += w[4 * q] * xv.x; a1 += w[4 * q + 1] * xv.y;
                 a0 += w[4 * q + 2] * xv.z; a1 += w[4 * q + 3] * xv.w;
             }
-            const int t = L - 1 - (l0 + ll);
+            const int t = m.cfg.add_stochastic_layer ? l0 + ll : L - 1 - (l0 + ll);   // rnn0 runs downward
             X1[((size_t)t * B + b) * nin1 + j] = prep_tanh(a0 + a1);
         }
     }
     // ---- memory concat -------------------------------------------------------------------------
     for (int idx = tid; idx < nl * nm; idx += PREP_THREADS) {
-        const int ll = idx / nm, k = idx - ll * nm, t = L - 1 - (l0 + ll);
+        const int ll = idx / nm, k = idx - ll * nm, t = m.cfg.add_stochastic_layer ? l0 + ll : L - 1 - (l0 + ll);
         const float v = m.cfg.legacy ? mem_in[((size_t)b * L + t) * nm + k]
                                      : mem_in[((size_t)(l0 + ll) * B + b) * nm + k];
         X1[((size_t)t * B + b) * nin1 + nh1 + k] = v;

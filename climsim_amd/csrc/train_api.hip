@@ -319,7 +319,7 @@ extern "C" int csa_train_forward(csa_trainer *h, int slot, int B, const float *x
     // rnn2: level order == sequence order, so the hidden sequence itself carries the extra slot 0
     if ((rc = launch_rec_train(nh2, h->dm.whh2p, S.GP2, S.hc0 + (size_t)2 * B * nhm, S.hc0 + (size_t)3 * B * nhm,
                                S.H2 + (size_t)B * nh2, B, L, 0, S.H2, S.C2, s))) return rc;
-    if ((rc = launch_head(h->dm, B, HEAD_RAW, S.H2 + (size_t)B * nh2, x_main_n, out, out_sfc, S.Z, s))) return rc;
+    if ((rc = launch_head(h->dm, B, HEAD_RAW, S.H2 + (size_t)B * nh2, x_main_n, nullptr, out, out_sfc, S.Z, s))) return rc;
     CSA_HIP_CHECK(hipMemcpyAsync(mem_out, S.Z, sizeof(float) * (size_t)L * B * nm, hipMemcpyDeviceToDevice, s));
     return CSA_OK;
 }

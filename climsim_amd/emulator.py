@@ -21,6 +21,9 @@ STATE_DICT_MAP = {
     "rnn1.bias_ih_l0": "rnn1_b_ih", "rnn1.bias_hh_l0": "rnn1_b_hh",
     "rnn2.weight_ih_l0": "rnn2_w_ih", "rnn2.weight_hh_l0": "rnn2_w_hh",
     "rnn2.bias_ih_l0": "rnn2_b_ih", "rnn2.bias_hh_l0": "rnn2_b_hh",
+    "rnn0.weight_ih_l0": "rnn0_w_ih", "rnn0.weight_hh_l0": "rnn0_w_hh",
+    "rnn0.bias_ih_l0": "rnn0_b_ih", "rnn0.bias_hh_l0": "rnn0_b_hh",
+    "rnn2.weight_encoder": "rnn2_weight_encoder",
     "mlp_latent.weight": "mlp_latent_w", "mlp_latent.bias": "mlp_latent_b",
     "mlp_output.weight": "mlp_output_w", "mlp_output.bias": "mlp_output_b",
     "mlp_surface_output.weight": "mlp_surface_output_w", "mlp_surface_output.bias": "mlp_surface_output_b",
@@ -75,11 +78,15 @@ class Emulator:
         cfg.nx_sfc = w["xmean_sca"].shape[0]
         cfg.ny = w["mlp_output_w"].shape[0]
         cfg.ny_sfc = w["mlp_surface_output_w"].shape[0]
+        # add_stochastic_layer (models.py:405-412) is recognised by its parameters: rnn0.* + rnn2.weight_encoder
+        stochastic = "rnn2_weight_encoder" in w
+        cfg.add_stochastic_layer = int(stochastic)
         cfg.nh1 = w["rnn1_w_hh"].shape[1]
-        cfg.nh2 = w["rnn2_w_hh"].shape[1]
+        cfg.nh2 = w["rnn2_weight_encoder"].shape[1] // 5 if stochastic else w["rnn2_w_hh"].shape[1]
         cfg.nh_mem = w["mlp_latent_w"].shape[0] if "mlp_latent_w" in w else 0
         G = 4 if use_lstm else 3
-        if w["rnn1_w_hh"].shape[0] != G * cfg.nh1 or w["rnn1_w_ih"].shape[1] != cfg.nh1 + cfg.nh_mem:
+        first = "rnn0_w_ih" if stochastic else "rnn1_w_ih"
+        if w["rnn1_w_hh"].shape[0] != G * cfg.nh1 or w[first].shape[1] != cfg.nh1 + cfg.nh_mem:
             raise RuntimeError("state_dict shapes inconsistent with use_lstm / nh_mem")
         cfg.use_lstm, cfg.legacy = int(use_lstm), int(legacy)
         cfg.output_prune, cfg.mp_mode = int(output_prune), int(mp_mode)
@@ -150,7 +157,17 @@ class Emulator:
         self._rc(rc, "csa_forward_packed")
         return y
 
-    def forward_tuple(self, x_main, x_sfc, rnn1_mem):
+    def _stoch_noise(self, B, noise):
+        """(hx0, cx0, eps): drawn here in the reference's order (models.py:466-468, models_torch_kernels.py:1497)
+        when not given, so a seeded torch generator reproduces a run."""
+        c = self.cfg
+        if noise is None:
+            noise = (torch.randn(B, c.nh1, device=self.device), torch.randn(B, c.nh1, device=self.device),
+                     torch.randn(c.nlev, B, c.nh2, device=self.device))
+        hx0, cx0, eps = noise
+        return _check(hx0, (B, c.nh1), "hx0"), _check(cx0, (B, c.nh1), "cx0"), _check(eps, (c.nlev, B, c.nh2), "eps")
+
+    def forward_tuple(self, x_main, x_sfc, rnn1_mem, noise=None):
         c = self.cfg
         B = x_main.shape[0]
         x_main = _check(x_main, (B, c.nlev, c.nx - (1 if c.q_input_mode == 1 else 0)), "x_main")
@@ -160,12 +177,19 @@ class Emulator:
         out_lev = torch.empty(B, c.nlev, nyo, device=self.device)
         out_sfc = torch.empty(B, c.ny_sfc, device=self.device)
         mem_out = torch.empty(c.nlev, B, c.nh_mem, device=self.device)
+        if c.add_stochastic_layer:
+            hx0, cx0, eps = self._stoch_noise(B, noise)
+            rc = _lib.lib().csa_forward_tuple_noise(self._h, B, _ptr(x_main), _ptr(x_sfc), _ptr(rnn1_mem), _ptr(hx0),
+                                                    _ptr(cx0), _ptr(eps), _ptr(out_lev), _ptr(out_sfc), _ptr(mem_out),
+                                                    self._stream())
+            self._rc(rc, "csa_forward_tuple_noise")
+            return out_lev, out_sfc, mem_out
         rc = _lib.lib().csa_forward_tuple(self._h, B, _ptr(x_main), _ptr(x_sfc), _ptr(rnn1_mem),
                                           _ptr(out_lev), _ptr(out_sfc), _ptr(mem_out), self._stream())
         self._rc(rc, "csa_forward_tuple")
         return out_lev, out_sfc, mem_out
 
-    def model_forward(self, x_main_n, x_sfc_n, rnn_mem=None, hx2=None, cx2=None):
+    def model_forward(self, x_main_n, x_sfc_n, rnn_mem=None, hx2=None, cx2=None, noise=None):
         c = self.cfg
         B = x_main_n.shape[0]
         x_main_n = _check(x_main_n, (B, c.nlev, c.nx), "x_main")
@@ -175,9 +199,16 @@ class Emulator:
         if c.nh_mem > 0:
             rnn_mem = _check(rnn_mem, mem_shape, "rnn_mem")
             mem_out = torch.empty(mem_shape, device=self.device)
-        hx2, cx2 = self._noise(B, hx2, cx2)
         out = torch.empty(B, c.nlev, c.ny, device=self.device)
         out_sfc = torch.empty(B, c.ny_sfc, device=self.device)
+        if c.add_stochastic_layer:
+            hx0, cx0, eps = self._stoch_noise(B, noise)
+            rc = _lib.lib().csa_model_forward_noise(self._h, B, _ptr(x_main_n), _ptr(x_sfc_n), _ptr(rnn_mem), _ptr(hx0),
+                                                    _ptr(cx0), _ptr(eps), _ptr(out), _ptr(out_sfc), _ptr(mem_out),
+                                                    self._stream())
+            self._rc(rc, "csa_model_forward_noise")
+            return out, out_sfc, mem_out
+        hx2, cx2 = self._noise(B, hx2, cx2)
         rc = _lib.lib().csa_model_forward(self._h, B, _ptr(x_main_n), _ptr(x_sfc_n), _ptr(rnn_mem),
                                           _ptr(hx2), _ptr(cx2), _ptr(out), _ptr(out_sfc), _ptr(mem_out),
                                           self._stream())

@@ -81,9 +81,11 @@ class RNN_autoreg(nn.Module):
                   "lbd_qc", "lbd_qi"):
             self.register_buffer(k, torch.from_numpy(np.ascontiguousarray(consts[k], np.float32)).to(dev))
 
-    def forward(self, inp_list):
+    def forward(self, inp_list, noise=None):
+        """noise = (hx0, cx0, eps) for add_stochastic_layer models; drawn with torch.randn when omitted, as the
+        reference does inside forward (models.py:466-468)."""
         x_main, x_sfc, rnn_mem = inp_list[0], inp_list[1], inp_list[2]
-        return self.emulator.model_forward(x_main, x_sfc, rnn_mem)
+        return self.emulator.model_forward(x_main, x_sfc, rnn_mem, noise=noise)
 
 
 class model_wrapper(nn.Module):
@@ -108,5 +110,5 @@ class model_wrapper(nn.Module):
         c = self.emulator.cfg
         self.nx, self.nmem, self.nlev_mem = c.nx, c.nh_mem, c.nlev
 
-    def forward(self, x_main0, x_sfc0, rnn1_mem):
-        return self.emulator.forward_tuple(x_main0, x_sfc0, rnn1_mem)
+    def forward(self, x_main0, x_sfc0, rnn1_mem, noise=None):
+        return self.emulator.forward_tuple(x_main0, x_sfc0, rnn1_mem, noise=noise)

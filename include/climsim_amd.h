@@ -53,6 +53,8 @@ typedef struct {
     int32_t q_input_mode;    /* rnn/utils.py:262-272: 0 none; 1 include_q_input: specific humidity from (RH,T,p) is
                                 appended as the LAST level input (nx counts it; raw x_main has nx-1 columns);
                                 2 rh_to_q: it replaces RH (input 1) */
+    int32_t add_stochastic_layer;/* models.py:405-412,464-474,521-534: rnn0 (down, noise init) -> rnn1 (up) -> stochastic
+                                LSTM "rnn2" (MyStochasticLSTMLayer4, down).  LSTM, current generation, nh1 == nh2 */
 } csa_config;
 
 /* HOST pointers, PyTorch state_dict layout (out_features,in_features); copied by csa_create. */
@@ -66,6 +68,10 @@ typedef struct {
     const float *rnn2_w_ih, *rnn2_w_hh, *rnn2_b_ih, *rnn2_b_hh;
     const float *mlp_latent_w, *mlp_latent_b, *mlp_output_w, *mlp_output_b;
     const float *mlp_surface_output_w, *mlp_surface_output_b;
+    /* add_stochastic_layer only: rnn0 = nn.LSTM(nh1+nh_mem, nh1); rnn1_* then is nn.LSTM(nh1, nh2);
+     * rnn2_weight_encoder (nh1+nh2, 5*nh2) in the reference's (in,out) layout; rnn2_w_* are unused */
+    const float *rnn0_w_ih, *rnn0_w_hh, *rnn0_b_ih, *rnn0_b_hh;
+    const float *rnn2_weight_encoder;
 } csa_params;
 
 typedef struct csa_emulator csa_emulator;
@@ -99,6 +105,16 @@ int csa_model_forward(csa_emulator *h, int B,
                       const float *x_main_n, const float *x_sfc_n, const float *mem_in,
                       const float *hx2, const float *cx2,
                       float *out, float *out_sfc, float *mem_out, void *stream);
+
+/* Stochastic variant (cfg.add_stochastic_layer): same as csa_forward_tuple / csa_model_forward with the three
+ * N(0,1) draws the reference makes inside forward passed explicitly, in its draw order (models.py:466-468 and
+ * models_torch_kernels.py:1497): hx0, cx0 (B,nh1) initial state of rnn0, eps (nlev,B,nh2). */
+int csa_forward_tuple_noise(csa_emulator *h, int B, const float *x_main, const float *x_sfc, const float *mem_in,
+                            const float *hx0, const float *cx0, const float *eps,
+                            float *out_lev, float *out_sfc, float *mem_out, void *stream);
+int csa_model_forward_noise(csa_emulator *h, int B, const float *x_main_n, const float *x_sfc_n, const float *mem_in,
+                            const float *hx0, const float *cx0, const float *eps,
+                            float *out, float *out_sfc, float *mem_out, void *stream);
 
 /* Debug taps of the last call: rnn1 / rnn2 hidden sequences, (nlev,B,nh) level order. */
 const float *csa_tap_rnn1(const csa_emulator *h);

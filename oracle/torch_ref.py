@@ -33,8 +33,10 @@ class EmulatorRef(nn.Module):
         self.nlev, self.nx = consts["xmean_lev"].shape
         self.nx_sfc = consts["xmean_sca"].shape[0]
         G = 4 if use_lstm else 3
+        # add_stochastic_layer (models.py:405-412): rnn0 -> rnn1 -> MyStochasticLSTMLayer4 as "rnn2"
+        self.stochastic = "rnn2.weight_encoder" in w
         self.nh1 = w["rnn1.weight_hh_l0"].shape[1]
-        self.nh2 = w["rnn2.weight_hh_l0"].shape[1]
+        self.nh2 = w["rnn2.weight_encoder"].shape[1] // 5 if self.stochastic else w["rnn2.weight_hh_l0"].shape[1]
         self.nh_mem = w["mlp_latent.weight"].shape[0] if "mlp_latent.weight" in w else 0
         self.ny = w["mlp_output.weight"].shape[0]
         self.ny_sfc = w["mlp_surface_output.weight"].shape[0]
@@ -55,9 +57,17 @@ class EmulatorRef(nn.Module):
             if use_lstm:
                 self.mlp_toa2 = lin("mlp_toa2")
         rnn = nn.LSTM if use_lstm else nn.GRU
-        self.rnn1 = rnn(self.nh1 + self.nh_mem, self.nh1, batch_first=False).to(dtype)
-        self.rnn2 = rnn(self.nh1, self.nh2, batch_first=False).to(dtype)
-        for r, n in ((self.rnn1, "rnn1"), (self.rnn2, "rnn2")):
+        if self.stochastic:
+            self.nh0 = w["rnn0.weight_hh_l0"].shape[1]
+            self.rnn0 = rnn(self.nh0 + self.nh_mem, self.nh0, batch_first=False).to(dtype)
+            self.rnn1 = rnn(self.nh0, self.nh1, batch_first=False).to(dtype)
+            self.register_buffer("w_enc", w["rnn2.weight_encoder"])
+            layers = ((self.rnn0, "rnn0"), (self.rnn1, "rnn1"))
+        else:
+            self.rnn1 = rnn(self.nh1 + self.nh_mem, self.nh1, batch_first=False).to(dtype)
+            self.rnn2 = rnn(self.nh1, self.nh2, batch_first=False).to(dtype)
+            layers = ((self.rnn1, "rnn1"), (self.rnn2, "rnn2"))
+        for r, n in layers:
             for p in ("weight_ih_l0", "weight_hh_l0", "bias_ih_l0", "bias_hh_l0"):
                 getattr(r, p).data.copy_(w[f"{n}.{p}"])
         if self.nh_mem > 0:
@@ -67,9 +77,12 @@ class EmulatorRef(nn.Module):
         assert self.rnn1.weight_hh_l0.shape[0] == G * self.nh1
 
     # ---- normalised-space model ---------------------------------------
-    def model_forward(self, x_main_n, x_sfc_n, mem_in=None, hx2=None, cx2=None):
+    def model_forward(self, x_main_n, x_sfc_n, mem_in=None, hx2=None, cx2=None, noise=None):
         """x_main_n (B,L,nx).  mem: legacy (B,L,nm) sequence order; current (L,B,nm) level order.
-        Returns out (B,L,ny), out_sfc (B,ny_sfc), mem_out (same layout as mem_in)."""
+        Returns out (B,L,ny), out_sfc (B,ny_sfc), mem_out (same layout as mem_in).
+        noise = (hx0, cx0, eps): the three randn draws of the stochastic variant, in the reference's draw order."""
+        if self.stochastic:
+            return self._stochastic_forward(x_main_n, x_sfc_n, mem_in, noise)
         x = x_main_n.transpose(0, 1)                                # (L,B,nx) level order
         sp = x_sfc_n[:, 0:1] * self.xdiv_sca[0] + self.xmean_sca[0]  # (B,1)
         pres = self.hyam.view(-1, 1, 1) * 100000.0 + sp.unsqueeze(0) * self.hybm.view(-1, 1, 1)
@@ -113,6 +126,31 @@ class EmulatorRef(nn.Module):
             out = out * mask
         out_sfc = self.mlp_surface_output(last_h.squeeze(0))
         self._taps = (r1, r2)
+        return out.transpose(0, 1), out_sfc, mem_out
+
+    def _stochastic_forward(self, x_main_n, x_sfc_n, mem_in, noise):
+        """models.py:464-474,521-534: LSTM down (randn init) -> LSTM up (surface init) -> stochastic LSTM down (TOA init)."""
+        hx0, cx0, eps = noise
+        x = x_main_n.transpose(0, 1)
+        sp = x_sfc_n[:, 0:1] * self.xdiv_sca[0] + self.xmean_sca[0]
+        pres = torch.sqrt(self.hyam.view(-1, 1, 1) * 100000.0 + sp.unsqueeze(0) * self.hybm.view(-1, 1, 1)) / 314.0
+        x = torch.tanh(self.mlp_initial(torch.cat((x, pres), dim=2)))
+        x = torch.cat((x, mem_in), dim=2)
+        r0, _ = self.rnn0(x, (hx0.unsqueeze(0), cx0.unsqueeze(0)))
+        hx = torch.tanh(self.mlp_surface1(x_sfc_n))
+        cx = self.mlp_surface2(x_sfc_n)
+        r1, _ = self.rnn1(torch.flip(r0, [0]), (hx.unsqueeze(0), cx.unsqueeze(0)))
+        r1 = torch.flip(r1, [0])
+        toa = torch.cat((x_sfc_n[:, 1:2], x_sfc_n[:, 6:7]), dim=1)
+        z, (last_h, _) = stoch_lstm4_ref(r1, self.mlp_toa1(toa), self.mlp_toa2(toa), eps, self.w_enc)
+        mem_out = self.mlp_latent(z)
+        out = self.mlp_output(mem_out)
+        if self.output_prune:
+            mask = torch.ones_like(out)
+            mask[0:12, :, 1:] = 0.0
+            out = out * mask
+        out_sfc = self.mlp_surface_output(last_h)
+        self._taps = (r0, r1, z)
         return out.transpose(0, 1), out_sfc, mem_out
 
     # ---- wrapper pieces ------------------------------------------------
@@ -169,18 +207,32 @@ class EmulatorRef(nn.Module):
         return x
 
     def postprocess(self, out, out_sfc, x_raw):
-        """models.py:273-339 (mp_mode 0 returns UN-denormalised outputs; mp_mode 1 -> 6 vars)."""
+        """models.py:273-339 (mp_mode 0 returns UN-denormalised outputs; mp_mode 1 -> 6 vars; -1 / -2: predicted
+        liquid fraction, total-water variant)."""
         if self.mp_mode == 0:
             return out, out_sfc
         o = out / self.yscale_lev
         os_ = out_sfc / self.yscale_sca
         T_old, ql, qi = x_raw[:, :, 0:1], x_raw[:, :, 2:3], x_raw[:, :, 3:4]
+        qn_old = ql + qi
+        dqv, dqn = o[:, :, 1:2], o[:, :, 2:3]
+        if self.mp_mode == -2:                                  # models.py:286-301
+            cf = torch.clamp(torch.square(torch.square(dqn)), min=0.0, max=1.0)
+            qv_old = x_raw[:, :, -1:]
+            qtot_new = (qn_old + qv_old) + dqv * 1200
+            dqv = ((1 - cf) * qtot_new - qv_old) * 0.0008333333333333334
+            dqn = (cf * qtot_new - qn_old) * 0.0008333333333333334
         T_new = T_old + o[:, :, 0:1] * 1200
-        lf = F.hardtanh((T_new - 253.16) * 0.05, 0.0, 1.0)
-        qn_new = (ql + qi) + o[:, :, 2:3] * 1200
+        if self.mp_mode == 1:
+            lf = F.hardtanh((T_new - 253.16) * 0.05, 0.0, 1.0)
+            rest = o[:, :, 3:]
+        else:
+            lf = o[:, :, 3:4]                                   # models.py:319 overwrites the clamped value
+            rest = o[:, :, 4:]
+        qn_new = qn_old + dqn * 1200
         dql = (lf * qn_new - ql) * 0.0008333333333333334
         dqi = ((1 - lf) * qn_new - qi) * 0.0008333333333333334
-        return torch.cat((o[:, :, 0:2], dql, dqi, o[:, :, 3:]), dim=2), os_
+        return torch.cat((o[:, :, 0:1], dqv, dql, dqi, rest), dim=2), os_
 
     def wrapper_forward(self, x_main, x_sfc, mem_in=None, hx2=None, cx2=None):
         """Packed wrapper (save_wrapper.py:255-298, save_wrapper_mem.py:499-545)."""
@@ -196,11 +248,11 @@ class EmulatorRef(nn.Module):
             y = torch.where(torch.isnan(y), torch.zeros((), dtype=y.dtype), y)
         return y
 
-    def wrapper_forward_tuple(self, x_main, x_sfc, mem_in):
+    def wrapper_forward_tuple(self, x_main, x_sfc, mem_in, noise=None):
         """rnn/utils.py:260-295 (forward_base)."""
         x_main = self.apply_q_input(x_main, x_sfc)
         xn, xs = self.preprocess(x_main, x_sfc)
-        out, out_sfc, mem_out = self.model_forward(xn, xs, mem_in)
+        out, out_sfc, mem_out = self.model_forward(xn, xs, mem_in, noise=noise)
         o, os_ = self.postprocess(out, out_sfc, x_main)
         o = torch.where(torch.isnan(o), torch.zeros((), dtype=o.dtype), o)
         return o, os_, mem_out

@@ -117,6 +117,31 @@ def test_oracles_vs_current_class(tag):
             assert rel_err(tos.numpy(), io[p + "out_sfc"]) <= 1e-6
 
 
+@pytest.mark.parametrize("tag", ["cur_mpm1", "cur_mpm2", "cur_stoch"])
+def test_torch_restatement_vs_current_class_variants(tag):
+    """mp_mode -1 / -2 post-processing and the 3-RNN stochastic model (tests/golden/make_golden_variants.py)."""
+    consts, weights, flags = load_npz_model(tag)
+    io = np.load(os.path.join(GOLDEN, f"{tag}_io.npz"))
+    ref = torch_ref.EmulatorRef(consts, weights, legacy=False, use_lstm=True, output_prune=bool(flags["output_prune"]),
+                                mp_mode=int(flags["mp_mode"]), scrub_inf=True)
+    T = torch.from_numpy
+    for B in (3, 10):
+        for t in range(int(io[f"B{B}.nsteps"])):
+            p = f"B{B}.t{t}."
+            noise = tuple(T(io[p + k]) for k in ("hx0", "cx0", "eps")) if tag == "cur_stoch" else None
+            with torch.no_grad():
+                xn, xs = ref.preprocess(T(io[p + "x_main"]), T(io[p + "x_sfc"]))
+                assert rel_err(xn.numpy(), io[p + "x_main_n"]) <= 1e-6
+                to, tos, tm = ref.model_forward(T(io[p + "x_main_n"]), T(io[p + "x_sfc_n"]), T(io[p + "mem_in"]), noise=noise)
+                assert rel_err(to.numpy(), io[p + "out"]) <= 2e-6
+                assert rel_err(tm.numpy(), io[p + "mem_out"]) <= 2e-6
+                assert rel_err(tos.numpy(), io[p + "out_sfc"]) <= 2e-6
+                o6, osd = ref.postprocess(T(io[p + "out"]), T(io[p + "out_sfc"]), T(io[p + "x_main"]))
+            for v in range(6):
+                assert rel_err(o6.numpy()[:, :, v], io[p + "post_lev"][:, :, v]) <= 1e-6, v
+            assert rel_err(osd.numpy(), io[p + "post_sfc"]) <= 1e-6
+
+
 def test_preprocess_edge_cases():
     """NaN/Inf scrub, snow/ice sentinel, zero divisors (xdiv has 66 exact zeros), RH clamp, q prune."""
     consts, weights, _ = load_npz_model("v4_memory")
