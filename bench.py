@@ -153,12 +153,85 @@ def train_workload(a, rank, local_rank, world, dist):
             "loss": sc["loss"]}), flush=True)
 
 
+def aux_workload(a, rank, world, dist):
+    """Secondary workloads (parity-test configurations, reported for DESIGN.md's tables; not the headline):
+    cur_lstm144_384   current-generation tuple wrapper at the reference's default width nh = 144
+    mlp_384 / cnn_384 offline Keras baselines (random weights of the reference architectures), forward."""
+    import climsim_amd
+    from climsim_amd.baselines import MLPBaseline, CNNBaseline
+    from synth import synth_inputs
+    B = 384
+    g = torch.Generator().manual_seed(100 + rank)
+    if a.workload == "cur_lstm144_384":
+        consts, weights = load_model("cur_lstm144")
+        m = climsim_amd.model_wrapper(consts, weights, use_lstm=True, output_prune=True, max_batch=B)
+        xm, xs = synth_inputs(consts, B, 9000 + rank)
+        xs_ = [torch.from_numpy(xm).cuda(), torch.from_numpy(xs).cuda()]
+        state = {"mem": torch.zeros(60, B, 16, device="cuda")}
+
+        def step():
+            o6, osfc, state["mem"] = m(xs_[0], xs_[1], state["mem"])
+        flop_col, what = 60 * 691360.0 + 13e3, "RNN_autoreg LSTM 144/144 tuple wrapper"
+    elif a.workload == "mlp_384":
+        dims = [124, 768, 640, 512, 640, 640, 128]   # step2_retrain.py hidden widths (best HPO trial) + 128 outputs
+        ws = [torch.randn(dims[i + 1], dims[i], generator=g) / dims[i] ** 0.5 for i in range(len(dims) - 1)]
+        bs = [torch.zeros(dims[i + 1]) for i in range(len(dims) - 1)]
+        m = MLPBaseline([w.numpy() for w in ws], [b.numpy() for b in bs], leaky_alpha=0.15, n_lin_out=120, max_batch=B)
+        x = torch.randn(B, 124, generator=g).cuda()
+
+        def step():
+            m(x)
+        flop_col, what = 2.0 * sum(dims[i] * dims[i + 1] for i in range(len(dims) - 1)), "Keras MLP baseline forward"
+    else:
+        depth, width = 12, 406
+        ws, bs = [], []
+        for i in range(depth):
+            ci = 6 if i == 0 else width
+            for co, cin, k in ((width, ci, 3), (width, width, 3), (width, ci, 1)):
+                ws.append(torch.randn(co, cin, k, generator=g) * (0.9 / (cin * k) ** 0.5)); bs.append(torch.zeros(co))
+        ws += [torch.randn(10, width, 1, generator=g) / width ** 0.5, torch.randn(10, 10, 1, generator=g) / 3]
+        bs += [torch.zeros(10), torch.zeros(10)]
+        m = CNNBaseline([w.numpy() for w in ws], [b.numpy() for b in bs], max_batch=B)
+        x = torch.randn(B, 60, 6, generator=g).cuda()
+
+        def step():
+            m(x)
+        flop_col, what = 1.58e9, "Keras CNN (12 residual Conv1D blocks) forward, implicit-GEMM"
+
+    def fence():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+    for _ in range(a.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    fence()
+    from climsim_amd.sharding import max_over_ranks
+    el = max_over_ranks(time.perf_counter() - t0, device="cuda")
+    if rank == 0:
+        tf = B * flop_col * a.steps / el / 1e12
+        print(json.dumps({
+            "metric": "grid-columns/sec emulator fwd", "value": world * B * a.steps / el, "unit": "grid-columns/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * el / a.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": a.workload, "columns_per_gpu": B, "what": what,
+                       "parallelism": f"columns sharded x{world}, no collective"},
+            "whole_path": {"flop_per_column": flop_col, "achieved_tflops": tf, "frac_fp32_peak": tf / PEAK_FP32_TFLOPS}}),
+            flush=True)
+
+
+AUX = ["cur_lstm144_384", "mlp_384", "cnn_384"]
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--workload", default="v4_stateless_384", choices=sorted(WORKLOADS) + ["train_tbptt3_384"])
+    ap.add_argument("--workload", default="v4_stateless_384", choices=sorted(WORKLOADS) + ["train_tbptt3_384"] + AUX)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     a = ap.parse_args()
 
@@ -176,6 +249,12 @@ def main():
     import climsim_amd
     from synth import synth_inputs
 
+    if a.workload in AUX:
+        aux_workload(a, rank, world, dist)
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
     if a.workload == "train_tbptt3_384":
         train_workload(a, rank, local_rank, world, dist)
         if dist is not None:

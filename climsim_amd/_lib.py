@@ -35,6 +35,9 @@ SYMBOLS = ["csa_create", "csa_destroy", "csa_set_params", "csa_packed_width", "c
            "csa_train_backward", "csa_train_loss", "csa_train_adam",
            "csa_mlp_create", "csa_mlp_destroy", "csa_mlp_forward",
            "csa_cnn_create", "csa_cnn_destroy", "csa_cnn_forward",
+           "csa_cnn_train_create", "csa_cnn_train_destroy", "csa_cnn_train_num_params", "csa_cnn_train_num_layers",
+           "csa_cnn_train_params", "csa_cnn_train_get_params", "csa_cnn_train_set_params", "csa_cnn_train_get_act", "csa_cnn_train_layer_info", "csa_cnn_train_forward", "csa_cnn_train_backward",
+           "csa_cnn_train_adam",
            "csa_stoch_gru5_create", "csa_stoch_lstm4_create", "csa_stoch_destroy", "csa_stoch_gru5_forward",
            "csa_stoch_lstm4_forward"]
 
@@ -104,6 +107,21 @@ def lib():
     L.csa_cnn_create.argtypes = [i, i, i, i, i, i, PP, PP, i, ctypes.POINTER(H)]
     L.csa_cnn_destroy.argtypes = [H]
     L.csa_cnn_forward.argtypes = [H, i, _F, _F, ctypes.c_void_p]
+    fl, PL, PI = ctypes.c_float, ctypes.POINTER(ctypes.c_long), ctypes.POINTER(ctypes.c_int)
+    L.csa_cnn_train_create.argtypes = [i, i, i, i, i, i, PP, PP, i, fl, ctypes.POINTER(H)]
+    L.csa_cnn_train_destroy.argtypes = [H]
+    L.csa_cnn_train_num_params.argtypes = [H]
+    L.csa_cnn_train_num_params.restype = ctypes.c_long
+    L.csa_cnn_train_num_layers.argtypes = [H]
+    L.csa_cnn_train_params.argtypes = [H]
+    L.csa_cnn_train_params.restype = ctypes.c_void_p
+    L.csa_cnn_train_get_params.argtypes = [H, _F, ctypes.c_void_p]
+    L.csa_cnn_train_set_params.argtypes = [H, _F, ctypes.c_void_p]
+    L.csa_cnn_train_get_act.argtypes = [H, i, i, _F, PI, ctypes.c_void_p]
+    L.csa_cnn_train_layer_info.argtypes = [H, i, PL, PL, PI, PI, PI, PI, PI]
+    L.csa_cnn_train_forward.argtypes = [H, i, _F, ctypes.c_void_p, _F, ctypes.c_void_p]
+    L.csa_cnn_train_backward.argtypes = [H, _F, fl, _F, _F, ctypes.c_void_p]
+    L.csa_cnn_train_adam.argtypes = [H, _F, fl, fl, fl, fl, i, ctypes.c_void_p]
     L.csa_stoch_gru5_create.argtypes = [i, i, Fp, Fp, Fp, Fp, Fp, i, ctypes.POINTER(H)]
     L.csa_stoch_lstm4_create.argtypes = [i, i, Fp, i, ctypes.POINTER(H)]
     L.csa_stoch_destroy.argtypes = [H]

@@ -102,3 +102,125 @@ class CNNBaseline(torch.nn.Module):
                 self._h = None
         except Exception:
             pass
+
+
+class CNNTrainer:
+    """One optimiser step of the Keras CNN baseline on the HIP path (hpo_train.py:124-236: Dropout(0.175), mae_adjusted,
+    keras Adam).  Columns are sharded across ranks; gradients live in ONE flat buffer, all-reduced once per step."""
+
+    def __init__(self, weights, biases, *, depth=12, nlev=60, cin=6, width=406, cout=10, n_lin=2, dropout=0.175,
+                 max_batch=512):
+        self._h = None
+        if not torch.cuda.is_available():
+            raise RuntimeError("climsim_amd needs a HIP device: the product path has no CPU fallback")
+        self.device = torch.device("cuda", torch.cuda.current_device())
+        ws = [np.ascontiguousarray(w, np.float32) for w in weights]
+        bs = [np.ascontiguousarray(b, np.float32) for b in biases]
+        if len(ws) != 3 * depth + 2:
+            raise RuntimeError("expected 3 weights per block plus pre-output conv and dense")
+        n = len(ws)
+        FP = ctypes.POINTER(ctypes.c_float)
+        warr = (FP * n)(*[w.ctypes.data_as(FP) for w in ws])
+        barr = (FP * n)(*[b.ctypes.data_as(FP) for b in bs])
+        h = ctypes.c_void_p()
+        L = _lib.lib()
+        rc = L.csa_cnn_train_create(depth, nlev, cin, width, cout, n_lin, warr, barr, int(max_batch), float(dropout), ctypes.byref(h))
+        if rc != 0:
+            raise RuntimeError(f"csa_cnn_train_create failed ({rc}): {_lib.last_error()}")
+        self._h = h
+        self.depth, self.nlev, self.cin, self.width, self.cout, self.dropout = depth, nlev, cin, width, cout, dropout
+        self.n_params = int(L.csa_cnn_train_num_params(h))
+        self.grads = torch.zeros(self.n_params, device=self.device)
+        self.loss = torch.zeros(1, device=self.device)
+        self.step_count = 0
+        self.layers = []
+        for i in range(L.csa_cnn_train_num_layers(h)):
+            wo, bo = ctypes.c_long(), ctypes.c_long()
+            v = [ctypes.c_int() for _ in range(5)]
+            L.csa_cnn_train_layer_info(h, i, ctypes.byref(wo), ctypes.byref(bo), *[ctypes.byref(q) for q in v])
+            self.layers.append((wo.value, bo.value) + tuple(q.value for q in v))
+
+    def _stream(self):
+        return ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _rc(self, rc, what):
+        if rc != 0:
+            raise RuntimeError(f"{what} failed ({rc}): {_lib.last_error()}")
+
+    def draw_masks(self, B):
+        """Keep-flags of the 2*depth Dropout layers, drawn on the device in layer order."""
+        if self.dropout <= 0:
+            return None
+        return (torch.rand(2 * self.depth, B * self.nlev, self.width, device=self.device) >= self.dropout).to(torch.uint8)
+
+    def forward(self, x, masks=None):
+        B = x.shape[0]
+        x = _check(x, (B, self.nlev, self.cin), "x")
+        if masks is not None:
+            if masks.dtype != torch.uint8 or tuple(masks.shape) != (2 * self.depth, B * self.nlev, self.width) or not masks.is_cuda:
+                raise RuntimeError("masks: expected a uint8 CUDA tensor of shape (2*depth, B*nlev, width)")
+            masks = masks.contiguous()
+        y = torch.empty(B, self.nlev, self.cout, device=self.device)
+        mp = None if masks is None else ctypes.c_void_p(masks.data_ptr())
+        self._rc(_lib.lib().csa_cnn_train_forward(self._h, B, _ptr(x), mp, _ptr(y), self._stream()), "csa_cnn_train_forward")
+        return y
+
+    def backward(self, y_true, grad_scale=1.0):
+        y_true = _check(y_true, tuple(y_true.shape), "y_true")
+        self._rc(_lib.lib().csa_cnn_train_backward(self._h, _ptr(y_true), float(grad_scale), _ptr(self.loss), _ptr(self.grads),
+                                                   self._stream()), "csa_cnn_train_backward")
+        return self.loss, self.grads
+
+    def adam(self, lr=1e-4, beta1=0.9, beta2=0.999, eps=1e-7):
+        self.step_count += 1
+        self._rc(_lib.lib().csa_cnn_train_adam(self._h, _ptr(self.grads), lr, beta1, beta2, eps, self.step_count, self._stream()),
+                 "csa_cnn_train_adam")
+
+    def train_step(self, x, y_true, masks="draw", lr=1e-4, world_size=1):
+        """forward + loss + backward + ONE flat-gradient all-reduce (world_size > 1) + Adam; returns the loss tensor
+        (this rank's share of the global mean; summed over ranks by the same all-reduce call pattern)."""
+        if isinstance(masks, str):
+            masks = self.draw_masks(x.shape[0])
+        self.forward(x, masks)
+        self.backward(y_true, 1.0 / world_size)
+        if world_size > 1:
+            import torch.distributed as dist
+            dist.all_reduce(self.grads)
+            dist.all_reduce(self.loss)
+        self.adam(lr=lr)
+        return self.loss
+
+    def flat_params(self):
+        t = torch.empty(self.n_params, device=self.device)
+        self._rc(_lib.lib().csa_cnn_train_get_params(self._h, _ptr(t), self._stream()), "csa_cnn_train_get_params")
+        return t
+
+    def saved_activation(self, block, which, B):
+        """(B, nlev, width) copy of a saved activation of the last forward (debug tap; which: 0 t1, 1 t2, 2 block output)."""
+        wp = (self.width + 7) // 8 * 8
+        t = torch.empty(B * self.nlev, wp, device=self.device)
+        ld = ctypes.c_int()
+        self._rc(_lib.lib().csa_cnn_train_get_act(self._h, block, which, _ptr(t), ctypes.byref(ld), self._stream()), "csa_cnn_train_get_act")
+        return t[:, :self.width].reshape(B, self.nlev, self.width)
+
+    def load_flat_params(self, flat):
+        flat = _check(flat, (self.n_params,), "flat")
+        self._rc(_lib.lib().csa_cnn_train_set_params(self._h, _ptr(flat), self._stream()), "csa_cnn_train_set_params")
+
+    def unpack(self, flat):
+        """Flat (padded GEMM layout) -> lists of Conv1d-layout weights (cout,cin,k) and biases, for tests / export."""
+        flat = flat.detach().cpu()
+        ws, bs = [], []
+        for (wo, bo, cout, cin, k, cout_p, cin_p) in self.layers:
+            w = flat[wo:wo + cout_p * k * cin_p].view(cout_p, k, cin_p)[:cout, :, :cin].permute(0, 2, 1).contiguous()
+            ws.append(w)
+            bs.append(flat[bo:bo + cout].clone())
+        return ws, bs
+
+    def __del__(self):
+        try:
+            if self._h is not None:
+                _lib.lib().csa_cnn_train_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass

@@ -65,6 +65,18 @@ int launch_proj_gemm(const float *A, const float *W, const float *bias, float *C
 int launch_gemm_act(const float *A, const float *W, const float *bias, float *C, int M, int N, int K,
                     int act, float alpha, int n_lin, hipStream_t s);
 
+// optional epilogue extras of the general GEMM (all null / zero = none); see gemm.hip
+struct GemmEpi {
+    const float *addsrc = nullptr;          // v += addsrc[row*ldc + col]
+    const unsigned char *mask = nullptr;    // v *= mask[row*ldmask + col] ? mscale : 0   (col < ldmask)
+    int ldmask = 0;
+    float mscale = 1.0f;
+    const float *gate = nullptr;            // v *= gate[row*ldc + col] > 0 ? gscale : 0
+    float gscale = 1.0f;
+};
+int launch_gemm_epi(const float *A, const float *W, const float *bias, float *C, int M, int N, int K, int act, float alpha,
+                    int n_lin, int lda, int ldc, int conv_L, int conv_cin, const GemmEpi &epi, hipStream_t s);
+
 // general form: leading dimensions, implicit-GEMM conv1d(k=3,'same') over (column, level) rows, C += mode, ELU
 int launch_gemm_ex(const float *A, const float *W, const float *bias, float *C, int M, int N, int K, int act, float alpha,
                    int n_lin, int lda, int ldc, int conv_L, int conv_cin, int accumulate, hipStream_t s);

@@ -22,8 +22,12 @@
 __global__ __launch_bounds__(GB_THREADS) void proj_gemm_kernel(
     const float *__restrict__ A, const float *__restrict__ W, const float *__restrict__ bias,
     float *__restrict__ C, int M, int N, int K, int tiles_m, int tiles_n, int act, float alpha, int n_lin,
-    int lda, int ldc, int conv_L, int conv_cin, int accumulate)
+    int lda, int ldc, int conv_L, int conv_cin, GemmEpi epi)
 {
+    // epi (training of the CNN baseline, cnn_train.hip): after bias + activation,
+    //   mask   : v *= mask[row*ldmask + col] ? mscale : 0      (inverted dropout, hpo_train.py:169,177)
+    //   gate   : v *= gate[row*ldc + col] > 0 ? gscale : 0     (backward of ReLU + dropout from the SAVED output)
+    //   addsrc : v += addsrc[row*ldc + col]                    (residual add; addsrc == C accumulates in place)
     // lda / ldc: leading dimensions of A and C (K and N for a plain GEMM).
     // conv_L > 0: implicit-GEMM 1-D convolution, kernel 3, 'same' padding, over rows = (column, level) with
     //   conv_L levels per column: A row r is the 3*cin contiguous floats [x(l-1), x(l), x(l+1)] starting at
@@ -93,19 +97,29 @@ __global__ __launch_bounds__(GB_THREADS) void proj_gemm_kernel(
     const int nchunk = (K + GB_K - 1) / GB_K;
     for (int c = 0; c < nchunk; ++c) {
         const int cur = c & 1;
+#ifndef GEMM_EXP_NO_GLOAD
         if (c + 1 < nchunk) gload((c + 1) * GB_K);
+#endif
         const float *as = As[cur], *ws = Ws[cur];
 #pragma unroll
         for (int kk = 0; kk < GB_K / 2; ++kk) {
+#ifdef GEMM_EXP_NO_LDSREAD   /* diagnostic builds only (tools/): wrong results, timing of the remaining parts */
+            const float a0 = 1e-3f * (lane + kk + c), a1 = a0 + 1.0f, b0 = a0 * 0.5f, b1 = a0 + 2.0f;
+#else
             const float a0 = as[arow + kk * 2], a1 = as[arow + 32 * GB_LD + kk * 2];
             const float b0 = ws[wrow + kk * 2], b1 = ws[wrow + 32 * GB_LD + kk * 2];
+#endif
             acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
             acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
             acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
             acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
         }
+#ifndef GEMM_EXP_NO_GLOAD
         if (c + 1 < nchunk) sstore(cur ^ 1);
+#endif
+#ifndef GEMM_EXP_NO_BARRIER
         __syncthreads();
+#endif
     }
 
     // epilogue: D[i][j] with j = lane&31 (column) and i = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
@@ -130,7 +144,8 @@ __global__ __launch_bounds__(GB_THREADS) void proj_gemm_kernel(
                 else if (act == 3) v = v > 0.0f ? v : expm1f(v);
                 acc[i][j][r] = v;
             }
-    const bool interior = (m0 + GB_M <= M) && (n0 + GB_N <= N) && !accumulate;
+    const bool plain = !epi.addsrc && !epi.mask && !epi.gate;
+    const bool interior = (m0 + GB_M <= M) && (n0 + GB_N <= N) && plain;
     if (interior) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
@@ -151,8 +166,12 @@ __global__ __launch_bounds__(GB_THREADS) void proj_gemm_kernel(
                 for (int r = 0; r < 16; ++r) {
                     const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                     if (row < M && col < N) {
-                        float *cp = C + (size_t)row * ldc + col;
-                        *cp = accumulate ? *cp + acc[i][j][r] : acc[i][j][r];
+                        const size_t idx = (size_t)row * ldc + col;
+                        float v = acc[i][j][r];
+                        if (epi.mask) v = (col < epi.ldmask && epi.mask[(size_t)row * epi.ldmask + col]) ? v * epi.mscale : 0.0f;
+                        if (epi.gate) v = epi.gate[idx] > 0.0f ? v * epi.gscale : 0.0f;
+                        if (epi.addsrc) v += epi.addsrc[idx];
+                        C[idx] = v;
                     }
                 }
         }
@@ -174,6 +193,14 @@ int launch_gemm_act(const float *A, const float *W, const float *bias, float *C,
 int launch_gemm_ex(const float *A, const float *W, const float *bias, float *C, int M, int N, int K, int act, float alpha,
                    int n_lin, int lda, int ldc, int conv_L, int conv_cin, int accumulate, hipStream_t s)
 {
+    GemmEpi e{};
+    if (accumulate) e.addsrc = C;
+    return launch_gemm_epi(A, W, bias, C, M, N, K, act, alpha, n_lin, lda, ldc, conv_L, conv_cin, e, s);
+}
+
+int launch_gemm_epi(const float *A, const float *W, const float *bias, float *C, int M, int N, int K, int act, float alpha,
+                    int n_lin, int lda, int ldc, int conv_L, int conv_cin, const GemmEpi &epi, hipStream_t s)
+{
     if ((lda % 4) || (conv_L > 0 && (conv_cin % 4 || K != 3 * conv_cin))) {
         csa_set_error_msg("gemm_ex: lda and cin must be multiples of 4, K = 3*cin in conv mode");
         return CSA_ERR_UNSUPPORTED;
@@ -184,7 +211,7 @@ int launch_gemm_ex(const float *A, const float *W, const float *bias, float *C, 
     }
     const int tiles_m = (M + GB_M - 1) / GB_M, tiles_n = (N + GB_N - 1) / GB_N;
     hipLaunchKernelGGL(proj_gemm_kernel, dim3(tiles_m * tiles_n), dim3(GB_THREADS), 0, s, A, W, bias, C, M, N, K,
-                       tiles_m, tiles_n, act, alpha, n_lin, lda, ldc, conv_L, conv_cin, accumulate);
+                       tiles_m, tiles_n, act, alpha, n_lin, lda, ldc, conv_L, conv_cin, epi);
     CSA_HIP_CHECK(hipGetLastError());
     return CSA_OK;
 }

@@ -292,6 +292,13 @@ __global__ __launch_bounds__(NH * 4, (NH / 16 + 3) / 4) void lstm_rec2_kernel(
     // LDS->VGPR return traffic (16 KB per wave per step) competing with the packed FMAs, not by
     // read latency: 1234 cycles per step with h in registers vs ~1650 with h from LDS
     // (tools/valu_bench.hip).
+#ifdef REC_EXP_HALF_LDS   /* diagnostic: half the LDS reads, same FMA count (results are wrong) */
+#define REC_HIDX(j) ((j) & ~1)
+#elif defined(REC_EXP_QUARTER_LDS)
+#define REC_HIDX(j) ((j) & ~3)
+#else
+#define REC_HIDX(j) (j)
+#endif
 #define LSTM2_STEP(T, CUR, NXT)                                                                    \
     {                                                                                              \
         const int t_ = (T);                                                                        \
@@ -302,7 +309,7 @@ __global__ __launch_bounds__(NH * 4, (NH / 16 + 3) / 4) void lstm_rec2_kernel(
         const f32x4 *hp = (const f32x4 *)&hbuf[t_ & 1][rdoff];                                     \
         f32x2 acc[4] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};                           \
         _Pragma("unroll") for (int j = 0; j < KR; ++j) {                                           \
-            const f32x4 hv = hp[j];                                                                \
+            const f32x4 hv = hp[REC_HIDX(j)];                                                      \
             const f32x2 ha = {hv.x, hv.y}, hb = {hv.z, hv.w};                                      \
             _Pragma("unroll") for (int s = 0; s < 4; ++s) PK_FMA_LO(acc[s], w[s][j], ha);          \
             _Pragma("unroll") for (int s = 0; s < 4; ++s) PK_FMA_HI(acc[s], w[s][j], hb);          \

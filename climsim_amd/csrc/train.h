@@ -9,6 +9,8 @@ int launch_bwd_rec(int nh, const float *wt_packed, float *GP, const float *Cseq,
 
 int launch_gemm_tn_partial(const float *A, int lda, const float *Bm, int ldb, float *Cpart, int M, int N1, int N2,
                            int nsplit, hipStream_t s);
+int launch_gemm_tn_conv(const float *A, int lda, const float *Bm, int ldb, float *Cpart, int M, int N1, int N2,
+                        int nsplit, int conv_L, int conv_cin, hipStream_t s);
 int launch_colsum_partial(const float *A, float *part, int M, int N, int nsplit, hipStream_t s);
 int launch_reduce_partials(const float *part, int nsplit, int n, const int *map, const int *map2, float *grad, hipStream_t s);
 

@@ -18,8 +18,11 @@
 #define TN_MK 16
 __global__ __launch_bounds__(256) void gemm_tn_partial_kernel(
     const float *__restrict__ A, int lda, const float *__restrict__ Bm, int ldb, float *__restrict__ Cpart,
-    int M, int N1, int N2, int rows_per_split)
+    int M, int N1, int N2, int rows_per_split, int conv_L, int conv_cin)
 {
+    // conv_L > 0: B is the implicit im2col of a kernel-3 'same' convolution input X (ldb = cin): row m is the
+    // 3*cin contiguous floats starting at X + (m-1)*ldb, first / last third masked on the first / last level of a
+    // column (the weight gradient of Conv1D, cnn_train.hip); N2 = 3*cin.
     __shared__ float As[TN_MK][TN_T];
     __shared__ float Bs[TN_MK][TN_T];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
@@ -42,11 +45,18 @@ __global__ __launch_bounds__(256) void gemm_tn_partial_kernel(
             f32x4 va = {0, 0, 0, 0}, vb = {0, 0, 0, 0};
             if (m < m_end) {
                 const float *pa = A + (size_t)m * lda + n10 + sc;
-                const float *pb = Bm + (size_t)m * ldb + n20 + sc;
+                const float *pb = conv_L > 0 ? Bm + ((long)m - 1) * ldb + n20 + sc : Bm + (size_t)m * ldb + n20 + sc;
                 if (n10 + sc + 3 < N1) va = *(const f32x4 *)pa;
                 else for (int e = 0; e < 4; ++e) if (n10 + sc + e < N1) va[e] = pa[e];
-                if (n20 + sc + 3 < N2) vb = *(const f32x4 *)pb;
-                else for (int e = 0; e < 4; ++e) if (n20 + sc + e < N2) vb[e] = pb[e];
+                bool okb = true;
+                if (conv_L > 0) {
+                    const int l = m % conv_L, c2 = n20 + sc;
+                    okb = !((l == 0 && c2 < conv_cin) || (l == conv_L - 1 && c2 >= 2 * conv_cin));
+                }
+                if (okb) {
+                    if (n20 + sc + 3 < N2) vb = *(const f32x4 *)pb;
+                    else for (int e = 0; e < 4; ++e) if (n20 + sc + e < N2) vb[e] = pb[e];
+                }
             }
             *(f32x4 *)&As[sr + 8 * h][sc] = va;
             *(f32x4 *)&Bs[sr + 8 * h][sc] = vb;
@@ -80,11 +90,18 @@ __global__ __launch_bounds__(256) void gemm_tn_partial_kernel(
 int launch_gemm_tn_partial(const float *A, int lda, const float *Bm, int ldb, float *Cpart, int M, int N1, int N2,
                            int nsplit, hipStream_t s)
 {
+    return launch_gemm_tn_conv(A, lda, Bm, ldb, Cpart, M, N1, N2, nsplit, 0, 0, s);
+}
+
+int launch_gemm_tn_conv(const float *A, int lda, const float *Bm, int ldb, float *Cpart, int M, int N1, int N2,
+                        int nsplit, int conv_L, int conv_cin, hipStream_t s)
+{
+    if (conv_L > 0 && (conv_cin % 4 || N2 != 3 * conv_cin)) { csa_set_error_msg("gemm_tn(conv): cin multiple of 4 and N2 = 3*cin required"); return CSA_ERR_UNSUPPORTED; }
     if ((lda % 4) || (ldb % 4)) { csa_set_error_msg("gemm_tn: leading dimensions must be multiples of 4"); return CSA_ERR_UNSUPPORTED; }
     int rps = (M + nsplit - 1) / nsplit;
     rps = (rps + TN_MK - 1) / TN_MK * TN_MK;
     dim3 grid((N1 + TN_T - 1) / TN_T, (N2 + TN_T - 1) / TN_T, nsplit);
-    hipLaunchKernelGGL(gemm_tn_partial_kernel, grid, dim3(256), 0, s, A, lda, Bm, ldb, Cpart, M, N1, N2, rps);
+    hipLaunchKernelGGL(gemm_tn_partial_kernel, grid, dim3(256), 0, s, A, lda, Bm, ldb, Cpart, M, N1, N2, rps, conv_L, conv_cin);
     CSA_HIP_CHECK(hipGetLastError());
     return CSA_OK;
 }

@@ -195,6 +195,31 @@ int csa_cnn_create(int depth, int nlev, int cin, int width, int cout, int n_lin,
 int csa_cnn_destroy(csa_cnn *h);
 int csa_cnn_forward(csa_cnn *h, int B, const float *x, float *y, void *stream);
 
+/* ---- CNN baseline, one training step (BASELINE.json configs[3]) ------------------------------------------------
+ * baseline_models/CNN/training/hpo_train.py:124-236: forward with Dropout(p) after both activations of a block,
+ * loss mae_adjusted (:118-120), keras Adam.  Parameters and gradients are flat fp32 device buffers in the GEMM layout
+ * (per layer: W (cout_p, k*cin_p) with channels padded to multiples of 8 / 4, then b (cout_p)); csa_cnn_train_layer_info
+ * gives the offsets.  masks: uint8 keep-flags (2*depth, B*nlev, width), drawn by the caller (NULL: no dropout).
+ * grad_scale multiplies dLoss/dy (data-parallel shares).  loss_out: one device float (nullable). */
+typedef struct csa_cnn_trainer csa_cnn_trainer;
+int csa_cnn_train_create(int depth, int nlev, int cin, int width, int cout, int n_lin, const float *const *weights,
+                         const float *const *biases, int max_batch, float dropout, csa_cnn_trainer **out);
+int csa_cnn_train_destroy(csa_cnn_trainer *h);
+long csa_cnn_train_num_params(const csa_cnn_trainer *h);
+int csa_cnn_train_num_layers(const csa_cnn_trainer *h);
+float *csa_cnn_train_params(csa_cnn_trainer *h);
+int csa_cnn_train_get_params(csa_cnn_trainer *h, float *dst, void *stream);       /* device-to-device copies of the */
+int csa_cnn_train_set_params(csa_cnn_trainer *h, const float *src, void *stream); /* flat parameter buffer */
+/* debug tap: saved activation of the last forward; which 0 = after conv_a+ReLU+dropout, 1 = after conv_b+..., 2 = block output */
+int csa_cnn_train_get_act(csa_cnn_trainer *h, int block, int which, float *dst, int *ld, void *stream);
+int csa_cnn_train_layer_info(const csa_cnn_trainer *h, int i, long *w_off, long *b_off, int *cout, int *cin, int *k,
+                             int *cout_p, int *cin_p);
+int csa_cnn_train_forward(csa_cnn_trainer *h, int B, const float *x, const unsigned char *masks, float *y_out, void *stream);
+int csa_cnn_train_backward(csa_cnn_trainer *h, const float *y_true, float grad_scale, float *loss_out, float *grads,
+                           void *stream);
+int csa_cnn_train_adam(csa_cnn_trainer *h, const float *grads, float lr, float beta1, float beta2, float eps, int step,
+                       void *stream);
+
 /* ---- stochastic recurrent layers ---------------------------------------------------
  * MyStochasticGRULayer5  rnn/models_torch_kernels.py:834-891 (its GPU path = the repo's inline CUDA, :29-252)
  * MyStochasticLSTMLayer4 rnn/models_torch_kernels.py:1474-1531

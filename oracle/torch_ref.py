@@ -360,19 +360,36 @@ def stoch_lstm4_ref(x, h, c, eps, weight_encoder):
 
 
 # ---- Keras CNN baseline restated in torch (TEST INFRASTRUCTURE) ---------------------------------------
-def cnn_ref(x, weights, biases, depth=12, n_lin=2):
+def cnn_ref(x, weights, biases, depth=12, n_lin=2, masks=None, dropout=0.0, gates=None):
     """baseline_models/CNN/training/hpo_train.py:159-200 (inference: Dropout is identity).  x (B,L,6) channels-last;
     weights in Conv1d layout (cout,cin,k): per block conv_a, conv_b, residual; then pre-output conv; then stacked
     dense (cout,cout,1).  No reference weights ship (model/saved_model.pb has no variables): parity UNPINNED."""
     h = x.transpose(1, 2)                      # (B, C, L)
     prev = h
     i = 0
-    for _ in range(depth):
-        h = F.relu(F.conv1d(prev, weights[i], biases[i], padding=1)); i += 1
-        h = F.relu(F.conv1d(h, weights[i], biases[i], padding=1)); i += 1
+    ms = 1.0 / (1.0 - dropout)
+
+    def act(v, k):
+        # gates (test only): ReLU as a product with a GIVEN 0/1 pattern, so that two fp32 evaluations whose
+        # pre-activations differ by rounding take the same branch at units within rounding of zero
+        return F.relu(v) if gates is None else v * gates[k].transpose(1, 2).to(v.dtype)
+    for blk in range(depth):
+        # training mode (masks given): keras Dropout after each activation = keep-mask * 1/(1-p), hpo_train.py:169,177
+        h = act(F.conv1d(prev, weights[i], biases[i], padding=1), 2 * blk); i += 1
+        if masks is not None:
+            h = h * masks[2 * blk].transpose(1, 2).to(h.dtype) * ms
+        h = act(F.conv1d(h, weights[i], biases[i], padding=1), 2 * blk + 1); i += 1
+        if masks is not None:
+            h = h * masks[2 * blk + 1].transpose(1, 2).to(h.dtype) * ms
         h = h + F.conv1d(prev, weights[i], biases[i]); i += 1
         prev = h
     h = F.elu(F.conv1d(h, weights[i], biases[i])); i += 1
     h = F.conv1d(h, weights[i], biases[i])
     h = torch.cat((h[:, :n_lin], F.relu(h[:, n_lin:])), dim=1)
     return h.transpose(1, 2)
+
+
+def mae_adjusted(y_true, y_pred, n_lin=2):
+    """baseline_models/CNN/training/hpo_train.py:118-120."""
+    ae = (y_pred - y_true).abs()
+    return ae[:, :, 0:n_lin].mean() * (120 / 128) + ae[:, :, n_lin:].mean() * (8 / 128)

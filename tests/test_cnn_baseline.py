@@ -43,3 +43,67 @@ def test_cnn_forward_matches_torch(depth, width, B):
     assert e <= 1e-5 * scale, e / scale
     assert e <= 4 * (ref32.double() - ref).abs().max().item() + 1e-7 * scale
     assert (y[:, :, 2:] >= 0).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("depth,width,B,dropout", [(2, 40, 3, 0.0), (3, 72, 4, 0.175), (3, 406, 6, 0.175), (6, 406, 6, 0.0),
+                                                  (12, 200, 6, 0.0), (12, 406, 6, 0.175)])
+def test_cnn_training_step_matches_autograd(depth, width, B, dropout):
+    """forward (with the caller's dropout masks), mae_adjusted, every weight / bias gradient and one Keras-Adam update
+    against torch autograd on the restatement (fp32, the arithmetic the reference trains in).
+
+    The gradient of a ReLU network is piecewise constant in the activations: a unit whose pre-activation is within
+    fp32 rounding of zero can take a different branch in two correct fp32 evaluations (torch fp32 on two CPUs, or vs
+    torch fp64, differ the same way: tools/cnn_dbg.py), and with B*60 = 360 rows ONE flipped unit moves a
+    weight-gradient row by ~1/sqrt(360) of its size.  The forward is therefore checked against the plain restatement,
+    and the gradients against the restatement evaluated with the ReLU branch pattern of the HIP forward (read back
+    through the csa_cnn_train_get_act tap); the patterns themselves must agree except at a handful of units."""
+    from climsim_amd.baselines import CNNTrainer
+    ws, bs = _arch(depth, width, seed=3)
+    tr = CNNTrainer([w.numpy() for w in ws], [b.numpy() for b in bs], depth=depth, width=width, dropout=dropout, max_batch=8)
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(B, 60, 6, generator=g)
+    yt = torch.randn(B, 60, 10, generator=g)
+    masks = None
+    if dropout > 0:
+        masks = (torch.rand(2 * depth, B * 60, width, generator=g) >= dropout).to(torch.uint8)
+    y = tr.forward(x.cuda(), None if masks is None else masks.cuda()).cpu()
+    loss, grads = tr.backward(yt.cuda())
+    # reference: fp64 autograd
+    wd = [w.clone().requires_grad_(True) for w in ws]
+    bd = [b.clone().requires_grad_(True) for b in bs]
+    mk = None if masks is None else [m.view(B, 60, width).float() for m in masks]
+    with torch.no_grad():
+        y_plain = torch_ref.cnn_ref(x, ws, bs, depth=depth, masks=mk, dropout=dropout)
+    assert (y - y_plain).abs().max().item() <= 1e-5 * y_plain.abs().max().item()
+    gates = []
+    for blk in range(depth):
+        for which in (0, 1):
+            t = tr.saved_activation(blk, which, B).cpu()
+            gates.append((t > 0).float() if masks is None else ((t > 0) | (masks[2 * blk + which].view(B, 60, width) == 0)).float())
+    yr = torch_ref.cnn_ref(x, wd, bd, depth=depth, masks=mk, dropout=dropout, gates=gates)
+    # branch patterns agree except at units within rounding of zero: outputs identical to rounding
+    assert (yr.detach() - y_plain).abs().max().item() <= 1e-5 * y_plain.abs().max().item()
+    lr_ = torch_ref.mae_adjusted(yt, yr)
+    lr_.backward()
+    scale = yr.abs().max().item()
+    assert (y.double() - yr.detach()).abs().max().item() <= 1e-5 * scale
+    assert abs(loss.item() - lr_.item()) <= 1e-5 * abs(lr_.item())
+    gw, gb = tr.unpack(grads)
+    for name, got, refs in (("w", gw, wd), ("b", gb, bd)):
+        for i, (a, r) in enumerate(zip(got, refs)):
+            ref = r.grad.double()
+            err = (a.double() - ref).abs()
+            assert err.max().item() <= 2e-5 * ref.abs().max().item() + 1e-12, (name, i)
+    # padding entries of the flat gradient are exactly zero
+    total = sum(a.numel() for a in gw) + sum(a.numel() for a in gb)
+    assert int((grads != 0).sum().item()) <= total
+    # one Keras-Adam step: p -= lr*sqrt(1-b2)/(1-b1) * m/(sqrt(v)+eps) with m=(1-b1)g, v=(1-b2)g^2
+    p0w, p0b = tr.unpack(tr.flat_params())
+    tr.adam(lr=1e-3)
+    p1w, p1b = tr.unpack(tr.flat_params())
+    for p0, p1, gq in zip(p0w + p0b, p1w + p1b, gw + gb):
+        gq = gq.double()
+        m, v = 0.1 * gq, 0.001 * gq * gq
+        upd = 1e-3 * (1 - 0.999) ** 0.5 / (1 - 0.9) * m / (v.sqrt() + 1e-7)
+        assert ((p0.double() - p1.double()) - upd).abs().max().item() <= 2e-6 * 1e-3 + 1e-4 * upd.abs().max().item()
