@@ -182,6 +182,23 @@ def aux_workload(a, rank, world, dist):
         def step():
             m(x)
         flop_col, what = 2.0 * sum(dims[i] * dims[i + 1] for i in range(len(dims) - 1)), "Keras MLP baseline forward"
+    elif a.workload == "cnn_train_384":
+        from climsim_amd.baselines import CNNTrainer
+        depth, width = 12, 406
+        ws, bs = [], []
+        for i in range(depth):
+            ci = 6 if i == 0 else width
+            for co, cin, k in ((width, ci, 3), (width, width, 3), (width, ci, 1)):
+                ws.append(torch.randn(co, cin, k, generator=g) * (0.9 / (cin * k) ** 0.5)); bs.append(torch.zeros(co))
+        ws += [torch.randn(10, width, 1, generator=g) / width ** 0.5, torch.randn(10, 10, 1, generator=g) / 3]
+        bs += [torch.zeros(10), torch.zeros(10)]
+        tr = CNNTrainer([w.numpy() for w in ws], [b.numpy() for b in bs], max_batch=B)
+        x = torch.randn(B, 60, 6, generator=g).cuda()
+        yt = torch.randn(B, 60, 10, generator=g).cuda()
+
+        def step():   # dropout masks drawn on the device, forward, mae_adjusted, backward, ONE flat all-reduce, Adam
+            tr.train_step(x, yt, lr=1e-4, world_size=world)
+        flop_col, what = 3 * 1.58e9, "Keras CNN training step (Dropout 0.175, mae_adjusted, Adam), fwd+bwd = 3x forward FLOP"
     else:
         depth, width = 12, 406
         ws, bs = [], []
@@ -214,7 +231,8 @@ def aux_workload(a, rank, world, dist):
     if rank == 0:
         tf = B * flop_col * a.steps / el / 1e12
         print(json.dumps({
-            "metric": "grid-columns/sec emulator fwd", "value": world * B * a.steps / el, "unit": "grid-columns/s",
+            "metric": "train-step columns/sec" if "train" in a.workload else "grid-columns/sec emulator fwd",
+            "value": world * B * a.steps / el, "unit": "grid-columns/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * el / a.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": a.workload, "columns_per_gpu": B, "what": what,
@@ -223,7 +241,7 @@ def aux_workload(a, rank, world, dist):
             flush=True)
 
 
-AUX = ["cur_lstm144_384", "mlp_384", "cnn_384"]
+AUX = ["cur_lstm144_384", "mlp_384", "cnn_384", "cnn_train_384"]
 
 
 def main():

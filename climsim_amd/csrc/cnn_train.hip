@@ -268,8 +268,9 @@ static int ct_wgrad(csa_cnn_trainer *h, const CtLayer &l, const float *dY, const
     const int N1 = l.cout_p, N2 = l.k * l.cin_p;
     if ((rc = launch_gemm_tn_conv(dY, l.cout_p, X, l.cin_p, h->part, M, N1, N2, h->nsplit, conv ? h->L : 0, conv ? l.cin_p : 0, s))) return rc;
     if ((rc = launch_reduce_partials(h->part, h->nsplit, N1 * N2, nullptr, nullptr, grads + l.w_off, s))) return rc;
-    if ((rc = launch_colsum_partial(dY, h->part, M, N1, h->nsplit, s))) return rc;
-    return launch_reduce_partials(h->part, h->nsplit, N1, nullptr, nullptr, grads + l.b_off, s);
+    const int cs = 128;   // bias gradient: more, shorter row slices than the GEMM split (the partial buffer is far larger)
+    if ((rc = launch_colsum_partial(dY, h->part, M, N1, cs, s))) return rc;
+    return launch_reduce_partials(h->part, cs, N1, nullptr, nullptr, grads + l.b_off, s);
 }
 
 static int ct_dgrad(csa_cnn_trainer *h, const CtLayer &l, const float *dY, float *dX, int M, const GemmEpi &e, hipStream_t s)

@@ -106,20 +106,28 @@ int launch_gemm_tn_conv(const float *A, int lda, const float *Bm, int ldb, float
     return CSA_OK;
 }
 
-// partial column sums of a (M, N) matrix: part[s][n]
-__global__ void colsum_partial_kernel(const float *__restrict__ A, float *__restrict__ part, int M, int N, int rps)
+// partial column sums of a (M, N) matrix: part[s][n].  HBM-bound (reads M*N floats once): a workgroup owns 64 columns
+// x one row slice, four row-interleaved thread groups read 256-B row segments, summed through LDS.
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const float *__restrict__ A, float *__restrict__ part, int M, int N, int rps)
 {
-    const int n = blockIdx.x * blockDim.x + threadIdx.x, s = blockIdx.y;
-    if (n >= N) return;
+    __shared__ float sm[4][64];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int n = blockIdx.x * 64 + tx, s = blockIdx.y;
     const int m0 = s * rps, m1 = min(M, m0 + rps);
-    float a = 0.0f;
-    for (int m = m0; m < m1; ++m) a += A[(size_t)m * N + n];
-    part[(size_t)s * N + n] = a;
+    float a0 = 0.0f, a1 = 0.0f;
+    if (n < N) {
+        int m = m0 + ty;
+        for (; m + 4 < m1; m += 8) { a0 += A[(size_t)m * N + n]; a1 += A[(size_t)(m + 4) * N + n]; }
+        if (m < m1) a0 += A[(size_t)m * N + n];
+    }
+    sm[ty][tx] = a0 + a1;
+    __syncthreads();
+    if (ty == 0 && n < N) part[(size_t)s * N + n] = (sm[0][tx] + sm[1][tx]) + (sm[2][tx] + sm[3][tx]);
 }
 int launch_colsum_partial(const float *A, float *part, int M, int N, int nsplit, hipStream_t s)
 {
     const int rps = (M + nsplit - 1) / nsplit;
-    hipLaunchKernelGGL(colsum_partial_kernel, dim3((N + 255) / 256, nsplit), dim3(256), 0, s, A, part, M, N, rps);
+    hipLaunchKernelGGL(colsum_partial_kernel, dim3((N + 63) / 64, nsplit), dim3(256), 0, s, A, part, M, N, rps);
     CSA_HIP_CHECK(hipGetLastError());
     return CSA_OK;
 }
