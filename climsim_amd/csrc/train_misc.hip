@@ -35,33 +35,43 @@ __global__ __launch_bounds__(256) void gemm_tn_partial_kernel(
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
-    // staging: 16 rows x 128 floats per operand = 512 float4, two per thread
+    // staging: 16 rows x 128 floats per operand = 512 float4, two per thread.  The global loads of chunk c+1 are
+    // issued before the MFMAs of chunk c (register prefetch), so their latency hides behind 2048 MFMA cycles.
     const int sr = tid >> 5, sc = (tid & 31) * 4;
-    for (int m0 = m_begin; m0 < m_end; m0 += TN_MK) {
-        __syncthreads();
+    f32x4 va[2], vb[2];
+    auto gload = [&](int m0) {
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             const int m = m0 + sr + 8 * h;
-            f32x4 va = {0, 0, 0, 0}, vb = {0, 0, 0, 0};
+            va[h] = f32x4{0, 0, 0, 0};
+            vb[h] = f32x4{0, 0, 0, 0};
             if (m < m_end) {
                 const float *pa = A + (size_t)m * lda + n10 + sc;
                 const float *pb = conv_L > 0 ? Bm + ((long)m - 1) * ldb + n20 + sc : Bm + (size_t)m * ldb + n20 + sc;
-                if (n10 + sc + 3 < N1) va = *(const f32x4 *)pa;
-                else for (int e = 0; e < 4; ++e) if (n10 + sc + e < N1) va[e] = pa[e];
+                if (n10 + sc + 3 < N1) va[h] = *(const f32x4 *)pa;
+                else for (int e = 0; e < 4; ++e) if (n10 + sc + e < N1) va[h][e] = pa[e];
                 bool okb = true;
                 if (conv_L > 0) {
                     const int l = m % conv_L, c2 = n20 + sc;
                     okb = !((l == 0 && c2 < conv_cin) || (l == conv_L - 1 && c2 >= 2 * conv_cin));
                 }
                 if (okb) {
-                    if (n20 + sc + 3 < N2) vb = *(const f32x4 *)pb;
-                    else for (int e = 0; e < 4; ++e) if (n20 + sc + e < N2) vb[e] = pb[e];
+                    if (n20 + sc + 3 < N2) vb[h] = *(const f32x4 *)pb;
+                    else for (int e = 0; e < 4; ++e) if (n20 + sc + e < N2) vb[h][e] = pb[e];
                 }
             }
-            *(f32x4 *)&As[sr + 8 * h][sc] = va;
-            *(f32x4 *)&Bs[sr + 8 * h][sc] = vb;
+        }
+    };
+    if (m_begin < m_end) gload(m_begin);
+    for (int m0 = m_begin; m0 < m_end; m0 += TN_MK) {
+        __syncthreads();
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            *(f32x4 *)&As[sr + 8 * h][sc] = va[h];
+            *(f32x4 *)&Bs[sr + 8 * h][sc] = vb[h];
         }
         __syncthreads();
+        if (m0 + TN_MK < m_end) gload(m0 + TN_MK);
 #pragma unroll
         for (int kk = 0; kk < TN_MK / 2; ++kk) {
             const int kr = kk * 2 + (lane >> 5);
@@ -140,8 +150,18 @@ __global__ void reduce_partials_kernel(const float *__restrict__ part, int nspli
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    float a = 0.0f;
-    for (int s = 0; s < nsplit; ++s) a += part[(size_t)s * n + i];
+    // fixed summation order (s ascending within each of four interleaved chains, chains combined pairwise):
+    // deterministic, and the four loads per trip are independent (a single dependent chain costs nsplit L2 latencies)
+    float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
+    int s = 0;
+    for (; s + 3 < nsplit; s += 4) {
+        a0 += part[(size_t)s * n + i];
+        a1 += part[(size_t)(s + 1) * n + i];
+        a2 += part[(size_t)(s + 2) * n + i];
+        a3 += part[(size_t)(s + 3) * n + i];
+    }
+    for (; s < nsplit; ++s) a0 += part[(size_t)s * n + i];
+    const float a = (a0 + a1) + (a2 + a3);
     const int d = map ? map[i] : i;
     if (d >= 0) grad[d] += a;
     if (map2) { const int d2 = map2[i]; if (d2 >= 0) grad[d2] += a; }
