@@ -464,8 +464,20 @@ int launch_rec_train(int nh, const float *whh_packed, float *P, const float *h0,
     case 64:  hipLaunchKernelGGL((lstm_rec2_kernel<64, true>), grid, block, 0, s, (const f32x4 *)whh_packed, P, h0, c0, Hout, B, L, reverse_out, Hseq, Cseq, 0, L, (float *)nullptr); break;
     case 96:  hipLaunchKernelGGL((lstm_rec2_kernel<96, true>), grid, block, 0, s, (const f32x4 *)whh_packed, P, h0, c0, Hout, B, L, reverse_out, Hseq, Cseq, 0, L, (float *)nullptr); break;
     case 128: hipLaunchKernelGGL((lstm_rec2_kernel<128, true>), grid, block, 0, s, (const f32x4 *)whh_packed, P, h0, c0, Hout, B, L, reverse_out, Hseq, Cseq, 0, L, (float *)nullptr); break;
+    case 144: {
+        constexpr int NL4 = 3;   // the TRAIN variant carries more live state: one more float4 per slot in LDS
+        constexpr size_t shm = (size_t)4 * NL4 * 144 * 4 * sizeof(f32x4);
+        auto kern = lstm_rec2_kernel<144, true, NL4>;
+        static bool attr_set = false;
+        if (!attr_set) {
+            CSA_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(kern, grid, block, shm, s, (const f32x4 *)whh_packed, P, h0, c0, Hout, B, L, reverse_out, Hseq, Cseq, 0, L, (float *)nullptr);
+        break;
+    }
     default:
-        csa_set_error_msg("rec(train): hidden size not supported (64, 96, 128)");
+        csa_set_error_msg("rec(train): hidden size not supported (64, 96, 128, 144)");
         return CSA_ERR_UNSUPPORTED;
     }
     CSA_HIP_CHECK(hipGetLastError());

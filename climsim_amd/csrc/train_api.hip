@@ -107,8 +107,8 @@ extern "C" int csa_train_create(const csa_config *cfg, const csa_params *p, cons
         csa_set_error_msg("csa_train_create: the HIP training step covers the current-generation LSTM with memory, mp_mode 1");
         return CSA_ERR_UNSUPPORTED;
     }
-    const bool ok = (c.nh1 == 64 || c.nh1 == 96 || c.nh1 == 128) && (c.nh2 == 64 || c.nh2 == 96 || c.nh2 == 128);
-    if (!ok) { csa_set_error_msg("csa_train_create: hidden size must be 64, 96 or 128"); return CSA_ERR_UNSUPPORTED; }
+    const bool ok = (c.nh1 == 64 || c.nh1 == 96 || c.nh1 == 128 || c.nh1 == 144) && (c.nh2 == 64 || c.nh2 == 96 || c.nh2 == 128 || c.nh2 == 144);
+    if (!ok) { csa_set_error_msg("csa_train_create: hidden size must be 64, 96, 128 or 144"); return CSA_ERR_UNSUPPORTED; }
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) { csa_set_error_msg("csa_train_create: no HIP device"); return CSA_ERR_HIP; }
 
@@ -260,7 +260,7 @@ extern "C" int csa_train_create(const csa_config *cfg, const csa_params *p, cons
     h->dH2 = dalloc<float>(h, LB * nh2, rc); h->dH1 = dalloc<float>(h, LB * nh1, rc);
     h->dX1 = dalloc<float>(h, LB * nin1, rc);
     h->dhc1 = dalloc<float>(h, 2 * Bm * nhm, rc); h->dhc2 = dalloc<float>(h, 2 * Bm * nhm, rc);
-    h->nsplit = 32;
+    h->nsplit = 64;
     size_t pf = (size_t)h->nsplit * 4 * nhm * (nin1 > nhm ? nin1 : nhm);
     const size_t pcol = Bm * (size_t)std::max(head_bwd_partial_floats(c), prep_bwd_partial_floats(c));
     h->part_floats = pf > pcol ? pf : pcol;

@@ -38,8 +38,10 @@ __device__ __forceinline__ float tanh_acc(float x)
     return (1.0f - t) * __builtin_amdgcn_rcpf(1.0f + t);
 }
 
-template <int NH>
-__global__ __launch_bounds__(NH * 4, 2) void lstm_bwd_rec_kernel(
+// NL4 > 0 (nh = 144): as in rec.hip, 9 waves cap a wave at 168 VGPRs, so the last NL4 float4 of every slot's
+// weight run live in (dynamic) LDS and are read once per step; the rest stays register-stationary.
+template <int NH, int NL4 = 0>
+__global__ __launch_bounds__(NH * 4, (NH / 16 + 3) / 4) void lstm_bwd_rec_kernel(
     const f32x4 *__restrict__ WTp4, float *__restrict__ GP, const float *__restrict__ Cseq,
     const float *__restrict__ dH, float *__restrict__ dh0, float *__restrict__ dc0,
     int B, int L, int rev)
@@ -49,7 +51,9 @@ __global__ __launch_bounds__(NH * 4, 2) void lstm_bwd_rec_kernel(
     constexpr int CH = 2 * RC + 4;      // floats per chunk incl. one 16-B pad slot
     constexpr int CPY = 16 * CH;
     static_assert(RC % 4 == 0, "nh must be a multiple of 16");
+    constexpr int KR = RC / 2 - 2 * NL4;   // weight pairs per slot kept in registers
     __shared__ __attribute__((aligned(16))) float dpbuf[2][2 * CPY];
+    extern __shared__ f32x4 wlds[];        // NL4 > 0: 4*NL4*NT float4
 
     const int tid = threadIdx.x, og = tid >> 4, rc = tid & 15, q4 = rc & 3, rcq = rc >> 2;
     const int col = q4 & 1, grp = q4 >> 1;
@@ -59,13 +63,39 @@ __global__ __launch_bounds__(NH * 4, 2) void lstm_bwd_rec_kernel(
     const bool cell = rcq < 2;                       // this lane owns one (u, col) cell
     const int u = 4 * og + 2 * grp + (rcq & 1);
 
-    f32x2 w[4][RC / 2];
+    f32x2 w[4][KR > 0 ? KR : 1];
 #pragma unroll
     for (int i = 0; i < RC; ++i) {
         const f32x4 v = WTp4[(size_t)i * NT + tid];
         const int s = (4 * i) / RC, kk = (4 * i) % RC;
-        w[s][kk / 2] = f32x2{v.x, v.y};
-        w[s][kk / 2 + 1] = f32x2{v.z, v.w};
+        if (kk / 2 < KR) {
+            w[s][kk / 2] = f32x2{v.x, v.y};
+            w[s][kk / 2 + 1] = f32x2{v.z, v.w};
+        } else {
+            wlds[(s * NL4 + (kk / 2 - KR) / 2) * NT + tid] = v;
+        }
+    }
+    // acc[s] += sum over this lane's rows of W^T * dp   (both columns), dp read from the LDS copy at dpp
+#define BWD_MATVEC(acc, dpp)                                                                       \
+    {                                                                                              \
+        _Pragma("unroll") for (int j = 0; j < KR; ++j) {                                           \
+            const f32x4 v = (dpp)[j];                                                              \
+            const f32x2 va = {v.x, v.y}, vb = {v.z, v.w};                                          \
+            _Pragma("unroll") for (int s = 0; s < 4; ++s) PK_FMA_LO(acc[s], w[s][j], va);          \
+            _Pragma("unroll") for (int s = 0; s < 4; ++s) PK_FMA_HI(acc[s], w[s][j], vb);          \
+        }                                                                                          \
+        _Pragma("unroll") for (int q = 0; q < NL4; ++q) {                                          \
+            const f32x4 v0 = (dpp)[KR + 2 * q], v1 = (dpp)[KR + 2 * q + 1];                        \
+            const f32x2 va0 = {v0.x, v0.y}, vb0 = {v0.z, v0.w}, va1 = {v1.x, v1.y}, vb1 = {v1.z, v1.w}; \
+            _Pragma("unroll") for (int s = 0; s < 4; ++s) {                                        \
+                const f32x4 wv = wlds[(s * NL4 + q) * NT + tid];                                   \
+                const f32x2 w0 = {wv.x, wv.y}, w1 = {wv.z, wv.w};                                  \
+                PK_FMA_LO(acc[s], w0, va0);                                                        \
+                PK_FMA_HI(acc[s], w0, vb0);                                                        \
+                PK_FMA_LO(acc[s], w1, va1);                                                        \
+                PK_FMA_HI(acc[s], w1, vb1);                                                        \
+            }                                                                                      \
+        }                                                                                          \
     }
 
     // LDS slots of this cell's four dp rows r' = u*4 + pos (normal and column-swapped copy)
@@ -118,15 +148,7 @@ __global__ __launch_bounds__(NH * 4, 2) void lstm_bwd_rec_kernel(
         // recurrent matvec on dp[t]: feeds step t-1
         f32x2 acc[4] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
         const f32x4 *dpp = (const f32x4 *)&dpbuf[cur][rdoff];
-#pragma unroll
-        for (int j = 0; j < RC / 2; ++j) {
-            const f32x4 v = dpp[j];
-            const f32x2 va = {v.x, v.y}, vb = {v.z, v.w};
-#pragma unroll
-            for (int s = 0; s < 4; ++s) PK_FMA_LO(acc[s], w[s][j], va);
-#pragma unroll
-            for (int s = 0; s < 4; ++s) PK_FMA_HI(acc[s], w[s][j], vb);
-        }
+        BWD_MATVEC(acc, dpp)
         float r[4];
 #pragma unroll
         for (int s = 0; s < 4; ++s) r[s] = acc[s].x + dpp_mov<0xB1>(acc[s].y);     // xor 1
@@ -141,15 +163,7 @@ __global__ __launch_bounds__(NH * 4, 2) void lstm_bwd_rec_kernel(
     {
         f32x2 acc[4] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
         const f32x4 *dpp = (const f32x4 *)&dpbuf[0][rdoff];
-#pragma unroll
-        for (int j = 0; j < RC / 2; ++j) {
-            const f32x4 v = dpp[j];
-            const f32x2 va = {v.x, v.y}, vb = {v.z, v.w};
-#pragma unroll
-            for (int s = 0; s < 4; ++s) PK_FMA_LO(acc[s], w[s][j], va);
-#pragma unroll
-            for (int s = 0; s < 4; ++s) PK_FMA_HI(acc[s], w[s][j], vb);
-        }
+        BWD_MATVEC(acc, dpp)
         float r[4];
 #pragma unroll
         for (int s = 0; s < 4; ++s) r[s] = acc[s].x + dpp_mov<0xB1>(acc[s].y);
@@ -194,8 +208,20 @@ int launch_bwd_rec(int nh, const float *wt_packed, float *GP, const float *Cseq,
     case 64:  hipLaunchKernelGGL((lstm_bwd_rec_kernel<64>), grid, block, 0, s, (const f32x4 *)wt_packed, GP, Cseq, dH, dh0, dc0, B, L, rev); break;
     case 96:  hipLaunchKernelGGL((lstm_bwd_rec_kernel<96>), grid, block, 0, s, (const f32x4 *)wt_packed, GP, Cseq, dH, dh0, dc0, B, L, rev); break;
     case 128: hipLaunchKernelGGL((lstm_bwd_rec_kernel<128>), grid, block, 0, s, (const f32x4 *)wt_packed, GP, Cseq, dH, dh0, dc0, B, L, rev); break;
+    case 144: {
+        constexpr int NL4 = 2;
+        constexpr size_t shm = (size_t)4 * NL4 * 144 * 4 * sizeof(f32x4);
+        auto kern = lstm_bwd_rec_kernel<144, NL4>;
+        static bool attr_set = false;
+        if (!attr_set) {
+            CSA_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(kern, grid, block, shm, s, (const f32x4 *)wt_packed, GP, Cseq, dH, dh0, dc0, B, L, rev);
+        break;
+    }
     default:
-        csa_set_error_msg("bwd_rec: hidden size not supported (64, 96, 128)");
+        csa_set_error_msg("bwd_rec: hidden size not supported (64, 96, 128, 144)");
         return CSA_ERR_UNSUPPORTED;
     }
     CSA_HIP_CHECK(hipGetLastError());

@@ -123,7 +123,7 @@ def main():
                 print(tag, B, t, "finite", bool(torch.isfinite(o6).all()), float(out.abs().max()))
 
         # ---- gradients through a T_w = 3 TBPTT window (config 3) ----------------
-        if tag != "cur_lstm144":
+        if True:
             B, T_w = 6, 3
             model.train()
             model.zero_grad()

@@ -35,8 +35,9 @@ def _window_inputs(ref, io):
     return B, Tw, xr, xs, xn, xsn, tgt, tgt_sfc, yto, yto_sfc
 
 
-def test_autograd_oracle_vs_reference_gradients():
-    consts, weights, flags, io, grid = _golden()
+@pytest.mark.parametrize("tag", ["cur_lstm128", "cur_lstm144"])
+def test_autograd_oracle_vs_reference_gradients(tag):
+    consts, weights, flags, io, grid = _golden(tag)
     ref = torch_ref.EmulatorRef(consts, weights, legacy=False, use_lstm=True, output_prune=bool(flags["output_prune"]),
                                 scrub_inf=True)
     B, Tw, xr, xs, xn, xsn, tgt, tgt_sfc, yto, yto_sfc = _window_inputs(ref, io)
@@ -60,9 +61,10 @@ def test_autograd_oracle_vs_reference_gradients():
 
 
 @pytest.mark.gpu
-def test_hip_training_step_vs_reference_gradients():
+@pytest.mark.parametrize("tag", ["cur_lstm128", "cur_lstm144"])
+def test_hip_training_step_vs_reference_gradients(tag):
     from climsim_amd.train import Trainer
-    consts, weights, flags, io, grid = _golden()
+    consts, weights, flags, io, grid = _golden(tag)
     ref = torch_ref.EmulatorRef(consts, weights, legacy=False, use_lstm=True, output_prune=bool(flags["output_prune"]),
                                 scrub_inf=True)
     B, Tw, xr, xs, xn, xsn, tgt, tgt_sfc, yto, yto_sfc = _window_inputs(ref, io)
