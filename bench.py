@@ -338,7 +338,7 @@ def main():
             "config": {"workload": a.workload, "columns_per_gpu": B, "nlev": 60,
                        "wrapper": "stateless v4 (rnn/v4_rnn_wrapper_constrained.pt weights)" if not stateful
                        else "stateful v4 memory wrapper", "parallelism": f"columns sharded x{world}, no collective"},
-            "roofline": {"bound": "mfma", "kernel": "rec_kernel<128,4> (one launch per LSTM, 2 per step)",
+            "roofline": {"bound": "mfma", "kernel": "lstm_rec2_kernel<128,false,0> (one launch per LSTM, 2 per step)",
                          "achieved": achieved, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_FP32_TFLOPS, "traffic": pmc_traffic(a.workload),
                          "traffic_unit": "HBM bytes per launch (rocprofv3 PMC, profiles/)",
