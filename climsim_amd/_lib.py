@@ -38,12 +38,28 @@ SYMBOLS = ["csa_create", "csa_destroy", "csa_set_params", "csa_packed_width", "c
            "csa_cnn_train_create", "csa_cnn_train_destroy", "csa_cnn_train_num_params", "csa_cnn_train_num_layers",
            "csa_cnn_train_params", "csa_cnn_train_get_params", "csa_cnn_train_set_params", "csa_cnn_train_get_act", "csa_cnn_train_layer_info", "csa_cnn_train_forward", "csa_cnn_train_backward",
            "csa_cnn_train_adam",
+           "csa_gen_create", "csa_gen_destroy", "csa_gen_dims", "csa_gen_batch",
            "csa_stoch_gru5_create", "csa_stoch_lstm4_create", "csa_stoch_destroy", "csa_stoch_gru5_forward",
            "csa_stoch_lstm4_forward"]
 
 
 class CsaConfig(ctypes.Structure):
     _fields_ = [(n, ctypes.c_int32) for n in CONFIG_FIELDS]
+
+
+GEN_CONFIG_FIELDS = ["nlev", "nx_in", "nx_sfc_in", "ny_sfc", "remove_past_sfc_inputs", "snowhice_fix", "rh_prune",
+                     "qinput_prune", "output_prune", "q_mode", "cld_inp_transformation", "v4_to_v5_inputs",
+                     "apply_new_input_scaling", "reverse_input_norm", "reverse_output_norm", "mp_mode"]
+GEN_COEFF_FIELDS = ["xmean_lev", "xdiv_lev", "xmean_sca", "xdiv_sca", "yscale_lev", "yscale_sca", "lbd_qc", "lbd_qi", "lbd_qn",
+                    "hyam", "hybm", "xref_mean", "xref_div", "xsref_mean", "xsref_div", "yref_lev", "yref_sca"]
+
+
+class CsaGenConfig(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_int32) for n in GEN_CONFIG_FIELDS]
+
+
+class CsaGenCoeffs(ctypes.Structure):
+    _fields_ = [(n, ctypes.POINTER(ctypes.c_float)) for n in GEN_COEFF_FIELDS]
 
 
 class CsaParams(ctypes.Structure):
@@ -122,6 +138,10 @@ def lib():
     L.csa_cnn_train_forward.argtypes = [H, i, _F, ctypes.c_void_p, _F, ctypes.c_void_p]
     L.csa_cnn_train_backward.argtypes = [H, _F, fl, _F, _F, ctypes.c_void_p]
     L.csa_cnn_train_adam.argtypes = [H, _F, fl, fl, fl, fl, i, ctypes.c_void_p]
+    L.csa_gen_create.argtypes = [ctypes.POINTER(CsaGenConfig), ctypes.POINTER(CsaGenCoeffs), ctypes.POINTER(H)]
+    L.csa_gen_destroy.argtypes = [H]
+    L.csa_gen_dims.argtypes = [H, PI, PI, PI]
+    L.csa_gen_batch.argtypes = [H, i] + [_F] * 11 + [ctypes.c_void_p]
     L.csa_stoch_gru5_create.argtypes = [i, i, Fp, Fp, Fp, Fp, Fp, i, ctypes.POINTER(H)]
     L.csa_stoch_lstm4_create.argtypes = [i, i, Fp, i, ctypes.POINTER(H)]
     L.csa_stoch_destroy.argtypes = [H]

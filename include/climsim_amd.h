@@ -220,6 +220,35 @@ int csa_cnn_train_backward(csa_cnn_trainer *h, const float *y_true, float grad_s
 int csa_cnn_train_adam(csa_cnn_trainer *h, const float *grads, float lr, float beta1, float beta2, float eps, int step,
                        void *stream);
 
+/* ---- training-data pipeline (the training twin of row a1 + target construction) -------------
+ * generator_xy.__getitem__ rnn/utils.py:2238-2371 as one device pass over a loaded chunk of N = ntime*ncol samples.
+ * The HDF5 reading stays with the host; arrays are device pointers. */
+typedef struct {
+    int32_t nlev, nx_in, nx_sfc_in, ny_sfc;         /* file layout: input_lev (.,nlev,nx_in), input_sca (.,nx_sfc_in), output_lev (.,nlev,6) */
+    int32_t remove_past_sfc_inputs;                 /* np.delete(x_sfc, (17..21)) :2172-2173 */
+    int32_t snowhice_fix, rh_prune, qinput_prune, output_prune;
+    int32_t q_mode;                                 /* 0 none, 1 include_q_input (append), 2 rh_input_to_q (replace RH) :2183-2194 */
+    int32_t cld_inp_transformation;                 /* 0 none, 1 exp, 2 sqrt */
+    int32_t v4_to_v5_inputs;                        /* qn + liquid fraction instead of qliq, qice :2211-2231 */
+    int32_t apply_new_input_scaling, reverse_input_norm, reverse_output_norm;
+    int32_t mp_mode;                                /* targets: 0 six outputs, 1 qn (5 outputs), -1 qn + liq_frac, -2 total water */
+} csa_gen_config;
+typedef struct {                                    /* HOST pointers; unused ones may be NULL */
+    const float *xmean_lev, *xdiv_lev;              /* xcoeffs (nlev, nx_out) */
+    const float *xmean_sca, *xdiv_sca;              /* (nx_sfc_out) */
+    const float *yscale_lev, *yscale_sca;           /* ycoeffs (nlev, ny_out), (ny_sfc) */
+    const float *lbd_qc, *lbd_qi, *lbd_qn, *hyam, *hybm;   /* (nlev) */
+    const float *xref_mean, *xref_div, *xsref_mean, *xsref_div, *yref_lev, *yref_sca;   /* xcoeffs_ref / ycoeffs_ref */
+} csa_gen_coeffs;
+typedef struct csa_generator csa_generator;
+int csa_gen_create(const csa_gen_config *cfg, const csa_gen_coeffs *coeffs, csa_generator **out);
+int csa_gen_destroy(csa_generator *h);
+int csa_gen_dims(const csa_generator *h, int *nx_out, int *nx_sfc_out, int *ny_out);
+/* -> (x_lev, x_sfc, y_lev, y_sfc, x_lev_denorm, y_lev_denorm, y_sfc_denorm) of __getitem__, all device buffers */
+int csa_gen_batch(csa_generator *h, int N, const float *x_lev, const float *x_sfc, const float *y_lev, const float *y_sfc,
+                  float *x_lev_n, float *x_sfc_n, float *y_lev_n, float *y_sfc_n, float *x_lev_denorm,
+                  float *y_lev_denorm, float *y_sfc_denorm, void *stream);
+
 /* ---- stochastic recurrent layers ---------------------------------------------------
  * MyStochasticGRULayer5  rnn/models_torch_kernels.py:834-891 (its GPU path = the repo's inline CUDA, :29-252)
  * MyStochasticLSTMLayer4 rnn/models_torch_kernels.py:1474-1531
