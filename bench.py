@@ -258,11 +258,21 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if a.gpus > 1 and world != a.gpus:
         sys.exit(f"--gpus {a.gpus} needs torch.distributed.run with WORLD_SIZE={a.gpus} (got {world})")
+    # one rank per GPU.  Rehearsal only (1-GPU box): CSA_BENCH_BACKEND=gloo lets several ranks share device 0 so that
+    # the N>1 control flow (barriers, max-over-ranks, the gradient all-reduce) can be exercised without RCCL.
+    backend = os.environ.get("CSA_BENCH_BACKEND", "nccl")
+    ndev = torch.cuda.device_count()
+    if backend == "nccl" and local_rank >= ndev:
+        sys.exit(f"LOCAL_RANK {local_rank} but only {ndev} GPU(s) visible")
+    local_rank = local_rank % max(ndev, 1)
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
 
     import climsim_amd
     from synth import synth_inputs
