@@ -251,6 +251,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="v4_stateless_384", choices=sorted(WORKLOADS) + ["train_tbptt3_384"] + AUX)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--halves", type=int, default=-1, help="1/0: force the two-stream column-half path on/off (default: library default)")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -293,6 +294,8 @@ def main():
     consts, weights = load_model(tag)
     model = climsim_amd.NewModel_constraint(consts, weights, max_batch=B)
     stateful = model.stateful
+    if a.halves >= 0:
+        model.emulator.set_halves(bool(a.halves))   # default: automatic (on from 640 columns per GPU)
     # each rank owns its own shard of columns (different seed), resident in HBM
     xm, xs = synth_inputs(consts, B, 9000 + rank)
     rng = np.random.Generator(np.random.PCG64(100 + rank))

@@ -219,6 +219,11 @@ class Emulator:
         """Select the dual-pipe fused LSTM kernels (default) or the six-launch path; returns True if fused is active."""
         return bool(_lib.lib().csa_set_fused(self._h, int(bool(enable))))
 
+    def set_halves(self, enable):
+        """Two column halves on two streams (legacy models, B >= 64); bit-identical results.
+        True / False force it, None restores the default (automatic from 640 columns)."""
+        return _lib.lib().csa_set_halves(self._h, 2 if enable is None else int(bool(enable)))
+
     def set_overlap(self, enable):
         """Level-split overlap of projection GEMMs with the recurrence on a side stream (default on)."""
         return bool(_lib.lib().csa_set_overlap(self._h, int(bool(enable))))

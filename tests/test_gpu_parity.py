@@ -282,6 +282,25 @@ def test_fused_and_unfused_paths_agree(memory):
     assert max(block_errors(y_f, y_u).values()) <= 1e-5
 
 
+@pytest.mark.parametrize("B", [64, 129, 384])
+def test_column_halves_path_is_bit_identical(memory, B):
+    """csa_set_halves: two column halves on two streams, one fork and one join event."""
+    consts, weights, model = memory
+    xm, xs = synth_inputs(consts, B, 77)
+    g = np.random.Generator(np.random.PCG64(3))
+    mem = (0.4 * g.standard_normal((B, 60, 16))).astype(np.float32)
+    hx, cx = g.standard_normal((2, B, 128)).astype(np.float32)
+    args = (_dev(xm), _dev(xs), _dev(mem), _dev(hx), _dev(cx))
+    model.emulator.set_halves(False)
+    y0 = model.emulator.forward_packed(*args).clone()
+    assert model.emulator.set_halves(True)
+    y1 = model.emulator.forward_packed(*args).clone()
+    y2 = model.emulator.forward_packed(*args).clone()
+    model.emulator.set_halves(None)
+    torch.cuda.synchronize()
+    assert torch.equal(y0, y1) and torch.equal(y1, y2)
+
+
 def test_overlap_path_is_bit_identical_to_sequential(memory):
     """The level-split overlap (rnn1 in three launches, GEMMs on a side stream) reorders launches only."""
     consts, weights, model = memory
