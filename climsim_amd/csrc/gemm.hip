@@ -91,6 +91,13 @@ __global__ __launch_bounds__(GB_THREADS) void proj_gemm_kernel(
     const int arow = (wm * 64 + (lane & 31)) * GB_LD + (lane >> 5);
     const int wrow = (wn * 64 + (lane & 31)) * GB_LD + (lane >> 5);
 
+#ifdef GEMM_EXP_STAGGER   /* diagnostic: de-phase co-resident workgroups (convoy test) */
+    {
+        const int ph = (blockIdx.x / GEMM_EXP_STAGGER) % 3;
+        const unsigned long long t0 = __builtin_readcyclecounter();
+        while (__builtin_readcyclecounter() - t0 < (unsigned long long)ph * 6000ull) __builtin_amdgcn_s_sleep(8);
+    }
+#endif
     gload(0);
     sstore(0);
     __syncthreads();
@@ -144,6 +151,14 @@ __global__ __launch_bounds__(GB_THREADS) void proj_gemm_kernel(
                 else if (act == 3) v = v > 0.0f ? v : expm1f(v);
                 acc[i][j][r] = v;
             }
+#ifdef GEMM_EXP_NO_STORE   /* diagnostic: keep the accumulators alive, store one value per wave */
+    {
+        float t = 0.0f;
+        for (int j = 0; j < 2; ++j) for (int i = 0; i < 2; ++i) for (int r = 0; r < 16; ++r) t += acc[i][j][r];
+        if (t == 123.456f) C[0] = t;
+        return;
+    }
+#endif
     const bool plain = !epi.addsrc && !epi.mask && !epi.gate;
     const bool interior = (m0 + GB_M <= M) && (n0 + GB_N <= N) && plain;
     if (interior) {
@@ -210,7 +225,12 @@ int launch_gemm_epi(const float *A, const float *W, const float *bias, float *C,
         return CSA_ERR_UNSUPPORTED;
     }
     const int tiles_m = (M + GB_M - 1) / GB_M, tiles_n = (N + GB_N - 1) / GB_N;
-    hipLaunchKernelGGL(proj_gemm_kernel, dim3(tiles_m * tiles_n), dim3(GB_THREADS), 0, s, A, W, bias, C, M, N, K,
+#ifdef GEMM_EXP_EXTRA_LDS
+    static const int extra_lds = getenv("CSA_GEMM_EXTRA_LDS") ? atoi(getenv("CSA_GEMM_EXTRA_LDS")) : 0;   // diagnostic: caps occupancy
+#else
+    const int extra_lds = 0;
+#endif
+    hipLaunchKernelGGL(proj_gemm_kernel, dim3(tiles_m * tiles_n), dim3(GB_THREADS), extra_lds, s, A, W, bias, C, M, N, K,
                        tiles_m, tiles_n, act, alpha, n_lin, lda, ldc, conv_L, conv_cin, epi);
     CSA_HIP_CHECK(hipGetLastError());
     return CSA_OK;
