@@ -18,6 +18,11 @@
 // well inside the ~2,000-cycle step of the VALU role.  No pre-activation ever reaches HBM and both
 // GEMM launches of the unfused path disappear.
 //
+// MEASURED AFTERWARDS (tools/coexec_bench.hip): on gfx950 v_mfma_f32_* and v_pk_fma_f32 from different waves of a SIMD do
+// NOT run concurrently -- together they take the sum of their separate times (they share the fp32 FMA lanes), so
+// the premise "the MFMA pipe idles meanwhile" is false for fp32 and this kernel cannot beat GEMM + rec.hip.
+// Kept as a parity-tested record (csa_set_fused), off by default.
+//
 // STATUS (round 1): parity-green (tests/test_gpu_parity.py::test_fused_and_unfused_paths_agree) but
 // NOT the default: 99-109 us per layer against 34 + 56 us for GEMM + recurrent kernel.  With 16-row
 // chunks every workgroup re-streams all of W_ih (288 KB) from L2 eight times per launch = 442 MB per
@@ -139,6 +144,9 @@ __global__ __launch_bounds__(NH * 6, 3) void fused_lstm_kernel(
     } else {
         // ================================ MFMA role: the input projection ================================
         const int mt = tid - NH * 4, lane = mt & 63, mw = mt >> 6;      // 4 waves, wave mw owns columns [128 mw, +128)
+#ifdef FZ_EXP_SETPRIO
+        __builtin_amdgcn_s_setprio(FZ_EXP_SETPRIO);   // diagnostic: let the (younger) MFMA waves issue ahead of the VALU waves
+#endif
         const int ai = lane & 15, akq = lane >> 4;
         // stage one chunk of layer input rows: row i <-> (level t0 + i/2, column b0 + (i&1))
         auto stage_x = [&](int q) {
