@@ -44,6 +44,11 @@ struct csa_trainer {
     float *dH2, *dH1, *dX1, *dhc1, *dhc2, *part, *samp, *ecoef, *sp;
     size_t part_floats;
     int nsplit;
+    // deferred weight gradients (csa_train_set_deferred): the W_ih / W_hh gradient GEMMs of the backward calls are
+    // postponed and done ONCE over all pending time steps of the window (csa_train_flush_wgrad)
+    bool defer = false;
+    std::vector<int> pending;
+    int pending_B = 0;
 };
 
 namespace {
@@ -343,24 +348,67 @@ extern "C" int csa_train_backward(csa_trainer *h, int slot, int B, const float *
     // rnn2 (downward): BPTT, then input / weight gradients from dP2 (stored in place in GP2)
     if ((rc = launch_bwd_rec(nh2, h->whh2Tp, S.GP2, S.C2, h->dH2, h->dhc2, h->dhc2 + (size_t)B * nhm, B, L, 0, s))) return rc;
     if ((rc = launch_proj_gemm(S.GP2, h->wih2T, nullptr, h->dH1, M, nh1, 4 * nh2, s))) return rc;
-    if ((rc = launch_gemm_tn_partial(S.GP2, 4 * nh2, S.H1lev, nh1, h->part, M, 4 * nh2, nh1, ns, s))) return rc;
-    if ((rc = launch_reduce_partials(h->part, ns, 4 * nh2 * nh1, h->map_wih2, nullptr, grads, s))) return rc;
-    if ((rc = launch_gemm_tn_partial(S.GP2, 4 * nh2, S.H2, nh2, h->part, M, 4 * nh2, nh2, ns, s))) return rc;
-    if ((rc = launch_reduce_partials(h->part, ns, 4 * nh2 * nh2, h->map_whh2, nullptr, grads, s))) return rc;
+    if (!h->defer) {
+        if ((rc = launch_gemm_tn_partial(S.GP2, 4 * nh2, S.H1lev, nh1, h->part, M, 4 * nh2, nh1, ns, s))) return rc;
+        if ((rc = launch_reduce_partials(h->part, ns, 4 * nh2 * nh1, h->map_wih2, nullptr, grads, s))) return rc;
+        if ((rc = launch_gemm_tn_partial(S.GP2, 4 * nh2, S.H2, nh2, h->part, M, 4 * nh2, nh2, ns, s))) return rc;
+        if ((rc = launch_reduce_partials(h->part, ns, 4 * nh2 * nh2, h->map_whh2, nullptr, grads, s))) return rc;
+    }
     if ((rc = launch_colsum_partial(S.GP2, h->part, M, 4 * nh2, ns, s))) return rc;
     if ((rc = launch_reduce_partials(h->part, ns, 4 * nh2, h->map_b2a, h->map_b2b, grads, s))) return rc;
     // rnn1 (upward): dH1 is in level order, the recurrence runs in sequence order
     if ((rc = launch_bwd_rec(nh1, h->whh1Tp, S.GP1, S.C1, h->dH1, h->dhc1, h->dhc1 + (size_t)B * nhm, B, L, 1, s))) return rc;
     if ((rc = launch_proj_gemm(S.GP1, h->wih1T, nullptr, h->dX1, M, nin1, 4 * nh1, s))) return rc;
-    if ((rc = launch_gemm_tn_partial(S.GP1, 4 * nh1, S.X1, nin1, h->part, M, 4 * nh1, nin1, ns, s))) return rc;
-    if ((rc = launch_reduce_partials(h->part, ns, 4 * nh1 * nin1, h->map_wih1, nullptr, grads, s))) return rc;
-    if ((rc = launch_gemm_tn_partial(S.GP1, 4 * nh1, S.H1seq, nh1, h->part, M, 4 * nh1, nh1, ns, s))) return rc;
-    if ((rc = launch_reduce_partials(h->part, ns, 4 * nh1 * nh1, h->map_whh1, nullptr, grads, s))) return rc;
+    if (!h->defer) {
+        if ((rc = launch_gemm_tn_partial(S.GP1, 4 * nh1, S.X1, nin1, h->part, M, 4 * nh1, nin1, ns, s))) return rc;
+        if ((rc = launch_reduce_partials(h->part, ns, 4 * nh1 * nin1, h->map_wih1, nullptr, grads, s))) return rc;
+        if ((rc = launch_gemm_tn_partial(S.GP1, 4 * nh1, S.H1seq, nh1, h->part, M, 4 * nh1, nh1, ns, s))) return rc;
+        if ((rc = launch_reduce_partials(h->part, ns, 4 * nh1 * nh1, h->map_whh1, nullptr, grads, s))) return rc;
+    } else {
+        if (!h->pending.empty() && h->pending_B != B) { csa_set_error_msg("csa_train_backward(deferred): batch size changed inside a window"); return CSA_ERR_ARG; }
+        if ((int)h->pending.size() >= TN_MAX_SEGS) { csa_set_error_msg("csa_train_backward(deferred): flush before more than 8 pending steps"); return CSA_ERR_ARG; }
+        h->pending.push_back(slot);
+        h->pending_B = B;
+    }
     if ((rc = launch_colsum_partial(S.GP1, h->part, M, 4 * nh1, ns, s))) return rc;
     if ((rc = launch_reduce_partials(h->part, ns, 4 * nh1, h->map_b1a, h->map_b1b, grads, s))) return rc;
     // mlp_initial / surface / TOA MLPs, gradient w.r.t. the incoming memory
     if ((rc = launch_prep_bwd(h->dm, B, h->dX1, S.X1, S.X16, S.xs, S.hc0, h->dhc1, h->dhc2, d_mem_in, h->part, s))) return rc;
     return launch_reduce_partials(h->part, B, prep_bwd_partial_floats(c), h->map_prep, nullptr, grads, s);
+}
+
+extern "C" int csa_train_set_deferred(csa_trainer *h, int enable)
+{
+    if (!h) return CSA_ERR_ARG;
+    if (!h->pending.empty()) { csa_set_error_msg("csa_train_set_deferred: flush pending gradients first"); return CSA_ERR_ARG; }
+    h->defer = enable != 0;
+    return CSA_OK;
+}
+
+// the W_ih / W_hh gradients of every backward call since the last flush, each as ONE split-M GEMM over all pending steps
+extern "C" int csa_train_flush_wgrad(csa_trainer *h, float *grads, void *stream)
+{
+    if (!h || !grads) return CSA_ERR_ARG;
+    if (h->pending.empty()) return CSA_OK;
+    hipStream_t s = (hipStream_t)stream;
+    const csa_config &c = h->dm.cfg;
+    const int nh1 = c.nh1, nh2 = c.nh2, nin1 = nh1 + c.nh_mem, M = c.nlev * h->pending_B;
+    const int nseg = (int)h->pending.size();
+    const int ns = (h->nsplit / nseg) * nseg;      // same number of partials as one per-step call, shared by the segments
+    int rc;
+    auto run = [&](float *Slot::*a, float *Slot::*b, int N1, int N2, const int *map) {
+        TnSegs g{};
+        g.n = nseg;
+        for (int i = 0; i < nseg; ++i) { g.A[i] = h->slots[h->pending[i]].*a; g.B[i] = h->slots[h->pending[i]].*b; }
+        if ((rc = launch_gemm_tn_segs(g, N1, N2, h->part, M, N1, N2, ns, 0, 0, s))) return rc;
+        return launch_reduce_partials(h->part, ns, N1 * N2, map, nullptr, grads, s);
+    };
+    if ((rc = run(&Slot::GP2, &Slot::H1lev, 4 * nh2, nh1, h->map_wih2))) return rc;
+    if ((rc = run(&Slot::GP2, &Slot::H2, 4 * nh2, nh2, h->map_whh2))) return rc;
+    if ((rc = run(&Slot::GP1, &Slot::X1, 4 * nh1, nin1, h->map_wih1))) return rc;
+    if ((rc = run(&Slot::GP1, &Slot::H1seq, 4 * nh1, nh1, h->map_whh1))) return rc;
+    h->pending.clear();
+    return CSA_OK;
 }
 
 __global__ void sp_kernel(const float *__restrict__ xs, int nxs, float a, float bconst, float *__restrict__ sp, int n)

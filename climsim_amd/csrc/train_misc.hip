@@ -17,9 +17,13 @@
 #define TN_T 128
 #define TN_MK 16
 __global__ __launch_bounds__(256) void gemm_tn_partial_kernel(
-    const float *__restrict__ A, int lda, const float *__restrict__ Bm, int ldb, float *__restrict__ Cpart,
-    int M, int N1, int N2, int rows_per_split, int conv_L, int conv_cin)
+    TnSegs segs, int lda, int ldb, float *__restrict__ Cpart,
+    int M, int N1, int N2, int rows_per_split, int splits_per_seg, int conv_L, int conv_cin)
 {
+    // segs: up to TN_MAX_SEGS (A, B) pairs of M rows each, contracted into ONE result (the T_w time steps of a TBPTT
+    // window share their weight gradient): split z works on segment z / splits_per_seg.
+    const float *__restrict__ A = segs.A[blockIdx.z / splits_per_seg];
+    const float *__restrict__ Bm = segs.B[blockIdx.z / splits_per_seg];
     // conv_L > 0: B is the implicit im2col of a kernel-3 'same' convolution input X (ldb = cin): row m is the
     // 3*cin contiguous floats starting at X + (m-1)*ldb, first / last third masked on the first / last level of a
     // column (the weight gradient of Conv1D, cnn_train.hip); N2 = 3*cin.
@@ -27,7 +31,7 @@ __global__ __launch_bounds__(256) void gemm_tn_partial_kernel(
     __shared__ float Bs[TN_MK][TN_T];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
     const int n10 = blockIdx.x * TN_T, n20 = blockIdx.y * TN_T, split = blockIdx.z;
-    const int m_begin = split * rows_per_split, m_end = min(M, m_begin + rows_per_split);
+    const int m_begin = (split % splits_per_seg) * rows_per_split, m_end = min(M, m_begin + rows_per_split);
     f32x16 acc[2][2];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -106,12 +110,23 @@ int launch_gemm_tn_partial(const float *A, int lda, const float *Bm, int ldb, fl
 int launch_gemm_tn_conv(const float *A, int lda, const float *Bm, int ldb, float *Cpart, int M, int N1, int N2,
                         int nsplit, int conv_L, int conv_cin, hipStream_t s)
 {
+    TnSegs g{};
+    g.A[0] = A; g.B[0] = Bm; g.n = 1;
+    return launch_gemm_tn_segs(g, lda, ldb, Cpart, M, N1, N2, nsplit, conv_L, conv_cin, s);
+}
+
+// nsplit = TOTAL number of partials (a multiple of segs.n); every segment has M rows
+int launch_gemm_tn_segs(const TnSegs &segs, int lda, int ldb, float *Cpart, int M, int N1, int N2,
+                        int nsplit, int conv_L, int conv_cin, hipStream_t s)
+{
+    if (segs.n <= 0 || segs.n > TN_MAX_SEGS || nsplit % segs.n) { csa_set_error_msg("gemm_tn: bad segment count"); return CSA_ERR_ARG; }
     if (conv_L > 0 && (conv_cin % 4 || N2 != 3 * conv_cin)) { csa_set_error_msg("gemm_tn(conv): cin multiple of 4 and N2 = 3*cin required"); return CSA_ERR_UNSUPPORTED; }
     if ((lda % 4) || (ldb % 4)) { csa_set_error_msg("gemm_tn: leading dimensions must be multiples of 4"); return CSA_ERR_UNSUPPORTED; }
-    int rps = (M + nsplit - 1) / nsplit;
+    const int sps = nsplit / segs.n;
+    int rps = (M + sps - 1) / sps;
     rps = (rps + TN_MK - 1) / TN_MK * TN_MK;
     dim3 grid((N1 + TN_T - 1) / TN_T, (N2 + TN_T - 1) / TN_T, nsplit);
-    hipLaunchKernelGGL(gemm_tn_partial_kernel, grid, dim3(256), 0, s, A, lda, Bm, ldb, Cpart, M, N1, N2, rps, conv_L, conv_cin);
+    hipLaunchKernelGGL(gemm_tn_partial_kernel, grid, dim3(256), 0, s, segs, lda, ldb, Cpart, M, N1, N2, rps, sps, conv_L, conv_cin);
     CSA_HIP_CHECK(hipGetLastError());
     return CSA_OK;
 }

@@ -141,6 +141,15 @@ class Trainer:
                  "csa_train_backward")
         return d_mem_in
 
+    def set_deferred_wgrad(self, enable):
+        """Postpone the W_ih / W_hh gradient GEMMs of backward() to flush_wgrad(): one contraction over all time steps
+        of the window instead of one per step (window_step uses this)."""
+        self._rc(_lib.lib().csa_train_set_deferred(self._h, int(bool(enable))), "csa_train_set_deferred")
+        self._deferred = bool(enable)
+
+    def flush_wgrad(self):
+        self._rc(_lib.lib().csa_train_flush_wgrad(self._h, _ptr(self.grads), self._stream()), "csa_train_flush_wgrad")
+
     def loss(self, B, Tw, pred, pred_sfc, tgt, tgt_sfc, yto, yto_sfc, x_raw, x_sfc_n, with_grad=True):
         c = self.cfg
         N = B * Tw
@@ -183,8 +192,13 @@ class Trainer:
             d_pred_sfc.mul_(scale)
         self.grads.zero_()
         d_mem = None
+        defer = Tw <= 8
+        if defer != getattr(self, "_deferred", False):
+            self.set_deferred_wgrad(defer)
         for t in reversed(range(Tw)):
             d_mem = self.backward(t, d_pred[t * B:(t + 1) * B], d_pred_sfc[t * B:(t + 1) * B], d_mem)
+        if defer:
+            self.flush_wgrad()
         if world_size > 1:
             allreduce_flat_(self.grads, world_size, average=not bool(global_columns))
         if optimise:

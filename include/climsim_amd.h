@@ -167,6 +167,11 @@ int csa_train_forward(csa_trainer *h, int slot, int B, const float *x_main_n, co
                       const float *mem_in, float *out, float *out_sfc, float *mem_out, void *stream);
 int csa_train_backward(csa_trainer *h, int slot, int B, const float *d_out, const float *d_out_sfc,
                        const float *d_mem_out /* nullable */, float *d_mem_in /* nullable */, float *grads, void *stream);
+/* Deferred weight gradients: with enable = 1 the backward calls skip the W_ih / W_hh gradient GEMMs and
+ * csa_train_flush_wgrad does each of them ONCE over all (at most 8) time steps backpropagated since the last flush
+ * (one contraction over T_w*nlev*B rows instead of T_w separate ones).  Call flush before using `grads`. */
+int csa_train_set_deferred(csa_trainer *h, int enable);
+int csa_train_flush_wgrad(csa_trainer *h, float *grads, void *stream);
 /* pred/tgt (Tw*B,nlev,ny) normalised, *_sfc (Tw*B,ny_sfc); yto (Tw*B,nlev,6), yto_sfc physical targets;
  * x_raw (Tw*B,nlev,nx) raw inputs; x_sfc_n (Tw*B,nx_sfc) normalised.  scalars (device, 7 floats):
  * loss, huber, mse, mae, energy, water, precip_sum_mse.  d_pred/d_pred_sfc nullable (evaluation). */
