@@ -27,8 +27,8 @@ __global__ __launch_bounds__(256) void gemm_tn_partial_kernel(
     // conv_L > 0: B is the implicit im2col of a kernel-3 'same' convolution input X (ldb = cin): row m is the
     // 3*cin contiguous floats starting at X + (m-1)*ldb, first / last third masked on the first / last level of a
     // column (the weight gradient of Conv1D, cnn_train.hip); N2 = 3*cin.
-    __shared__ float As[TN_MK][TN_T];
-    __shared__ float Bs[TN_MK][TN_T];
+    __shared__ float As[2][TN_MK][TN_T];     // double-buffered: one barrier per 16-row chunk
+    __shared__ float Bs[2][TN_MK][TN_T];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
     const int n10 = blockIdx.x * TN_T, n20 = blockIdx.y * TN_T, split = blockIdx.z;
     const int m_begin = (split % splits_per_seg) * rows_per_split, m_end = min(M, m_begin + rows_per_split);
@@ -66,26 +66,34 @@ __global__ __launch_bounds__(256) void gemm_tn_partial_kernel(
             }
         }
     };
-    if (m_begin < m_end) gload(m_begin);
-    for (int m0 = m_begin; m0 < m_end; m0 += TN_MK) {
-        __syncthreads();
+    auto sstore = [&](int buf) {
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-            *(f32x4 *)&As[sr + 8 * h][sc] = va[h];
-            *(f32x4 *)&Bs[sr + 8 * h][sc] = vb[h];
+            *(f32x4 *)&As[buf][sr + 8 * h][sc] = va[h];
+            *(f32x4 *)&Bs[buf][sr + 8 * h][sc] = vb[h];
         }
-        __syncthreads();
-        if (m0 + TN_MK < m_end) gload(m0 + TN_MK);
+    };
+    if (m_begin < m_end) {
+        gload(m_begin);
+        sstore(0);
+    }
+    __syncthreads();
+    int cur = 0;
+    for (int m0 = m_begin; m0 < m_end; m0 += TN_MK, cur ^= 1) {
+        const bool more = m0 + TN_MK < m_end;
+        if (more) gload(m0 + TN_MK);
 #pragma unroll
         for (int kk = 0; kk < TN_MK / 2; ++kk) {
             const int kr = kk * 2 + (lane >> 5);
-            const float a0 = As[kr][wm * 64 + (lane & 31)], a1 = As[kr][wm * 64 + 32 + (lane & 31)];
-            const float b0 = Bs[kr][wn * 64 + (lane & 31)], b1 = Bs[kr][wn * 64 + 32 + (lane & 31)];
+            const float a0 = As[cur][kr][wm * 64 + (lane & 31)], a1 = As[cur][kr][wm * 64 + 32 + (lane & 31)];
+            const float b0 = Bs[cur][kr][wn * 64 + (lane & 31)], b1 = Bs[cur][kr][wn * 64 + 32 + (lane & 31)];
             acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
             acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
             acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
             acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
         }
+        if (more) sstore(cur ^ 1);
+        __syncthreads();
     }
     float *C = Cpart + (size_t)split * N1 * N2;
 #pragma unroll
