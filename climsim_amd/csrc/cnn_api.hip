@@ -110,3 +110,52 @@ extern "C" int csa_cnn_forward(csa_cnn *h, int B, const float *x, float *y, void
     return launch_gemm_ex(h->y10, h->dense.w, h->dense.b, y, M, h->cout, h->cout_p, /*split*/ 2, 0.0f, h->n_lin, h->cout_p,
                           h->cout, 0, 0, 0, s);
 }
+
+// ---- data-format adapters either side of the CNN (climsim_utils/data_utils.py:2104-2175, V1 variables) ----------------
+// flat (N, nprof*nlev + nscal) -> channels-last (N, nlev, nprof + nscal): profiles become channels, scalars are repeated
+// over the levels (reshape_input_for_cnn: nprof 2, nscal 4; reshape_target_for_cnn: nprof 2, nscal 8)
+__global__ void cnn_reshape_to_kernel(const float *__restrict__ x, float *__restrict__ y, long total, int nlev, int nprof, int nscal)
+{
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int C = nprof + nscal, W = nprof * nlev + nscal;
+    const int c = (int)(i % C);
+    const long r = i / C;
+    const int l = (int)(r % nlev);
+    const long n = r / nlev;
+    y[i] = c < nprof ? x[n * W + (long)c * nlev + l] : x[n * W + (long)nprof * nlev + (c - nprof)];
+}
+// channels-last (N, nlev, nprof + nscal) -> flat (N, nprof*nlev + nscal): scalars = mean over the levels
+// (reshape_target_from_cnn)
+__global__ void cnn_reshape_from_kernel(const float *__restrict__ y, float *__restrict__ x, long total, int nlev, int nprof, int nscal)
+{
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int C = nprof + nscal, W = nprof * nlev + nscal;
+    const int w = (int)(i % W);
+    const long n = i / W;
+    if (w < nprof * nlev) {
+        x[i] = y[(n * nlev + w % nlev) * C + w / nlev];
+    } else {
+        const int c = nprof + (w - nprof * nlev);
+        float a = 0.0f;
+        for (int l = 0; l < nlev; ++l) a += y[(n * nlev + l) * C + c];
+        x[i] = a / (float)nlev;
+    }
+}
+extern "C" int csa_cnn_reshape_to(int N, int nlev, int nprof, int nscal, const float *flat, float *chan, void *stream)
+{
+    if (N <= 0 || nlev <= 0 || nprof < 0 || nscal < 0 || !flat || !chan) { csa_set_error_msg("csa_cnn_reshape_to: bad argument"); return CSA_ERR_ARG; }
+    const long total = (long)N * nlev * (nprof + nscal);
+    hipLaunchKernelGGL(cnn_reshape_to_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, flat, chan, total, nlev, nprof, nscal);
+    CSA_HIP_CHECK(hipGetLastError());
+    return CSA_OK;
+}
+extern "C" int csa_cnn_reshape_from(int N, int nlev, int nprof, int nscal, const float *chan, float *flat, void *stream)
+{
+    if (N <= 0 || nlev <= 0 || nprof < 0 || nscal < 0 || !flat || !chan) { csa_set_error_msg("csa_cnn_reshape_from: bad argument"); return CSA_ERR_ARG; }
+    const long total = (long)N * (nprof * nlev + nscal);
+    hipLaunchKernelGGL(cnn_reshape_from_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, chan, flat, total, nlev, nprof, nscal);
+    CSA_HIP_CHECK(hipGetLastError());
+    return CSA_OK;
+}

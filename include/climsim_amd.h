@@ -204,6 +204,11 @@ int csa_cnn_create(int depth, int nlev, int cin, int width, int cout, int n_lin,
 int csa_cnn_destroy(csa_cnn *h);
 int csa_cnn_forward(csa_cnn *h, int B, const float *x, float *y, void *stream);
 
+/* data-format adapters either side of the CNN (climsim_utils/data_utils.py:2104-2175): flat (N, nprof*nlev + nscal)
+ * <-> channels-last (N, nlev, nprof + nscal); scalars are repeated over the levels one way and level-averaged back */
+int csa_cnn_reshape_to(int N, int nlev, int nprof, int nscal, const float *flat, float *chan, void *stream);
+int csa_cnn_reshape_from(int N, int nlev, int nprof, int nscal, const float *chan, float *flat, void *stream);
+
 /* ---- CNN baseline, one training step (BASELINE.json configs[3]) ------------------------------------------------
  * baseline_models/CNN/training/hpo_train.py:124-236: forward with Dropout(p) after both activations of a block,
  * loss mae_adjusted (:118-120), keras Adam.  Parameters and gradients are flat fp32 device buffers in the GEMM layout

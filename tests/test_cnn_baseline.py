@@ -107,3 +107,29 @@ def test_cnn_training_step_matches_autograd(depth, width, B, dropout):
         m, v = 0.1 * gq, 0.001 * gq * gq
         upd = 1e-3 * (1 - 0.999) ** 0.5 / (1 - 0.9) * m / (v.sqrt() + 1e-7)
         assert ((p0.double() - p1.double()) - upd).abs().max().item() <= 2e-6 * 1e-3 + 1e-4 * upd.abs().max().item()
+
+
+def _np_reshape_to(a, nscal):      # climsim_utils/data_utils.py:2104-2150 restated (test infrastructure)
+    return np.stack([a[:, 0:60], a[:, 60:120]] + [np.repeat(a[:, 120 + i][:, None], 60, axis=1) for i in range(nscal)], axis=2)
+
+
+def _np_reshape_from(p):           # :2152-2175
+    return np.concatenate([p[:, :, 0], p[:, :, 1]] + [np.mean(p[:, :, c], axis=1)[:, None] for c in range(2, 10)], axis=1)
+
+
+@pytest.mark.gpu
+def test_cnn_data_format_adapters():
+    from climsim_amd.data_utils import data_utils
+    g = np.random.Generator(np.random.PCG64(4))
+    x = g.standard_normal((37, 124)).astype(np.float32)
+    t = g.standard_normal((37, 128)).astype(np.float32)
+    p = g.standard_normal((37, 60, 10)).astype(np.float32)
+    d = lambda a: torch.from_numpy(a).cuda()
+    assert np.array_equal(data_utils.reshape_input_for_cnn(d(x)).cpu().numpy(), _np_reshape_to(x, 4))
+    assert np.array_equal(data_utils.reshape_target_for_cnn(d(t)).cpu().numpy(), _np_reshape_to(t, 8))
+    back = data_utils.reshape_target_from_cnn(d(p)).cpu().numpy()
+    ref = _np_reshape_from(p)
+    assert np.array_equal(back[:, :120], ref[:, :120])
+    assert np.abs(back[:, 120:] - ref[:, 120:]).max() <= 2e-7        # level mean: summation order only
+    # round trip: scalars repeated over the levels average back exactly
+    assert np.abs(data_utils.reshape_target_from_cnn(data_utils.reshape_target_for_cnn(d(t))).cpu().numpy() - t).max() <= 1e-6 * np.abs(t).max()
