@@ -428,26 +428,28 @@ static int run_forward_stoch(csa_emulator *h, int B, int normalised, int mode, c
     return launch_head(h->dm, B, mode, h->H1, x_main, x_sfc, y0, y1, y2, s);
 }
 
-// Column-half concurrency (legacy, batch-first layouts only): columns are independent, so the batch is cut in two
+// Column-half concurrency: columns are independent, so the batch is cut in two
 // and each half runs its own six launches on its own stream, with ONE fork and ONE join event.  While one half is in
 // its recurrence (192 columns = 96 workgroups, VALU pipe, 2 of the 3 wave slots' registers) the other half's
 // projection GEMM (MFMA pipe) can run on the same and on the idle CUs.  Scratch buffers are simply split in two.
 static int run_chain(csa_emulator *h, int B, int normalised, int mode, const float *x_main, const float *x_sfc,
                      const float *mem_in, const float *hx2, const float *cx2, float *y0, float *y1, float *y2,
-                     float *X1, float *P, float *H1, float *H2, float *hc0, hipStream_t s)
+                     float *X1, float *P, float *H1, float *H2, float *hc0, int mem_B, int mem_off, hipStream_t s)
 {
     const csa_config &c = h->dm.cfg;
+    DevModel dm = h->dm;
+    dm.mem_B = mem_B; dm.mem_off = mem_off;
     const int L = c.nlev;
     const size_t nhm = c.nh1 > c.nh2 ? c.nh1 : c.nh2;
     int rc;
-    if ((rc = launch_prep(h->dm, B, normalised, x_main, x_sfc, mem_in, hx2, cx2, X1, hc0, s))) return rc;
+    if ((rc = launch_prep(dm, B, normalised, x_main, x_sfc, mem_in, hx2, cx2, X1, hc0, s))) return rc;
     const float *h2 = c.legacy ? hx2 : hc0 + (size_t)2 * B * nhm;
     const float *c2 = c.legacy ? cx2 : hc0 + (size_t)3 * B * nhm;
     if ((rc = launch_proj_gemm(X1, h->dm.wih1, h->dm.bias1, P, L * B, 4 * c.nh1, c.nh1 + c.nh_mem, s))) return rc;
     if ((rc = launch_rec(c.use_lstm, c.nh1, h->dm.whh1p, h->dm.bhn1, P, hc0, hc0 + (size_t)B * nhm, H1, B, L, 1, s))) return rc;
     if ((rc = launch_proj_gemm(H1, h->dm.wih2, h->dm.bias2, P, L * B, 4 * c.nh2, c.nh1, s))) return rc;
     if ((rc = launch_rec(c.use_lstm, c.nh2, h->dm.whh2p, h->dm.bhn2, P, h2, c2, H2, B, L, 0, s))) return rc;
-    return launch_head(h->dm, B, mode, H2, x_main, x_sfc, y0, y1, y2, s);
+    return launch_head(dm, B, mode, H2, x_main, x_sfc, y0, y1, y2, s);
 }
 
 static int run_forward_halves(csa_emulator *h, int B, int normalised, int mode, const float *x_main, const float *x_sfc,
@@ -463,14 +465,18 @@ static int run_forward_halves(csa_emulator *h, int B, int normalised, int mode, 
     int rc;
     CSA_HIP_CHECK(hipEventRecord(h->ov_ev[0], s));
     CSA_HIP_CHECK(hipStreamWaitEvent(T, h->ov_ev[0], 0));
-    if ((rc = run_chain(h, B0, normalised, mode, x_main, x_sfc, mem_in, hx2, cx2, y0, y1, y2, h->X1, h->P, h->H1, h->H2, h->hc0, s))) return rc;
+    // level-major memory tensors (current generation) are addressed through (mem_B, mem_off); batch-first ones by pointer
+    const bool lm = !c.legacy && c.nh_mem > 0;
+    if ((rc = run_chain(h, B0, normalised, mode, x_main, x_sfc, mem_in, hx2, cx2, y0, y1, y2, h->X1, h->P, h->H1, h->H2, h->hc0,
+                        lm ? B : 0, 0, s))) return rc;
     // second half: batch-first offsets of every caller tensor, the upper part of every scratch buffer
     const size_t o = B0;
     float *y0b = y0 + (mode == HEAD_PACKED ? o * W : o * L * (mode == HEAD_RAW || c.mp_mode == 0 ? c.ny : 6));
-    rc = run_chain(h, B1, normalised, mode, x_main + o * L * nxr, x_sfc + o * c.nx_sfc, mem_in ? mem_in + o * L * c.nh_mem : nullptr,
+    rc = run_chain(h, B1, normalised, mode, x_main + o * L * nxr, x_sfc + o * c.nx_sfc,
+                   mem_in ? (lm ? mem_in : mem_in + o * L * c.nh_mem) : nullptr,
                    hx2 ? hx2 + o * c.nh2 : nullptr, cx2 ? cx2 + o * c.nh2 : nullptr, y0b, y1 ? y1 + o * c.ny_sfc : nullptr,
-                   y2 ? y2 + o * L * c.nh_mem : nullptr, h->X1 + (size_t)L * o * nin1, h->P + (size_t)L * o * 4 * nhm,
-                   h->H1 + (size_t)L * o * c.nh1, h->H2 + (size_t)L * o * c.nh2, h->hc0 + 4 * o * nhm, T);
+                   y2 ? (lm ? y2 : y2 + o * L * c.nh_mem) : nullptr, h->X1 + (size_t)L * o * nin1, h->P + (size_t)L * o * 4 * nhm,
+                   h->H1 + (size_t)L * o * c.nh1, h->H2 + (size_t)L * o * c.nh2, h->hc0 + 4 * o * nhm, lm ? B : 0, lm ? B0 : 0, T);
     if (rc) return rc;
     CSA_HIP_CHECK(hipEventRecord(h->ov_ev[1], T));
     CSA_HIP_CHECK(hipStreamWaitEvent(s, h->ov_ev[1], 0));
@@ -501,7 +507,7 @@ static int run_forward(csa_emulator *h, int B, int normalised, int mode,
     int rc;
     // measured (tools/halves_sweep.py, memory wrapper): 0.90x at 384 columns (the co-running GEMM slows the latency-bound
     // recurrence of the other half), 1.04-1.09x from 768 columns up -> automatic from 640
-    if ((h->halves == 1 || (h->halves == 2 && B >= 640)) && !h->profiling && !h->fused && c.legacy && B >= 64)
+    if ((h->halves == 1 || (h->halves == 2 && B >= 640)) && !h->profiling && !h->fused && B >= 64)
         return run_forward_halves(h, B, normalised, mode, x_main, x_sfc, mem_in, hx2, cx2, y0, y1, y2, s);
     if (h->overlap && !h->profiling && !h->fused && c.use_lstm && c.nh1 == 128 && c.nh2 == 128 && L >= 8)
         return run_forward_overlap(h, B, normalised, mode, x_main, x_sfc, mem_in, hx2, cx2, y0, y1, y2, s);

@@ -14,6 +14,9 @@ enum HeadMode { HEAD_PACKED = 0, HEAD_TUPLE = 1, HEAD_RAW = 2 };
 // Device-side view of one model (all pointers are device pointers).
 struct DevModel {
     csa_config cfg;
+    // level-major memory tensors (current generation, (L, B, nh_mem)) of a sub-batch: row (l, b) of this call sits at
+    // (l * mem_B + mem_off + b); mem_B == 0 means the call's own B and no offset (api.hip::run_forward_halves)
+    int mem_B, mem_off;
     // constants
     const float *xmean_lev, *xdiv_lev, *xmean_sca, *xdiv_sca, *lbd_qc, *lbd_qi;
     const float *yscale_lev, *yscale_sca, *hyam, *hybm;

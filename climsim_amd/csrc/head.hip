@@ -77,7 +77,7 @@ __global__ __launch_bounds__(HEAD_THREADS) void head_kernel(
                 } else if (legacy) {
                     mem_out[((size_t)b * L + (L - 1 - l)) * nm + j] = v;
                 } else {
-                    mem_out[((size_t)l * B + b) * nm + j] = v;
+                    mem_out[((size_t)l * (m.mem_B > 0 ? m.mem_B : B) + m.mem_off + b) * nm + j] = v;
                 }
             } else {
                 os[l * ny + j] = (m.cfg.output_prune && l < 12 && j >= 1) ? 0.0f : a;

@@ -143,7 +143,7 @@ __global__ __launch_bounds__(PREP_THREADS) void prep_kernel(
     for (int idx = tid; idx < nl * nm; idx += PREP_THREADS) {
         const int ll = idx / nm, k = idx - ll * nm, t = m.cfg.add_stochastic_layer ? l0 + ll : L - 1 - (l0 + ll);
         const float v = m.cfg.legacy ? mem_in[((size_t)b * L + t) * nm + k]
-                                     : mem_in[((size_t)(l0 + ll) * B + b) * nm + k];
+                                     : mem_in[((size_t)(l0 + ll) * (m.mem_B > 0 ? m.mem_B : B) + m.mem_off + b) * nm + k];
         X1[((size_t)t * B + b) * nin1 + nh1 + k] = v;
     }
 }

@@ -137,7 +137,7 @@ int csa_set_fused(csa_emulator *h, int enable);
  * of the next layer run concurrently on an internal side stream (same results, bit for bit);
  * 0 (default) = strictly sequential six launches.  Measured on MI355X at 384 columns: 230 us vs 202 us
  * (the cross-queue event waits cost more than the GEMM time they hide), so it is opt-in. */
-/* Two column halves on two streams with one fork / one join event (legacy batch-first layouts, B >= 64); results are
+/* Two column halves on two streams with one fork / one join event (B >= 64; not the stochastic variant); results are
  * bit-identical to the single-stream path.  enable: 0 off, 1 on, 2 automatic (default: on from 640 columns, where it
  * measures 4-9 % faster; slower below).  Returns the new state. */
 int csa_set_halves(csa_emulator *h, int enable);

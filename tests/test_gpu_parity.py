@@ -301,6 +301,27 @@ def test_column_halves_path_is_bit_identical(memory, B):
     assert torch.equal(y0, y1) and torch.equal(y1, y2)
 
 
+@pytest.mark.parametrize("tag", ["cur_lstm128", "cur_gru128"])
+def test_column_halves_path_current_generation(tag):
+    """Same for the tuple wrapper, whose memory tensors are level-major (L, B, nh_mem): addressed by stride + offset."""
+    import climsim_amd
+    consts, weights, flags = load_npz_model(tag)
+    wrap = climsim_amd.model_wrapper(consts, weights, max_batch=300, use_lstm=bool(flags["use_lstm"]),
+                                     output_prune=bool(flags["output_prune"]))
+    B = 277
+    xm, xs = synth_inputs(consts, B, 31)
+    mem = (0.3 * np.random.Generator(np.random.PCG64(9)).standard_normal((60, B, 16))).astype(np.float32)
+    args = (_dev(xm), _dev(xs), _dev(mem))
+    wrap.emulator.set_halves(False)
+    a = [t.clone() for t in wrap(*args)]
+    wrap.emulator.set_halves(True)
+    b = [t.clone() for t in wrap(*args)]
+    wrap.emulator.set_halves(None)
+    torch.cuda.synchronize()
+    for x, y in zip(a, b):
+        assert torch.equal(x, y)
+
+
 def test_overlap_path_is_bit_identical_to_sequential(memory):
     """The level-split overlap (rnn1 in three launches, GEMMs on a side stream) reorders launches only."""
     consts, weights, model = memory
