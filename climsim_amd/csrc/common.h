@@ -80,6 +80,10 @@ struct GemmEpi {
 int launch_gemm_epi(const float *A, const float *W, const float *bias, float *C, int M, int N, int K, int act, float alpha,
                     int n_lin, int lda, int ldc, int conv_L, int conv_cin, const GemmEpi &epi, hipStream_t s);
 
+// small-M variant: 32x32 tile per workgroup, K split over its four waves (gemm.hip)
+int launch_gemm_small(const float *A, const float *W, const float *bias, float *C, int M, int N, int K, int act, float alpha,
+                      int n_lin, hipStream_t s);
+
 // general form: leading dimensions, implicit-GEMM conv1d(k=3,'same') over (column, level) rows, C += mode, ELU
 int launch_gemm_ex(const float *A, const float *W, const float *bias, float *C, int M, int N, int K, int act, float alpha,
                    int n_lin, int lda, int ldc, int conv_L, int conv_cin, int accumulate, hipStream_t s);

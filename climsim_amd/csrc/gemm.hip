@@ -235,3 +235,72 @@ int launch_gemm_epi(const float *A, const float *W, const float *bias, float *C,
     CSA_HIP_CHECK(hipGetLastError());
     return CSA_OK;
 }
+
+// ------------------------------------------------------------------------------------------------------------------
+// Small-M variant (the MLP baseline at a few hundred rows): the 128x128 tiling above leaves a 384-row problem with
+// 3 x N/128 workgroups on a 256-CU part and a K-long serial MFMA chain in each.  Here a workgroup owns one 32x32
+// output tile and its four waves split K between them (each wave one MFMA accumulator, operands straight from
+// global memory as float4: lanes < 32 take k..k+3 and lanes >= 32 take k+4..k+7 of a row, i.e. MFMA e contracts
+// the pair (k+e, k+4+e)); the four partial tiles are summed through LDS in a fixed order (deterministic), then bias +
+// activation.  384 x 768: 288 workgroups, each wave K/8 MFMAs.
+__global__ __launch_bounds__(256) void gemm_small_kernel(
+    const float *__restrict__ A, const float *__restrict__ W, const float *__restrict__ bias, float *__restrict__ C,
+    int M, int N, int K, int act, float alpha, int n_lin)
+{
+    __shared__ float red[3][32 * 33];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int m0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
+    const int r = lane & 31, half = lane >> 5;
+    const bool am = m0 + r < M, wn = n0 + r < N;
+    const float *ap = A + (size_t)(am ? m0 + r : 0) * K + 4 * half;
+    const float *wp = W + (size_t)(wn ? n0 + r : 0) * K + 4 * half;
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
+    const int nch = (K + 7) / 8;                     // chunks of 8 k-values, dealt round-robin to the waves
+    f32x4 a = {0, 0, 0, 0}, w = {0, 0, 0, 0};
+    int c = wave;
+    if (c < nch) {
+        const int k = 8 * c + 4 * half;
+        if (k < K) { if (am) a = *(const f32x4 *)(ap + 8 * c); if (wn) w = *(const f32x4 *)(wp + 8 * c); }
+    }
+    for (; c < nch; c += 4) {
+        f32x4 an = {0, 0, 0, 0}, wnx = {0, 0, 0, 0};
+        const int cn = c + 4;
+        if (cn < nch && 8 * cn + 4 * half < K) {      // prefetch the wave's next chunk
+            if (am) an = *(const f32x4 *)(ap + 8 * cn);
+            if (wn) wnx = *(const f32x4 *)(wp + 8 * cn);
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], w[e], acc, 0, 0, 0);
+        a = an; w = wnx;
+    }
+    // acc[i]: row (i&3) + 8*(i>>2) + 4*half, column r of the tile
+    if (wave > 0) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) red[wave - 1][((i & 3) + 8 * (i >> 2) + 4 * half) * 33 + r] = acc[i];
+    }
+    __syncthreads();
+    if (wave == 0) {
+        const int col = n0 + r;
+        const float bv = (bias && col < N) ? bias[col] : 0.0f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int rr = (i & 3) + 8 * (i >> 2) + 4 * half, row = m0 + rr;
+            float v = ((acc[i] + red[0][rr * 33 + r]) + (red[1][rr * 33 + r] + red[2][rr * 33 + r])) + bv;
+            if (act == 1) v = v > 0.0f ? v : alpha * v;
+            else if (act == 2 && col >= n_lin) v = fmaxf(v, 0.0f);
+            else if (act == 3) v = v > 0.0f ? v : expm1f(v);
+            if (row < M && col < N) C[(size_t)row * N + col] = v;
+        }
+    }
+}
+
+int launch_gemm_small(const float *A, const float *W, const float *bias, float *C, int M, int N, int K, int act, float alpha,
+                      int n_lin, hipStream_t s)
+{
+    if (K % 4) { csa_set_error_msg("gemm_small: K must be a multiple of 4"); return CSA_ERR_UNSUPPORTED; }
+    hipLaunchKernelGGL(gemm_small_kernel, dim3((N + 31) / 32, (M + 31) / 32), dim3(256), 0, s, A, W, bias, C, M, N, K, act, alpha, n_lin);
+    CSA_HIP_CHECK(hipGetLastError());
+    return CSA_OK;
+}

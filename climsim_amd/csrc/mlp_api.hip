@@ -65,8 +65,11 @@ extern "C" int csa_mlp_forward(csa_mlp *h, int B, const float *x, float *y, void
     for (int l = 0; l < h->nlayers; ++l) {
         const bool last = l + 1 == h->nlayers;
         float *o = last ? y : h->buf[l & 1];
-        int rc = launch_gemm_act(in, h->W[l], h->b[l], o, B, h->dims[l + 1], h->dims[l], last ? 2 : 1, h->alpha,
-                                 last ? h->n_lin : 0, s);
+        // up to 1,024 rows the 128x128 tiling cannot fill the part (384 rows x 768 columns = 18 tiles): 32x32 split-K tiles
+        int rc = B <= 1024
+                     ? launch_gemm_small(in, h->W[l], h->b[l], o, B, h->dims[l + 1], h->dims[l], last ? 2 : 1, h->alpha, last ? h->n_lin : 0, s)
+                     : launch_gemm_act(in, h->W[l], h->b[l], o, B, h->dims[l + 1], h->dims[l], last ? 2 : 1, h->alpha,
+                                       last ? h->n_lin : 0, s);
         if (rc) return rc;
         in = o;
     }
