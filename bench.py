@@ -162,16 +162,19 @@ def aux_workload(a, rank, world, dist):
     from synth import synth_inputs
     B = 384
     g = torch.Generator().manual_seed(100 + rank)
-    if a.workload == "cur_lstm144_384":
-        consts, weights = load_model("cur_lstm144")
-        m = climsim_amd.model_wrapper(consts, weights, use_lstm=True, output_prune=True, max_batch=B)
+    if a.workload in ("cur_lstm144_384", "cur_gru128_384", "cur_lstm128_384"):
+        tag = a.workload[:-4]
+        consts, weights = load_model(tag)
+        m = climsim_amd.model_wrapper(consts, weights, use_lstm="lstm" in tag, output_prune="lstm" in tag, max_batch=B)
         xm, xs = synth_inputs(consts, B, 9000 + rank)
         xs_ = [torch.from_numpy(xm).cuda(), torch.from_numpy(xs).cuda()]
         state = {"mem": torch.zeros(60, B, 16, device="cuda")}
 
         def step():
             o6, osfc, state["mem"] = m(xs_[0], xs_[1], state["mem"])
-        flop_col, what = 60 * 691360.0 + 13e3, "RNN_autoreg LSTM 144/144 tuple wrapper"
+        nh, G = (144 if "144" in tag else 128), (4 if "lstm" in tag else 3)
+        flop_col = 60 * (2.0 * G * nh * (nh + 16) + 2.0 * G * nh * nh + 2 * 2.0 * G * nh * nh + 4096 + 2 * 16 * nh + 160) + 13e3
+        what = f"RNN_autoreg {'LSTM' if G == 4 else 'GRU'} {nh}/{nh} tuple wrapper"
     elif a.workload == "mlp_384":
         dims = [124, 768, 640, 512, 640, 640, 128]   # step2_retrain.py hidden widths (best HPO trial) + 128 outputs
         ws = [torch.randn(dims[i + 1], dims[i], generator=g) / dims[i] ** 0.5 for i in range(len(dims) - 1)]
@@ -241,7 +244,7 @@ def aux_workload(a, rank, world, dist):
             flush=True)
 
 
-AUX = ["cur_lstm144_384", "mlp_384", "cnn_384", "cnn_train_384"]
+AUX = ["cur_lstm144_384", "cur_lstm128_384", "cur_gru128_384", "mlp_384", "cnn_384", "cnn_train_384"]
 
 
 def main():
