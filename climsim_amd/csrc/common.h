@@ -96,6 +96,8 @@ int launch_rec(int use_lstm, int nh, const float *whh_packed, const float *bhn, 
 // training forward: as launch_rec (LSTM) + saves gates in place over P, c_t to Cseq and h_t to Hseq
 int launch_rec_train(int nh, const float *whh_packed, float *P, const float *h0, const float *c0, float *Hout,
                      int B, int L, int reverse_out, float *Hseq, float *Cseq, hipStream_t s);
+int launch_rec_train_gru(int nh, const float *whh_packed, const float *bhn, float *P, const float *h0, float *Hout, int B, int L,
+                         int reverse_out, float *Hseq, hipStream_t s);
 int launch_rec_range(int nh, const float *whh_packed, const float *P, const float *h0, const float *c0, float *Hout,
                      int B, int L, int reverse_out, int t0, int t1, float *Cfin, hipStream_t s);
 size_t rec_packed_floats(int use_lstm, int nh);

@@ -72,11 +72,13 @@ __device__ __forceinline__ float dpp_xor2(float v)
 // Packed weight layout (host packer below): thread tid owns G*KC weights, KC = NH/4, stored as
 // float4 number i (0 <= i < G*KC/4) at Wp4[i*NT + tid]; within a thread the order is
 // idx = g*KC + kk  <->  W_hh[g*NH + u][p*KC + kk].
-template <int NH, int G>
+// TRAIN (GRU): additionally saves what BPTT needs -- [r, z, n, W_hn h + b_hn] written IN PLACE over the (4-padded)
+// pre-activation row P(t,b,u,:) it came from, and h_t into Hseq (L+1 slots in SEQUENCE order, slot 0 = h_init).
+template <int NH, int G, bool TRAIN = false>
 __global__ __launch_bounds__(NH * 4, 2) void rec_kernel(
-    const f32x4 *__restrict__ Wp4, const float *__restrict__ bhn, const float *__restrict__ P,
+    const f32x4 *__restrict__ Wp4, const float *__restrict__ bhn, const float *P,
     const float *__restrict__ h0, const float *__restrict__ c0, float *__restrict__ Hout,
-    int B, int L, int reverse_out)
+    int B, int L, int reverse_out, float *Pw = nullptr, float *__restrict__ Hseq = nullptr)
 {
     constexpr int NT = NH * 4;          // threads
     constexpr int KC = NH / 4;          // k per thread
@@ -110,6 +112,7 @@ __global__ __launch_bounds__(NH * 4, 2) void rec_kernel(
     float c = (G == 4) ? c0[(size_t)b * NH + u] : 0.0f;
     const int hslot = 2 * u + col + 4 * (u / KC);   // position of (k=u, col) in an hbuf
     if (p < 2) hbuf[0][hslot] = h;
+    if (TRAIN && writer) Hseq[(size_t)b * NH + u] = h;
 
     constexpr int PS = G == 4 ? 4 : 4;               // P row stride per unit (GRU rows padded to 4)
     const float *Pb = P + (size_t)b * (PS * NH) + u * PS;
@@ -128,6 +131,7 @@ __global__ __launch_bounds__(NH * 4, 2) void rec_kernel(
         if (t > 0 && writer) {
             const int lvl = reverse_out ? L - t : t - 1;
             Hout[((size_t)lvl * B + b) * NH + u] = h;
+            if (TRAIN) Hseq[((size_t)t * B + b) * NH + u] = h;
         }
 #endif
         f32x4 pre2 = pre1;
@@ -173,8 +177,10 @@ __global__ __launch_bounds__(NH * 4, 2) void rec_kernel(
         } else {
             const float r = sigmoid_f(pre.x + s[0]);
             const float z = sigmoid_f(pre.y + s[1]);
-            const float n = tanh_f(pre.z + r * (s[2] + bn));
+            const float hn = s[2] + bn;
+            const float n = tanh_f(pre.z + r * hn);
             h = (1.0f - z) * n + z * h;
+            if (TRAIN && writer) *(f32x4 *)(Pw + ((size_t)t * B + b) * (PS * NH) + u * PS) = f32x4{r, z, n, hn};
         }
 #endif
         if (p < 2) hbuf[cur ^ 1][hslot] = h;
@@ -185,6 +191,7 @@ __global__ __launch_bounds__(NH * 4, 2) void rec_kernel(
     if (writer) {
         const int lvl = reverse_out ? 0 : L - 1;
         Hout[((size_t)lvl * B + b) * NH + u] = h;
+        if (TRAIN) Hseq[((size_t)L * B + b) * NH + u] = h;
     }
 #ifdef REC_EXP_CLOCK
     if (tid == 0 && blockIdx.x == 0) {   // diagnostic build only: shader cycles and 100 MHz ticks of block 0
@@ -478,6 +485,23 @@ int launch_rec_train(int nh, const float *whh_packed, float *P, const float *h0,
     }
     default:
         csa_set_error_msg("rec(train): hidden size not supported (64, 96, 128, 144)");
+        return CSA_ERR_UNSUPPORTED;
+    }
+    CSA_HIP_CHECK(hipGetLastError());
+    return CSA_OK;
+}
+
+// GRU training forward: gates saved in place over P, h sequence into Hseq (L+1 slots)
+int launch_rec_train_gru(int nh, const float *whh_packed, const float *bhn, float *P, const float *h0, float *Hout, int B, int L,
+                         int reverse_out, float *Hseq, hipStream_t s)
+{
+    const dim3 grid((B + 1) / 2), block(nh * 4);
+    switch (nh) {
+    case 64:  hipLaunchKernelGGL((rec_kernel<64, 3, true>), grid, block, 0, s, (const f32x4 *)whh_packed, bhn, P, h0, (const float *)nullptr, Hout, B, L, reverse_out, P, Hseq); break;
+    case 96:  hipLaunchKernelGGL((rec_kernel<96, 3, true>), grid, block, 0, s, (const f32x4 *)whh_packed, bhn, P, h0, (const float *)nullptr, Hout, B, L, reverse_out, P, Hseq); break;
+    case 128: hipLaunchKernelGGL((rec_kernel<128, 3, true>), grid, block, 0, s, (const f32x4 *)whh_packed, bhn, P, h0, (const float *)nullptr, Hout, B, L, reverse_out, P, Hseq); break;
+    default:
+        csa_set_error_msg("rec(train, GRU): hidden size not supported (64, 96, 128)");
         return CSA_ERR_UNSUPPORTED;
     }
     CSA_HIP_CHECK(hipGetLastError());

@@ -7,6 +7,11 @@ void bwd_rec_pack_weights(int nh, const float *w_hh, float *packed);
 int launch_bwd_rec(int nh, const float *wt_packed, float *GP, const float *Cseq, const float *dH,
                    float *dh0, float *dc0, int B, int L, int rev, hipStream_t s);
 
+size_t bwd_rec_packed_floats_gru(int nh);
+void bwd_rec_pack_weights_gru(int nh, const float *w_hh, float *packed);
+int launch_bwd_rec_gru(int nh, const float *wt_packed, float *GP, const float *Hseq, const float *dH, float *dh0, int B, int L,
+                       int rev, hipStream_t s);
+
 int launch_gemm_tn_partial(const float *A, int lda, const float *Bm, int ldb, float *Cpart, int M, int N1, int N2,
                            int nsplit, hipStream_t s);
 #define TN_MAX_SEGS 8

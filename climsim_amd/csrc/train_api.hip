@@ -108,8 +108,12 @@ extern "C" int csa_train_create(const csa_config *cfg, const csa_params *p, cons
 {
     if (!cfg || !p || !hyai || !hybi || !out || max_batch <= 0 || max_window <= 0) { csa_set_error_msg("csa_train_create: bad argument"); return CSA_ERR_ARG; }
     const csa_config &c = *cfg;
-    if (c.legacy || !c.use_lstm || c.nh_mem <= 0 || c.mp_mode != 1) {
-        csa_set_error_msg("csa_train_create: the HIP training step covers the current-generation LSTM with memory, mp_mode 1");
+    if (c.legacy || c.nh_mem <= 0 || c.mp_mode != 1 || c.add_stochastic_layer) {
+        csa_set_error_msg("csa_train_create: the HIP training step covers the current-generation LSTM / GRU with memory, mp_mode 1");
+        return CSA_ERR_UNSUPPORTED;
+    }
+    if (!c.use_lstm && !((c.nh1 == 64 || c.nh1 == 128) && (c.nh2 == 64 || c.nh2 == 128))) {
+        csa_set_error_msg("csa_train_create: GRU training is built for hidden sizes 64 and 128");
         return CSA_ERR_UNSUPPORTED;
     }
     const bool ok = (c.nh1 == 64 || c.nh1 == 96 || c.nh1 == 128 || c.nh1 == 144) && (c.nh2 == 64 || c.nh2 == 96 || c.nh2 == 128 || c.nh2 == 144);
@@ -128,21 +132,22 @@ extern "C" int csa_train_create(const csa_config *cfg, const csa_params *p, cons
 
     // ---- canonical flat layout (state_dict order of rnn/models/models.py::RNN_autoreg) ----------
     struct Src { const char *name; const float *ptr; int rows, cols; };
-    const Src srcs[] = {
-        {"mlp_toa1.weight", p->mlp_toa1_w, nh2, 2}, {"mlp_toa1.bias", p->mlp_toa1_b, nh2, 1},
-        {"mlp_toa2.weight", p->mlp_toa2_w, nh2, 2}, {"mlp_toa2.bias", p->mlp_toa2_b, nh2, 1},
-        {"mlp_initial.weight", p->mlp_initial_w, nh1, nxp}, {"mlp_initial.bias", p->mlp_initial_b, nh1, 1},
-        {"mlp_surface1.weight", p->mlp_surface1_w, nh1, nxs}, {"mlp_surface1.bias", p->mlp_surface1_b, nh1, 1},
-        {"mlp_surface2.weight", p->mlp_surface2_w, nh1, nxs}, {"mlp_surface2.bias", p->mlp_surface2_b, nh1, 1},
-        {"rnn1.weight_ih_l0", p->rnn1_w_ih, 4 * nh1, nin1}, {"rnn1.weight_hh_l0", p->rnn1_w_hh, 4 * nh1, nh1},
-        {"rnn1.bias_ih_l0", p->rnn1_b_ih, 4 * nh1, 1}, {"rnn1.bias_hh_l0", p->rnn1_b_hh, 4 * nh1, 1},
-        {"rnn2.weight_ih_l0", p->rnn2_w_ih, 4 * nh2, nh1}, {"rnn2.weight_hh_l0", p->rnn2_w_hh, 4 * nh2, nh2},
-        {"rnn2.bias_ih_l0", p->rnn2_b_ih, 4 * nh2, 1}, {"rnn2.bias_hh_l0", p->rnn2_b_hh, 4 * nh2, 1},
+    const bool lstm = c.use_lstm != 0;
+    const int G = lstm ? 4 : 3;                 // gate rows per unit in the state_dict (kernel layouts are padded to 4)
+    std::vector<Src> srcs = {{"mlp_toa1.weight", p->mlp_toa1_w, nh2, 2}, {"mlp_toa1.bias", p->mlp_toa1_b, nh2, 1}};
+    if (lstm) { srcs.push_back({"mlp_toa2.weight", p->mlp_toa2_w, nh2, 2}); srcs.push_back({"mlp_toa2.bias", p->mlp_toa2_b, nh2, 1}); }
+    srcs.insert(srcs.end(), {{"mlp_initial.weight", p->mlp_initial_w, nh1, nxp}, {"mlp_initial.bias", p->mlp_initial_b, nh1, 1},
+                             {"mlp_surface1.weight", p->mlp_surface1_w, nh1, nxs}, {"mlp_surface1.bias", p->mlp_surface1_b, nh1, 1}});
+    if (lstm) { srcs.push_back({"mlp_surface2.weight", p->mlp_surface2_w, nh1, nxs}); srcs.push_back({"mlp_surface2.bias", p->mlp_surface2_b, nh1, 1}); }
+    srcs.insert(srcs.end(), {
+        {"rnn1.weight_ih_l0", p->rnn1_w_ih, G * nh1, nin1}, {"rnn1.weight_hh_l0", p->rnn1_w_hh, G * nh1, nh1},
+        {"rnn1.bias_ih_l0", p->rnn1_b_ih, G * nh1, 1}, {"rnn1.bias_hh_l0", p->rnn1_b_hh, G * nh1, 1},
+        {"rnn2.weight_ih_l0", p->rnn2_w_ih, G * nh2, nh1}, {"rnn2.weight_hh_l0", p->rnn2_w_hh, G * nh2, nh2},
+        {"rnn2.bias_ih_l0", p->rnn2_b_ih, G * nh2, 1}, {"rnn2.bias_hh_l0", p->rnn2_b_hh, G * nh2, 1},
         {"mlp_latent.weight", p->mlp_latent_w, nm, nh2}, {"mlp_latent.bias", p->mlp_latent_b, nm, 1},
         {"mlp_output.weight", p->mlp_output_w, c.ny, nm}, {"mlp_output.bias", p->mlp_output_b, c.ny, 1},
         {"mlp_surface_output.weight", p->mlp_surface_output_w, c.ny_sfc, nh2},
-        {"mlp_surface_output.bias", p->mlp_surface_output_b, c.ny_sfc, 1},
-    };
+        {"mlp_surface_output.bias", p->mlp_surface_output_b, c.ny_sfc, 1}});
     int off = 0;
     std::vector<float> flat;
     for (const Src &s : srcs) {
@@ -174,14 +179,18 @@ extern "C" int csa_train_create(const csa_config *cfg, const csa_params *p, cons
     // ---- gathers: canonical flat -> kernel layouts -------------------------------------------------
     d.toa1_wt = add_gather(h, transposed_idx(O("mlp_toa1.weight"), nh2, 2), nullptr, rc);
     d.toa1_b = add_gather(h, iota_off(O("mlp_toa1.bias"), nh2), nullptr, rc);
-    d.toa2_wt = add_gather(h, transposed_idx(O("mlp_toa2.weight"), nh2, 2), nullptr, rc);
-    d.toa2_b = add_gather(h, iota_off(O("mlp_toa2.bias"), nh2), nullptr, rc);
+    if (lstm) {
+        d.toa2_wt = add_gather(h, transposed_idx(O("mlp_toa2.weight"), nh2, 2), nullptr, rc);
+        d.toa2_b = add_gather(h, iota_off(O("mlp_toa2.bias"), nh2), nullptr, rc);
+    }
     d.init_wt = add_gather(h, transposed_idx(O("mlp_initial.weight"), nh1, nxp), nullptr, rc);
     d.init_b = add_gather(h, iota_off(O("mlp_initial.bias"), nh1), nullptr, rc);
     d.s1_wt = add_gather(h, transposed_idx(O("mlp_surface1.weight"), nh1, nxs), nullptr, rc);
     d.s1_b = add_gather(h, iota_off(O("mlp_surface1.bias"), nh1), nullptr, rc);
-    d.s2_wt = add_gather(h, transposed_idx(O("mlp_surface2.weight"), nh1, nxs), nullptr, rc);
-    d.s2_b = add_gather(h, iota_off(O("mlp_surface2.bias"), nh1), nullptr, rc);
+    if (lstm) {
+        d.s2_wt = add_gather(h, transposed_idx(O("mlp_surface2.weight"), nh1, nxs), nullptr, rc);
+        d.s2_b = add_gather(h, iota_off(O("mlp_surface2.bias"), nh1), nullptr, rc);
+    }
     std::vector<int> rowmap1, rowmap2;   // permuted row n' -> PyTorch gate row, per LSTM
     auto lstm_pack = [&](int nh, int K, int o_wih, int o_whh, int o_bih, int o_bhh, const float *&wih, const float *&bias,
                          const float *&whhp, float *&whhTp, float *&wihT, std::vector<int> &rowmap) {
@@ -204,10 +213,56 @@ extern "C" int csa_train_create(const csa_config *cfg, const csa_params *p, cons
         for (int k = 0; k < K; ++k) for (int n = 0; n < 4 * nh; ++n) t[(size_t)k * 4 * nh + n] = o_wih + rowmap[n] * K + k;
         wihT = (float *)add_gather(h, t, nullptr, rc);
     };
-    lstm_pack(nh1, nin1, O("rnn1.weight_ih_l0"), O("rnn1.weight_hh_l0"), O("rnn1.bias_ih_l0"), O("rnn1.bias_hh_l0"),
-              d.wih1, d.bias1, d.whh1p, h->whh1Tp, h->wih1T, rowmap1);
-    lstm_pack(nh2, nh1, O("rnn2.weight_ih_l0"), O("rnn2.weight_hh_l0"), O("rnn2.bias_ih_l0"), O("rnn2.bias_hh_l0"),
-              d.wih2, d.bias2, d.whh2p, h->whh2Tp, h->wih2T, rowmap2);
+    // GRU (pack.h: n' = u*4 + [r, z, n, pad]): explicit index maps; -1 = padding (gathers read 0, scatters skip).
+    // The saved-gate buffer after BPTT holds [dr~, dz~, dn~, g_hn] per unit (train_rec.hip): W_ih / b_ih gradients take
+    // columns 0,1,2, W_hh / b_hh gradients take columns 0,1 and 3 (as gate row n).
+    struct GruMaps { std::vector<int> wih, whh, ba, bb; } gm1, gm2;
+    auto gru_pack = [&](int nh, int K, int o_wih, int o_whh, int o_bih, int o_bhh, const float *&wih, const float *&bias,
+                        const float *&bhn, const float *&whhp, float *&whhTp, float *&wihT, GruMaps &gm) {
+        std::vector<int> iw((size_t)4 * nh * K, -1), b1(4 * nh, -1), b2(4 * nh, -1), ibhn(nh), t((size_t)K * 4 * nh, -1);
+        gm.wih.assign((size_t)4 * nh * K, -1); gm.whh.assign((size_t)4 * nh * nh, -1); gm.ba.assign(4 * nh, -1); gm.bb.assign(4 * nh, -1);
+        for (int u = 0; u < nh; ++u) {
+            for (int g = 0; g < 3; ++g) {
+                const int src = g * nh + u, dst = u * 4 + g;
+                for (int k = 0; k < K; ++k) {
+                    iw[(size_t)dst * K + k] = o_wih + src * K + k;
+                    t[(size_t)k * 4 * nh + dst] = o_wih + src * K + k;
+                    gm.wih[(size_t)dst * K + k] = o_wih + src * K + k;
+                }
+                b1[dst] = o_bih + src;
+                gm.ba[dst] = o_bih + src;
+                if (g < 2) {
+                    b2[dst] = o_bhh + src;
+                    gm.bb[dst] = o_bhh + src;
+                    for (int k = 0; k < nh; ++k) gm.whh[(size_t)dst * nh + k] = o_whh + src * nh + k;
+                }
+            }
+            ibhn[u] = o_bhh + 2 * nh + u;
+            gm.bb[u * 4 + 3] = o_bhh + 2 * nh + u;
+            for (int k = 0; k < nh; ++k) gm.whh[(size_t)(u * 4 + 3) * nh + k] = o_whh + (2 * nh + u) * nh + k;
+        }
+        wih = add_gather(h, iw, nullptr, rc);
+        bias = add_gather(h, b1, &b2, rc);
+        bhn = add_gather(h, ibhn, nullptr, rc);
+        std::vector<float> ih = index_values((size_t)3 * nh * nh), pk(rec_packed_floats(0, nh));
+        rec_pack_weights(0, nh, ih.data(), pk.data());
+        whhp = add_gather(h, to_int(pk, o_whh), nullptr, rc);
+        std::vector<float> pkT(bwd_rec_packed_floats_gru(nh));
+        bwd_rec_pack_weights_gru(nh, ih.data(), pkT.data());
+        whhTp = (float *)add_gather(h, to_int(pkT, o_whh), nullptr, rc);
+        wihT = (float *)add_gather(h, t, nullptr, rc);
+    };
+    if (lstm) {
+        lstm_pack(nh1, nin1, O("rnn1.weight_ih_l0"), O("rnn1.weight_hh_l0"), O("rnn1.bias_ih_l0"), O("rnn1.bias_hh_l0"),
+                  d.wih1, d.bias1, d.whh1p, h->whh1Tp, h->wih1T, rowmap1);
+        lstm_pack(nh2, nh1, O("rnn2.weight_ih_l0"), O("rnn2.weight_hh_l0"), O("rnn2.bias_ih_l0"), O("rnn2.bias_hh_l0"),
+                  d.wih2, d.bias2, d.whh2p, h->whh2Tp, h->wih2T, rowmap2);
+    } else {
+        gru_pack(nh1, nin1, O("rnn1.weight_ih_l0"), O("rnn1.weight_hh_l0"), O("rnn1.bias_ih_l0"), O("rnn1.bias_hh_l0"),
+                 d.wih1, d.bias1, d.bhn1, d.whh1p, h->whh1Tp, h->wih1T, gm1);
+        gru_pack(nh2, nh1, O("rnn2.weight_ih_l0"), O("rnn2.weight_hh_l0"), O("rnn2.bias_ih_l0"), O("rnn2.bias_hh_l0"),
+                 d.wih2, d.bias2, d.bhn2, d.whh2p, h->whh2Tp, h->wih2T, gm2);
+    }
     d.lat_wt = add_gather(h, transposed_idx(O("mlp_latent.weight"), nm, nh2), nullptr, rc);
     d.lat_b = add_gather(h, iota_off(O("mlp_latent.bias"), nm), nullptr, rc);
     d.out_w = add_gather(h, iota_off(O("mlp_output.weight"), c.ny * nm), nullptr, rc);
@@ -222,14 +277,21 @@ extern "C" int csa_train_create(const csa_config *cfg, const csa_params *p, cons
         return v;
     };
     auto bmap = [&](const std::vector<int> &rowmap, int o) { std::vector<int> v(rowmap.size()); for (size_t n = 0; n < rowmap.size(); ++n) v[n] = o + rowmap[n]; return v; };
-    h->map_wih1 = upload_idx(h, wmap(rowmap1, nin1, O("rnn1.weight_ih_l0")), rc);
-    h->map_whh1 = upload_idx(h, wmap(rowmap1, nh1, O("rnn1.weight_hh_l0")), rc);
-    h->map_b1a = upload_idx(h, bmap(rowmap1, O("rnn1.bias_ih_l0")), rc);
-    h->map_b1b = upload_idx(h, bmap(rowmap1, O("rnn1.bias_hh_l0")), rc);
-    h->map_wih2 = upload_idx(h, wmap(rowmap2, nh1, O("rnn2.weight_ih_l0")), rc);
-    h->map_whh2 = upload_idx(h, wmap(rowmap2, nh2, O("rnn2.weight_hh_l0")), rc);
-    h->map_b2a = upload_idx(h, bmap(rowmap2, O("rnn2.bias_ih_l0")), rc);
-    h->map_b2b = upload_idx(h, bmap(rowmap2, O("rnn2.bias_hh_l0")), rc);
+    if (lstm) {
+        h->map_wih1 = upload_idx(h, wmap(rowmap1, nin1, O("rnn1.weight_ih_l0")), rc);
+        h->map_whh1 = upload_idx(h, wmap(rowmap1, nh1, O("rnn1.weight_hh_l0")), rc);
+        h->map_b1a = upload_idx(h, bmap(rowmap1, O("rnn1.bias_ih_l0")), rc);
+        h->map_b1b = upload_idx(h, bmap(rowmap1, O("rnn1.bias_hh_l0")), rc);
+        h->map_wih2 = upload_idx(h, wmap(rowmap2, nh1, O("rnn2.weight_ih_l0")), rc);
+        h->map_whh2 = upload_idx(h, wmap(rowmap2, nh2, O("rnn2.weight_hh_l0")), rc);
+        h->map_b2a = upload_idx(h, bmap(rowmap2, O("rnn2.bias_ih_l0")), rc);
+        h->map_b2b = upload_idx(h, bmap(rowmap2, O("rnn2.bias_hh_l0")), rc);
+    } else {
+        h->map_wih1 = upload_idx(h, gm1.wih, rc); h->map_whh1 = upload_idx(h, gm1.whh, rc);
+        h->map_b1a = upload_idx(h, gm1.ba, rc); h->map_b1b = upload_idx(h, gm1.bb, rc);
+        h->map_wih2 = upload_idx(h, gm2.wih, rc); h->map_whh2 = upload_idx(h, gm2.whh, rc);
+        h->map_b2a = upload_idx(h, gm2.ba, rc); h->map_b2b = upload_idx(h, gm2.bb, rc);
+    }
     {   // head partial layout: [W_out | b_out | W_lat | b_lat | W_sfo | b_sfo]
         std::vector<int> v;
         auto app = [&](const char *n, int cnt) { const int o = O(n); for (int i = 0; i < cnt; ++i) v.push_back(o + i); };
@@ -239,8 +301,9 @@ extern "C" int csa_train_create(const csa_config *cfg, const csa_params *p, cons
         h->map_head = upload_idx(h, v, rc);
     }
     {   // prep partial layout: [W_init | b_init | W_s1 | b_s1 | W_s2 | b_s2 | W_toa1 | b_toa1 | W_toa2 | b_toa2]
+        // (GRU: the cell-state MLPs do not exist; their slots are written as zeros by the kernel and dropped here)
         std::vector<int> v;
-        auto app = [&](const char *n, int cnt) { const int o = O(n); for (int i = 0; i < cnt; ++i) v.push_back(o + i); };
+        auto app = [&](const char *n, int cnt) { const int o = O(n); for (int i = 0; i < cnt; ++i) v.push_back(o < 0 ? -1 : o + i); };
         app("mlp_initial.weight", nh1 * nxp); app("mlp_initial.bias", nh1);
         app("mlp_surface1.weight", nh1 * nxs); app("mlp_surface1.bias", nh1);
         app("mlp_surface2.weight", nh1 * nxs); app("mlp_surface2.bias", nh1);
@@ -265,6 +328,8 @@ extern "C" int csa_train_create(const csa_config *cfg, const csa_params *p, cons
     h->dH2 = dalloc<float>(h, LB * nh2, rc); h->dH1 = dalloc<float>(h, LB * nh1, rc);
     h->dX1 = dalloc<float>(h, LB * nin1, rc);
     h->dhc1 = dalloc<float>(h, 2 * Bm * nhm, rc); h->dhc2 = dalloc<float>(h, 2 * Bm * nhm, rc);
+    if (rc == CSA_OK && (hipMemset(h->dhc1, 0, sizeof(float) * 2 * Bm * nhm) != hipSuccess ||
+                         hipMemset(h->dhc2, 0, sizeof(float) * 2 * Bm * nhm) != hipSuccess)) rc = CSA_ERR_HIP;
     h->nsplit = 64;
     size_t pf = (size_t)h->nsplit * 4 * nhm * (nin1 > nhm ? nin1 : nhm);
     const size_t pcol = Bm * (size_t)std::max(head_bwd_partial_floats(c), prep_bwd_partial_floats(c));
@@ -319,11 +384,20 @@ extern "C" int csa_train_forward(csa_trainer *h, int slot, int B, const float *x
     int rc;
     if ((rc = launch_prep_train(h->dm, B, 1, x_main_n, x_sfc_n, mem_in, S.X1, S.hc0, S.X16, S.xs, s))) return rc;
     if ((rc = launch_proj_gemm(S.X1, h->dm.wih1, h->dm.bias1, S.GP1, L * B, 4 * nh1, nh1 + nm, s))) return rc;
-    if ((rc = launch_rec_train(nh1, h->dm.whh1p, S.GP1, S.hc0, S.hc0 + (size_t)B * nhm, S.H1lev, B, L, 1, S.H1seq, S.C1, s))) return rc;
+    if (c.use_lstm) {
+        if ((rc = launch_rec_train(nh1, h->dm.whh1p, S.GP1, S.hc0, S.hc0 + (size_t)B * nhm, S.H1lev, B, L, 1, S.H1seq, S.C1, s))) return rc;
+    } else {
+        if ((rc = launch_rec_train_gru(nh1, h->dm.whh1p, h->dm.bhn1, S.GP1, S.hc0, S.H1lev, B, L, 1, S.H1seq, s))) return rc;
+    }
     if ((rc = launch_proj_gemm(S.H1lev, h->dm.wih2, h->dm.bias2, S.GP2, L * B, 4 * nh2, nh1, s))) return rc;
     // rnn2: level order == sequence order, so the hidden sequence itself carries the extra slot 0
-    if ((rc = launch_rec_train(nh2, h->dm.whh2p, S.GP2, S.hc0 + (size_t)2 * B * nhm, S.hc0 + (size_t)3 * B * nhm,
-                               S.H2 + (size_t)B * nh2, B, L, 0, S.H2, S.C2, s))) return rc;
+    if (c.use_lstm) {
+        if ((rc = launch_rec_train(nh2, h->dm.whh2p, S.GP2, S.hc0 + (size_t)2 * B * nhm, S.hc0 + (size_t)3 * B * nhm,
+                                   S.H2 + (size_t)B * nh2, B, L, 0, S.H2, S.C2, s))) return rc;
+    } else {
+        if ((rc = launch_rec_train_gru(nh2, h->dm.whh2p, h->dm.bhn2, S.GP2, S.hc0 + (size_t)2 * B * nhm, S.H2 + (size_t)B * nh2, B, L, 0,
+                                       S.H2, s))) return rc;
+    }
     if ((rc = launch_head(h->dm, B, HEAD_RAW, S.H2 + (size_t)B * nh2, x_main_n, nullptr, out, out_sfc, S.Z, s))) return rc;
     CSA_HIP_CHECK(hipMemcpyAsync(mem_out, S.Z, sizeof(float) * (size_t)L * B * nm, hipMemcpyDeviceToDevice, s));
     return CSA_OK;
@@ -346,7 +420,11 @@ extern "C" int csa_train_backward(csa_trainer *h, int slot, int B, const float *
     if ((rc = launch_head_bwd(h->dm, B, d_out, d_out_sfc, d_mem_out, S.Z, S.H2 + (size_t)B * nh2, h->dH2, h->part, s))) return rc;
     if ((rc = launch_reduce_partials(h->part, B, head_bwd_partial_floats(c), h->map_head, nullptr, grads, s))) return rc;
     // rnn2 (downward): BPTT, then input / weight gradients from dP2 (stored in place in GP2)
-    if ((rc = launch_bwd_rec(nh2, h->whh2Tp, S.GP2, S.C2, h->dH2, h->dhc2, h->dhc2 + (size_t)B * nhm, B, L, 0, s))) return rc;
+    if (c.use_lstm) {
+        if ((rc = launch_bwd_rec(nh2, h->whh2Tp, S.GP2, S.C2, h->dH2, h->dhc2, h->dhc2 + (size_t)B * nhm, B, L, 0, s))) return rc;
+    } else {
+        if ((rc = launch_bwd_rec_gru(nh2, h->whh2Tp, S.GP2, S.H2, h->dH2, h->dhc2, B, L, 0, s))) return rc;
+    }
     if ((rc = launch_proj_gemm(S.GP2, h->wih2T, nullptr, h->dH1, M, nh1, 4 * nh2, s))) return rc;
     if (!h->defer) {
         if ((rc = launch_gemm_tn_partial(S.GP2, 4 * nh2, S.H1lev, nh1, h->part, M, 4 * nh2, nh1, ns, s))) return rc;
@@ -357,7 +435,11 @@ extern "C" int csa_train_backward(csa_trainer *h, int slot, int B, const float *
     if ((rc = launch_colsum_partial(S.GP2, h->part, M, 4 * nh2, ns, s))) return rc;
     if ((rc = launch_reduce_partials(h->part, ns, 4 * nh2, h->map_b2a, h->map_b2b, grads, s))) return rc;
     // rnn1 (upward): dH1 is in level order, the recurrence runs in sequence order
-    if ((rc = launch_bwd_rec(nh1, h->whh1Tp, S.GP1, S.C1, h->dH1, h->dhc1, h->dhc1 + (size_t)B * nhm, B, L, 1, s))) return rc;
+    if (c.use_lstm) {
+        if ((rc = launch_bwd_rec(nh1, h->whh1Tp, S.GP1, S.C1, h->dH1, h->dhc1, h->dhc1 + (size_t)B * nhm, B, L, 1, s))) return rc;
+    } else {
+        if ((rc = launch_bwd_rec_gru(nh1, h->whh1Tp, S.GP1, S.H1seq, h->dH1, h->dhc1, B, L, 1, s))) return rc;
+    }
     if ((rc = launch_proj_gemm(S.GP1, h->wih1T, nullptr, h->dX1, M, nin1, 4 * nh1, s))) return rc;
     if (!h->defer) {
         if ((rc = launch_gemm_tn_partial(S.GP1, 4 * nh1, S.X1, nin1, h->part, M, 4 * nh1, nin1, ns, s))) return rc;

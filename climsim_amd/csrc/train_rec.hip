@@ -178,6 +178,137 @@ __global__ __launch_bounds__(NH * 4, (NH / 16 + 3) / 4) void lstm_bwd_rec_kernel
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// GRU backward (autograd through nn.GRU: r,z,n gates, n = tanh(x_n + r*(W_hn h + b_hn)), h' = (1-z) n + z h).
+// Same mapping: W_hh^T (nh x 3nh) register-stationary, rows r' = u*3 + [r, z, hn] in 16 chunks, two columns per
+// workgroup.  Saved per (t, b, u): [r, z, n, hn] (written by the TRAIN forward over the 4-padded pre-activations).
+//   dh   = dH_ext[t] + dh_rec;   dn = dh (1-z);  dz = dh (h_{t-1} - n);  dh_direct = dh z
+//   dn~  = dn (1-n^2);  g_hn = dn~ r;  dr~ = dn~ hn r(1-r);  dz~ = dz z(1-z)
+//   dh_rec(t-1) = W_hh^T [dr~, dz~, g_hn] + dh_direct
+// [dr~, dz~, dn~, g_hn] overwrites the saved gates in place: columns 0,1,2 are the gradient w.r.t. the input
+// projection (dW_ih, dX, db_ih), columns 0,1,3 the one w.r.t. the recurrent projection (dW_hh, db_hh) -- the
+// weight-gradient GEMMs run on all four columns and the scatter maps drop the unused one.
+template <int NH>
+__global__ __launch_bounds__(NH * 4, 2) void gru_bwd_rec_kernel(
+    const f32x4 *__restrict__ WTp4, float *__restrict__ GP, const float *__restrict__ Hseq,
+    const float *__restrict__ dH, float *__restrict__ dh0, int B, int L, int rev)
+{
+    constexpr int NT = NH * 4;
+    constexpr int RC = 3 * NH / 16;     // rows per chunk
+    constexpr int CH = 2 * RC + 4;
+    constexpr int CPY = 16 * CH;
+    static_assert(RC % 4 == 0 && RC % 3 == 0, "nh must be a multiple of 64");
+    __shared__ __attribute__((aligned(16))) float dpbuf[2][2 * CPY];
+
+    const int tid = threadIdx.x, og = tid >> 4, rc = tid & 15, q4 = rc & 3, rcq = rc >> 2;
+    const int col = q4 & 1, grp = q4 >> 1;
+    int b = 2 * blockIdx.x + col;
+    const bool valid = b < B;
+    if (!valid) b = B - 1;
+    const bool cell = rcq < 2;
+    const int u = 4 * og + 2 * grp + (rcq & 1);
+
+    f32x2 w[4][RC / 2];
+#pragma unroll
+    for (int i = 0; i < RC; ++i) {
+        const f32x4 v = WTp4[(size_t)i * NT + tid];
+        const int s = (4 * i) / RC, kk = (4 * i) % RC;
+        w[s][kk / 2] = f32x2{v.x, v.y};
+        w[s][kk / 2 + 1] = f32x2{v.z, v.w};
+    }
+    const int r0 = u * 3;
+    const int cslot = (r0 / RC) * CH + (r0 % RC) * 2;
+    const int rdoff = col * CPY + rc * CH;
+    float dh_rec = 0.0f, dh_dir = 0.0f;
+    const size_t cidx = (size_t)b * NH + u, cstep = (size_t)B * NH;
+
+    f32x4 g4 = {0, 0, 0, 0}, g4n = {0, 0, 0, 0};
+    float hp = 0.f, hpn = 0.f, dhe = 0.f, dhen = 0.f;
+    if (cell) {
+        const int t = L - 1;
+        g4 = *(const f32x4 *)(GP + ((size_t)t * B + b) * (4 * NH) + u * 4);
+        hp = Hseq[(size_t)t * cstep + cidx];
+        dhe = dH[((size_t)(rev ? L - 1 - t : t) * B + b) * NH + u];
+    }
+#define GRU_MATVEC(acc, dpp)                                                                       \
+    _Pragma("unroll") for (int j = 0; j < RC / 2; ++j) {                                           \
+        const f32x4 v = (dpp)[j];                                                                  \
+        const f32x2 va = {v.x, v.y}, vb = {v.z, v.w};                                              \
+        _Pragma("unroll") for (int s = 0; s < 4; ++s) PK_FMA_LO(acc[s], w[s][j], va);              \
+        _Pragma("unroll") for (int s = 0; s < 4; ++s) PK_FMA_HI(acc[s], w[s][j], vb);              \
+    }
+    for (int t = L - 1; t >= 0; --t) {
+        const int cur = t & 1;
+        if (cell) {
+            if (t > 0) {
+                const int tn = t - 1;
+                g4n = *(const f32x4 *)(GP + ((size_t)tn * B + b) * (4 * NH) + u * 4);
+                hpn = Hseq[(size_t)tn * cstep + cidx];
+                dhen = dH[((size_t)(rev ? L - 1 - tn : tn) * B + b) * NH + u];
+            }
+            const float dh = dhe + dh_rec;
+            const float r = g4.x, z = g4.y, n = g4.z, hn = g4.w;
+            const float dn = dh * (1.0f - z), dz = dh * (hp - n);
+            dh_dir = dh * z;
+            f32x4 dp;
+            dp.z = dn * (1.0f - n * n);              // dn~  (input-projection side)
+            dp.w = dp.z * r;                         // g_hn (recurrent side)
+            dp.x = dp.z * hn * r * (1.0f - r);       // dr~
+            dp.y = dz * z * (1.0f - z);              // dz~
+            if (valid) *(f32x4 *)(GP + ((size_t)t * B + b) * (4 * NH) + u * 4) = dp;
+            float *nn = &dpbuf[cur][cslot + col], *sw = &dpbuf[cur][CPY + cslot + (1 - col)];
+            nn[0] = dp.x; nn[2] = dp.y; nn[4] = dp.w;
+            sw[0] = dp.x; sw[2] = dp.y; sw[4] = dp.w;
+        }
+        LDS_BARRIER();
+        f32x2 acc[4] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
+        const f32x4 *dpp = (const f32x4 *)&dpbuf[cur][rdoff];
+        GRU_MATVEC(acc, dpp)
+        float rr[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) rr[s] = acc[s].x + dpp_mov<0xB1>(acc[s].y);
+        float v0 = rr[0] + dpp_mov<0x4E>(rr[2]);
+        float v1 = rr[1] + dpp_mov<0x4E>(rr[3]);
+        v0 += dpp_mov<0x124>(v0); v1 += dpp_mov<0x124>(v1);
+        v0 += dpp_mov<0x128>(v0); v1 += dpp_mov<0x128>(v1);
+        dh_rec = ((rcq & 1) ? v1 : v0) + dh_dir;
+        g4 = g4n; hp = hpn; dhe = dhen;
+    }
+#undef GRU_MATVEC
+    if (cell && valid) dh0[cidx] = dh_rec;       // gradient w.r.t. the initial hidden state
+}
+
+size_t bwd_rec_packed_floats_gru(int nh) { return (size_t)3 * nh * nh; }
+void bwd_rec_pack_weights_gru(int nh, const float *w_hh, float *packed)
+{
+    const int NT = nh * 4, RC = 3 * nh / 16;
+    for (int tid = 0; tid < NT; ++tid) {
+        const int og = tid >> 4, rc = tid & 15, grp = (rc & 3) >> 1;
+        for (int idx = 0; idx < 4 * RC; ++idx) {
+            const int s = idx / RC, rr = idx % RC;
+            const int k = 4 * og + (s + 2 * grp) % 4;
+            const int rp = rc * RC + rr;                    // r' = u*3 + pos, pos over [r, z, hn]
+            const int uu = rp / 3, pos = rp % 3;
+            const int i = idx / 4, e = idx % 4;
+            packed[((size_t)i * NT + tid) * 4 + e] = w_hh[(size_t)(pos * nh + uu) * nh + k];
+        }
+    }
+}
+int launch_bwd_rec_gru(int nh, const float *wt_packed, float *GP, const float *Hseq, const float *dH, float *dh0, int B, int L,
+                       int rev, hipStream_t s)
+{
+    const dim3 grid((B + 1) / 2), block(nh * 4);
+    switch (nh) {
+    case 64:  hipLaunchKernelGGL((gru_bwd_rec_kernel<64>), grid, block, 0, s, (const f32x4 *)wt_packed, GP, Hseq, dH, dh0, B, L, rev); break;
+    case 128: hipLaunchKernelGGL((gru_bwd_rec_kernel<128>), grid, block, 0, s, (const f32x4 *)wt_packed, GP, Hseq, dH, dh0, B, L, rev); break;
+    default:
+        csa_set_error_msg("bwd_rec(GRU): hidden size not supported (64, 128)");
+        return CSA_ERR_UNSUPPORTED;
+    }
+    CSA_HIP_CHECK(hipGetLastError());
+    return CSA_OK;
+}
+
 // slot s of a lane with group grp accumulates output j = (s + 2*grp) % 4 of its quad of outputs
 // row order inside a chunk: r' = u*4 + pos, pos over [i, g~, f, o]  ->  PyTorch gate row
 static const int kPosGate[4] = {0, 2, 1, 3};

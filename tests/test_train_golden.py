@@ -35,10 +35,10 @@ def _window_inputs(ref, io):
     return B, Tw, xr, xs, xn, xsn, tgt, tgt_sfc, yto, yto_sfc
 
 
-@pytest.mark.parametrize("tag", ["cur_lstm128", "cur_lstm144"])
+@pytest.mark.parametrize("tag", ["cur_lstm128", "cur_lstm144", "cur_gru128"])
 def test_autograd_oracle_vs_reference_gradients(tag):
     consts, weights, flags, io, grid = _golden(tag)
-    ref = torch_ref.EmulatorRef(consts, weights, legacy=False, use_lstm=True, output_prune=bool(flags["output_prune"]),
+    ref = torch_ref.EmulatorRef(consts, weights, legacy=False, use_lstm=bool(flags["use_lstm"]), output_prune=bool(flags["output_prune"]),
                                 scrub_inf=True)
     B, Tw, xr, xs, xn, xsn, tgt, tgt_sfc, yto, yto_sfc = _window_inputs(ref, io)
     mem0 = torch.from_numpy(io["grad.mem0"]).requires_grad_(True)
@@ -61,15 +61,15 @@ def test_autograd_oracle_vs_reference_gradients(tag):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("tag", ["cur_lstm128", "cur_lstm144"])
+@pytest.mark.parametrize("tag", ["cur_lstm128", "cur_lstm144", "cur_gru128"])
 def test_hip_training_step_vs_reference_gradients(tag):
     from climsim_amd.train import Trainer
     consts, weights, flags, io, grid = _golden(tag)
-    ref = torch_ref.EmulatorRef(consts, weights, legacy=False, use_lstm=True, output_prune=bool(flags["output_prune"]),
-                                scrub_inf=True)
+    ref = torch_ref.EmulatorRef(consts, weights, legacy=False, use_lstm=bool(flags["use_lstm"]),
+                                output_prune=bool(flags["output_prune"]), scrub_inf=True)
     B, Tw, xr, xs, xn, xsn, tgt, tgt_sfc, yto, yto_sfc = _window_inputs(ref, io)
-    tr = Trainer(consts, weights, grid["hyai"], grid["hybi"], output_prune=bool(flags["output_prune"]), max_batch=8,
-                 max_window=3)
+    tr = Trainer(consts, weights, grid["hyai"], grid["hybi"], use_lstm=bool(flags["use_lstm"]),
+                 output_prune=bool(flags["output_prune"]), max_batch=8, max_window=3)
     d = lambda t: t.contiguous().cuda()
     sc, mem, d_mem0 = tr.window_step([d(a) for a in xn], [d(a) for a in xsn], [d(a) for a in xr],
                                      [d(tgt[t * B:(t + 1) * B]) for t in range(Tw)],
