@@ -31,7 +31,7 @@ SYMBOLS = ["csa_create", "csa_destroy", "csa_set_params", "csa_packed_width", "c
            "csa_tap_rnn2", "csa_last_error", "csa_version", "csa_set_profiling", "csa_reset_profile",
            "csa_get_profile", "csa_stage_name", "csa_set_fused", "csa_set_overlap", "csa_set_halves",
            "csa_train_create", "csa_train_destroy", "csa_train_num_params", "csa_train_num_tensors",
-           "csa_train_param_info", "csa_train_params", "csa_train_sync_params", "csa_train_forward",
+           "csa_train_param_info", "csa_train_params", "csa_train_sync_params", "csa_train_copy_state", "csa_train_forward",
            "csa_train_backward", "csa_train_set_deferred", "csa_train_flush_wgrad", "csa_train_loss", "csa_train_adam",
            "csa_mlp_create", "csa_mlp_destroy", "csa_mlp_forward",
            "csa_cnn_create", "csa_cnn_destroy", "csa_cnn_forward", "csa_cnn_reshape_to", "csa_cnn_reshape_from",
@@ -115,6 +115,7 @@ def lib():
     L.csa_train_sync_params.argtypes = [H, ctypes.c_void_p]
     L.csa_train_forward.argtypes = [H, i, i, _F, _F, _F, _F, _F, _F, ctypes.c_void_p]
     L.csa_train_backward.argtypes = [H, i, i, _F, _F, _F, _F, _F, ctypes.c_void_p]
+    L.csa_train_copy_state.argtypes = [H, i, i, _F, ctypes.c_void_p]
     L.csa_train_set_deferred.argtypes = [H, i]
     L.csa_train_flush_wgrad.argtypes = [H, _F, ctypes.c_void_p]
     L.csa_train_loss.argtypes = [H, i, i, f, f] + [_F] * 11 + [ctypes.c_void_p]

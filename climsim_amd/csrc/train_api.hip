@@ -368,6 +368,17 @@ extern "C" int csa_train_param_info(const csa_trainer *h, int i, const char **na
     return CSA_OK;
 }
 extern "C" float *csa_train_params(csa_trainer *h) { return h ? h->params : nullptr; }
+// which = 0 parameters, 1 Adam first moment, 2 Adam second moment; dir = 0 copy out to buf, 1 copy in from buf
+// (device buffers of csa_train_num_params floats).  Copying parameters in re-packs the kernel layouts.
+extern "C" int csa_train_copy_state(csa_trainer *h, int which, int dir, float *buf, void *stream)
+{
+    if (!h || !buf || which < 0 || which > 2 || dir < 0 || dir > 1) { csa_set_error_msg("csa_train_copy_state: bad argument"); return CSA_ERR_ARG; }
+    float *st = which == 0 ? h->params : (which == 1 ? h->adam_m : h->adam_v);
+    hipStream_t s = (hipStream_t)stream;
+    CSA_HIP_CHECK(hipMemcpyAsync(dir ? st : buf, dir ? buf : st, sizeof(float) * h->nparam, hipMemcpyDeviceToDevice, s));
+    if (dir == 1 && which == 0) return repack(h, s);
+    return CSA_OK;
+}
 extern "C" int csa_train_sync_params(csa_trainer *h, void *stream) { return h ? repack(h, (hipStream_t)stream) : CSA_ERR_ARG; }
 
 extern "C" int csa_train_forward(csa_trainer *h, int slot, int B, const float *x_main_n, const float *x_sfc_n,

@@ -85,22 +85,38 @@ class Trainer:
             pass
 
     # ---- parameter access (state_dict layout) --------------------------------------------------
-    def flat_params(self):
-        """A torch view is not possible over foreign memory without dlpack; copy out instead."""
-        out = torch.empty(self.nparam, device=self.device)
-        hip = ctypes.CDLL("libamdhip64.so")
-        hip.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
-        torch.cuda.synchronize(self.device)
-        rc = hip.hipMemcpy(ctypes.c_void_p(out.data_ptr()), ctypes.c_void_p(_lib.lib().csa_train_params(self._h)),
-                           self.nparam * 4, 3)
-        if rc != 0:
-            raise RuntimeError(f"hipMemcpy failed ({rc})")
+    def _copy_state(self, which, buf=None):
+        out = torch.empty(self.nparam, device=self.device) if buf is None else _check(buf, (self.nparam,), "state")
+        self._rc(_lib.lib().csa_train_copy_state(self._h, which, 0 if buf is None else 1, _ptr(out), self._stream()),
+                 "csa_train_copy_state")
         return out
+
+    def flat_params(self):
+        return self._copy_state(0)
 
     def state_dict(self):
         flat = self.flat_params()
         return {n: flat[o:o + r * c].reshape((r, c) if c > 1 or n.endswith("weight") else (r,)).clone()
                 for n, (o, r, c) in self.layout.items()}
+
+    def load_state_dict(self, sd):
+        """Parameters from a state_dict with the reference's key names (resume / warm start, :761-794)."""
+        flat = self.flat_params()
+        for n, (o, r, c) in self.layout.items():
+            flat[o:o + r * c] = torch.as_tensor(sd[n], dtype=torch.float32).to(self.device).reshape(-1)
+        self._copy_state(0, flat)
+
+    def checkpoint(self):
+        """Everything a resume needs (cf. the torch.save dict of :1003-1009): parameters by name, Adam moments, step."""
+        return {"model_state_dict": {k: v.cpu() for k, v in self.state_dict().items()},
+                "adam_m": self._copy_state(1).cpu(), "adam_v": self._copy_state(2).cpu(), "step": self.step_count}
+
+    def load_checkpoint(self, ck, only_load_model=False):
+        self.load_state_dict(ck["model_state_dict"])
+        if not only_load_model:
+            self._copy_state(1, ck["adam_m"].to(self.device))
+            self._copy_state(2, ck["adam_v"].to(self.device))
+            self.step_count = int(ck["step"])
 
     def grad_dict(self):
         return {n: self.grads[o:o + r * c].reshape((r, c) if c > 1 or n.endswith("weight") else (r,))

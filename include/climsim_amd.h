@@ -163,6 +163,9 @@ int csa_train_num_tensors(const csa_trainer *h);
 int csa_train_param_info(const csa_trainer *h, int i, const char **name, int *offset, int *rows, int *cols);
 float *csa_train_params(csa_trainer *h);                     /* device pointer, canonical flat parameters */
 int csa_train_sync_params(csa_trainer *h, void *stream);     /* re-pack after writing csa_train_params() */
+/* checkpoint / resume (rnn/train_rnn_rollout_torchscript_hydra.py:761-794,1003-1009): which = 0 parameters, 1 / 2 the two
+ * Adam moments; dir = 0 copy out to buf, 1 copy in (device buffers of csa_train_num_params floats, state_dict order) */
+int csa_train_copy_state(csa_trainer *h, int which, int dir, float *buf, void *stream);
 int csa_train_forward(csa_trainer *h, int slot, int B, const float *x_main_n, const float *x_sfc_n,
                       const float *mem_in, float *out, float *out_sfc, float *mem_out, void *stream);
 int csa_train_backward(csa_trainer *h, int slot, int B, const float *d_out, const float *d_out_sfc,

@@ -282,6 +282,26 @@ def test_fused_and_unfused_paths_agree(memory):
     assert max(block_errors(y_f, y_u).values()) <= 1e-5
 
 
+def test_rollout_harness_matches_golden_and_shards(memory):
+    """climsim_amd.rollout: the reference's evaluation loop; sharded blocks reproduce the unsharded rows exactly."""
+    from climsim_amd.rollout import rollout, sharded_rollout
+    consts, weights, model = memory
+    io = np.load(os.path.join(GOLDEN, "v4_memory_io.npz"))
+    B, nt = 8, int(io["B8.nsteps"])
+    get = lambda t, k: io[f"B8.t{t}.{k}"]
+    if "B8.t0.x_main" in io.files:
+        xl = np.stack([get(t, "x_main") for t in range(nt)]); xs = np.stack([get(t, "x_sfc") for t in range(nt)])
+    else:
+        pairs = [synth_inputs(consts, B, int(get(t, "seed"))) for t in range(nt)]
+        xl = np.stack([p[0] for p in pairs]); xs = np.stack([p[1] for p in pairs])
+    noise = [(_dev(get(t, "hx2")), _dev(get(t, "cx2"))) for t in range(nt)]
+    outs, mem = rollout(model, _dev(xl), _dev(xs), noise=noise)
+    for t in range(nt):
+        assert rel_err(outs[t].cpu().numpy()[:, :360], get(t, "yout")[:, :360]) <= 1e-5
+    (o1, m1), (lo, hi) = sharded_rollout(model, _dev(xl), _dev(xs), 2, 1, noise=[(a[4:], b[4:]) for a, b in noise])
+    assert (lo, hi) == (4, 8) and torch.equal(o1, outs[:, 4:8]) and torch.equal(m1, mem[4:8])
+
+
 @pytest.mark.parametrize("B", [64, 129, 384])
 def test_column_halves_path_is_bit_identical(memory, B):
     """csa_set_halves: two column halves on two streams, one fork and one join event."""
