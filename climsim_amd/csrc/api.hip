@@ -39,6 +39,7 @@ struct csa_emulator {
     hipStream_t side = nullptr;
     hipEvent_t ov_ev[12] = {};
     float *P2 = nullptr, *cstate = nullptr;
+    int rec1_max_batch = 256;    // largest batch that uses the one-column-per-workgroup recurrent kernel (csa_set_rec1_max_batch)
     int halves = 2;              // two column halves on two streams (run_forward_halves): 0 off, 1 on, 2 auto (B >= 640)
     bool fused = false;          // dual-pipe fused LSTM kernel (csa_set_fused); off by default: measured slower
                                  // than GEMM + recurrent kernel because W_ih is re-streamed from L2 per 8-level chunk
@@ -158,6 +159,15 @@ int upload_params(csa_emulator *h, const csa_params *p, bool first)
     packed.resize(rec_packed_floats(c.use_lstm, c.nh2));
     rec_pack_weights(c.use_lstm, c.nh2, b_hh, packed.data());
     d.whh2p = U.up(packed);
+    d.whh1q = d.whh2q = nullptr;
+    if (c.use_lstm && c.nh1 <= 128 && c.nh2 <= 128) {     // one-column-per-workgroup latency kernel (small batches)
+        packed.resize((size_t)4 * c.nh1 * c.nh1);
+        rec1_pack_weights(c.nh1, a_hh, packed.data());
+        d.whh1q = U.up(packed);
+        packed.resize((size_t)4 * c.nh2 * c.nh2);
+        rec1_pack_weights(c.nh2, b_hh, packed.data());
+        d.whh2q = U.up(packed);
+    }
     if (c.nh_mem > 0) {
         d.lat_wt = U.up(transposed(p->mlp_latent_w, c.nh_mem, c.nh2));
         d.lat_b = U.up(p->mlp_latent_b, c.nh_mem);
@@ -406,6 +416,30 @@ extern "C" int csa_set_overlap(csa_emulator *h, int enable)
     return h->overlap ? 1 : 0;
 }
 
+// Recurrent layer `layer` (1 or 2): up to 256 columns every column gets its own workgroup / CU (lstm_rec1_kernel, ~1.6x
+// shorter steps); above that two columns share a workgroup (lstm_rec2_kernel), which is what saturates the chip.
+static int launch_rec_auto(const csa_emulator *h, int layer, const float *P, const float *h0, const float *c0, float *Hout,
+                           int B, int L, int reverse_out, hipStream_t s, int Bclass = 0)
+{
+    // Bclass: the batch the kernel class is chosen for (a column half inherits the class of the whole call, so that
+    // the halves path stays bit-identical to the single-stream path)
+    if (Bclass <= 0) Bclass = B;
+    const DevModel &d = h->dm;
+    const int nh = layer == 1 ? d.cfg.nh1 : d.cfg.nh2;
+    const float *wq = layer == 1 ? d.whh1q : d.whh2q;
+    if (d.cfg.use_lstm && wq && Bclass <= h->rec1_max_batch)
+        return launch_rec1(nh, wq, P, h0, c0, Hout, B, L, reverse_out, s);
+    return launch_rec(d.cfg.use_lstm, nh, layer == 1 ? d.whh1p : d.whh2p, layer == 1 ? d.bhn1 : d.bhn2, P, h0, c0, Hout, B, L,
+                      reverse_out, s);
+}
+
+extern "C" int csa_set_rec1_max_batch(csa_emulator *h, int max_batch)
+{
+    if (!h || max_batch < 0) return CSA_ERR_ARG;
+    h->rec1_max_batch = max_batch;
+    return CSA_OK;
+}
+
 // Stochastic variant: LSTM down (noise init) -> LSTM up (surface init) -> stochastic LSTM down (TOA init).
 // prep writes X1 in LEVEL order here (no flip), so the first recurrence runs downward and stores its hidden
 // sequence flipped (= the sequence order of the upward pass), the second stores level order again.
@@ -420,9 +454,9 @@ static int run_forward_stoch(csa_emulator *h, int B, int normalised, int mode, c
     int rc;
     if ((rc = launch_prep(h->dm, B, normalised, x_main, x_sfc, mem_in, nullptr, nullptr, h->X1, h->hc0, s))) return rc;
     if ((rc = launch_proj_gemm(h->X1, h->dm.wih1, h->dm.bias1, h->P, L * B, 4 * nh, nh + c.nh_mem, s))) return rc;
-    if ((rc = launch_rec(1, nh, h->dm.whh1p, nullptr, h->P, hx0, cx0, h->H1, B, L, /*reverse_out=*/1, s))) return rc;
+    if ((rc = launch_rec_auto(h, 1, h->P, hx0, cx0, h->H1, B, L, /*reverse_out=*/1, s))) return rc;
     if ((rc = launch_proj_gemm(h->H1, h->dm.wih2, h->dm.bias2, h->P, L * B, 4 * nh, nh, s))) return rc;
-    if ((rc = launch_rec(1, nh, h->dm.whh2p, nullptr, h->P, h->hc0, h->hc0 + (size_t)B * nh, h->H2, B, L, /*reverse_out=*/1, s))) return rc;
+    if ((rc = launch_rec_auto(h, 2, h->P, h->hc0, h->hc0 + (size_t)B * nh, h->H2, B, L, /*reverse_out=*/1, s))) return rc;
     if ((rc = csa_stoch_lstm4_forward(h->stoch, L, B, h->H2, h->hc0 + (size_t)2 * B * nh, h->hc0 + (size_t)3 * B * nh, eps,
                                       h->H1, nullptr, nullptr, s))) return rc;
     return launch_head(h->dm, B, mode, h->H1, x_main, x_sfc, y0, y1, y2, s);
@@ -434,7 +468,7 @@ static int run_forward_stoch(csa_emulator *h, int B, int normalised, int mode, c
 // projection GEMM (MFMA pipe) can run on the same and on the idle CUs.  Scratch buffers are simply split in two.
 static int run_chain(csa_emulator *h, int B, int normalised, int mode, const float *x_main, const float *x_sfc,
                      const float *mem_in, const float *hx2, const float *cx2, float *y0, float *y1, float *y2,
-                     float *X1, float *P, float *H1, float *H2, float *hc0, int mem_B, int mem_off, hipStream_t s)
+                     float *X1, float *P, float *H1, float *H2, float *hc0, int mem_B, int mem_off, hipStream_t s, int Bclass)
 {
     const csa_config &c = h->dm.cfg;
     DevModel dm = h->dm;
@@ -446,9 +480,9 @@ static int run_chain(csa_emulator *h, int B, int normalised, int mode, const flo
     const float *h2 = c.legacy ? hx2 : hc0 + (size_t)2 * B * nhm;
     const float *c2 = c.legacy ? cx2 : hc0 + (size_t)3 * B * nhm;
     if ((rc = launch_proj_gemm(X1, h->dm.wih1, h->dm.bias1, P, L * B, 4 * c.nh1, c.nh1 + c.nh_mem, s))) return rc;
-    if ((rc = launch_rec(c.use_lstm, c.nh1, h->dm.whh1p, h->dm.bhn1, P, hc0, hc0 + (size_t)B * nhm, H1, B, L, 1, s))) return rc;
+    if ((rc = launch_rec_auto(h, 1, P, hc0, hc0 + (size_t)B * nhm, H1, B, L, 1, s, Bclass))) return rc;
     if ((rc = launch_proj_gemm(H1, h->dm.wih2, h->dm.bias2, P, L * B, 4 * c.nh2, c.nh1, s))) return rc;
-    if ((rc = launch_rec(c.use_lstm, c.nh2, h->dm.whh2p, h->dm.bhn2, P, h2, c2, H2, B, L, 0, s))) return rc;
+    if ((rc = launch_rec_auto(h, 2, P, h2, c2, H2, B, L, 0, s, Bclass))) return rc;
     return launch_head(dm, B, mode, H2, x_main, x_sfc, y0, y1, y2, s);
 }
 
@@ -468,7 +502,7 @@ static int run_forward_halves(csa_emulator *h, int B, int normalised, int mode, 
     // level-major memory tensors (current generation) are addressed through (mem_B, mem_off); batch-first ones by pointer
     const bool lm = !c.legacy && c.nh_mem > 0;
     if ((rc = run_chain(h, B0, normalised, mode, x_main, x_sfc, mem_in, hx2, cx2, y0, y1, y2, h->X1, h->P, h->H1, h->H2, h->hc0,
-                        lm ? B : 0, 0, s))) return rc;
+                        lm ? B : 0, 0, s, B))) return rc;
     // second half: batch-first offsets of every caller tensor, the upper part of every scratch buffer
     const size_t o = B0;
     float *y0b = y0 + (mode == HEAD_PACKED ? o * W : o * L * (mode == HEAD_RAW || c.mp_mode == 0 ? c.ny : 6));
@@ -476,7 +510,7 @@ static int run_forward_halves(csa_emulator *h, int B, int normalised, int mode, 
                    mem_in ? (lm ? mem_in : mem_in + o * L * c.nh_mem) : nullptr,
                    hx2 ? hx2 + o * c.nh2 : nullptr, cx2 ? cx2 + o * c.nh2 : nullptr, y0b, y1 ? y1 + o * c.ny_sfc : nullptr,
                    y2 ? (lm ? y2 : y2 + o * L * c.nh_mem) : nullptr, h->X1 + (size_t)L * o * nin1, h->P + (size_t)L * o * 4 * nhm,
-                   h->H1 + (size_t)L * o * c.nh1, h->H2 + (size_t)L * o * c.nh2, h->hc0 + 4 * o * nhm, lm ? B : 0, lm ? B0 : 0, T);
+                   h->H1 + (size_t)L * o * c.nh1, h->H2 + (size_t)L * o * c.nh2, h->hc0 + 4 * o * nhm, lm ? B : 0, lm ? B0 : 0, T, B);
     if (rc) return rc;
     CSA_HIP_CHECK(hipEventRecord(h->ov_ev[1], T));
     CSA_HIP_CHECK(hipStreamWaitEvent(s, h->ov_ev[1], 0));
@@ -509,7 +543,7 @@ static int run_forward(csa_emulator *h, int B, int normalised, int mode,
     // recurrence of the other half), 1.04-1.09x from 768 columns up -> automatic from 640
     if ((h->halves == 1 || (h->halves == 2 && B >= 640)) && !h->profiling && !h->fused && B >= 64)
         return run_forward_halves(h, B, normalised, mode, x_main, x_sfc, mem_in, hx2, cx2, y0, y1, y2, s);
-    if (h->overlap && !h->profiling && !h->fused && c.use_lstm && c.nh1 == 128 && c.nh2 == 128 && L >= 8)
+    if (h->overlap && !h->profiling && !h->fused && c.use_lstm && c.nh1 == 128 && c.nh2 == 128 && L >= 8 && B > h->rec1_max_batch)
         return run_forward_overlap(h, B, normalised, mode, x_main, x_sfc, mem_in, hx2, cx2, y0, y1, y2, s);
     if (h->profiling) prof_collect(h);   // previous profiled call (host sync: profiling mode only)
     PROF_MARK(0);
@@ -532,13 +566,12 @@ static int run_forward(csa_emulator *h, int B, int normalised, int mode,
         // rnn1: upward over the flipped sequence; hidden sequence stored back in level order
         if ((rc = launch_proj_gemm(h->X1, h->dm.wih1, h->dm.bias1, h->P, L * B, 4 * c.nh1, c.nh1 + c.nh_mem, s))) return rc;
         PROF_MARK(2);
-        if ((rc = launch_rec(c.use_lstm, c.nh1, h->dm.whh1p, h->dm.bhn1, h->P, h->hc0, h->hc0 + (size_t)B * nhm,
-                             h->H1, B, L, /*reverse_out=*/1, s))) return rc;
+        if ((rc = launch_rec_auto(h, 1, h->P, h->hc0, h->hc0 + (size_t)B * nhm, h->H1, B, L, /*reverse_out=*/1, s))) return rc;
         PROF_MARK(3);
         // rnn2: downward in level order
         if ((rc = launch_proj_gemm(h->H1, h->dm.wih2, h->dm.bias2, h->P, L * B, 4 * c.nh2, c.nh1, s))) return rc;
         PROF_MARK(4);
-        if ((rc = launch_rec(c.use_lstm, c.nh2, h->dm.whh2p, h->dm.bhn2, h->P, h2, c2, h->H2, B, L, /*reverse_out=*/0, s))) return rc;
+        if ((rc = launch_rec_auto(h, 2, h->P, h2, c2, h->H2, B, L, /*reverse_out=*/0, s))) return rc;
     }
     PROF_MARK(5);
     rc = launch_head(h->dm, B, mode, h->H2, x_main, x_sfc, y0, y1, y2, s);

@@ -32,6 +32,7 @@ struct DevModel {
     const float *bhn1, *bhn2;           // GRU only: b_hn (nh)
     // recurrent weights packed for the register-stationary kernel (see rec.hip)
     const float *whh1p, *whh2p;
+    const float *whh1q, *whh2q;         // the same matrices packed for the one-column kernel (lstm_rec1_kernel), LSTM only
     // W_ih in MFMA-operand order for the dual-pipe fused LSTM kernel (fused.hip); null if not built
     const float *wih1f, *wih2f;
     // heads
@@ -94,6 +95,10 @@ int launch_rec(int use_lstm, int nh, const float *whh_packed, const float *bhn, 
                const float *h0, const float *c0, float *Hout, int B, int L, int reverse_out,
                hipStream_t s);
 // training forward: as launch_rec (LSTM) + saves gates in place over P, c_t to Cseq and h_t to Hseq
+// one-column-per-workgroup LSTM kernel (small batches) and its weight packing
+void rec1_pack_weights(int nh, const float *w_hh, float *packed);
+int launch_rec1(int nh, const float *whh_packed1, const float *P, const float *h0, const float *c0, float *Hout, int B, int L,
+                int reverse_out, hipStream_t s);
 int launch_rec_train(int nh, const float *whh_packed, float *P, const float *h0, const float *c0, float *Hout,
                      int B, int L, int reverse_out, float *Hseq, float *Cseq, hipStream_t s);
 int launch_rec_train_gru(int nh, const float *whh_packed, const float *bhn, float *P, const float *h0, float *Hout, int B, int L,

@@ -401,6 +401,127 @@ __global__ __launch_bounds__(NH * 4, (NH / 16 + 3) / 4) void lstm_rec2_kernel(
 #endif
 }
 
+// ------------------------------------------------------------------------------------------------
+// LSTM kernel, ONE column per workgroup: the latency variant for small batches (B <= 256: every column gets its own
+// CU).  Same register-stationary weights (4 gate rows x nh/4 k-values per lane), but the packed FMA pairs two
+// consecutive k of the SAME column (acc.x + acc.y at the end), so a step costs 64 v_pk_fma_f32 per lane instead of
+// 128, half the LDS reads and four instead of six transcendental pairs.  The sum over the four k-quarters is a
+// reduce-scatter of 3 DPP adds that leaves lane p of a quad with the complete pre-activation of gate p of its unit
+// (slot order per lane sigma_p = [p, p^1, p^2, p^3] over [i, g~, f, o], baked into the host packing); lane p applies
+// that gate's activation, three DPP moves bring i*g~, f and o to every lane, and c_t / h_t are kept redundantly by all
+// four lanes of the quad.  P rows are [i, g~, f, o] per unit: lane p reads one float.
+template <int NH>
+__global__ __launch_bounds__(NH * 4, 2) void lstm_rec1_kernel(
+    const f32x4 *__restrict__ Wp4, const float *__restrict__ P,
+    const float *__restrict__ h0, const float *__restrict__ c0, float *__restrict__ Hout,
+    int B, int L, int reverse_out)
+{
+    constexpr int NT = NH * 4;
+    constexpr int KC = NH / 4;
+    constexpr int CH = KC + 4;          // floats per k-quarter incl. one 16-B pad slot (4 distinct addresses -> 4 bank groups)
+    static_assert(KC % 4 == 0, "nh must be a multiple of 16");
+    __shared__ __attribute__((aligned(16))) float hbuf[2][4 * CH];
+
+    const int tid = threadIdx.x, u = tid >> 2, p = tid & 3;
+    const int b = blockIdx.x;
+
+    f32x2 w[4][KC / 2];
+#pragma unroll
+    for (int i = 0; i < KC; ++i) {
+        const f32x4 v = Wp4[(size_t)i * NT + tid];
+        const int s = (4 * i) / KC, kk = (4 * i) % KC;
+        w[s][kk / 2] = f32x2{v.x, v.y};
+        w[s][kk / 2 + 1] = f32x2{v.z, v.w};
+    }
+    // gate p: sigmoid for i (0), f (2), o (3); tanh for g~ (1) -- both as (1 - nb*t)/(1 + t), t = exp2(k*x)
+    const float kact = p == 1 ? -2.88539008177792681f : -1.44269504088896341f;
+    const float nb = p == 1 ? 1.0f : 0.0f;
+
+    float h = h0[(size_t)b * NH + u];
+    float c = c0[(size_t)b * NH + u];
+    const int hslot = u + 4 * (u / KC);
+    if (p == 0) hbuf[0][hslot] = h;
+    asm volatile("" : "+v"(c), "+v"(h));
+    const float *Pb = P + (size_t)b * (4 * NH) + u * 4 + p;
+    const size_t Pstep = (size_t)B * (4 * NH);
+    float preA = Pb[0], preB = preA;
+    __syncthreads();
+
+#define LSTM1_STEP(T, CUR, NXT)                                                                    \
+    {                                                                                              \
+        const int t_ = (T);                                                                        \
+        if (t_ + 1 < L) {                                                                          \
+            const float *pn = Pb + (size_t)(t_ + 1) * Pstep;                                       \
+            asm volatile("global_load_dword %0, %1, off" : "=&v"(NXT) : "v"(pn) : "memory");       \
+        }                                                                                          \
+        const f32x4 *hp = (const f32x4 *)&hbuf[t_ & 1][p * CH];                                    \
+        f32x2 acc[4] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};                           \
+        _Pragma("unroll") for (int j = 0; j < KC / 4; ++j) {                                       \
+            const f32x4 hv = hp[j];                                                                \
+            const f32x2 ha = {hv.x, hv.y}, hb = {hv.z, hv.w};                                      \
+            _Pragma("unroll") for (int s = 0; s < 4; ++s) acc[s] = __builtin_elementwise_fma(w[s][2 * j], ha, acc[s]);     \
+            _Pragma("unroll") for (int s = 0; s < 4; ++s) acc[s] = __builtin_elementwise_fma(w[s][2 * j + 1], hb, acc[s]); \
+        }                                                                                          \
+        float sm[4];                                                                               \
+        _Pragma("unroll") for (int s = 0; s < 4; ++s) sm[s] = acc[s].x + acc[s].y;                 \
+        const float r0 = sm[0] + dpp_xor1(sm[1]);                                                  \
+        const float r1 = sm[2] + dpp_xor1(sm[3]);                                                  \
+        if (t_ > 0) asm volatile("s_waitcnt vmcnt(1)" : "+v"(CUR));                                \
+        const float v = r0 + dpp_xor2(r1) + CUR;                                                   \
+        const float te = fminf(__builtin_amdgcn_exp2f(kact * v), 1e30f);                           \
+        const float a = (1.0f - nb * te) * __builtin_amdgcn_rcpf(1.0f + te);     /* gate p of unit u */ \
+        const float ig = a * dpp_xor1(a);                                        /* lanes 0,1: i*g~ */ \
+        const float igq = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, ig), 0x00, 0xF, 0xF, true)); \
+        const float fq = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, a), 0xAA, 0xF, 0xF, true));  \
+        const float oq = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, a), 0xFF, 0xF, 0xF, true));  \
+        c = fq * c + igq;                                                                          \
+        const float tc = fminf(__builtin_amdgcn_exp2f(-2.88539008177792681f * c), 1e30f);          \
+        h = oq * ((1.0f - tc) * __builtin_amdgcn_rcpf(1.0f + tc));                                 \
+        if (p == 0) {                                                                              \
+            hbuf[(t_ & 1) ^ 1][hslot] = h;                                                         \
+            Hout[((size_t)(reverse_out ? L - 1 - t_ : t_) * B + b) * NH + u] = h;                  \
+        }                                                                                          \
+        LDS_BARRIER();                                                                             \
+    }
+    for (int t = 0; t < L; t += 2) {
+        LSTM1_STEP(t, preA, preB)
+        if (t + 1 < L) LSTM1_STEP(t + 1, preB, preA)
+    }
+#undef LSTM1_STEP
+}
+
+// lane p, slot s holds gate (p ^ s) of [i, g~, f, o]  ->  PyTorch gate rows (i, f, g, o)
+static void lstm1_pack_weights(int nh, const float *w_hh, float *packed)
+{
+    static const int pos2gate[4] = {0, 2, 1, 3};     // position in [i, g~, f, o] -> PyTorch gate index
+    const int NT = nh * 4, KC = nh / 4;
+    for (int tid = 0; tid < NT; ++tid) {
+        const int u = tid >> 2, p = tid & 3;
+        for (int idx = 0; idx < 4 * KC; ++idx) {
+            const int s = idx / KC, kk = idx % KC, g = pos2gate[p ^ s];
+            const int i = idx / 4, e = idx % 4;
+            packed[((size_t)i * NT + tid) * 4 + e] = w_hh[(size_t)(g * nh + u) * nh + p * KC + kk];
+        }
+    }
+}
+void rec1_pack_weights(int nh, const float *w_hh, float *packed) { lstm1_pack_weights(nh, w_hh, packed); }
+
+int launch_rec1(int nh, const float *whh_packed1, const float *P, const float *h0, const float *c0, float *Hout, int B, int L,
+                int reverse_out, hipStream_t s)
+{
+    const dim3 grid(B), block(nh * 4);
+    switch (nh) {
+    case 64:  hipLaunchKernelGGL((lstm_rec1_kernel<64>), grid, block, 0, s, (const f32x4 *)whh_packed1, P, h0, c0, Hout, B, L, reverse_out); break;
+    case 96:  hipLaunchKernelGGL((lstm_rec1_kernel<96>), grid, block, 0, s, (const f32x4 *)whh_packed1, P, h0, c0, Hout, B, L, reverse_out); break;
+    case 128: hipLaunchKernelGGL((lstm_rec1_kernel<128>), grid, block, 0, s, (const f32x4 *)whh_packed1, P, h0, c0, Hout, B, L, reverse_out); break;
+    default:
+        csa_set_error_msg("rec1: hidden size not supported (64, 96, 128)");
+        return CSA_ERR_UNSUPPORTED;
+    }
+    CSA_HIP_CHECK(hipGetLastError());
+    return CSA_OK;
+}
+
 // slot -> PyTorch gate index (i,f,g,o = 0,1,2,3) for lane groups p<2 and p>=2
 static const int kLstm2Slot[2][4] = {{0, 2, 1, 3}, {1, 3, 0, 2}};
 

@@ -224,6 +224,10 @@ class Emulator:
         True / False force it, None restores the default (automatic from 640 columns)."""
         return _lib.lib().csa_set_halves(self._h, 2 if enable is None else int(bool(enable)))
 
+    def set_rec1_max_batch(self, max_batch):
+        """Largest batch that uses the one-column-per-workgroup recurrent kernel (default 256); 0 disables it."""
+        self._rc(_lib.lib().csa_set_rec1_max_batch(self._h, int(max_batch)), "csa_set_rec1_max_batch")
+
     def set_overlap(self, enable):
         """Level-split overlap of projection GEMMs with the recurrence on a side stream (default on)."""
         return bool(_lib.lib().csa_set_overlap(self._h, int(bool(enable))))

@@ -141,6 +141,9 @@ int csa_set_fused(csa_emulator *h, int enable);
  * bit-identical to the single-stream path.  enable: 0 off, 1 on, 2 automatic (default: on from 640 columns, where it
  * measures 4-9 % faster; slower below).  Returns the new state. */
 int csa_set_halves(csa_emulator *h, int enable);
+/* Largest batch that runs the recurrence with one column per workgroup (latency variant, LSTM nh <= 128; default 256 =
+ * one column per CU).  0 forces the two-column kernel everywhere. */
+int csa_set_rec1_max_batch(csa_emulator *h, int max_batch);
 int csa_set_overlap(csa_emulator *h, int enable);
 
 /* ---- training step (e) ---------------------------------------------
