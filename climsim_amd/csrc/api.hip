@@ -160,7 +160,7 @@ int upload_params(csa_emulator *h, const csa_params *p, bool first)
     rec_pack_weights(c.use_lstm, c.nh2, b_hh, packed.data());
     d.whh2p = U.up(packed);
     d.whh1q = d.whh2q = nullptr;
-    if (c.use_lstm && c.nh1 <= 128 && c.nh2 <= 128) {     // one-column-per-workgroup latency kernel (small batches)
+    if (c.use_lstm && c.nh1 <= 144 && c.nh2 <= 144) {     // one-column-per-workgroup latency kernel (small batches)
         packed.resize((size_t)4 * c.nh1 * c.nh1);
         rec1_pack_weights(c.nh1, a_hh, packed.data());
         d.whh1q = U.up(packed);

@@ -411,7 +411,7 @@ __global__ __launch_bounds__(NH * 4, (NH / 16 + 3) / 4) void lstm_rec2_kernel(
 // that gate's activation, three DPP moves bring i*g~, f and o to every lane, and c_t / h_t are kept redundantly by all
 // four lanes of the quad.  P rows are [i, g~, f, o] per unit: lane p reads one float.
 template <int NH>
-__global__ __launch_bounds__(NH * 4, 2) void lstm_rec1_kernel(
+__global__ __launch_bounds__(NH * 4, (NH / 16 + 3) / 4) void lstm_rec1_kernel(
     const f32x4 *__restrict__ Wp4, const float *__restrict__ P,
     const float *__restrict__ h0, const float *__restrict__ c0, float *__restrict__ Hout,
     int B, int L, int reverse_out)
@@ -514,8 +514,9 @@ int launch_rec1(int nh, const float *whh_packed1, const float *P, const float *h
     case 64:  hipLaunchKernelGGL((lstm_rec1_kernel<64>), grid, block, 0, s, (const f32x4 *)whh_packed1, P, h0, c0, Hout, B, L, reverse_out); break;
     case 96:  hipLaunchKernelGGL((lstm_rec1_kernel<96>), grid, block, 0, s, (const f32x4 *)whh_packed1, P, h0, c0, Hout, B, L, reverse_out); break;
     case 128: hipLaunchKernelGGL((lstm_rec1_kernel<128>), grid, block, 0, s, (const f32x4 *)whh_packed1, P, h0, c0, Hout, B, L, reverse_out); break;
+    case 144: hipLaunchKernelGGL((lstm_rec1_kernel<144>), grid, block, 0, s, (const f32x4 *)whh_packed1, P, h0, c0, Hout, B, L, reverse_out); break;
     default:
-        csa_set_error_msg("rec1: hidden size not supported (64, 96, 128)");
+        csa_set_error_msg("rec1: hidden size not supported (64, 96, 128, 144)");
         return CSA_ERR_UNSUPPORTED;
     }
     CSA_HIP_CHECK(hipGetLastError());
