@@ -39,6 +39,7 @@ SYMBOLS = ["csa_create", "csa_destroy", "csa_set_params", "csa_packed_width", "c
            "csa_cnn_train_params", "csa_cnn_train_get_params", "csa_cnn_train_set_params", "csa_cnn_train_get_act", "csa_cnn_train_layer_info", "csa_cnn_train_forward", "csa_cnn_train_backward",
            "csa_cnn_train_adam",
            "csa_gen_create", "csa_gen_destroy", "csa_gen_dims", "csa_gen_batch",
+           "csa_crps",
            "csa_stoch_gru5_create", "csa_stoch_lstm4_create", "csa_stoch_destroy", "csa_stoch_gru5_forward",
            "csa_stoch_lstm4_forward"]
 
@@ -149,6 +150,7 @@ def lib():
     L.csa_gen_destroy.argtypes = [H]
     L.csa_gen_dims.argtypes = [H, PI, PI, PI]
     L.csa_gen_batch.argtypes = [H, i] + [_F] * 11 + [ctypes.c_void_p]
+    L.csa_crps.argtypes = [i, i, i, i, i, _F, _F, _F, _F, fl, fl, _F, _F, ctypes.c_void_p]
     L.csa_stoch_gru5_create.argtypes = [i, i, Fp, Fp, Fp, Fp, Fp, i, ctypes.POINTER(H)]
     L.csa_stoch_lstm4_create.argtypes = [i, i, Fp, i, ctypes.POINTER(H)]
     L.csa_stoch_destroy.argtypes = [H]

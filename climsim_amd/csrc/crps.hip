@@ -1,0 +1,84 @@
+// crps.hip -- the ensemble score of the reference's probabilistic training, forward / evaluation:
+//   rnn/metrics.py:535-626  CRPS(y, y_sfc, y_pred, y_sfc_pred, timesteps, beta, alpha)
+// an energy-score form: with z = [level outputs | surface outputs] (D values per sample),
+//   skill  = mean over samples and members of ||z_true - z_e||_2 / sqrt(D)
+//   spread = (1 - eps) * sum_{e,e'} mean over samples of ||z_e - z_e'||_2 / (E (E-1)) / sqrt(D),   eps = (1 - alpha) / E
+//   CRPS   = 2 beta skill - spread
+// Predictions are ordered (time, member, column) as the ensemble forward produces them (rnn/utils.py:1065-1075).
+// One workgroup per (time, column) sample: truth and all member vectors staged in LDS, E + E(E-1)/2 distances by
+// block reductions, per-sample sums to a buffer; a second single-workgroup pass adds them in a fixed order.
+#include "common.h"
+
+__device__ __forceinline__ float crps_block_sum(float v, float *red)
+{
+    const int tid = threadIdx.x;
+    red[tid] = v;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) { if (tid < s) red[tid] += red[tid + s]; __syncthreads(); }
+    const float r = red[0];
+    __syncthreads();
+    return r;
+}
+
+__global__ __launch_bounds__(256) void crps_sample_kernel(
+    const float *__restrict__ y, const float *__restrict__ ys, const float *__restrict__ yp, const float *__restrict__ yps,
+    float *__restrict__ part, int B, int E, int D1, int D2)
+{
+    extern __shared__ float sm[];
+    const int D = D1 + D2, n = blockIdx.x, t = n / B, b = n - t * B, tid = threadIdx.x;
+    float *zt = sm, *ze = sm + D, *red = sm + (size_t)(E + 1) * D;
+    for (int i = tid; i < D; i += 256) zt[i] = i < D1 ? y[(size_t)n * D1 + i] : ys[(size_t)n * D2 + (i - D1)];
+    for (int e = 0; e < E; ++e) {
+        const size_t r = ((size_t)t * E + e) * B + b;
+        for (int i = tid; i < D; i += 256) ze[(size_t)e * D + i] = i < D1 ? yp[r * D1 + i] : yps[r * D2 + (i - D1)];
+    }
+    __syncthreads();
+    float skill = 0.0f, spread = 0.0f;
+    for (int e = 0; e < E; ++e) {
+        float a = 0.0f;
+        for (int i = tid; i < D; i += 256) { const float d = zt[i] - ze[(size_t)e * D + i]; a += d * d; }
+        skill += sqrtf(crps_block_sum(a, red));
+        for (int f = e + 1; f < E; ++f) {
+            float c = 0.0f;
+            for (int i = tid; i < D; i += 256) { const float d = ze[(size_t)e * D + i] - ze[(size_t)f * D + i]; c += d * d; }
+            spread += 2.0f * sqrtf(crps_block_sum(c, red));      // (e,f) and (f,e)
+        }
+    }
+    if (tid == 0) { part[2 * (size_t)n] = skill; part[2 * (size_t)n + 1] = spread; }
+}
+
+__global__ __launch_bounds__(256) void crps_final_kernel(const float *__restrict__ part, int N, int E, int D, float beta, float alpha,
+                                                         float *__restrict__ out)
+{
+    __shared__ float red[256];
+    float a = 0.0f, c = 0.0f;
+    for (int i = threadIdx.x; i < N; i += 256) { a += part[2 * (size_t)i]; c += part[2 * (size_t)i + 1]; }
+    const float sk = crps_block_sum(a, red), sp = crps_block_sum(c, red);
+    if (threadIdx.x == 0) {
+        const float rs = rsqrtf((float)D), eps = (1.0f - alpha) / (float)E;
+        const float mse = sk / ((float)N * (float)E) * rs;
+        const float var = E > 1 ? (1.0f - eps) * (sp / (float)N) / ((float)E * (float)(E - 1)) * rs : 0.0f;
+        out[0] = beta * 2.0f * mse - var;
+        out[1] = mse;
+        out[2] = var;
+    }
+}
+
+// y (T*B, nlev*ny) / y_sfc (T*B, ny_sfc): truth; y_pred (T*E*B, nlev*ny) / y_sfc_pred: ensemble forward outputs ordered
+// (time, member, column); scratch: 2*T*B floats; out: 3 device floats [CRPS, skill term, spread term]
+extern "C" int csa_crps(int T, int B, int E, int D_lev, int D_sfc, const float *y, const float *y_sfc, const float *y_pred,
+                        const float *y_sfc_pred, float beta, float alpha, float *scratch, float *out, void *stream)
+{
+    if (T <= 0 || B <= 0 || E <= 0 || D_lev <= 0 || D_sfc < 0 || !y || !y_pred || (D_sfc > 0 && (!y_sfc || !y_sfc_pred)) || !scratch || !out) {
+        csa_set_error_msg("csa_crps: bad argument");
+        return CSA_ERR_ARG;
+    }
+    const int D = D_lev + D_sfc, N = T * B;
+    const size_t shm = sizeof(float) * ((size_t)(E + 1) * D + 256);
+    if (shm > 64 * 1024) { csa_set_error_msg("csa_crps: ensemble x features exceed the 64 KB LDS staging (E*D too large)"); return CSA_ERR_UNSUPPORTED; }
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(crps_sample_kernel, dim3(N), dim3(256), shm, s, y, y_sfc, y_pred, y_sfc_pred, scratch, B, E, D_lev, D_sfc);
+    hipLaunchKernelGGL(crps_final_kernel, dim3(1), dim3(256), 0, s, scratch, N, E, D, beta, alpha, out);
+    CSA_HIP_CHECK(hipGetLastError());
+    return CSA_OK;
+}

@@ -1,0 +1,27 @@
+"""Device-side mirror of the reference's ensemble score (rnn/metrics.py:535-626), evaluation only."""
+import ctypes
+
+import torch
+
+from . import _lib
+from .emulator import _check, _ptr
+
+
+def CRPS(y, y_sfc, y_pred, y_sfc_pred, timesteps, beta=1, alpha=1.0, return_terms=False):
+    """Same arguments as the reference: y (T*B, nlev, ny), y_sfc (T*B, ny_sfc), y_pred (T*E*B, nlev, ny) ordered
+    (time, member, column), y_sfc_pred (T*E*B, ny_sfc).  Returns the score (a 0-d tensor), optionally with its two terms."""
+    ns, L, F = y.shape
+    B = ns // timesteps
+    E = y_pred.shape[0] // (timesteps * B)
+    y = _check(y, (ns, L, F), "y")
+    y_sfc = _check(y_sfc, (ns, y_sfc.shape[-1]), "y_sfc")
+    y_pred = _check(y_pred, (timesteps * E * B, L, F), "y_pred")
+    y_sfc_pred = _check(y_sfc_pred, (timesteps * E * B, y_sfc.shape[-1]), "y_sfc_pred")
+    scratch = torch.empty(2 * ns, device=y.device)
+    out = torch.empty(3, device=y.device)
+    rc = _lib.lib().csa_crps(timesteps, B, E, L * F, y_sfc.shape[-1], _ptr(y), _ptr(y_sfc), _ptr(y_pred), _ptr(y_sfc_pred),
+                             float(beta), float(alpha), _ptr(scratch), _ptr(out),
+                             ctypes.c_void_p(torch.cuda.current_stream(y.device).cuda_stream))
+    if rc != 0:
+        raise RuntimeError(f"csa_crps failed ({rc}): {_lib.last_error()}")
+    return (out[0], out[1], out[2]) if return_terms else out[0]

@@ -269,6 +269,14 @@ int csa_gen_batch(csa_generator *h, int N, const float *x_lev, const float *x_sf
                   float *x_lev_n, float *x_sfc_n, float *y_lev_n, float *y_sfc_n, float *x_lev_denorm,
                   float *y_lev_denorm, float *y_sfc_denorm, void *stream);
 
+/* ---- ensemble score, evaluation --------------------------------------------------------------
+ * rnn/metrics.py:535-626 CRPS(y, y_sfc, y_pred, y_sfc_pred, timesteps, beta, alpha): energy-score form over the
+ * concatenated [level | surface] outputs.  y (T*B, D_lev), y_sfc (T*B, D_sfc): truth; y_pred (T*E*B, D_lev), y_sfc_pred:
+ * ensemble outputs ordered (time, member, column).  scratch: 2*T*B device floats; out: 3 device floats
+ * [CRPS, skill term, spread term]. */
+int csa_crps(int T, int B, int E, int D_lev, int D_sfc, const float *y, const float *y_sfc, const float *y_pred,
+             const float *y_sfc_pred, float beta, float alpha, float *scratch, float *out, void *stream);
+
 /* ---- stochastic recurrent layers ---------------------------------------------------
  * MyStochasticGRULayer5  rnn/models_torch_kernels.py:834-891 (its GPU path = the repo's inline CUDA, :29-252)
  * MyStochasticLSTMLayer4 rnn/models_torch_kernels.py:1474-1531
