@@ -41,7 +41,7 @@ struct csa_emulator {
     float *P2 = nullptr, *cstate = nullptr;
     int rec1_max_batch = 256;    // largest batch that uses the one-column-per-workgroup recurrent kernel (csa_set_rec1_max_batch)
     int halves = 2;              // two column halves on two streams (run_forward_halves): 0 off, 1 on, 2 auto (B >= 640)
-    bool fused = false;          // dual-pipe fused LSTM kernel (csa_set_fused); off by default: measured slower
+    bool fused = false;          // fused projection+recurrence layer kernel (csa_set_fused); off by default: measured slower
                                  // than GEMM + recurrent kernel because W_ih is re-streamed from L2 per 8-level chunk
     // slots of device weight buffers that csa_set_params refreshes
     struct Slot { float **dst; size_t n; };
@@ -140,7 +140,7 @@ int upload_params(csa_emulator *h, const csa_params *p, bool first)
     d.wih1 = U.up(w); d.bias1 = U.up(bias); d.bhn1 = U.up(bhn);
     pack_ih(c.use_lstm, c.nh2, c.nh1, b_ih, b_bi, b_bh, w, bias, bhn);
     d.wih2 = U.up(w); d.bias2 = U.up(bias); d.bhn2 = U.up(bhn);
-    // dual-pipe fused LSTM path (fused.hip): nh = 128, K in {128,144}
+    // fused layer kernel (fused.hip, off by default): nh = 128, K in {128,144}
     d.wih1f = d.wih2f = nullptr;
     if (!st && c.use_lstm && c.nh1 == 128 && c.nh2 == 128 && (nin1 == 128 || nin1 == 144)) {
         std::vector<float> wp, fp;
@@ -551,7 +551,7 @@ static int run_forward(csa_emulator *h, int B, int normalised, int mode,
     const float *h2 = c.legacy ? hx2 : h->hc0 + (size_t)2 * B * nhm;
     const float *c2 = c.legacy ? cx2 : h->hc0 + (size_t)3 * B * nhm;
     if (h->fused && h->dm.wih1f) {
-        // dual-pipe path: each LSTM layer is ONE launch (projection on the MFMA pipe, recurrence on the
+        // fused path: each LSTM layer is ONE launch (projection by four MFMA waves, recurrence by eight vector waves on the
         // VALU pipe of the same CUs); the two GEMM stages are empty
         PROF_MARK(1);
         PROF_MARK(2);

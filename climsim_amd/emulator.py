@@ -216,7 +216,8 @@ class Emulator:
         return out, out_sfc, mem_out
 
     def set_fused(self, enable):
-        """Select the dual-pipe fused LSTM kernels (default) or the six-launch path; returns True if fused is active."""
+        """Select the fused projection+recurrence layer kernel (fused.hip; off by default: measured slower, fp32 MFMA and
+        packed FMA do not co-execute on gfx950) instead of the six-launch path; returns True if fused is active."""
         return bool(_lib.lib().csa_set_fused(self._h, int(bool(enable))))
 
     def set_halves(self, enable):
@@ -229,7 +230,7 @@ class Emulator:
         self._rc(_lib.lib().csa_set_rec1_max_batch(self._h, int(max_batch)), "csa_set_rec1_max_batch")
 
     def set_overlap(self, enable):
-        """Level-split overlap of projection GEMMs with the recurrence on a side stream (default on)."""
+        """Level-split overlap of projection GEMMs with the recurrence on a side stream (off by default: measured slower)."""
         return bool(_lib.lib().csa_set_overlap(self._h, int(bool(enable))))
 
     def set_profiling(self, enable):

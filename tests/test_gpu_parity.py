@@ -265,7 +265,7 @@ def test_error_behaviour(memory):
 
 
 def test_fused_and_unfused_paths_agree(memory):
-    """The dual-pipe fused LSTM kernel (default) and the six-launch path (projection GEMM + recurrent
+    """The fused projection+recurrence layer kernel (csa_set_fused, off by default) and the six-launch path (projection GEMM + recurrent
     kernel) are two implementations of the same arithmetic: both within 1e-5 of the oracle, and of each
     other."""
     from oracle.pyoracle import OracleModel
