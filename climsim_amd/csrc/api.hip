@@ -39,6 +39,10 @@ struct csa_emulator {
     hipStream_t side = nullptr;
     hipEvent_t ov_ev[12] = {};
     float *P2 = nullptr, *cstate = nullptr;
+    // hipGraph replay of the six launches of a call (csa_set_graph): one cached graph, keyed by every argument
+    int graph_mode = 0;          // 0 off, 1 on
+    hipGraphExec_t gexec = nullptr;
+    struct GKey { int B, normalised, mode; const void *p[8]; hipStream_t s; bool valid = false; } gkey;
     int rec1_max_batch = 256;    // largest batch that uses the one-column-per-workgroup recurrent kernel (csa_set_rec1_max_batch)
     int halves = 2;              // two column halves on two streams (run_forward_halves): 0 off, 1 on, 2 auto (B >= 640)
     bool fused = false;          // fused projection+recurrence layer kernel (csa_set_fused); off by default: measured slower
@@ -262,6 +266,7 @@ extern "C" int csa_create(const csa_config *cfg, const csa_params *hp, int max_b
 extern "C" int csa_destroy(csa_emulator *h)
 {
     if (!h) return CSA_ERR_ARG;
+    if (h->gexec) (void)hipGraphExecDestroy(h->gexec);
     free_all(h);
     if (h->stoch) (void)csa_stoch_destroy(h->stoch);
     for (int i = 0; i < 7; ++i) if (h->ev[i]) (void)hipEventDestroy(h->ev[i]);
@@ -433,6 +438,14 @@ static int launch_rec_auto(const csa_emulator *h, int layer, const float *P, con
                       reverse_out, s);
 }
 
+extern "C" int csa_set_graph(csa_emulator *h, int enable)
+{
+    if (!h) return CSA_ERR_ARG;
+    h->graph_mode = enable != 0;
+    if (!h->graph_mode && h->gexec) { (void)hipGraphExecDestroy(h->gexec); h->gexec = nullptr; h->gkey.valid = false; }
+    return h->graph_mode;
+}
+
 extern "C" int csa_set_rec1_max_batch(csa_emulator *h, int max_batch)
 {
     if (!h || max_batch < 0) return CSA_ERR_ARG;
@@ -545,6 +558,32 @@ static int run_forward(csa_emulator *h, int B, int normalised, int mode,
         return run_forward_halves(h, B, normalised, mode, x_main, x_sfc, mem_in, hx2, cx2, y0, y1, y2, s);
     if (h->overlap && !h->profiling && !h->fused && c.use_lstm && c.nh1 == 128 && c.nh2 == 128 && L >= 8 && B > h->rec1_max_batch)
         return run_forward_overlap(h, B, normalised, mode, x_main, x_sfc, mem_in, hx2, cx2, y0, y1, y2, s);
+    if (h->graph_mode && !h->profiling && !h->fused && s != nullptr) {
+        // Rollout loops call with the same buffers every step: replay the six launches as ONE graph launch (removes the
+        // inter-kernel dispatch gaps that matter at small batches).  Any change of an argument re-captures.
+        csa_emulator::GKey k;
+        k.B = B; k.normalised = normalised; k.mode = mode; k.s = s; k.valid = true;
+        const void *ps[8] = {x_main, x_sfc, mem_in, hx2, cx2, y0, y1, y2};
+        for (int i = 0; i < 8; ++i) k.p[i] = ps[i];
+        const csa_emulator::GKey &o = h->gkey;
+        bool same = o.valid && o.B == B && o.normalised == normalised && o.mode == mode && o.s == s;
+        for (int i = 0; same && i < 8; ++i) same = o.p[i] == k.p[i];
+        if (!same) {
+            if (h->gexec) { (void)hipGraphExecDestroy(h->gexec); h->gexec = nullptr; h->gkey.valid = false; }
+            hipGraph_t g = nullptr;
+            CSA_HIP_CHECK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+            rc = run_chain(h, B, normalised, mode, x_main, x_sfc, mem_in, hx2, cx2, y0, y1, y2, h->X1, h->P, h->H1, h->H2, h->hc0, 0, 0, s, B);
+            const hipError_t e = hipStreamEndCapture(s, &g);
+            if (rc) { if (g) (void)hipGraphDestroy(g); return rc; }
+            if (e != hipSuccess) { csa_set_error("hipStreamEndCapture", e); return CSA_ERR_HIP; }
+            const hipError_t e2 = hipGraphInstantiate(&h->gexec, g, nullptr, nullptr, 0);
+            (void)hipGraphDestroy(g);
+            if (e2 != hipSuccess) { h->gexec = nullptr; csa_set_error("hipGraphInstantiate", e2); return CSA_ERR_HIP; }
+            h->gkey = k;
+        }
+        CSA_HIP_CHECK(hipGraphLaunch(h->gexec, s));
+        return CSA_OK;
+    }
     if (h->profiling) prof_collect(h);   // previous profiled call (host sync: profiling mode only)
     PROF_MARK(0);
     if ((rc = launch_prep(h->dm, B, normalised, x_main, x_sfc, mem_in, hx2, cx2, h->X1, h->hc0, s))) return rc;

@@ -225,6 +225,11 @@ class Emulator:
         True / False force it, None restores the default (automatic from 640 columns)."""
         return _lib.lib().csa_set_halves(self._h, 2 if enable is None else int(bool(enable)))
 
+    def set_graph(self, enable):
+        """Replay the launches of a forward call as one hipGraph while all arguments stay the same (rollout loops over
+        persistent buffers, on a non-default stream)."""
+        return bool(_lib.lib().csa_set_graph(self._h, int(bool(enable))))
+
     def set_rec1_max_batch(self, max_batch):
         """Largest batch that uses the one-column-per-workgroup recurrent kernel (default 256); 0 disables it."""
         self._rc(_lib.lib().csa_set_rec1_max_batch(self._h, int(max_batch)), "csa_set_rec1_max_batch")

@@ -142,6 +142,10 @@ int csa_set_fused(csa_emulator *h, int enable);
  * bit-identical to the single-stream path.  enable: 0 off, 1 on, 2 automatic (default: on from 640 columns, where it
  * measures 4-9 % faster; slower below).  Returns the new state. */
 int csa_set_halves(csa_emulator *h, int enable);
+/* hipGraph replay (enable = 1): the six launches of a forward call are captured once and replayed as one graph launch while
+ * every argument (batch, pointers, stream) stays the same, as in a rollout loop over persistent buffers; any change
+ * re-captures.  Needs a non-default stream.  Off by default.  Returns the new state. */
+int csa_set_graph(csa_emulator *h, int enable);
 /* Largest batch that runs the recurrence with one column per workgroup (latency variant, LSTM nh <= 128; default 256 =
  * one column per CU).  0 forces the two-column kernel everywhere. */
 int csa_set_rec1_max_batch(csa_emulator *h, int max_batch);

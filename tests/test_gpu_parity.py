@@ -309,6 +309,39 @@ def test_one_column_and_two_column_recurrent_kernels_agree(memory, B):
     assert not torch.equal(y1, y2) or B == 0      # two different kernels really ran
 
 
+def test_graph_replay_is_bit_identical(memory):
+    """csa_set_graph: the launches of a call are captured once and replayed while the arguments stay the same; a change of
+    any argument (here: the batch and the buffers) re-captures."""
+    consts, weights, model = memory
+    st = torch.cuda.Stream()
+    for B in (3, 48, 300):
+        xm, xs = synth_inputs(consts, B, 21 + B)
+        g = np.random.Generator(np.random.PCG64(B))
+        mem = (0.4 * g.standard_normal((B, 60, 16))).astype(np.float32)
+        hx, cx = g.standard_normal((2, B, 128)).astype(np.float32)
+        args = (_dev(xm), _dev(xs), _dev(mem), _dev(hx), _dev(cx))
+        y_ref = model.emulator.forward_packed(*args).clone()
+        torch.cuda.synchronize()
+        with torch.cuda.stream(st):
+            out = torch.empty_like(y_ref)
+            assert model.emulator.set_graph(True)
+            ys = []
+            for _ in range(3):                       # capture, then two replays
+                model.emulator.forward_packed(*args, out=out)
+                st.synchronize()
+                ys.append(out.clone())
+            args[2].mul_(0.5)                        # same pointers, new contents: the replay must see them
+            model.emulator.forward_packed(*args, out=out)
+            st.synchronize()
+            y_half = out.clone()
+            model.emulator.set_graph(False)
+            model.emulator.forward_packed(*args, out=out)
+            st.synchronize()
+        for y in ys:
+            assert torch.equal(y, y_ref)
+        assert torch.equal(y_half, out) and not torch.equal(y_half, y_ref)
+
+
 def test_rollout_harness_matches_golden_and_shards(memory):
     """climsim_amd.rollout: the reference's evaluation loop; sharded blocks reproduce the unsharded rows exactly."""
     from climsim_amd.rollout import rollout, sharded_rollout
