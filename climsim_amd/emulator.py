@@ -102,6 +102,24 @@ class Emulator:
             raise RuntimeError(f"csa_create failed ({rc}): {_lib.last_error()}")
         self._h = h
 
+    def load_state_dict(self, state_dict):
+        """Replace the weights of this handle (same shapes): load_state_dict of the reference module.  Constants
+        (normalisation, grid) are kept."""
+        params = _lib.CsaParams()
+        for k in CONST_KEYS:
+            setattr(params, k, self._host[k].ctypes.data_as(ctypes.POINTER(ctypes.c_float)))
+        for sd, f in STATE_DICT_MAP.items():
+            if sd in state_dict:
+                a = _np32(state_dict[sd])
+                if f in self._host and a.shape != self._host[f].shape:
+                    raise RuntimeError(f"{sd}: shape {a.shape} does not match the handle's {self._host[f].shape}")
+                self._host[f] = a
+                setattr(params, f, a.ctypes.data_as(ctypes.POINTER(ctypes.c_float)))
+        with torch.cuda.device(self.device):
+            rc = _lib.lib().csa_set_params(self._h, ctypes.byref(params))
+        if rc != 0:
+            raise RuntimeError(f"csa_set_params failed ({rc}): {_lib.last_error()}")
+
     def close(self):
         if self._h is not None:
             _lib.lib().csa_destroy(self._h)

@@ -309,6 +309,27 @@ def test_one_column_and_two_column_recurrent_kernels_agree(memory, B):
     assert not torch.equal(y1, y2) or B == 0      # two different kernels really ran
 
 
+def test_load_state_dict_refreshes_every_packed_layout():
+    """csa_set_params: a handle re-loaded with other weights behaves exactly like a fresh one (both recurrent packings,
+    the projection layouts, heads)."""
+    import climsim_amd
+    consts, weights, flags = load_npz_model("cur_lstm128")
+    g = np.random.Generator(np.random.PCG64(11))
+    other = {k: (v + 0.02 * g.standard_normal(v.shape)).astype(np.float32) for k, v in weights.items()}
+    a = climsim_amd.model_wrapper(consts, weights, max_batch=400, use_lstm=True, output_prune=True)
+    b = climsim_amd.model_wrapper(consts, other, max_batch=400, use_lstm=True, output_prune=True)
+    a.emulator.load_state_dict(other)
+    for B in (7, 300):                                   # one-column and two-column recurrent kernels
+        xm, xs = synth_inputs(consts, B, B)
+        mem = (0.2 * g.standard_normal((60, B, 16))).astype(np.float32)
+        ya = a(_dev(xm), _dev(xs), _dev(mem))
+        yb = b(_dev(xm), _dev(xs), _dev(mem))
+        for x, y in zip(ya, yb):
+            assert torch.equal(x, y)
+    with pytest.raises(RuntimeError):
+        a.emulator.load_state_dict({"mlp_output.weight": np.zeros((3, 3), np.float32)})
+
+
 def test_graph_replay_is_bit_identical(memory):
     """csa_set_graph: the launches of a call are captured once and replayed while the arguments stay the same; a change of
     any argument (here: the batch and the buffers) re-captures."""
