@@ -49,3 +49,31 @@ def test_product_package_never_imports_the_oracle():
             if f.endswith((".py", ".hip", ".h", ".cpp")):
                 src = open(os.path.join(dirpath, f)).read()
                 assert "oracle" not in src.replace("no CPU fallback", ""), f
+
+
+@pytest.mark.gpu
+def test_small_accessors_of_the_abi():
+    """The getters no Python mirror method needs: packed width, max batch, version string, raw parameter pointers."""
+    import ctypes
+    import numpy as np
+    import climsim_amd
+    from climsim_amd import _lib
+    from climsim_amd.train import Trainer
+    from climsim_amd.baselines import CNNTrainer
+    L = _lib.lib()
+    consts, weights, _ = load_npz_model("v4_memory")
+    m = climsim_amd.NewModel_constraint(consts, weights, max_batch=33)
+    assert L.csa_packed_width(m.emulator._h) == 368 + 960 == m.emulator.packed_width
+    assert L.csa_max_batch(m.emulator._h) == 33
+    L.csa_version.restype = ctypes.c_char_p
+    assert b"climsim" in L.csa_version().lower() or len(L.csa_version()) > 0
+    consts, weights, flags = load_npz_model("cur_lstm128")
+    grid = np.load(os.path.join(os.path.dirname(__file__), "golden", "grid_consts.npz"))
+    tr = Trainer(consts, weights, grid["hyai"], grid["hybi"], max_batch=4, max_window=1)
+    L.csa_train_params.restype = ctypes.c_void_p
+    assert L.csa_train_params(tr._h)
+    assert L.csa_train_sync_params(tr._h, None) == 0
+    ws = [np.zeros((8, 6, 3), np.float32), np.zeros((8, 8, 3), np.float32), np.zeros((8, 6, 1), np.float32),
+          np.zeros((10, 8, 1), np.float32), np.zeros((10, 10, 1), np.float32)]
+    ct = CNNTrainer(ws, [np.zeros(w.shape[0], np.float32) for w in ws], depth=1, width=8, dropout=0.0, max_batch=2)
+    assert L.csa_cnn_train_params(ct._h)
