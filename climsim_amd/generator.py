@@ -24,8 +24,7 @@ class generator_xy:
         self._h = None
         if not torch.cuda.is_available():
             raise RuntimeError("climsim_amd needs a HIP device: the product path has no CPU fallback")
-        if include_prev_inputs or include_prev_outputs:
-            raise NotImplementedError("include_prev_inputs / include_prev_outputs are not built")
+        self.include_prev_inputs, self.include_prev_outputs = bool(include_prev_inputs), bool(include_prev_outputs)
         if cld_inp_transformation not in _CLD:
             raise NotImplementedError()
         if ycoeffs is None:
@@ -37,6 +36,11 @@ class generator_xy:
             raise NotImplementedError("expected input_lev of shape (ntime, nloc, nlev, nx)")
         self.ntimesteps, self.nloc, self.nlev, nx_in = dims
         self.ncol = self.nloc
+        # rnn/utils.py:2012-2023: the previous step's outputs (5) / inputs (6) are appended as extra level inputs and the
+        # first time step is lost to them
+        nx_in += (5 if include_prev_outputs else 0) + (6 if include_prev_inputs else 0)
+        if include_prev_inputs or include_prev_outputs:
+            self.ntimesteps -= 1
         cfg = _lib.CsaGenConfig()
         cfg.nlev, cfg.nx_in = self.nlev, nx_in
         cfg.nx_sfc_in = data["input_sca"].shape[-1]
@@ -110,7 +114,16 @@ class generator_xy:
     def __getitem__(self, indices):
         d = self.data
         idx = list(indices)
-        return self.prepare(d["input_lev"][idx], d["input_sca"][idx], d["output_lev"][idx], d["output_sca"][idx])
+        x_lev = self._dev(d["input_lev"][idx])
+        if self.include_prev_inputs or self.include_prev_outputs:      # rnn/utils.py:2242-2249, 2262-2279, 2291-2297
+            if idx[0] <= 0:
+                raise NotImplementedError("First time index cannot be zero as it's used for memory")
+            prev = [idx[0] - 1] + idx[:-1]
+            if self.include_prev_outputs:
+                x_lev = torch.cat((x_lev, self._dev(d["output_lev"][prev])[..., 0:5]), dim=-1)
+            if self.include_prev_inputs:
+                x_lev = torch.cat((x_lev, self._dev(d["input_lev"][prev])[..., 0:6]), dim=-1)
+        return self.prepare(x_lev, d["input_sca"][idx], d["output_lev"][idx], d["output_sca"][idx])
 
     def __del__(self):
         try:

@@ -108,3 +108,34 @@ def test_hip_generator_matches_numpy_restatement(kw):
         else:
             assert rel_err(np.where(m, a, 0), np.where(m, b, 0)) <= 2e-6, name
     assert len(gen) == 3 * 7
+
+
+@pytest.mark.gpu
+def test_previous_step_inputs_and_outputs_are_appended():
+    """include_prev_outputs / include_prev_inputs (rnn/utils.py:2242-2297): 5 + 6 extra level inputs from time step t-1."""
+    from climsim_amd.generator import generator_xy
+    consts, data, full = _setup(dict(mp_mode=1, remove_past_sfc_inputs=True))
+    g = np.random.Generator(np.random.PCG64(3))
+    nx = 15 + 5 + 6
+    xm = np.concatenate([full["xcoeffs"][0][0], g.standard_normal((60, 11)).astype(np.float32)], 1)
+    xd = np.concatenate([full["xcoeffs"][0][1], (1 + g.random((60, 11))).astype(np.float32)], 1)
+    full["xcoeffs"] = ((xm, xd), full["xcoeffs"][1])
+    gen = generator_xy(data, nloc=7, include_prev_inputs=True, include_prev_outputs=True, **full)
+    assert gen.nx == nx and gen.ntimesteps == 2
+    idx, prev = [1, 2], [0, 1]
+    got = gen[idx]
+    x_lev = np.concatenate([data["input_lev"][idx], data["output_lev"][prev][..., 0:5], data["input_lev"][prev][..., 0:6]], -1)
+    with np.errstate(all="ignore"):
+        ref = generator_ref.getitem(x_lev.reshape(-1, 60, nx), data["input_sca"][idx].reshape(-1, 24),
+                                    data["output_lev"][idx].reshape(-1, 60, 6), data["output_sca"][idx].reshape(-1, 8), **full)
+    for a, b in zip(got, ref):
+        a = a.cpu().numpy()
+        m = np.isfinite(b)
+        assert a.shape == b.shape and np.array_equal(np.isfinite(a), m)
+        if a.ndim == 3:
+            for v in range(a.shape[2]):
+                assert rel_err(np.where(m, a, 0)[:, :, v], np.where(m, b, 0)[:, :, v]) <= 2e-6, v
+        else:
+            assert rel_err(np.where(m, a, 0), np.where(m, b, 0)) <= 2e-6
+    with pytest.raises(NotImplementedError):
+        gen[[0, 1]]
