@@ -384,10 +384,10 @@ static int run_forward_overlap(csa_emulator *h, int B, int normalised, int mode,
     for (int i = 1; i < NS; ++i) {                               // T: layer-1 projection of the later pieces
         const size_t r0 = (size_t)bnd[i] * B;
         if ((rc = launch_proj_gemm(h->X1 + r0 * K1, h->dm.wih1, h->dm.bias1, h->P + r0 * 4 * nh, (bnd[i + 1] - bnd[i]) * B,
-                                   4 * nh, K1, T))) return rc;
+                                   4 * nh, K1, T, L * B))) return rc;
         CSA_HIP_CHECK(hipEventRecord(ev[i], T));
     }
-    if ((rc = launch_proj_gemm(h->X1, h->dm.wih1, h->dm.bias1, h->P, bnd[1] * B, 4 * nh, K1, S))) return rc;
+    if ((rc = launch_proj_gemm(h->X1, h->dm.wih1, h->dm.bias1, h->P, bnd[1] * B, 4 * nh, K1, S, L * B))) return rc;
     for (int i = 0; i < NS; ++i) {
         if (i > 0) CSA_HIP_CHECK(hipStreamWaitEvent(S, ev[i], 0));
         // state entering piece i: h of step bnd[i]-1 sits in H1 at level L - bnd[i]; c in cstate
@@ -401,9 +401,9 @@ static int run_forward_overlap(csa_emulator *h, int B, int normalised, int mode,
         if (i + 1 < NS) {
             CSA_HIP_CHECK(hipEventRecord(ev[4 + i], S));
             CSA_HIP_CHECK(hipStreamWaitEvent(T, ev[4 + i], 0));
-            if ((rc = launch_proj_gemm(h->H1 + r0 * nh, h->dm.wih2, h->dm.bias2, h->P2 + r0 * 4 * nh, rows, 4 * nh, nh, T))) return rc;
+            if ((rc = launch_proj_gemm(h->H1 + r0 * nh, h->dm.wih2, h->dm.bias2, h->P2 + r0 * 4 * nh, rows, 4 * nh, nh, T, L * B))) return rc;
         } else {
-            if ((rc = launch_proj_gemm(h->H1 + r0 * nh, h->dm.wih2, h->dm.bias2, h->P2 + r0 * 4 * nh, rows, 4 * nh, nh, S))) return rc;
+            if ((rc = launch_proj_gemm(h->H1 + r0 * nh, h->dm.wih2, h->dm.bias2, h->P2 + r0 * 4 * nh, rows, 4 * nh, nh, S, L * B))) return rc;
         }
     }
     CSA_HIP_CHECK(hipEventRecord(ev[8], T));
@@ -492,9 +492,9 @@ static int run_chain(csa_emulator *h, int B, int normalised, int mode, const flo
     if ((rc = launch_prep(dm, B, normalised, x_main, x_sfc, mem_in, hx2, cx2, X1, hc0, s))) return rc;
     const float *h2 = c.legacy ? hx2 : hc0 + (size_t)2 * B * nhm;
     const float *c2 = c.legacy ? cx2 : hc0 + (size_t)3 * B * nhm;
-    if ((rc = launch_proj_gemm(X1, h->dm.wih1, h->dm.bias1, P, L * B, 4 * c.nh1, c.nh1 + c.nh_mem, s))) return rc;
+    if ((rc = launch_proj_gemm(X1, h->dm.wih1, h->dm.bias1, P, L * B, 4 * c.nh1, c.nh1 + c.nh_mem, s, L * Bclass))) return rc;
     if ((rc = launch_rec_auto(h, 1, P, hc0, hc0 + (size_t)B * nhm, H1, B, L, 1, s, Bclass))) return rc;
-    if ((rc = launch_proj_gemm(H1, h->dm.wih2, h->dm.bias2, P, L * B, 4 * c.nh2, c.nh1, s))) return rc;
+    if ((rc = launch_proj_gemm(H1, h->dm.wih2, h->dm.bias2, P, L * B, 4 * c.nh2, c.nh1, s, L * Bclass))) return rc;
     if ((rc = launch_rec_auto(h, 2, P, h2, c2, H2, B, L, 0, s, Bclass))) return rc;
     return launch_head(dm, B, mode, H2, x_main, x_sfc, y0, y1, y2, s);
 }

@@ -63,7 +63,7 @@ int launch_prep(const DevModel &m, int B, int normalised, const float *x_main, c
 
 // gemm.hip: C(M,N) = A(M,K) * W(N,K)^T + bias(N), fp32 MFMA.
 int launch_proj_gemm(const float *A, const float *W, const float *bias, float *C,
-                     int M, int N, int K, hipStream_t s);
+                     int M, int N, int K, hipStream_t s, int class_rows = 0);
 
 // same GEMM with a fused activation epilogue (MLP baseline): act 0 none, 1 LeakyReLU(alpha), 2 split linear|ReLU head
 int launch_gemm_act(const float *A, const float *W, const float *bias, float *C, int M, int N, int K,

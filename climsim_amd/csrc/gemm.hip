@@ -13,6 +13,9 @@
 // buffer after them (register + LDS double buffer, one barrier per chunk).
 #include "common.h"
 
+#ifndef CSA_SMALL_GEMM_ROWS_DEFAULT
+#define CSA_SMALL_GEMM_ROWS_DEFAULT 11520   // 192 columns x 60 levels: measured crossover (tools/latency_sweep.py)
+#endif
 #define GB_M 128
 #define GB_N 128
 #define GB_K 16
@@ -193,9 +196,23 @@ __global__ __launch_bounds__(GB_THREADS) void proj_gemm_kernel(
     }
 }
 
-int launch_proj_gemm(const float *A, const float *W, const float *bias, float *C,
-                     int M, int N, int K, hipStream_t s)
+static int g_small_rows = -1;      // rows up to which the projection uses the small-M kernel (csa_set_small_gemm_rows)
+extern "C" int csa_set_small_gemm_rows(int rows)
 {
+    if (rows < 0) return CSA_ERR_ARG;
+    g_small_rows = rows;
+    return CSA_OK;
+}
+
+int launch_proj_gemm(const float *A, const float *W, const float *bias, float *C,
+                     int M, int N, int K, hipStream_t s, int class_rows)
+{
+    // class_rows: the row count the kernel class is chosen for (a column half inherits the class of the whole call)
+    if (g_small_rows < 0) {
+        const char *e = getenv("CSA_SMALL_GEMM_ROWS");
+        g_small_rows = e ? atoi(e) : CSA_SMALL_GEMM_ROWS_DEFAULT;
+    }
+    if ((class_rows > 0 ? class_rows : M) <= g_small_rows) return launch_gemm_small(A, W, bias, C, M, N, K, 0, 0.0f, 0, s);
     return launch_gemm_act(A, W, bias, C, M, N, K, 0, 0.0f, 0, s);
 }
 

@@ -146,6 +146,9 @@ int csa_set_halves(csa_emulator *h, int enable);
  * every argument (batch, pointers, stream) stays the same, as in a rollout loop over persistent buffers; any change
  * re-captures.  Needs a non-default stream.  Off by default.  Returns the new state. */
 int csa_set_graph(csa_emulator *h, int enable);
+/* Process-wide: projections with at most `rows` rows (= nlev * B) use the small-M split-K GEMM (32x32 tiles; default
+ * 11,520 = 192 columns, the measured crossover; also settable with CSA_SMALL_GEMM_ROWS before the first call). */
+int csa_set_small_gemm_rows(int rows);
 /* Largest batch that runs the recurrence with one column per workgroup (latency variant, LSTM nh <= 128; default 256 =
  * one column per CU).  0 forces the two-column kernel everywhere. */
 int csa_set_rec1_max_batch(csa_emulator *h, int max_batch);
