@@ -434,6 +434,8 @@ static int launch_rec_auto(const csa_emulator *h, int layer, const float *P, con
     const float *wq = layer == 1 ? d.whh1q : d.whh2q;
     if (d.cfg.use_lstm && wq && Bclass <= h->rec1_max_batch)
         return launch_rec1(nh, wq, P, h0, c0, Hout, B, L, reverse_out, s);
+    if (!d.cfg.use_lstm && Bclass <= h->rec1_max_batch)
+        return launch_rec1_gru(nh, layer == 1 ? d.whh1p : d.whh2p, layer == 1 ? d.bhn1 : d.bhn2, P, h0, Hout, B, L, reverse_out, s);
     return launch_rec(d.cfg.use_lstm, nh, layer == 1 ? d.whh1p : d.whh2p, layer == 1 ? d.bhn1 : d.bhn2, P, h0, c0, Hout, B, L,
                       reverse_out, s);
 }

@@ -95,6 +95,8 @@ int launch_rec(int use_lstm, int nh, const float *whh_packed, const float *bhn, 
                const float *h0, const float *c0, float *Hout, int B, int L, int reverse_out,
                hipStream_t s);
 // training forward: as launch_rec (LSTM) + saves gates in place over P, c_t to Cseq and h_t to Hseq
+int launch_rec1_gru(int nh, const float *whh_packed, const float *bhn, const float *P, const float *h0, float *Hout, int B, int L,
+                    int reverse_out, hipStream_t s);
 // one-column-per-workgroup LSTM kernel (small batches) and its weight packing
 void rec1_pack_weights(int nh, const float *w_hh, float *packed);
 int launch_rec1(int nh, const float *whh_packed1, const float *P, const float *h0, const float *c0, float *Hout, int B, int L,

@@ -490,6 +490,90 @@ __global__ __launch_bounds__(NH * 4, (NH / 16 + 3) / 4) void lstm_rec1_kernel(
 #undef LSTM1_STEP
 }
 
+// GRU, one column per workgroup (small batches): lane (u, p) holds the three gate rows of unit u for its k-quarter as
+// k-pairs (48 v_pk_fma_f32 per step), the quad all-reduces the three sums (6 DPP adds) and every lane of the quad
+// evaluates the cell redundantly.  P rows are [r, z, n, pad] per unit (pack.h), b_hn is kept apart as in rec_kernel.
+template <int NH>
+__global__ __launch_bounds__(NH * 4, 2) void gru_rec1_kernel(
+    const f32x4 *__restrict__ Wp4, const float *__restrict__ bhn, const float *__restrict__ P,
+    const float *__restrict__ h0, float *__restrict__ Hout, int B, int L, int reverse_out)
+{
+    constexpr int NT = NH * 4;
+    constexpr int KC = NH / 4;
+    constexpr int CH = KC + 4;
+    static_assert(KC % 4 == 0, "nh must be a multiple of 16");
+    __shared__ __attribute__((aligned(16))) float hbuf[2][4 * CH];
+    const int tid = threadIdx.x, u = tid >> 2, p = tid & 3;
+    const int b = blockIdx.x;
+    f32x2 w[3][KC / 2];
+#pragma unroll
+    for (int i = 0; i < 3 * KC / 4; ++i) {
+        const f32x4 v = Wp4[(size_t)i * NT + tid];
+        const int g = (4 * i) / KC, kk = (4 * i) % KC;
+        w[g][kk / 2] = f32x2{v.x, v.y};
+        w[g][kk / 2 + 1] = f32x2{v.z, v.w};
+    }
+    const float bn = bhn[u];
+    float h = h0[(size_t)b * NH + u];
+    const int hslot = u + 4 * (u / KC);
+    if (p == 0) hbuf[0][hslot] = h;
+    asm volatile("" : "+v"(h));
+    const float *Pb = P + (size_t)b * (4 * NH) + u * 4;
+    const size_t Pstep = (size_t)B * (4 * NH);
+    f32x4 preA = *(const f32x4 *)Pb, preB = preA;
+    __syncthreads();
+#define GRU1_STEP(T, CUR, NXT)                                                                     \
+    {                                                                                              \
+        const int t_ = (T);                                                                        \
+        if (t_ + 1 < L) {                                                                          \
+            const float *pn = Pb + (size_t)(t_ + 1) * Pstep;                                       \
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(NXT) : "v"(pn) : "memory");     \
+        }                                                                                          \
+        const f32x4 *hp = (const f32x4 *)&hbuf[t_ & 1][p * CH];                                    \
+        f32x2 acc[3] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};                                       \
+        _Pragma("unroll") for (int j = 0; j < KC / 4; ++j) {                                       \
+            const f32x4 hv = hp[j];                                                                \
+            const f32x2 ha = {hv.x, hv.y}, hb = {hv.z, hv.w};                                      \
+            _Pragma("unroll") for (int g = 0; g < 3; ++g) acc[g] = __builtin_elementwise_fma(w[g][2 * j], ha, acc[g]);     \
+            _Pragma("unroll") for (int g = 0; g < 3; ++g) acc[g] = __builtin_elementwise_fma(w[g][2 * j + 1], hb, acc[g]); \
+        }                                                                                          \
+        const float sr = quad_sum(acc[0].x + acc[0].y), sz = quad_sum(acc[1].x + acc[1].y);        \
+        const float sn = quad_sum(acc[2].x + acc[2].y);                                            \
+        if (t_ > 0) asm volatile("s_waitcnt vmcnt(1)" : "+v"(CUR));                                \
+        const float r = sigmoid_f(CUR.x + sr);                                                     \
+        const float z = sigmoid_f(CUR.y + sz);                                                     \
+        const float n = tanh_f(CUR.z + r * (sn + bn));                                             \
+        h = (1.0f - z) * n + z * h;                                                                \
+        if (p == 0) {                                                                              \
+            hbuf[(t_ & 1) ^ 1][hslot] = h;                                                         \
+            Hout[((size_t)(reverse_out ? L - 1 - t_ : t_) * B + b) * NH + u] = h;                  \
+        }                                                                                          \
+        LDS_BARRIER();                                                                             \
+    }
+    for (int t = 0; t < L; t += 2) {
+        GRU1_STEP(t, preA, preB)
+        if (t + 1 < L) GRU1_STEP(t + 1, preB, preA)
+    }
+#undef GRU1_STEP
+}
+
+int launch_rec1_gru(int nh, const float *whh_packed, const float *bhn, const float *P, const float *h0, float *Hout, int B, int L,
+                    int reverse_out, hipStream_t s)
+{
+    // the GRU packing of rec_pack_weights (thread-major: [g][kk] for unit u, k-quarter p) is exactly what this kernel reads
+    const dim3 grid(B), block(nh * 4);
+    switch (nh) {
+    case 64:  hipLaunchKernelGGL((gru_rec1_kernel<64>), grid, block, 0, s, (const f32x4 *)whh_packed, bhn, P, h0, Hout, B, L, reverse_out); break;
+    case 96:  hipLaunchKernelGGL((gru_rec1_kernel<96>), grid, block, 0, s, (const f32x4 *)whh_packed, bhn, P, h0, Hout, B, L, reverse_out); break;
+    case 128: hipLaunchKernelGGL((gru_rec1_kernel<128>), grid, block, 0, s, (const f32x4 *)whh_packed, bhn, P, h0, Hout, B, L, reverse_out); break;
+    default:
+        csa_set_error_msg("rec1(GRU): hidden size not supported (64, 96, 128)");
+        return CSA_ERR_UNSUPPORTED;
+    }
+    CSA_HIP_CHECK(hipGetLastError());
+    return CSA_OK;
+}
+
 // lane p, slot s holds gate (p ^ s) of [i, g~, f, o]  ->  PyTorch gate rows (i, f, g, o)
 static void lstm1_pack_weights(int nh, const float *w_hh, float *packed)
 {

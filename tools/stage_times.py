@@ -3,7 +3,7 @@ import sys, numpy as np, torch
 sys.path[:0] = ["/root/repo", "/root/repo/tests/golden"]
 import climsim_amd
 from synth import synth_inputs
-for tag, B in (("cur_lstm128", 384), ("cur_lstm144", 384), ("cur_lstm144", 256), ("cur_gru128", 384), ("cur_lstm128", 48)):
+for tag, B in (("cur_lstm128", 384), ("cur_lstm144", 384), ("cur_lstm144", 256), ("cur_gru128", 384), ("cur_lstm128", 48), ("cur_gru128", 48), ("cur_gru128", 256)):
     d = np.load(f"/root/repo/tests/golden/{tag}_model.npz")
     consts = {k[2:]: d[k] for k in d.files if k.startswith("c.")}
     weights = {k[2:]: d[k] for k in d.files if k.startswith("w.")}
