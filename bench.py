@@ -34,6 +34,7 @@ WORKLOADS = {
     "v4_stateless_384": ("v4_stateless", 384, 31.79e6, 5148),
     "v4_memory_384": ("v4_memory", 384, 32.95e6, 12828),
     "v4_memory_2700": ("v4_memory", 2700, 32.95e6, 12828),
+    "v4_memory_48": ("v4_memory", 48, 32.95e6, 12828),      # the low-res grid strong-scaled over 8 GPUs: latency case
 }
 
 
@@ -354,7 +355,7 @@ def main():
             "config": {"workload": a.workload, "columns_per_gpu": B, "nlev": 60,
                        "wrapper": "stateless v4 (rnn/v4_rnn_wrapper_constrained.pt weights)" if not stateful
                        else "stateful v4 memory wrapper", "parallelism": f"columns sharded x{world}, no collective"},
-            "roofline": {"bound": "mfma", "kernel": "lstm_rec2_kernel<128,false,0> (one launch per LSTM, 2 per step)",
+            "roofline": {"bound": "mfma", "kernel": ("lstm_rec1_kernel<128>" if B <= 256 else "lstm_rec2_kernel<128,false,0>") + " (one launch per LSTM, 2 per step)",
                          "achieved": achieved, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_FP32_TFLOPS, "traffic": pmc_traffic(a.workload),
                          "traffic_unit": "HBM bytes per launch (rocprofv3 PMC, profiles/)",
