@@ -24,7 +24,8 @@ extern "C" const char *csa_version(void) { return "climsim_amd 0.1 (gfx950)"; }
 struct csa_emulator {
     DevModel dm;
     int max_batch;
-    std::vector<void *> owned;   // every device allocation
+    std::vector<void *> owned;   // every device allocation: parameters first, then scratch
+    size_t n_param_allocs = 0;
     // scratch
     float *X1, *P, *H1, *H2, *hc0;
     csa_stoch *stoch = nullptr;  // add_stochastic_layer: the MyStochasticLSTMLayer4 stage (stoch.hip)
@@ -232,6 +233,7 @@ extern "C" int csa_create(const csa_config *cfg, const csa_params *hp, int max_b
     h->dm.cfg = *cfg;
     h->max_batch = max_batch;
     rc = upload_params(h, hp, true);
+    h->n_param_allocs = h->owned.size();     // everything allocated after this point is scratch (kept by csa_set_params)
     if (rc == CSA_OK) {
         Uploader U{h};
         const size_t L = cfg->nlev, Bm = max_batch;
@@ -280,12 +282,13 @@ extern "C" int csa_set_params(csa_emulator *h, const csa_params *hp)
 {
     if (!h || !hp || !params_complete(h->dm.cfg, hp)) { csa_set_error_msg("csa_set_params: bad argument"); return CSA_ERR_ARG; }
     if (h->stoch) { csa_set_error_msg("csa_set_params: not available for the stochastic variant (re-create the handle)"); return CSA_ERR_UNSUPPORTED; }
-    // Rebuild all parameter buffers; scratch (the last seven allocations) is kept.
-    std::vector<void *> scratch(h->owned.end() - 7, h->owned.end());
-    h->owned.resize(h->owned.size() - 7);
+    // Rebuild all parameter buffers; the scratch buffers (allocated after the parameters at creation) are kept.
+    std::vector<void *> scratch(h->owned.begin() + h->n_param_allocs, h->owned.end());
+    h->owned.resize(h->n_param_allocs);
     if (hipDeviceSynchronize() != hipSuccess) return CSA_ERR_HIP;
     free_all(h);
     int rc = upload_params(h, hp, false);
+    h->n_param_allocs = h->owned.size();
     for (void *p : scratch) h->owned.push_back(p);
     return rc;
 }
