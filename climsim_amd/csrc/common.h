@@ -51,6 +51,18 @@ struct DevModel {
         }                                                                          \
     } while (0)
 
+// raise a kernel's dynamic-LDS limit once per device (kernels that keep part of their weights in LDS, nh = 144)
+#define CSA_SET_DYN_LDS_ONCE(kern, bytes)                                                                          \
+    do {                                                                                                           \
+        static unsigned long long done_ = 0;                                                                       \
+        int dev_ = 0;                                                                                              \
+        (void)hipGetDevice(&dev_);                                                                                 \
+        if (!((done_ >> (dev_ & 63)) & 1ull)) {                                                                    \
+            CSA_HIP_CHECK(hipFuncSetAttribute((const void *)(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(bytes))); \
+            done_ |= 1ull << (dev_ & 63);                                                                          \
+        }                                                                                                          \
+    } while (0)
+
 void csa_set_error(const char *what, hipError_t e);
 void csa_set_error_msg(const char *msg);
 

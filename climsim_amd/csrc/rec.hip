@@ -649,11 +649,7 @@ static int launch_rec_nh(int use_lstm, const float *whh, const float *bhn, const
         constexpr size_t shm = (size_t)4 * NL4 * NH * 4 * sizeof(f32x4);
         auto kern = lstm_rec2_kernel<NH, false, NL4>;
         if (shm > 0) {
-            static bool attr_set = false;   // per process; idempotent
-            if (!attr_set) {
-                CSA_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
-                attr_set = true;
-            }
+            CSA_SET_DYN_LDS_ONCE(kern, shm);
         }
         hipLaunchKernelGGL(kern, grid, block, shm, s, (const f32x4 *)whh, (float *)P,
                            h0, c0, Hout, B, L, reverse_out, (float *)nullptr, (float *)nullptr, 0, L, (float *)nullptr);
@@ -681,11 +677,7 @@ int launch_rec_train(int nh, const float *whh_packed, float *P, const float *h0,
         constexpr int NL4 = 3;   // the TRAIN variant carries more live state: one more float4 per slot in LDS
         constexpr size_t shm = (size_t)4 * NL4 * 144 * 4 * sizeof(f32x4);
         auto kern = lstm_rec2_kernel<144, true, NL4>;
-        static bool attr_set = false;
-        if (!attr_set) {
-            CSA_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
-            attr_set = true;
-        }
+        CSA_SET_DYN_LDS_ONCE(kern, shm);
         hipLaunchKernelGGL(kern, grid, block, shm, s, (const f32x4 *)whh_packed, P, h0, c0, Hout, B, L, reverse_out, Hseq, Cseq, 0, L, (float *)nullptr);
         break;
     }

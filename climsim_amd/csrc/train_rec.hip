@@ -343,11 +343,7 @@ int launch_bwd_rec(int nh, const float *wt_packed, float *GP, const float *Cseq,
         constexpr int NL4 = 2;
         constexpr size_t shm = (size_t)4 * NL4 * 144 * 4 * sizeof(f32x4);
         auto kern = lstm_bwd_rec_kernel<144, NL4>;
-        static bool attr_set = false;
-        if (!attr_set) {
-            CSA_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
-            attr_set = true;
-        }
+        CSA_SET_DYN_LDS_ONCE(kern, shm);
         hipLaunchKernelGGL(kern, grid, block, shm, s, (const f32x4 *)wt_packed, GP, Cseq, dH, dh0, dc0, B, L, rev);
         break;
     }
