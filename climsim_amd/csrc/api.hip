@@ -218,10 +218,9 @@ extern "C" int csa_create(const csa_config *cfg, const csa_params *hp, int max_b
     if (!params_complete(*cfg, hp)) { csa_set_error_msg("csa_create: missing parameter array"); return CSA_ERR_ARG; }
     {
         // the register-stationary recurrent kernel is instantiated for these hidden sizes only
-        const int big = cfg->use_lstm ? 144 : 128;   // nh = 144: LSTM only (rec.hip, NL4 variant)
-        const int ok1 = cfg->nh1 == 64 || cfg->nh1 == 96 || cfg->nh1 == 128 || cfg->nh1 == big;
-        const int ok2 = cfg->nh2 == 64 || cfg->nh2 == 96 || cfg->nh2 == 128 || cfg->nh2 == big;
-        if (!ok1 || !ok2) { csa_set_error_msg("csa_create: hidden size must be 64, 96, 128 (or 144, LSTM)"); return CSA_ERR_UNSUPPORTED; }
+        const int ok1 = cfg->nh1 == 64 || cfg->nh1 == 96 || cfg->nh1 == 128 || cfg->nh1 == 144;
+        const int ok2 = cfg->nh2 == 64 || cfg->nh2 == 96 || cfg->nh2 == 128 || cfg->nh2 == 144;
+        if (!ok1 || !ok2) { csa_set_error_msg("csa_create: hidden size must be 64, 96, 128 or 144"); return CSA_ERR_UNSUPPORTED; }
     }
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {

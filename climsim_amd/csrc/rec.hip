@@ -75,7 +75,7 @@ __device__ __forceinline__ float dpp_xor2(float v)
 // TRAIN (GRU): additionally saves what BPTT needs -- [r, z, n, W_hn h + b_hn] written IN PLACE over the (4-padded)
 // pre-activation row P(t,b,u,:) it came from, and h_t into Hseq (L+1 slots in SEQUENCE order, slot 0 = h_init).
 template <int NH, int G, bool TRAIN = false>
-__global__ __launch_bounds__(NH * 4, 2) void rec_kernel(
+__global__ __launch_bounds__(NH * 4, (NH / 16 + 3) / 4) void rec_kernel(
     const f32x4 *__restrict__ Wp4, const float *__restrict__ bhn, const float *P,
     const float *__restrict__ h0, const float *__restrict__ c0, float *__restrict__ Hout,
     int B, int L, int reverse_out, float *Pw = nullptr, float *__restrict__ Hseq = nullptr)
@@ -494,7 +494,7 @@ __global__ __launch_bounds__(NH * 4, (NH / 16 + 3) / 4) void lstm_rec1_kernel(
 // k-pairs (48 v_pk_fma_f32 per step), the quad all-reduces the three sums (6 DPP adds) and every lane of the quad
 // evaluates the cell redundantly.  P rows are [r, z, n, pad] per unit (pack.h), b_hn is kept apart as in rec_kernel.
 template <int NH>
-__global__ __launch_bounds__(NH * 4, 2) void gru_rec1_kernel(
+__global__ __launch_bounds__(NH * 4, (NH / 16 + 3) / 4) void gru_rec1_kernel(
     const f32x4 *__restrict__ Wp4, const float *__restrict__ bhn, const float *__restrict__ P,
     const float *__restrict__ h0, float *__restrict__ Hout, int B, int L, int reverse_out)
 {
@@ -566,8 +566,9 @@ int launch_rec1_gru(int nh, const float *whh_packed, const float *bhn, const flo
     case 64:  hipLaunchKernelGGL((gru_rec1_kernel<64>), grid, block, 0, s, (const f32x4 *)whh_packed, bhn, P, h0, Hout, B, L, reverse_out); break;
     case 96:  hipLaunchKernelGGL((gru_rec1_kernel<96>), grid, block, 0, s, (const f32x4 *)whh_packed, bhn, P, h0, Hout, B, L, reverse_out); break;
     case 128: hipLaunchKernelGGL((gru_rec1_kernel<128>), grid, block, 0, s, (const f32x4 *)whh_packed, bhn, P, h0, Hout, B, L, reverse_out); break;
+    case 144: hipLaunchKernelGGL((gru_rec1_kernel<144>), grid, block, 0, s, (const f32x4 *)whh_packed, bhn, P, h0, Hout, B, L, reverse_out); break;
     default:
-        csa_set_error_msg("rec1(GRU): hidden size not supported (64, 96, 128)");
+        csa_set_error_msg("rec1(GRU): hidden size not supported (64, 96, 128, 144)");
         return CSA_ERR_UNSUPPORTED;
     }
     CSA_HIP_CHECK(hipGetLastError());
@@ -654,13 +655,9 @@ static int launch_rec_nh(int use_lstm, const float *whh, const float *bhn, const
         hipLaunchKernelGGL(kern, grid, block, shm, s, (const f32x4 *)whh, (float *)P,
                            h0, c0, Hout, B, L, reverse_out, (float *)nullptr, (float *)nullptr, 0, L, (float *)nullptr);
     }
-    else if constexpr (NH <= 128)
+    else   // GRU: 3*nh/4 weights per lane (108 at nh = 144) fit the 168-VGPR budget of a 9-wave workgroup as they are
         hipLaunchKernelGGL((rec_kernel<NH, 3>), grid, block, 0, s, (const f32x4 *)whh, bhn, P, h0, c0, Hout, B, L,
                            reverse_out);
-    else {
-        csa_set_error_msg("rec: the GRU kernel supports hidden sizes 64, 96, 128");
-        return CSA_ERR_UNSUPPORTED;
-    }
     CSA_HIP_CHECK(hipGetLastError());
     return CSA_OK;
 }

@@ -330,6 +330,34 @@ def test_load_state_dict_refreshes_every_packed_layout():
         a.emulator.load_state_dict({"mlp_output.weight": np.zeros((3, 3), np.float32)})
 
 
+@pytest.mark.parametrize("B", [5, 300])
+def test_gru_at_the_default_width_144_vs_oracle(B):
+    """GRU with nh = 144 (the reference's default width; no reference-class golden of this combination is committed):
+    random weights, HIP vs the C oracle that is pinned on GRU-128 and LSTM-144.  B = 5: one-column kernel, 300: two-column."""
+    import climsim_amd
+    from oracle.pyoracle import OracleModel
+    consts, w128, _ = load_npz_model("cur_gru128")
+    g = np.random.Generator(np.random.PCG64(144))
+    nh = 144
+    shapes = {"mlp_toa1.weight": (nh, 2), "mlp_toa1.bias": (nh,), "mlp_initial.weight": (nh, 16), "mlp_initial.bias": (nh,),
+              "mlp_surface1.weight": (nh, 19), "mlp_surface1.bias": (nh,),
+              "rnn1.weight_ih_l0": (3 * nh, nh + 16), "rnn1.weight_hh_l0": (3 * nh, nh), "rnn1.bias_ih_l0": (3 * nh,), "rnn1.bias_hh_l0": (3 * nh,),
+              "rnn2.weight_ih_l0": (3 * nh, nh), "rnn2.weight_hh_l0": (3 * nh, nh), "rnn2.bias_ih_l0": (3 * nh,), "rnn2.bias_hh_l0": (3 * nh,),
+              "mlp_latent.weight": (16, nh), "mlp_latent.bias": (16,), "mlp_output.weight": (5, 16), "mlp_output.bias": (5,),
+              "mlp_surface_output.weight": (8, nh), "mlp_surface_output.bias": (8,)}
+    weights = {k: (g.uniform(-1, 1, s) / np.sqrt(s[-1] if len(s) > 1 else nh)).astype(np.float32) for k, s in shapes.items()}
+    om = OracleModel(consts, weights, legacy=False, use_lstm=False, scrub_inf=True, snowhice_fix=True)
+    wrap = climsim_amd.model_wrapper(consts, weights, use_lstm=False, max_batch=B, snowhice_fix=True)
+    xm, xs = synth_inputs(consts, B, 9)
+    mem = (0.3 * g.standard_normal((60, B, 16))).astype(np.float32)
+    o6, osf, mo = om.wrapper_forward_tuple(xm, xs, mem)
+    h6, hsf, hmo = wrap(_dev(xm), _dev(xs), _dev(mem))
+    for v in range(6):
+        assert rel_err(h6.cpu().numpy()[:, :, v], o6[:, :, v]) <= 1e-5, v
+    assert rel_err(hsf.cpu().numpy(), osf) <= 1e-5
+    assert rel_err(hmo.cpu().numpy(), mo) <= 1e-5
+
+
 def test_graph_replay_is_bit_identical(memory):
     """csa_set_graph: the launches of a call are captured once and replayed while the arguments stay the same; a change of
     any argument (here: the batch and the buffers) re-captures."""
