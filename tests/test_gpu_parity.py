@@ -358,6 +358,30 @@ def test_gru_at_the_default_width_144_vs_oracle(B):
     assert rel_err(hmo.cpu().numpy(), mo) <= 1e-5
 
 
+def test_long_rollout_stays_within_tolerance(memory):
+    """40 coupled steps, each implementation feeding back ITS OWN memory (a true rollout on both sides): the error does
+    not accumulate through the state (the memory model is contractive in fp32), every step stays within 1e-5."""
+    from oracle.pyoracle import OracleModel
+    consts, weights, model = memory
+    om = OracleModel(consts, weights, legacy=True)
+    B, nt = 6, 40
+    g = np.random.Generator(np.random.PCG64(77))
+    mem_o = np.zeros((B, 60, 16), np.float32)
+    mem_h = torch.zeros(B, 60, 16, device="cuda")
+    worst = 0.0
+    for t in range(nt):
+        xm, xs = synth_inputs(consts, B, 5000 + t)
+        hx, cx = g.standard_normal((2, B, 128)).astype(np.float32)
+        yo = om.wrapper_forward(xm, xs, mem_o, hx, cx)
+        yh = model(_dev(xm), _dev(xs), mem_h, noise=(_dev(hx), _dev(cx)))
+        err = max(block_errors(yh.cpu().numpy(), yo).values())
+        worst = max(worst, err)
+        assert err <= 1e-5, (t, err)
+        mem_o = yo[:, 368:].reshape(B, 60, 16).copy()
+        mem_h = yh[:, 368:].reshape(B, 60, 16).contiguous()
+    print("long rollout worst block error", worst)
+
+
 def test_graph_replay_is_bit_identical(memory):
     """csa_set_graph: the launches of a call are captured once and replayed while the arguments stay the same; a change of
     any argument (here: the batch and the buffers) re-captures."""
