@@ -47,6 +47,15 @@ __global__ __launch_bounds__(PREP_THREADS) void prep_kernel(
     float *xl = smem;                 // (lper, NXP), zero padded beyond nxp
     float *xs = smem + lper * NXP;    // (nxs)
     if (nl <= 0) return;
+    // the mlp_initial column of this thread's first unit is fetched now, so that its L2 round trip overlaps the input
+    // loads and the two barriers below instead of following them
+    float w0[NXP];
+    float bj0 = 0.0f;
+    if (tid < nh1) {
+#pragma unroll
+        for (int v = 0; v < NXP; ++v) w0[v] = v < nxp ? m.init_wt[v * nh1 + tid] : 0.0f;
+        bj0 = m.init_b[tid];
+    }
 
     // ---- surface inputs -----------------------------------------------------------------
     for (int v = tid; v < nxs; v += PREP_THREADS) {
@@ -123,9 +132,14 @@ __global__ __launch_bounds__(PREP_THREADS) void prep_kernel(
     // ---- mlp_initial + tanh, written in sequence order (t = L-1-l) ------------------------------
     for (int j = tid; j < nh1; j += PREP_THREADS) {
         float w[NXP];
+        float bj = bj0;
 #pragma unroll
-        for (int v = 0; v < NXP; ++v) w[v] = v < nxp ? m.init_wt[v * nh1 + j] : 0.0f;
-        const float bj = m.init_b[j];
+        for (int v = 0; v < NXP; ++v) w[v] = w0[v];
+        if (j != tid) {
+#pragma unroll
+            for (int v = 0; v < NXP; ++v) w[v] = v < nxp ? m.init_wt[v * nh1 + j] : 0.0f;
+            bj = m.init_b[j];
+        }
         for (int ll = 0; ll < nl; ++ll) {
             const f32x4 *xr = (const f32x4 *)(xl + ll * NXP);
             float a0 = bj, a1 = 0.0f;
