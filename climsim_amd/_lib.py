@@ -34,6 +34,8 @@ SYMBOLS = ["csa_create", "csa_destroy", "csa_set_params", "csa_packed_width", "c
            "csa_train_param_info", "csa_train_params", "csa_train_sync_params", "csa_train_copy_state", "csa_train_forward",
            "csa_train_backward", "csa_train_set_deferred", "csa_train_flush_wgrad", "csa_train_loss", "csa_train_adam",
            "csa_mlp_create", "csa_mlp_destroy", "csa_mlp_forward",
+           "csa_mlp_train_create", "csa_mlp_train_destroy", "csa_mlp_train_num_params", "csa_mlp_train_copy_params",
+           "csa_mlp_train_forward", "csa_mlp_train_backward", "csa_mlp_train_adam",
            "csa_cnn_create", "csa_cnn_destroy", "csa_cnn_forward", "csa_cnn_reshape_to", "csa_cnn_reshape_from",
            "csa_cnn_train_create", "csa_cnn_train_destroy", "csa_cnn_train_num_params", "csa_cnn_train_num_layers",
            "csa_cnn_train_params", "csa_cnn_train_get_params", "csa_cnn_train_set_params", "csa_cnn_train_get_act", "csa_cnn_train_layer_info", "csa_cnn_train_forward", "csa_cnn_train_backward",
@@ -128,6 +130,14 @@ def lib():
     L.csa_mlp_create.argtypes = [i, ctypes.POINTER(i), PP, PP, f, i, i, ctypes.POINTER(H)]
     L.csa_mlp_destroy.argtypes = [H]
     L.csa_mlp_forward.argtypes = [H, i, _F, _F, ctypes.c_void_p]
+    L.csa_mlp_train_create.argtypes = [i, ctypes.POINTER(i), PP, PP, ctypes.c_float, i, i, ctypes.POINTER(H)]
+    L.csa_mlp_train_destroy.argtypes = [H]
+    L.csa_mlp_train_num_params.argtypes = [H]
+    L.csa_mlp_train_num_params.restype = ctypes.c_long
+    L.csa_mlp_train_copy_params.argtypes = [H, i, _F, ctypes.c_void_p]
+    L.csa_mlp_train_forward.argtypes = [H, i, _F, _F, ctypes.c_void_p]
+    L.csa_mlp_train_backward.argtypes = [H, _F, ctypes.c_float, _F, _F, ctypes.c_void_p]
+    L.csa_mlp_train_adam.argtypes = [H, _F, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float, i, ctypes.c_void_p]
     L.csa_cnn_create.argtypes = [i, i, i, i, i, i, PP, PP, i, ctypes.POINTER(H)]
     L.csa_cnn_destroy.argtypes = [H]
     L.csa_cnn_forward.argtypes = [H, i, _F, _F, ctypes.c_void_p]

@@ -224,3 +224,87 @@ class CNNTrainer:
                 self._h = None
         except Exception:
             pass
+
+
+class MLPTrainer:
+    """One optimiser step of the Keras MLP baseline on the HIP path (step2_retrain.py:93-155: loss 'mse', keras Adam)."""
+
+    def __init__(self, weights, biases, *, leaky_alpha=0.15, n_lin_out=120, max_batch=4096):
+        self._h = None
+        if not torch.cuda.is_available():
+            raise RuntimeError("climsim_amd needs a HIP device: the product path has no CPU fallback")
+        self.device = torch.device("cuda", torch.cuda.current_device())
+        ws = [np.ascontiguousarray(w, np.float32) for w in weights]
+        bs = [np.ascontiguousarray(b, np.float32) for b in biases]
+        self.dims = [ws[0].shape[1]] + [w.shape[0] for w in ws]
+        n = len(ws)
+        FP = ctypes.POINTER(ctypes.c_float)
+        warr = (FP * n)(*[w.ctypes.data_as(FP) for w in ws])
+        barr = (FP * n)(*[b.ctypes.data_as(FP) for b in bs])
+        darr = (ctypes.c_int * (n + 1))(*self.dims)
+        h = ctypes.c_void_p()
+        rc = _lib.lib().csa_mlp_train_create(n, darr, warr, barr, float(leaky_alpha), int(n_lin_out), int(max_batch), ctypes.byref(h))
+        if rc != 0:
+            raise RuntimeError(f"csa_mlp_train_create failed ({rc}): {_lib.last_error()}")
+        self._h = h
+        self.n_params = int(_lib.lib().csa_mlp_train_num_params(h))
+        self.grads = torch.zeros(self.n_params, device=self.device)
+        self.loss = torch.zeros(1, device=self.device)
+        self.step_count = 0
+
+    def _stream(self):
+        return ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _rc(self, rc, what):
+        if rc != 0:
+            raise RuntimeError(f"{what} failed ({rc}): {_lib.last_error()}")
+
+    def forward(self, x):
+        B = x.shape[0]
+        self._x = _check(x, (B, self.dims[0]), "x")          # kept alive: the backward reads it
+        y = torch.empty(B, self.dims[-1], device=self.device)
+        self._rc(_lib.lib().csa_mlp_train_forward(self._h, B, _ptr(self._x), _ptr(y), self._stream()), "csa_mlp_train_forward")
+        return y
+
+    def backward(self, y_true, grad_scale=1.0):
+        y_true = _check(y_true, tuple(y_true.shape), "y_true")
+        self._rc(_lib.lib().csa_mlp_train_backward(self._h, _ptr(y_true), float(grad_scale), _ptr(self.loss), _ptr(self.grads),
+                                                   self._stream()), "csa_mlp_train_backward")
+        return self.loss, self.grads
+
+    def adam(self, lr=2.5e-4, beta1=0.9, beta2=0.999, eps=1e-7):
+        self.step_count += 1
+        self._rc(_lib.lib().csa_mlp_train_adam(self._h, _ptr(self.grads), lr, beta1, beta2, eps, self.step_count, self._stream()),
+                 "csa_mlp_train_adam")
+
+    def train_step(self, x, y_true, lr=2.5e-4, world_size=1):
+        self.forward(x)
+        self.backward(y_true, 1.0 / world_size)
+        if world_size > 1:
+            import torch.distributed as dist
+            dist.all_reduce(self.grads)
+            dist.all_reduce(self.loss)
+        self.adam(lr=lr)
+        return self.loss
+
+    def flat_params(self):
+        t = torch.empty(self.n_params, device=self.device)
+        self._rc(_lib.lib().csa_mlp_train_copy_params(self._h, 0, _ptr(t), self._stream()), "csa_mlp_train_copy_params")
+        return t
+
+    def unpack(self, flat):
+        flat = flat.detach().cpu()
+        ws, bs, o = [], [], 0
+        for i in range(len(self.dims) - 1):
+            n = self.dims[i + 1] * self.dims[i]
+            ws.append(flat[o:o + n].view(self.dims[i + 1], self.dims[i]).clone()); o += n
+            bs.append(flat[o:o + self.dims[i + 1]].clone()); o += self.dims[i + 1]
+        return ws, bs
+
+    def __del__(self):
+        try:
+            if self._h is not None:
+                _lib.lib().csa_mlp_train_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass

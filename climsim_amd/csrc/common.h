@@ -87,8 +87,8 @@ struct GemmEpi {
     const unsigned char *mask = nullptr;    // v *= mask[row*ldmask + col] ? mscale : 0   (col < ldmask)
     int ldmask = 0;
     float mscale = 1.0f;
-    const float *gate = nullptr;            // v *= gate[row*ldc + col] > 0 ? gscale : 0
-    float gscale = 1.0f;
+    const float *gate = nullptr;            // v *= gate[row*ldc + col] > 0 ? gscale : gneg
+    float gscale = 1.0f, gneg = 0.0f;       // (ReLU + dropout backward: gneg 0; LeakyReLU(alpha) backward: gscale 1, gneg alpha)
 };
 int launch_gemm_epi(const float *A, const float *W, const float *bias, float *C, int M, int N, int K, int act, float alpha,
                     int n_lin, int lda, int ldc, int conv_L, int conv_cin, const GemmEpi &epi, hipStream_t s);

@@ -187,7 +187,7 @@ __global__ __launch_bounds__(GB_THREADS) void proj_gemm_kernel(
                         const size_t idx = (size_t)row * ldc + col;
                         float v = acc[i][j][r];
                         if (epi.mask) v = (col < epi.ldmask && epi.mask[(size_t)row * epi.ldmask + col]) ? v * epi.mscale : 0.0f;
-                        if (epi.gate) v = epi.gate[idx] > 0.0f ? v * epi.gscale : 0.0f;
+                        if (epi.gate) v *= epi.gate[idx] > 0.0f ? epi.gscale : epi.gneg;
                         if (epi.addsrc) v += epi.addsrc[idx];
                         C[idx] = v;
                     }

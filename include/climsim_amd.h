@@ -207,6 +207,19 @@ int csa_mlp_create(int nlayers, const int *dims, const float *const *weights, co
 int csa_mlp_destroy(csa_mlp *h);
 int csa_mlp_forward(csa_mlp *h, int B, const float *x, float *y, void *stream);
 
+/* MLP baseline, one training step (step2_retrain.py:93-155: LeakyReLU stack, split head, loss 'mse', keras Adam).  Flat
+ * parameters / gradients in layer order [W_l (out,in) | b_l]; grad_scale multiplies dLoss/dy (data-parallel shares). */
+typedef struct csa_mlp_trainer csa_mlp_trainer;
+int csa_mlp_train_create(int nlayers, const int *dims, const float *const *weights, const float *const *biases,
+                         float leaky_alpha, int n_lin_out, int max_batch, csa_mlp_trainer **out);
+int csa_mlp_train_destroy(csa_mlp_trainer *h);
+long csa_mlp_train_num_params(const csa_mlp_trainer *h);
+int csa_mlp_train_copy_params(csa_mlp_trainer *h, int dir /* 0 out, 1 in */, float *buf, void *stream);
+int csa_mlp_train_forward(csa_mlp_trainer *h, int B, const float *x, float *y, void *stream);
+int csa_mlp_train_backward(csa_mlp_trainer *h, const float *y_true, float grad_scale, float *loss_out, float *grads, void *stream);
+int csa_mlp_train_adam(csa_mlp_trainer *h, const float *grads, float lr, float beta1, float beta2, float eps, int step,
+                       void *stream);
+
 /* ---- offline CNN baseline, forward --------------------------------------------------
  * baseline_models/CNN/training/hpo_train.py:124-200: 12 residual blocks of two Conv1D(406,3,same)+ReLU plus a 1x1
  * projection of the block input, Conv1D(10,1,elu), Dense(2,linear) || Dense(8,relu).  weights/biases: HOST

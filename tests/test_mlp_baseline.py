@@ -38,3 +38,40 @@ def test_mlp_forward_matches_torch(B):
     # and no worse than torch's own fp32 evaluation
     assert (y.double() - ref).abs().max().item() <= 4 * (ref32.double() - ref).abs().max().item() + 1e-7 * scale
     assert (y[:, 120:] >= 0).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B", [37, 384])
+def test_mlp_training_step_matches_autograd(B):
+    """forward, 'mse' loss, every weight / bias gradient and one Keras-Adam update against torch autograd on the restatement
+    (LeakyReLU has a kink at zero: a unit within fp32 rounding of it can take the other slope in two correct evaluations,
+    so 0.1 % of a tensor's entries may exceed the tolerance as long as its relative L2 error stays below 1e-3)."""
+    from climsim_amd.baselines import MLPTrainer
+    dims, ws, bs = _arch()
+    tr = MLPTrainer([w.numpy() for w in ws], [b.numpy() for b in bs], max_batch=512)
+    g = torch.Generator().manual_seed(B)
+    x = torch.randn(B, 124, generator=g)
+    yt = torch.randn(B, 128, generator=g)
+    y = tr.forward(x.cuda()).cpu()
+    loss, grads = tr.backward(yt.cuda())
+    wd = [w.clone().requires_grad_(True) for w in ws]
+    bd = [b.clone().requires_grad_(True) for b in bs]
+    yr = torch_ref.mlp_ref(x, wd, bd)
+    lr_ = torch.mean((yr - yt) ** 2)
+    lr_.backward()
+    assert (y - yr.detach()).abs().max().item() <= 1e-5 * yr.abs().max().item()
+    assert abs(loss.item() - lr_.item()) <= 1e-5 * lr_.item()
+    gw, gb = tr.unpack(grads)
+    for name, got, refs in (("w", gw, wd), ("b", gb, bd)):
+        for i, (a, r) in enumerate(zip(got, refs)):
+            ref = r.grad
+            err = (a - ref).abs()
+            tol = 2e-5 * ref.abs().max().item() + 1e-12
+            assert (err > tol).float().mean().item() <= 1e-3, (name, i, err.max().item() / ref.abs().max().item())
+            assert err.norm().item() <= 1e-3 * ref.norm().item() + 1e-12, (name, i)
+    p0 = tr.flat_params()
+    tr.adam(lr=1e-3)
+    p1 = tr.flat_params()
+    gq = grads.double()
+    upd = 1e-3 * (1 - 0.999) ** 0.5 / (1 - 0.9) * (0.1 * gq) / ((0.001 * gq * gq).sqrt() + 1e-7)
+    assert ((p0.double() - p1.double()) - upd).abs().max().item() <= 2e-6 * 1e-3 + 1e-4 * upd.abs().max().item()
