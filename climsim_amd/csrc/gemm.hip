@@ -260,6 +260,7 @@ int launch_gemm_epi(const float *A, const float *W, const float *bias, float *C,
 // global memory as float4: lanes < 32 take k..k+3 and lanes >= 32 take k+4..k+7 of a row, i.e. MFMA e contracts
 // the pair (k+e, k+4+e)); the four partial tiles are summed through LDS in a fixed order (deterministic), then bias +
 // activation.  384 x 768: 288 workgroups, each wave K/8 MFMAs.
+template <int PD>
 __global__ __launch_bounds__(256) void gemm_small_kernel(
     const float *__restrict__ A, const float *__restrict__ W, const float *__restrict__ bias, float *__restrict__ C,
     int M, int N, int K, int act, float alpha, int n_lin)
@@ -275,22 +276,30 @@ __global__ __launch_bounds__(256) void gemm_small_kernel(
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
     const int nch = (K + 7) / 8;                     // chunks of 8 k-values, dealt round-robin to the waves
-    f32x4 a = {0, 0, 0, 0}, w = {0, 0, 0, 0};
-    int c = wave;
-    if (c < nch) {
-        const int k = 8 * c + 4 * half;
-        if (k < K) { if (am) a = *(const f32x4 *)(ap + 8 * c); if (wn) w = *(const f32x4 *)(wp + 8 * c); }
-    }
-    for (; c < nch; c += 4) {
-        f32x4 an = {0, 0, 0, 0}, wnx = {0, 0, 0, 0};
-        const int cn = c + 4;
-        if (cn < nch && 8 * cn + 4 * half < K) {      // prefetch the wave's next chunk
-            if (am) an = *(const f32x4 *)(ap + 8 * cn);
-            if (wn) wnx = *(const f32x4 *)(wp + 8 * cn);
+    // rolling prefetch, PD chunks deep: the operands come straight from global memory (L2), so the loop is a chain of
+    // load -> 4 MFMA.  PD = 4 for long K (MLP, K up to 768: 84 -> 67 us per 384-row forward), 1 for the K <= 160 projections
+    // (a wave has only 4-5 chunks there and the extra registers cost more than the prefetch gains)
+    f32x4 a[PD], w[PD];
+    auto fetch = [&](int c, f32x4 &av, f32x4 &wv) {
+        av = f32x4{0, 0, 0, 0};
+        wv = f32x4{0, 0, 0, 0};
+        if (c < nch && 8 * c + 4 * half < K) {
+            if (am) av = *(const f32x4 *)(ap + 8 * c);
+            if (wn) wv = *(const f32x4 *)(wp + 8 * c);
         }
+    };
 #pragma unroll
-        for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], w[e], acc, 0, 0, 0);
-        a = an; w = wnx;
+    for (int d = 0; d < PD; ++d) fetch(wave + 4 * d, a[d], w[d]);
+    for (int c = wave; c < nch; c += 4 * PD) {
+#pragma unroll
+        for (int d = 0; d < PD; ++d) {
+            const f32x4 ac = a[d], wc = w[d];
+            fetch(c + 4 * (d + PD), a[d], w[d]);
+            if (c + 4 * d < nch) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[e], wc[e], acc, 0, 0, 0);
+            }
+        }
     }
     // acc[i]: row (i&3) + 8*(i>>2) + 4*half, column r of the tile
     if (wave > 0) {
@@ -317,7 +326,10 @@ int launch_gemm_small(const float *A, const float *W, const float *bias, float *
                       int n_lin, hipStream_t s)
 {
     if (K % 4) { csa_set_error_msg("gemm_small: K must be a multiple of 4"); return CSA_ERR_UNSUPPORTED; }
-    hipLaunchKernelGGL(gemm_small_kernel, dim3((N + 31) / 32, (M + 31) / 32), dim3(256), 0, s, A, W, bias, C, M, N, K, act, alpha, n_lin);
+    if (K >= 256)
+        hipLaunchKernelGGL(gemm_small_kernel<4>, dim3((N + 31) / 32, (M + 31) / 32), dim3(256), 0, s, A, W, bias, C, M, N, K, act, alpha, n_lin);
+    else
+        hipLaunchKernelGGL(gemm_small_kernel<1>, dim3((N + 31) / 32, (M + 31) / 32), dim3(256), 0, s, A, W, bias, C, M, N, K, act, alpha, n_lin);
     CSA_HIP_CHECK(hipGetLastError());
     return CSA_OK;
 }
