@@ -39,6 +39,8 @@ int launch_loss(const DevModel &m, const float *hyai, const float *hybi, int B, 
                 float *d_pred, float *d_pred_sfc, hipStream_t s);
 int launch_adam(float *p, const float *g, float *m1, float *m2, int n, float lr, float b1, float b2, float eps, int step,
                 float wd, hipStream_t s);
+struct GatherEntry { float *dst; const int *idx; const int *idx2; int n; };
+int launch_gather_multi(const GatherEntry *tab_dev, int count, int max_n, const float *src, hipStream_t s);
 int launch_gather(float *dst, const float *src, const int *idx, const int *idx2, int n, hipStream_t s);
 
 // prep.hip, training variant: also saves X16 (B,L,nx+1) and the normalised surface inputs (B,nx_sfc)

@@ -36,6 +36,8 @@ struct csa_trainer {
     float *params, *adam_m, *adam_v;
     float *hyai, *hybi;
     std::vector<Gather> gathers;
+    GatherEntry *gtab = nullptr;     // device copy of the gather table (repack = one launch)
+    int gmax = 0;
     float *wih1T, *wih2T, *whh1Tp, *whh2Tp;
     // gradient scatter maps
     int *map_wih1, *map_whh1, *map_b1a, *map_b1b, *map_wih2, *map_whh2, *map_b2a, *map_b2b, *map_head, *map_prep;
@@ -94,11 +96,16 @@ std::vector<float> index_values(size_t n) { std::vector<float> v(n); for (size_t
 
 int repack(csa_trainer *h, hipStream_t s)
 {
-    for (const Gather &g : h->gathers) {
-        int rc = launch_gather(g.dst, h->params, g.idx, g.idx2, g.n, s);
-        if (rc) return rc;
+    if (!h->gtab) {      // first call: the table of all gathers goes to the device once
+        std::vector<GatherEntry> t;
+        for (const Gather &g : h->gathers) { t.push_back({g.dst, g.idx, g.idx2, g.n}); h->gmax = g.n > h->gmax ? g.n : h->gmax; }
+        void *d = nullptr;
+        if (hipMalloc(&d, sizeof(GatherEntry) * t.size()) != hipSuccess) return CSA_ERR_NOMEM;
+        h->owned.push_back(d);
+        if (hipMemcpy(d, t.data(), sizeof(GatherEntry) * t.size(), hipMemcpyHostToDevice) != hipSuccess) return CSA_ERR_HIP;
+        h->gtab = (GatherEntry *)d;
     }
-    return CSA_OK;
+    return launch_gather_multi(h->gtab, (int)h->gathers.size(), h->gmax, h->params, s);
 }
 
 }  // namespace

@@ -598,6 +598,23 @@ __global__ void gather_kernel(float *__restrict__ dst, const float *__restrict__
     if (idx2) { const int c = idx2[i]; if (c >= 0) v += src[c]; }
     dst[i] = v;
 }
+// all re-packings of an optimiser step in ONE launch: blockIdx.y selects the table entry (27 separate 4-us launches before)
+__global__ void gather_multi_kernel(const GatherEntry *__restrict__ tab, const float *__restrict__ src)
+{
+    const GatherEntry g = tab[blockIdx.y];
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= g.n) return;
+    const int a = g.idx[i];
+    float v = a >= 0 ? src[a] : 0.0f;
+    if (g.idx2) { const int c = g.idx2[i]; if (c >= 0) v += src[c]; }
+    g.dst[i] = v;
+}
+int launch_gather_multi(const GatherEntry *tab_dev, int count, int max_n, const float *src, hipStream_t s)
+{
+    hipLaunchKernelGGL(gather_multi_kernel, dim3((max_n + 255) / 256, count), dim3(256), 0, s, tab_dev, src);
+    CSA_HIP_CHECK(hipGetLastError());
+    return CSA_OK;
+}
 int launch_gather(float *dst, const float *src, const int *idx, const int *idx2, int n, hipStream_t s)
 {
     hipLaunchKernelGGL(gather_kernel, dim3((n + 255) / 256), dim3(256), 0, s, dst, src, idx, idx2, n);
