@@ -22,6 +22,8 @@ int launch_gemm_tn_conv(const float *A, int lda, const float *Bm, int ldb, float
                         int nsplit, int conv_L, int conv_cin, hipStream_t s);
 int launch_colsum_partial(const float *A, float *part, int M, int N, int nsplit, hipStream_t s);
 int launch_reduce_partials(const float *part, int nsplit, int n, const int *map, const int *map2, float *grad, hipStream_t s);
+int launch_reduce_partials_2stage(const float *part, int nsplit, int n, const int *map, const int *map2, float *grad, float *tmp,
+                                  int chunks, hipStream_t s);
 
 int head_bwd_partial_floats(const csa_config &c);
 int launch_head_bwd(const DevModel &m, int B, const float *d_out, const float *d_out_sfc, const float *d_mem_out,

@@ -44,6 +44,7 @@ struct csa_trainer {
     std::vector<Slot> slots;
     // work buffers
     float *dH2, *dH1, *dX1, *dhc1, *dhc2, *part, *samp, *ecoef, *sp;
+    float *rtmp = nullptr;           // first-stage sums of the per-column partial reductions
     size_t part_floats;
     int nsplit;
     // deferred weight gradients (csa_train_set_deferred): the W_ih / W_hh gradient GEMMs of the backward calls are
@@ -342,6 +343,7 @@ extern "C" int csa_train_create(const csa_config *cfg, const csa_params *p, cons
     const size_t pcol = Bm * (size_t)std::max(head_bwd_partial_floats(c), prep_bwd_partial_floats(c));
     h->part_floats = pf > pcol ? pf : pcol;
     h->part = dalloc<float>(h, h->part_floats, rc);
+    h->rtmp = dalloc<float>(h, (size_t)32 * std::max(head_bwd_partial_floats(c), prep_bwd_partial_floats(c)), rc);
     h->samp = dalloc<float>(h, (size_t)max_window * Bm * 9, rc);
     h->ecoef = dalloc<float>(h, Bm, rc);
     h->sp = dalloc<float>(h, (size_t)max_window * Bm, rc);
@@ -436,7 +438,7 @@ extern "C" int csa_train_backward(csa_trainer *h, int slot, int B, const float *
     int rc;
     // head
     if ((rc = launch_head_bwd(h->dm, B, d_out, d_out_sfc, d_mem_out, S.Z, S.H2 + (size_t)B * nh2, h->dH2, h->part, s))) return rc;
-    if ((rc = launch_reduce_partials(h->part, B, head_bwd_partial_floats(c), h->map_head, nullptr, grads, s))) return rc;
+    if ((rc = launch_reduce_partials_2stage(h->part, B, head_bwd_partial_floats(c), h->map_head, nullptr, grads, h->rtmp, 32, s))) return rc;
     // rnn2 (downward): BPTT, then input / weight gradients from dP2 (stored in place in GP2)
     if (c.use_lstm) {
         if ((rc = launch_bwd_rec(nh2, h->whh2Tp, S.GP2, S.C2, h->dH2, h->dhc2, h->dhc2 + (size_t)B * nhm, B, L, 0, s))) return rc;
@@ -474,7 +476,7 @@ extern "C" int csa_train_backward(csa_trainer *h, int slot, int B, const float *
     if ((rc = launch_reduce_partials(h->part, ns, 4 * nh1, h->map_b1a, h->map_b1b, grads, s))) return rc;
     // mlp_initial / surface / TOA MLPs, gradient w.r.t. the incoming memory
     if ((rc = launch_prep_bwd(h->dm, B, h->dX1, S.X1, S.X16, S.xs, S.hc0, h->dhc1, h->dhc2, d_mem_in, h->part, s))) return rc;
-    return launch_reduce_partials(h->part, B, prep_bwd_partial_floats(c), h->map_prep, nullptr, grads, s);
+    return launch_reduce_partials_2stage(h->part, B, prep_bwd_partial_floats(c), h->map_prep, nullptr, grads, h->rtmp, 32, s);
 }
 
 extern "C" int csa_train_set_deferred(csa_trainer *h, int enable)

@@ -189,6 +189,28 @@ __global__ void reduce_partials_kernel(const float *__restrict__ part, int nspli
     if (d >= 0) grad[d] += a;
     if (map2) { const int d2 = map2[i]; if (d2 >= 0) grad[d2] += a; }
 }
+// first stage for MANY partials (one per column: head / prep backward): chunk c of `chunks` sums its contiguous run of
+// partials into tmp[c][i]; the ordinary reduction then finishes over `chunks`.  Fixed order -> deterministic.
+__global__ void reduce_stage1_kernel(const float *__restrict__ part, int nsplit, int n, int per, float *__restrict__ tmp)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x, c = blockIdx.y;
+    if (i >= n) return;
+    const int s0 = c * per, s1 = min(nsplit, s0 + per);
+    float a0 = 0.0f, a1 = 0.0f;
+    int s = s0;
+    for (; s + 1 < s1; s += 2) { a0 += part[(size_t)s * n + i]; a1 += part[(size_t)(s + 1) * n + i]; }
+    if (s < s1) a0 += part[(size_t)s * n + i];
+    tmp[(size_t)c * n + i] = a0 + a1;
+}
+int launch_reduce_partials_2stage(const float *part, int nsplit, int n, const int *map, const int *map2, float *grad, float *tmp,
+                                  int chunks, hipStream_t s)
+{
+    if (nsplit <= chunks || !tmp) return launch_reduce_partials(part, nsplit, n, map, map2, grad, s);
+    const int per = (nsplit + chunks - 1) / chunks;
+    hipLaunchKernelGGL(reduce_stage1_kernel, dim3((n + 255) / 256, chunks), dim3(256), 0, s, part, nsplit, n, per, tmp);
+    return launch_reduce_partials(tmp, chunks, n, map, map2, grad, s);
+}
+
 int launch_reduce_partials(const float *part, int nsplit, int n, const int *map, const int *map2, float *grad, hipStream_t s)
 {
     hipLaunchKernelGGL(reduce_partials_kernel, dim3((n + 255) / 256), dim3(256), 0, s, part, nsplit, n, map, map2, grad);
