@@ -22,6 +22,9 @@
 #define GB_LD (GB_K + 1)
 #define GB_THREADS 256
 
+// MI = 32-row MFMA sub-tiles per wave in M: 2 -> 128x128 block tile (default), 1 -> 64x128 (problems whose 128-row
+// tiling would leave CUs without work: the input-gradient GEMMs of training, N <= 144, K = 512)
+template <int MI>
 __global__ __launch_bounds__(GB_THREADS) void proj_gemm_kernel(
     const float *__restrict__ A, const float *__restrict__ W, const float *__restrict__ bias,
     float *__restrict__ C, int M, int N, int K, int tiles_m, int tiles_n, int act, float alpha, int n_lin,
@@ -42,7 +45,8 @@ __global__ __launch_bounds__(GB_THREADS) void proj_gemm_kernel(
     // (the Keras MLP baseline's Dense(120,linear) || Dense(8,relu) output, step2_retrain.py:118-121)
     // double-buffered LDS: chunk c+1 is written while chunk c is being multiplied -> one barrier
     // per 16-deep K chunk (8 k-steps x 4 MFMA = 2048 MFMA cycles per wave between barriers)
-    __shared__ float As[2][GB_M * GB_LD];
+    constexpr int TM = 64 * MI;
+    __shared__ float As[2][TM * GB_LD];
     __shared__ float Ws[2][GB_N * GB_LD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
@@ -54,7 +58,7 @@ __global__ __launch_bounds__(GB_THREADS) void proj_gemm_kernel(
         const int nwg = tiles_m * tiles_n;
         if (nwg % 8 == 0) bid = (bid & 7) * (nwg >> 3) + (bid >> 3);
     }
-    const int m0 = (bid / tiles_n) * GB_M, n0 = (bid % tiles_n) * GB_N;
+    const int m0 = (bid / tiles_n) * TM, n0 = (bid % tiles_n) * GB_N;
 
     // staging map: thread -> (row r, r+64; k quad kq)
     const int lr = tid >> 2, kq = (tid & 3) * 4;
@@ -69,7 +73,7 @@ __global__ __launch_bounds__(GB_THREADS) void proj_gemm_kernel(
                 ok = !((l == 0 && k < conv_cin) || (l == conv_L - 1 && k >= 2 * conv_cin));
             }
             const float *ap = conv_L > 0 ? A + ((long)row - 1) * lda + k : A + (size_t)row * lda + k;
-            ra[i] = ok ? *(const f32x4 *)ap : f32x4{0, 0, 0, 0};
+            if (i < MI) ra[i] = ok ? *(const f32x4 *)ap : f32x4{0, 0, 0, 0};
             rw[i] = (col < N && k < K) ? *(const f32x4 *)(W + (size_t)col * K + k) : f32x4{0, 0, 0, 0};
         }
     };
@@ -78,20 +82,20 @@ __global__ __launch_bounds__(GB_THREADS) void proj_gemm_kernel(
         for (int i = 0; i < 2; ++i) {
             float *pa = As[buf] + (lr + 64 * i) * GB_LD + kq;
             float *pw = Ws[buf] + (lr + 64 * i) * GB_LD + kq;
-            pa[0] = ra[i].x; pa[1] = ra[i].y; pa[2] = ra[i].z; pa[3] = ra[i].w;
+            if (i < MI) { pa[0] = ra[i].x; pa[1] = ra[i].y; pa[2] = ra[i].z; pa[3] = ra[i].w; }
             pw[0] = rw[i].x; pw[1] = rw[i].y; pw[2] = rw[i].z; pw[3] = rw[i].w;
         }
     };
 
-    f32x16 acc[2][2];
+    f32x16 acc[MI][2];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
-    const int arow = (wm * 64 + (lane & 31)) * GB_LD + (lane >> 5);
+    const int arow = (wm * 32 * MI + (lane & 31)) * GB_LD + (lane >> 5);
     const int wrow = (wn * 64 + (lane & 31)) * GB_LD + (lane >> 5);
 
 #ifdef GEMM_EXP_STAGGER   /* diagnostic: de-phase co-resident workgroups (convoy test) */
@@ -116,13 +120,15 @@ __global__ __launch_bounds__(GB_THREADS) void proj_gemm_kernel(
 #ifdef GEMM_EXP_NO_LDSREAD   /* diagnostic builds only (tools/): wrong results, timing of the remaining parts */
             const float a0 = 1e-3f * (lane + kk + c), a1 = a0 + 1.0f, b0 = a0 * 0.5f, b1 = a0 + 2.0f;
 #else
-            const float a0 = as[arow + kk * 2], a1 = as[arow + 32 * GB_LD + kk * 2];
+            const float a0 = as[arow + kk * 2], a1 = MI > 1 ? as[arow + 32 * GB_LD + kk * 2] : 0.0f;
             const float b0 = ws[wrow + kk * 2], b1 = ws[wrow + 32 * GB_LD + kk * 2];
 #endif
             acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
             acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+            if constexpr (MI > 1) {
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+            }
         }
 #ifndef GEMM_EXP_NO_GLOAD
         if (c + 1 < nchunk) sstore(cur ^ 1);
@@ -145,7 +151,7 @@ __global__ __launch_bounds__(GB_THREADS) void proj_gemm_kernel(
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < MI; ++i)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 float v = acc[i][j][r] + bv[j];
@@ -157,19 +163,19 @@ __global__ __launch_bounds__(GB_THREADS) void proj_gemm_kernel(
 #ifdef GEMM_EXP_NO_STORE   /* diagnostic: keep the accumulators alive, store one value per wave */
     {
         float t = 0.0f;
-        for (int j = 0; j < 2; ++j) for (int i = 0; i < 2; ++i) for (int r = 0; r < 16; ++r) t += acc[i][j][r];
+        for (int j = 0; j < 2; ++j) for (int i = 0; i < MI; ++i) for (int r = 0; r < 16; ++r) t += acc[i][j][r];
         if (t == 123.456f) C[0] = t;
         return;
     }
 #endif
     const bool plain = !epi.addsrc && !epi.mask && !epi.gate;
-    const bool interior = (m0 + GB_M <= M) && (n0 + GB_N <= N) && plain;
+    const bool interior = (m0 + TM <= M) && (n0 + GB_N <= N) && plain;
     if (interior) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            float *cp = C + (size_t)(m0 + wm * 64 + 4 * (lane >> 5)) * ldc + n0 + wn * 64 + j * 32 + (lane & 31);
+            float *cp = C + (size_t)(m0 + wm * 32 * MI + 4 * (lane >> 5)) * ldc + n0 + wn * 64 + j * 32 + (lane & 31);
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < MI; ++i)
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
                     cp[(size_t)(i * 32 + (r & 3) + 8 * (r >> 2)) * ldc] = acc[i][j][r];
@@ -179,10 +185,10 @@ __global__ __launch_bounds__(GB_THREADS) void proj_gemm_kernel(
         for (int j = 0; j < 2; ++j) {
             const int col = n0 + wn * 64 + j * 32 + (lane & 31);
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < MI; ++i)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    const int row = m0 + wm * 32 * MI + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                     if (row < M && col < N) {
                         const size_t idx = (size_t)row * ldc + col;
                         float v = acc[i][j][r];
@@ -241,14 +247,23 @@ int launch_gemm_epi(const float *A, const float *W, const float *bias, float *C,
         csa_set_error_msg("proj_gemm: K must be a multiple of 4");
         return CSA_ERR_UNSUPPORTED;
     }
-    const int tiles_m = (M + GB_M - 1) / GB_M, tiles_n = (N + GB_N - 1) / GB_N;
+    int tiles_m = (M + GB_M - 1) / GB_M;
+    const int tiles_n = (N + GB_N - 1) / GB_N;
+    // narrow outputs (N <= 256) whose 128-row tiling gives the 256 CUs fewer than two workgroups each: 64-row tiles
+    static const int m64 = getenv("CSA_GEMM_M64") ? atoi(getenv("CSA_GEMM_M64")) : 1;
+    const bool half_m = m64 && tiles_n <= 2 && tiles_m * tiles_n < 512 && M > 64;
+    if (half_m) tiles_m = (M + 63) / 64;
 #ifdef GEMM_EXP_EXTRA_LDS
     static const int extra_lds = getenv("CSA_GEMM_EXTRA_LDS") ? atoi(getenv("CSA_GEMM_EXTRA_LDS")) : 0;   // diagnostic: caps occupancy
 #else
     const int extra_lds = 0;
 #endif
-    hipLaunchKernelGGL(proj_gemm_kernel, dim3(tiles_m * tiles_n), dim3(GB_THREADS), extra_lds, s, A, W, bias, C, M, N, K,
-                       tiles_m, tiles_n, act, alpha, n_lin, lda, ldc, conv_L, conv_cin, epi);
+    if (half_m)
+        hipLaunchKernelGGL(proj_gemm_kernel<1>, dim3(tiles_m * tiles_n), dim3(GB_THREADS), extra_lds, s, A, W, bias, C, M, N, K,
+                           tiles_m, tiles_n, act, alpha, n_lin, lda, ldc, conv_L, conv_cin, epi);
+    else
+        hipLaunchKernelGGL(proj_gemm_kernel<2>, dim3(tiles_m * tiles_n), dim3(GB_THREADS), extra_lds, s, A, W, bias, C, M, N, K,
+                           tiles_m, tiles_n, act, alpha, n_lin, lda, ldc, conv_L, conv_cin, epi);
     CSA_HIP_CHECK(hipGetLastError());
     return CSA_OK;
 }
