@@ -186,6 +186,18 @@ def aux_workload(a, rank, world, dist):
         def step():
             m(x)
         flop_col, what = 2.0 * sum(dims[i] * dims[i + 1] for i in range(len(dims) - 1)), "Keras MLP baseline forward"
+    elif a.workload == "online_mlp_384":
+        from climsim_amd.online import MLP, NewModel
+        n_in, hidden = 557, [384, 1024, 640]              # v2_rh input vector, slurm/v2rh_mlp_*_3l_lr1em3.sbatch widths
+        mm = MLP(n_in, 368, hidden, 3, output_prune=True, strato_lev_out=12)
+        m = NewModel(mm, torch.zeros(n_in).numpy(), torch.ones(n_in).numpy(), torch.ones(368).numpy(),
+                     torch.full((60,), 1e4).numpy(), torch.full((60,), 1e4).numpy(), max_batch=B)
+        x = torch.randn(B, n_in, generator=g).cuda()
+
+        def step():
+            m(x)
+        dims = [n_in] + hidden + [368]
+        flop_col, what = 2.0 * sum(dims[i] * dims[i + 1] for i in range(len(dims) - 1)), "online MLP_v2rh wrapper forward (B, 557) -> (B, 368)"
     elif a.workload == "cnn_train_384":
         from climsim_amd.baselines import CNNTrainer
         depth, width = 12, 406
@@ -245,7 +257,7 @@ def aux_workload(a, rank, world, dist):
             flush=True)
 
 
-AUX = ["cur_lstm144_384", "cur_lstm128_384", "cur_gru128_384", "mlp_384", "cnn_384", "cnn_train_384"]
+AUX = ["cur_lstm144_384", "cur_lstm128_384", "cur_gru128_384", "mlp_384", "online_mlp_384", "cnn_384", "cnn_train_384"]
 
 
 def main():

@@ -42,6 +42,8 @@ SYMBOLS = ["csa_create", "csa_destroy", "csa_set_params", "csa_packed_width", "c
            "csa_cnn_train_adam",
            "csa_gen_create", "csa_gen_destroy", "csa_gen_dims", "csa_gen_batch",
            "csa_crps",
+           "csa_eval_scratch_bytes", "csa_eval_metrics", "csa_eval_crps",
+           "csa_online_create", "csa_online_destroy", "csa_online_dims", "csa_online_forward",
            "csa_stoch_gru5_create", "csa_stoch_lstm4_create", "csa_stoch_destroy", "csa_stoch_gru5_forward",
            "csa_stoch_lstm4_forward"]
 
@@ -163,6 +165,15 @@ def lib():
     L.csa_gen_dims.argtypes = [H, PI, PI, PI]
     L.csa_gen_batch.argtypes = [H, i] + [_F] * 11 + [ctypes.c_void_p]
     L.csa_crps.argtypes = [i, i, i, i, i, _F, _F, _F, _F, fl, fl, _F, _F, ctypes.c_void_p]
+    L.csa_eval_scratch_bytes.argtypes = [i, i, i, i]
+    L.csa_eval_scratch_bytes.restype = ctypes.c_long
+    L.csa_eval_metrics.argtypes = [i, i, i, _F, _F, i, ctypes.c_void_p, _F, ctypes.c_void_p]
+    L.csa_eval_crps.argtypes = [i, i, i, i, _F, _F, i, ctypes.c_void_p, _F, ctypes.c_void_p]
+    U8 = ctypes.POINTER(ctypes.c_ubyte)
+    L.csa_online_create.argtypes = [i, i, ctypes.POINTER(i), PP, PP, _F, _F, _F, U8, fl, fl, _F, U8, i, i, ctypes.POINTER(H)]
+    L.csa_online_destroy.argtypes = [H]
+    L.csa_online_dims.argtypes = [H, ctypes.POINTER(i), ctypes.POINTER(i)]
+    L.csa_online_forward.argtypes = [H, i, _F, _F, ctypes.c_void_p]
     L.csa_stoch_gru5_create.argtypes = [i, i, Fp, Fp, Fp, Fp, Fp, i, ctypes.POINTER(H)]
     L.csa_stoch_lstm4_create.argtypes = [i, i, Fp, i, ctypes.POINTER(H)]
     L.csa_stoch_destroy.argtypes = [H]

@@ -298,6 +298,35 @@ int csa_gen_batch(csa_generator *h, int N, const float *x_lev, const float *x_sf
 int csa_crps(int T, int B, int E, int D_lev, int D_sfc, const float *y, const float *y_sfc, const float *y_pred,
              const float *y_sfc_pred, float beta, float alpha, float *scratch, float *out, void *stream);
 
+/* ---- evaluation scores of data_utils ---------------------------------------------------------
+ * climsim_utils/data_utils.py:1843-1935 calc_MAE / calc_RMSE / calc_R2 / calc_bias / calc_CRPS.  pred, target:
+ * (T, G, L) device floats (time, grid column, level; scalars L = 1); reductions over time per (grid, level) cell, then
+ * with avg_grid != 0 the mean over grid.  csa_eval_metrics: out (4, G, L) or (4, L), rows MAE, RMSE, R2, bias.
+ * csa_eval_crps: samplepreds (T, G, L, S), out (G, L) or (L).  scratch: csa_eval_scratch_bytes(T, G, L, S) device bytes
+ * (S = 0 for csa_eval_metrics). */
+long csa_eval_scratch_bytes(int T, int G, int L, int S);
+int csa_eval_metrics(int T, int G, int L, const float *pred, const float *target, int avg_grid, void *scratch,
+                     float *out, void *stream);
+int csa_eval_crps(int T, int G, int L, int S, const float *samplepreds, const float *target, int avg_grid,
+                  void *scratch, float *out, void *stream);
+
+/* ---- generic online wrapper (SURVEY section 8b "generic online": forward(x (B, n_in)) -> (B, 368)) ------------------
+ * online_testing/model_postprocessing/v4_nn_wrapper.ipynb cell 5 (NewModel.preprocessing / forward / postprocessing)
+ * around online_testing/baseline_models/MLP_v2rh/training/mlp.py:25-67 (Linear + ReLU layers, final Linear, ReLU on the
+ * last n_relu_tail outputs); host contract online_testing/README.md:47-50.
+ * Per input column j: x = in_lbd[j] != 0 ? 1 - exp(-x in_lbd[j]) : x;  x = (x - in_sub[j]) / in_div[j];  NaN/Inf -> 0;
+ * in_flags[j] bit 0: x = 0 (pruned level), bit 1: x = clamp(x, clip_lo, clip_hi).  Per output column j:
+ * y = (out_keep[j] ? y : 0) / out_scale[j].  weights[l]: (dims[l+1], dims[l]) row-major HOST pointers, dims[0] = n_in
+ * (any value; padded to a multiple of 4 internally), dims[1..nlayers-1] multiples of 4.  x is not modified. */
+typedef struct csa_online csa_online;
+int csa_online_create(int n_in, int nlayers, const int *dims, const float *const *weights, const float *const *biases,
+                      const float *in_sub, const float *in_div, const float *in_lbd, const unsigned char *in_flags,
+                      float clip_lo, float clip_hi, const float *out_scale, const unsigned char *out_keep,
+                      int n_relu_tail, int max_batch, csa_online **out);
+int csa_online_destroy(csa_online *h);
+int csa_online_dims(const csa_online *h, int *n_in, int *n_out);
+int csa_online_forward(csa_online *h, int B, const float *x, float *y, void *stream);
+
 /* ---- stochastic recurrent layers ---------------------------------------------------
  * MyStochasticGRULayer5  rnn/models_torch_kernels.py:834-891 (its GPU path = the repo's inline CUDA, :29-252)
  * MyStochasticLSTMLayer4 rnn/models_torch_kernels.py:1474-1531
