@@ -82,3 +82,92 @@ extern "C" int csa_crps(int T, int B, int E, int D_lev, int D_sfc, const float *
     CSA_HIP_CHECK(hipGetLastError());
     return CSA_OK;
 }
+
+// ------------------------------------------------------------------------------------------------------------------
+// rnn/metrics.py:509-533 compute_spread_skill_ratio (logged next to the ensemble score in the stochastic training loop,
+// rnn/utils.py:1214-1215) and rnn/metrics.py:628-699 CRPS_l1 (the two-member L1 form: mean|z_e - z| - 0.5 mean|z_0 - z_1|).
+// One pass over the ensemble outputs: a thread owns one (sample, feature) cell, walks its E members (consecutive lanes ->
+// consecutive features: coalesced) and produces the unbiased member variance (shifted by member 0, so no cancellation),
+// the squared error of the member mean, the summed |z_e - z| and |z_0 - z_1|; float64 workgroup partials in a fixed
+// tree order, a single-workgroup second pass adds them in a fixed order (deterministic).
+#define SS_BLOCKS 1024
+
+__global__ __launch_bounds__(256) void spread_skill_partial_kernel(
+    const float *__restrict__ y, const float *__restrict__ ys, const float *__restrict__ yp, const float *__restrict__ yps,
+    double *__restrict__ part, int T, int B, int E, int D1, int D2)
+{
+    __shared__ double red[4][256];
+    const int D = D1 + D2, tid = threadIdx.x;
+    const long total = (long)T * B * D;
+    double a_var = 0.0, a_se = 0.0, a_l1 = 0.0, a_d01 = 0.0;
+    for (long c = (long)blockIdx.x * 256 + tid; c < total; c += (long)gridDim.x * 256) {
+        const long n = c / D;
+        const int d = (int)(c - n * D), t = (int)(n / B), b = (int)(n - (long)t * B);
+        const float yt = d < D1 ? y[n * D1 + d] : ys[n * D2 + (d - D1)];
+        float x0 = 0.0f, x1 = 0.0f, s1 = 0.0f, s2 = 0.0f, l1 = 0.0f;
+        for (int e = 0; e < E; ++e) {
+            const long r = ((long)t * E + e) * B + b;
+            const float x = d < D1 ? yp[r * D1 + d] : yps[r * D2 + (d - D1)];
+            if (e == 0) x0 = x;
+            if (e == 1) x1 = x;
+            const float u = x - x0;
+            s1 += u;
+            s2 += u * u;
+            l1 += fabsf(x - yt);
+        }
+        const float mean = x0 + s1 / (float)E;
+        a_var += E > 1 ? (double)((s2 - s1 * s1 / (float)E) / (float)(E - 1)) : 0.0;
+        a_se += (double)(mean - yt) * (double)(mean - yt);
+        a_l1 += l1;
+        a_d01 += E > 1 ? fabsf(x0 - x1) : 0.0f;
+    }
+    red[0][tid] = a_var; red[1][tid] = a_se; red[2][tid] = a_l1; red[3][tid] = a_d01;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (tid < s) for (int k = 0; k < 4; ++k) red[k][tid] += red[k][tid + s];
+        __syncthreads();
+    }
+    if (tid < 4) part[4 * (size_t)blockIdx.x + tid] = red[tid][0];
+}
+
+__global__ __launch_bounds__(256) void spread_skill_final_kernel(const double *__restrict__ part, int nblk, double cells, int E,
+                                                                 float *__restrict__ out)
+{
+    __shared__ double red[4][256];
+    const int tid = threadIdx.x;
+    double a[4] = {0, 0, 0, 0};
+    for (int i = tid; i < nblk; i += 256) for (int k = 0; k < 4; ++k) a[k] += part[4 * (size_t)i + k];
+    for (int k = 0; k < 4; ++k) red[k][tid] = a[k];
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (tid < s) for (int k = 0; k < 4; ++k) red[k][tid] += red[k][tid + s];
+        __syncthreads();
+    }
+    if (tid == 0) {
+        out[0] = (float)(sqrt(red[0][0] / cells) * sqrt((double)(E + 1) / (double)E));   // spread, with the sqrt((M+1)/M) correction
+        out[1] = (float)sqrt(red[1][0] / cells);                                         // RMSE of the member mean
+        const double skill = red[2][0] / (cells * E), d01 = red[3][0] / cells;
+        out[2] = (float)(skill - 0.5 * d01);                                             // CRPS_l1 (meaningful for E = 2, as in the reference)
+        out[3] = (float)skill;
+    }
+}
+
+// same tensor arguments as csa_crps; scratch: 4 * 1024 doubles (32 KB); out: 4 device floats
+// [spread, rmse (compute_spread_skill_ratio), CRPS_l1, its skill term]
+extern "C" int csa_spread_skill(int T, int B, int E, int D_lev, int D_sfc, const float *y, const float *y_sfc,
+                                const float *y_pred, const float *y_sfc_pred, void *scratch, float *out, void *stream)
+{
+    if (T <= 0 || B <= 0 || E <= 0 || D_lev <= 0 || D_sfc < 0 || !y || !y_pred || (D_sfc > 0 && (!y_sfc || !y_sfc_pred)) || !scratch || !out) {
+        csa_set_error_msg("csa_spread_skill: bad argument");
+        return CSA_ERR_ARG;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    const double cells = (double)T * B * (D_lev + D_sfc);
+    const long nb = ((long)cells + 255) / 256;
+    const int nblk = (int)(nb < SS_BLOCKS ? nb : SS_BLOCKS);
+    hipLaunchKernelGGL(spread_skill_partial_kernel, dim3(nblk), dim3(256), 0, s, y, y_sfc, y_pred, y_sfc_pred, (double *)scratch,
+                       T, B, E, D_lev, D_sfc);
+    hipLaunchKernelGGL(spread_skill_final_kernel, dim3(1), dim3(256), 0, s, (const double *)scratch, nblk, cells, E, out);
+    CSA_HIP_CHECK(hipGetLastError());
+    return CSA_OK;
+}

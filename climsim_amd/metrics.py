@@ -1,4 +1,5 @@
-"""Device-side mirror of the reference's ensemble score (rnn/metrics.py:535-626), evaluation only."""
+"""Device-side mirror of the reference's ensemble scores (rnn/metrics.py: CRPS :535-626, compute_spread_skill_ratio
+:509-533, CRPS_l1 :628-699), evaluation only."""
 import ctypes
 
 import torch
@@ -25,3 +26,32 @@ def CRPS(y, y_sfc, y_pred, y_sfc_pred, timesteps, beta=1, alpha=1.0, return_term
     if rc != 0:
         raise RuntimeError(f"csa_crps failed ({rc}): {_lib.last_error()}")
     return (out[0], out[1], out[2]) if return_terms else out[0]
+
+
+def _ens_scores(y, y_sfc, y_pred, y_sfc_pred, timesteps):
+    ns, L, F = y.shape
+    B = ns // timesteps
+    E = y_pred.shape[0] // (timesteps * B)
+    y = _check(y, (ns, L, F), "y")
+    y_sfc = _check(y_sfc, (ns, y_sfc.shape[-1]), "y_sfc")
+    y_pred = _check(y_pred, (timesteps * E * B, L, F), "y_pred")
+    y_sfc_pred = _check(y_sfc_pred, (timesteps * E * B, y_sfc.shape[-1]), "y_sfc_pred")
+    scratch = torch.empty(4 * 1024, dtype=torch.float64, device=y.device)
+    out = torch.empty(4, device=y.device)
+    rc = _lib.lib().csa_spread_skill(timesteps, B, E, L * F, y_sfc.shape[-1], _ptr(y), _ptr(y_sfc), _ptr(y_pred),
+                                     _ptr(y_sfc_pred), ctypes.c_void_p(scratch.data_ptr()), _ptr(out),
+                                     ctypes.c_void_p(torch.cuda.current_stream(y.device).cuda_stream))
+    if rc != 0:
+        raise RuntimeError(f"csa_spread_skill failed ({rc}): {_lib.last_error()}")
+    return out
+
+
+def compute_spread_skill_ratio(y, y_sfc, y_pred, y_sfc_pred, timesteps):
+    """rnn/metrics.py:509-533: (spread, rmse) of the ensemble, same arguments and return order."""
+    out = _ens_scores(y, y_sfc, y_pred, y_sfc_pred, timesteps)
+    return out[0], out[1]
+
+
+def CRPS_l1(y, y_sfc, y_pred, y_sfc_pred, timesteps, beta=1):
+    """rnn/metrics.py:628-699: skill - 0.5 * |member 0 - member 1| (the reference assumes two members; beta is unused there too)."""
+    return _ens_scores(y, y_sfc, y_pred, y_sfc_pred, timesteps)[2]

@@ -298,6 +298,12 @@ int csa_gen_batch(csa_generator *h, int N, const float *x_lev, const float *x_sf
 int csa_crps(int T, int B, int E, int D_lev, int D_sfc, const float *y, const float *y_sfc, const float *y_pred,
              const float *y_sfc_pred, float beta, float alpha, float *scratch, float *out, void *stream);
 
+/* rnn/metrics.py:509-533 compute_spread_skill_ratio and rnn/metrics.py:628-699 CRPS_l1 on the same tensors as csa_crps.
+ * scratch: 32 KB device; out: 4 device floats [spread (with the sqrt((E+1)/E) correction), RMSE of the member mean,
+ * CRPS_l1 = mean|z_e - z| - 0.5 mean|z_0 - z_1|, its skill term]. */
+int csa_spread_skill(int T, int B, int E, int D_lev, int D_sfc, const float *y, const float *y_sfc, const float *y_pred,
+                     const float *y_sfc_pred, void *scratch, float *out, void *stream);
+
 /* ---- evaluation scores of data_utils ---------------------------------------------------------
  * climsim_utils/data_utils.py:1843-1935 calc_MAE / calc_RMSE / calc_R2 / calc_bias / calc_CRPS.  pred, target:
  * (T, G, L) device floats (time, grid column, level; scalars L = 1); reductions over time per (grid, level) cell, then
