@@ -43,6 +43,7 @@ SYMBOLS = ["csa_create", "csa_destroy", "csa_set_params", "csa_packed_width", "c
            "csa_gen_create", "csa_gen_destroy", "csa_gen_dims", "csa_gen_batch",
            "csa_crps", "csa_spread_skill",
            "csa_eval_scratch_bytes", "csa_eval_metrics", "csa_eval_crps",
+           "csa_phys_create", "csa_phys_destroy", "csa_phys_forward", "csa_phys_tap",
            "csa_online_create", "csa_online_destroy", "csa_online_dims", "csa_online_forward",
            "csa_stoch_gru5_create", "csa_stoch_lstm4_create", "csa_stoch_destroy", "csa_stoch_gru5_forward",
            "csa_stoch_lstm4_forward"]
@@ -172,6 +173,10 @@ def lib():
     L.csa_eval_crps.argtypes = [i, i, i, i, _F, _F, i, ctypes.c_void_p, _F, ctypes.c_void_p]
     U8 = ctypes.POINTER(ctypes.c_ubyte)
     L.csa_online_create.argtypes = [i, i, ctypes.POINTER(i), PP, PP, _F, _F, _F, U8, fl, fl, _F, U8, i, i, ctypes.POINTER(H)]
+    L.csa_phys_create.argtypes = [i, i, i, i, i, i, PP, i, ctypes.POINTER(H)]
+    L.csa_phys_destroy.argtypes = [H]
+    L.csa_phys_forward.argtypes = [H, i, _F, _F, _F, _F, i, _F, _F, _F, _F, ctypes.c_void_p]
+    L.csa_phys_tap.argtypes = [H, i, i, _F, ctypes.c_void_p]
     L.csa_online_destroy.argtypes = [H]
     L.csa_online_dims.argtypes = [H, ctypes.POINTER(i), ctypes.POINTER(i)]
     L.csa_online_forward.argtypes = [H, i, _F, _F, ctypes.c_void_p]

@@ -1,0 +1,83 @@
+"""Host mirror of the reference's physRNN "Hidden" model (rnn/models/models_phys.py::physical_RNN_autoreg, forward
+:1586-1823) in the geometry of the shipped `rnn/saved_models/physRNN-Hidden_*_script_cpu.pt` artefacts.  Same call
+convention as the TorchScript module: `forward([x_main_norm, x_sfc_norm, rnn_mem, x_denorm]) -> (out, out_sfc, rnn_mem)`;
+the reference draws rnn2's initial state with torch.randn inside forward -- pass `hx2=` to make a call reproducible.
+All arithmetic runs in the HIP library (`csa_phys_*`, csrc/phys.hip); there is no CPU fallback."""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib
+from .emulator import _check, _ptr
+
+_HEADS = ["mlp_qv_crm", "mlp_qn_crm", "mlp_t_crm", "mlp_subgrid_area_frac", "mlp_massflux", "mlp_eddy_diff", "mlp_qice_crm",
+          "mlp_sed_qn_crm", "mlp_evap_prec_crm", "mlp_evap_cond_vapor_crm", "mlp_mp_aa_crm"]
+_ORDER = (["hyam", "hybm", "hyai", "hybi", "yscale_lev", "yscale_sca", "xdiv_sca", "xmean_sca",
+           "mlp_initial.weight", "mlp_initial.bias", "mlp_surface1.weight", "mlp_surface1.bias"]
+          + [f"rnn{r}.{n}_l0" for r in (1, 2) for n in ("weight_ih", "weight_hh", "bias_ih", "bias_hh")]
+          + [f"{m}.{n}" for m in ("mlp_latent", "mlp_output", "mlp_surface_output_rad", "mlp_output_rad", "mlp_precip_release")
+             for n in ("weight", "bias")]
+          + [f"{m}.{n}" for m in _HEADS for n in ("weight", "bias")])
+
+
+class physical_RNN_autoreg(torch.nn.Module):
+    def __init__(self, state_dict, *, ilev_crm=10, mp_ncol=16, nh_mem0=15, max_batch=4096):
+        super().__init__()
+        self._h = None
+        if not torch.cuda.is_available():
+            raise RuntimeError("climsim_amd needs a HIP device: the product path has no CPU fallback")
+        self.device = torch.device("cuda", torch.cuda.current_device())
+        arrs = []
+        for k in _ORDER:
+            if k not in state_dict:
+                raise RuntimeError(f"physRNN state_dict lacks {k}")
+            v = state_dict[k]
+            v = v.detach().cpu().numpy() if isinstance(v, torch.Tensor) else np.asarray(v)
+            arrs.append(np.ascontiguousarray(v, np.float32))
+        sd = dict(zip(_ORDER, arrs))
+        self.nh = sd["mlp_initial.weight"].shape[0]
+        self.nx = sd["mlp_initial.weight"].shape[1] - 1
+        self.nx_sfc = sd["mlp_surface1.weight"].shape[1]
+        self.nlev, self.nlev_mem, self.nh_mem = 60, 60 - ilev_crm, nh_mem0 + 1
+        FP = ctypes.POINTER(ctypes.c_float)
+        warr = (FP * len(arrs))(*[a.ctypes.data_as(FP) for a in arrs])
+        h = ctypes.c_void_p()
+        rc = _lib.lib().csa_phys_create(self.nx, self.nx_sfc, self.nh, int(ilev_crm), int(mp_ncol), int(nh_mem0), warr,
+                                        int(max_batch), ctypes.byref(h))
+        if rc != 0:
+            raise RuntimeError(f"csa_phys_create failed ({rc}): {_lib.last_error()}")
+        self._h, self.max_batch = h, max_batch
+
+    def forward(self, inp_list, hx2=None):
+        x_main, x_sfc, rnn_mem, x_denorm = inp_list[0], inp_list[1], inp_list[2], inp_list[3]
+        B = x_main.shape[0]
+        x_main = _check(x_main, (B, self.nlev, self.nx), "inputs_main")
+        x_sfc = _check(x_sfc, (B, self.nx_sfc), "inputs_aux")
+        rnn_mem = _check(rnn_mem, (B, self.nlev_mem, self.nh_mem), "rnn_mem")
+        x_denorm = _check(x_denorm, (B, self.nlev, x_denorm.shape[-1]), "inputs_denorm")
+        hx2 = torch.randn(B, self.nh, device=self.device) if hx2 is None else _check(hx2, (B, self.nh), "hx2")
+        out = torch.empty(B, self.nlev, 5, device=self.device)
+        out_sfc = torch.empty(B, 8, device=self.device)
+        mem_out = torch.empty(B, self.nlev_mem, self.nh_mem, device=self.device)
+        rc = _lib.lib().csa_phys_forward(self._h, B, _ptr(x_main), _ptr(x_sfc), _ptr(rnn_mem), _ptr(x_denorm),
+                                         int(x_denorm.shape[-1]), _ptr(hx2), _ptr(out), _ptr(out_sfc), _ptr(mem_out),
+                                         ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream))
+        if rc != 0:
+            raise RuntimeError(f"csa_phys_forward failed ({rc}): {_lib.last_error()}")
+        return out, out_sfc, mem_out
+
+    def tap(self, which, B):
+        t = torch.empty(60, B, self.nh, device=self.device)
+        rc = _lib.lib().csa_phys_tap(self._h, which, B, _ptr(t), ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream))
+        if rc != 0:
+            raise RuntimeError(f"csa_phys_tap failed ({rc})")
+        return t
+
+    def __del__(self):
+        try:
+            if self._h is not None:
+                _lib.lib().csa_phys_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass

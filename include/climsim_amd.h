@@ -333,6 +333,29 @@ int csa_online_destroy(csa_online *h);
 int csa_online_dims(const csa_online *h, int *n_in, int *n_out);
 int csa_online_forward(csa_online *h, int B, const float *x, float *y, void *stream);
 
+/* ---- physRNN "Hidden" model, forward -----------------------------------------------------------
+ * rnn/models/models_phys.py:1586-1823 (forward), :414-748 (microphysics_decode), rnn/layers.py:117-168 (pressure layers),
+ * in the geometry of the shipped rnn/saved_models/physRNN-Hidden_*_script_cpu.pt artefacts (GRU 128/128, nx = 21,
+ * ilev_crm = 10, mp_ncol = 16, 15 + 1 memory channels on 50 levels).  w: HOST pointers, PyTorch layouts, in this order:
+ *   hyam(60) hybm(60) hyai(61) hybi(61) yscale_lev(60,5) yscale_sca(8) xdiv_sca(nx_sfc) xmean_sca(nx_sfc)
+ *   mlp_initial.{weight (nh,nx+1), bias} mlp_surface1.{weight (nh,nx_sfc), bias}
+ *   rnn1.{weight_ih_l0 (3nh,nh+15), weight_hh_l0, bias_ih_l0, bias_hh_l0} rnn2.{weight_ih_l0 (3nh,nh), weight_hh_l0, bias_ih_l0, bias_hh_l0}
+ *   mlp_latent.{w (15,nh), b} mlp_output.{w (5,15), b} mlp_surface_output_rad.{w (6,nh), b} mlp_output_rad.{w (1,nh), b}
+ *   mlp_precip_release.{w (1,nh), b}
+ *   then {weight (16,nh), bias} of mlp_qv_crm, mlp_qn_crm, mlp_t_crm, mlp_subgrid_area_frac, mlp_massflux, mlp_eddy_diff,
+ *   mlp_qice_crm, mlp_sed_qn_crm, mlp_evap_prec_crm, mlp_evap_cond_vapor_crm, mlp_mp_aa_crm        (52 pointers)
+ * Forward: device pointers; x_main (B,60,nx) and x_sfc (B,nx_sfc) normalised, rnn_mem (B,50,16) (last channel = stored
+ * water), x_denorm (B,60,nxd) raw inputs (T first, qliq, qice at 2, 3, qv last), hx2 (B,nh) = the N(0,1) draw the
+ * reference makes inside forward for rnn2's initial state.  Outputs out_lev (B,60,5), out_sfc (B,8), mem_out (B,50,16). */
+typedef struct csa_phys csa_phys;
+int csa_phys_create(int nx, int nx_sfc, int nh, int ilev_crm, int mp_ncol, int nh_mem0, const float *const *w,
+                    int max_batch, csa_phys **out);
+int csa_phys_destroy(csa_phys *h);
+int csa_phys_forward(csa_phys *h, int B, const float *x_main, const float *x_sfc, const float *rnn_mem,
+                     const float *x_denorm, int nxd, const float *hx2, float *out_lev, float *out_sfc, float *mem_out,
+                     void *stream);
+int csa_phys_tap(csa_phys *h, int which, int B, float *dst, void *stream);
+
 /* ---- stochastic recurrent layers ---------------------------------------------------
  * MyStochasticGRULayer5  rnn/models_torch_kernels.py:834-891 (its GPU path = the repo's inline CUDA, :29-252)
  * MyStochasticLSTMLayer4 rnn/models_torch_kernels.py:1474-1531

@@ -1,0 +1,52 @@
+#!/usr/bin/env python3
+"""Golden vectors for the physRNN "Hidden" model from the shipped TorchScript artefact itself:
+rnn/saved_models/physRNN-Hidden_lr0.0007.neur128-128_xv4_mp1_num14564_BEST_script_cpu.pt, loaded with torch.jit.load on
+the CPU (pure torch, executes only TorchScript).  The artefact draws rnn2's initial state with torch.randn inside forward;
+the same draw is reproduced here by re-seeding and stored with the inputs.  Stores: weights + buffers (data), seeded
+inputs, outputs.  Fixtures are data only; no reference source text is kept."""
+import os, sys
+import numpy as np
+import torch
+ART = "/root/reference/rnn/saved_models/physRNN-Hidden_lr0.0007.neur128-128_xv4_mp1_num14564_BEST_script_cpu.pt"
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+
+def inputs(P, B, seed):
+    g = torch.Generator().manual_seed(seed)
+    u = lambda *s: torch.rand(*s, generator=g)
+    xd = P["xmean_lev"] + P["xdiv_lev"] * (u(B, 60, 21) - 0.5)
+    xd[:, :, 0] = 200.0 + 100.0 * (torch.arange(60) / 59.0) + 4.0 * (u(B, 60) - 0.5)      # temperature, K
+    xd[:, :, 2] = 2e-5 * u(B, 60) * (u(B, 60) > 0.4)                                        # cloud liquid (with exact zeros)
+    xd[:, :, 3] = 2e-5 * u(B, 60) * (u(B, 60) > 0.4)                                        # cloud ice
+    xd[:, :, -1] = 1e-5 + 5e-3 * u(B, 60) * (torch.arange(60) / 59.0) ** 2                  # specific humidity
+    xm = 1.2 * (u(B, 60, 21) - 0.5)
+    xs = 1.2 * (u(B, 19) - 0.5)
+    mem = 0.3 * torch.randn(B, 50, 16, generator=g)
+    mem[:, :, -1] = (0.5 * u(B, 1)).expand(B, 50)                                           # stored precipitating water
+    return xm, xs, mem, xd.contiguous()
+
+
+def main():
+    m = torch.jit.load(ART, map_location="cpu").eval()
+    P = {k: v.detach().float() for k, v in m.state_dict().items()}
+    d = {"w." + k: v.numpy() for k, v in P.items() if "." not in k or k.split(".")[0].startswith(("mlp", "rnn"))}
+    for a in ("ilev_crm", "mp_ncol", "nh_mem", "nh_mem0", "nlev_mem", "nh_rnn2"):
+        d["attr." + a] = np.array(int(getattr(m, a)), np.int64)
+    for i, (B, seed) in enumerate(((8, 11), (37, 12))):
+        xm, xs, mem, xd = inputs(P, B, seed)
+        torch.manual_seed(1000 + seed)
+        with torch.no_grad():
+            out, out_sfc, mem_out = m([xm.clone(), xs.clone(), mem.clone(), xd.clone()])
+        torch.manual_seed(1000 + seed)
+        hx2 = torch.randn(B, 128)
+        d[f"case{i}.cfg"] = np.array([B, seed], np.int64)
+        for k, v in (("hx2", hx2), ("out", out), ("out_sfc", out_sfc), ("mem_out", mem_out)):
+            d[f"case{i}.{k}"] = v.numpy()
+        print(i, B, out.abs().max().item(), out_sfc.abs().max().item(), mem_out.abs().max().item(), torch.isfinite(out).all().item())
+    np.savez_compressed(f"{OUT}/physrnn_hidden.npz", **d)
+
+
+if __name__ == "__main__":
+    if not os.path.exists(ART):
+        sys.exit("reference not present: golden fixtures can only be regenerated in the build container")
+    main()
