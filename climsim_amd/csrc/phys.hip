@@ -57,30 +57,40 @@ __device__ __forceinline__ float ph_max16(float v)
 __global__ __launch_bounds__(128) void phys_prep_kernel(PhysDev d, int B, const float *__restrict__ x_main, const float *__restrict__ x_sfc,
                                                         const float *__restrict__ mem, float *__restrict__ X1, float *__restrict__ hx)
 {
-    extern __shared__ float sm[];                     // [L][nx+1] inputs incl. pressure feature, then [nx_sfc]
+    // [L][32] inputs incl. the pressure feature, zero-padded to 32 per level; then [64] surface inputs, zero-padded.
+    // The padding makes every inner loop below branch-free with a compile-time trip count: with the runtime bound
+    // (nx + 1 = 22) the compiler emitted one scalar branch and one s_waitcnt per LDS read -- 80 us instead of 13.
+    __shared__ float xin[PH_L * 32];
+    __shared__ float xs[64];
     const int b = blockIdx.x, j = threadIdx.x, nx1 = d.nx + 1, nh = d.nh, K1 = nh + 16;
-    float *xin = sm, *xs = sm + PH_L * nx1;
-    for (int i = j; i < d.nx_sfc; i += 128) xs[i] = x_sfc[(size_t)b * d.nx_sfc + i];
+    for (int i = j; i < PH_L * 32; i += 128) xin[i] = 0.0f;
+    if (j < 64) xs[j] = j < d.nx_sfc ? x_sfc[(size_t)b * d.nx_sfc + j] : 0.0f;
+    __syncthreads();
     for (int i = j; i < PH_L * d.nx; i += 128) {
         const int l = i / d.nx, v = i - l * d.nx;
-        xin[l * nx1 + v] = x_main[(size_t)b * PH_L * d.nx + i];
+        xin[l * 32 + v] = x_main[(size_t)b * PH_L * d.nx + i];
     }
-    __syncthreads();
     const float sp = xs[0] * d.xdiv_sca0 + d.xmean_sca0;
-    for (int l = j; l < PH_L; l += 128) xin[l * nx1 + d.nx] = sqrtf(d.hyam[l] * 100000.0f + sp * d.hybm[l]) / 314.0f;
+    for (int l = j; l < PH_L; l += 128) xin[l * 32 + d.nx] = sqrtf(d.hyam[l] * 100000.0f + sp * d.hybm[l]) / 314.0f;
     __syncthreads();
     if (j < nh) {
         float a = d.s1_b[j];
-        for (int k = 0; k < d.nx_sfc; ++k) a = fmaf(xs[k], d.s1_wt[k * nh + j], a);
+        for (int k0 = 0; k0 < d.nx_sfc; k0 += 8) {
+            float t[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) t[u] = d.s1_wt[min(k0 + u, d.nx_sfc - 1) * nh + j];     // clamped index: xs is zero there
+#pragma unroll
+            for (int u = 0; u < 8; ++u) a = fmaf(xs[k0 + u], t[u], a);
+        }
         hx[(size_t)b * nh + j] = tanhf(a);
         float w[32];
         const float bj = d.init_b[j];
 #pragma unroll
-        for (int k = 0; k < 32; ++k) w[k] = k < nx1 ? d.init_wt[k * nh + j] : 0.0f;
+        for (int k = 0; k < 32; ++k) w[k] = d.init_wt[min(k, nx1 - 1) * nh + j];                  // xin is zero for k >= nx + 1
         for (int l = 0; l < PH_L; ++l) {
             float acc = bj;
 #pragma unroll
-            for (int k = 0; k < 32; ++k) if (k < nx1) acc = fmaf(xin[l * nx1 + k], w[k], acc);
+            for (int k = 0; k < 32; ++k) acc = fmaf(xin[l * 32 + k], w[k], acc);
             X1[((size_t)(PH_L - 1 - l) * B + b) * K1 + j] = tanhf(acc);      // rnn1 runs over the flipped level axis
         }
     }
@@ -104,7 +114,8 @@ __global__ __launch_bounds__(256) void phys_decode_kernel(PhysDev d, int B, cons
     __shared__ float s_out[LC][5], s_pv[LC], s_pd[LC], s_dprec[LC], s_red[8];
     __shared__ float s_area[LC * NC], s_qv[LC * NC], s_qn[LC * NC], s_fH[LC * NC], s_fqv[LC * NC], s_fqn[LC * NC], s_sed[LC * NC];
     __shared__ float s_scal[16];
-    const int b = blockIdx.x, tid = threadIdx.x, ilev = d.ilev, nh = d.nh, nm0 = d.nm0;
+    constexpr int nh = 128, nm0 = 15;                 // enforced by csa_phys_create: compile-time trip counts (see phys_prep_kernel)
+    const int b = blockIdx.x, tid = threadIdx.x, ilev = d.ilev;
     const float CP = 1004.64f, G = 9.80665f, LV = 2510400.0f, LS = 2844000.0f, OOG = 0.1019716213f;
     const float sp = x_sfc[(size_t)b * d.nx_sfc] * d.xdiv_sca0 + d.xmean_sca0;
     const float P_old = mem[((size_t)b * LC + (LC - 1)) * (nm0 + 1) + nm0];
@@ -114,9 +125,12 @@ __global__ __launch_bounds__(256) void phys_decode_kernel(PhysDev d, int B, cons
     for (int l = tid; l < LC; l += 256) {
         const float *hd = HD + ((size_t)(l + ilev) * B + b) * PH_HD + PH_NHEAD * NC;
         float lat[16];
+#pragma unroll
         for (int k = 0; k < nm0; ++k) { lat[k] = hd[k]; mem_out[((size_t)b * LC + l) * (nm0 + 1) + k] = lat[k]; }
+#pragma unroll
         for (int v = 0; v < 5; ++v) {
             float a = d.out_b[v];
+#pragma unroll
             for (int k = 0; k < nm0; ++k) a = fmaf(lat[k], d.out_w[v * nm0 + k], a);
             s_out[l][v] = a;
         }
@@ -127,7 +141,8 @@ __global__ __launch_bounds__(256) void phys_decode_kernel(PhysDev d, int B, cons
         const int o = (tid - 64) >> 3, part = tid & 7;
         const float *w = o < 6 ? d.sfo_w + o * nh : d.rel_w;
         float a = 0.0f;
-        for (int k = part; k < nh; k += 8) a = fmaf(last_h[k], w[k], a);
+#pragma unroll
+        for (int k = 0; k < nh / 8; ++k) a = fmaf(last_h[part + 8 * k], w[part + 8 * k], a);
         a += __shfl_xor(a, 4); a += __shfl_xor(a, 2); a += __shfl_xor(a, 1);
         if (part == 0) s_scal[o] = a + (o < 6 ? d.sfo_b[o] : d.rel_b[0]);
     }
@@ -338,8 +353,7 @@ extern "C" int csa_phys_forward(csa_phys *h, int B, const float *x_main, const f
     const PhysDev &d = h->d;
     const int nh = d.nh, M = PH_L * B;
     int rc;
-    const size_t shm = sizeof(float) * ((size_t)PH_L * (d.nx + 1) + d.nx_sfc);
-    hipLaunchKernelGGL(phys_prep_kernel, dim3(B), dim3(128), shm, s, d, B, x_main, x_sfc, rnn_mem, h->X1, h->hx);
+    hipLaunchKernelGGL(phys_prep_kernel, dim3(B), dim3(128), 0, s, d, B, x_main, x_sfc, rnn_mem, h->X1, h->hx);
     CSA_HIP_CHECK(hipGetLastError());
     auto rec = [&](const float *whh, const float *bhn, const float *h0, float *Hout, int reverse) {
         return B <= 256 ? launch_rec1_gru(nh, whh, bhn, h->P, h0, Hout, B, PH_L, reverse, s)

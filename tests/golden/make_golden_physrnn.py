@@ -7,7 +7,9 @@ inputs, outputs.  Fixtures are data only; no reference source text is kept."""
 import os, sys
 import numpy as np
 import torch
-ART = "/root/reference/rnn/saved_models/physRNN-Hidden_lr0.0007.neur128-128_xv4_mp1_num14564_BEST_script_cpu.pt"
+DIR = "/root/reference/rnn/saved_models/"
+ART = DIR + "physRNN-Hidden_lr0.0007.neur128-128_xv4_mp1_num14564_BEST_script_cpu.pt"
+ART_B = DIR + "physRNN-Hidden_lr0.0007.neur128-128_xv4_mp1_num49672_BEST_script_cpu.pt"    # same graph, another training run
 OUT = os.path.dirname(os.path.abspath(__file__))
 
 
@@ -26,13 +28,13 @@ def inputs(P, B, seed):
     return xm, xs, mem, xd.contiguous()
 
 
-def main():
-    m = torch.jit.load(ART, map_location="cpu").eval()
+def main(art=ART, name="physrnn_hidden", cases=((8, 11), (37, 12))):
+    m = torch.jit.load(art, map_location="cpu").eval()
     P = {k: v.detach().float() for k, v in m.state_dict().items()}
     d = {"w." + k: v.numpy() for k, v in P.items() if "." not in k or k.split(".")[0].startswith(("mlp", "rnn"))}
     for a in ("ilev_crm", "mp_ncol", "nh_mem", "nh_mem0", "nlev_mem", "nh_rnn2"):
         d["attr." + a] = np.array(int(getattr(m, a)), np.int64)
-    for i, (B, seed) in enumerate(((8, 11), (37, 12))):
+    for i, (B, seed) in enumerate(cases):
         xm, xs, mem, xd = inputs(P, B, seed)
         torch.manual_seed(1000 + seed)
         with torch.no_grad():
@@ -43,10 +45,11 @@ def main():
         for k, v in (("hx2", hx2), ("out", out), ("out_sfc", out_sfc), ("mem_out", mem_out)):
             d[f"case{i}.{k}"] = v.numpy()
         print(i, B, out.abs().max().item(), out_sfc.abs().max().item(), mem_out.abs().max().item(), torch.isfinite(out).all().item())
-    np.savez_compressed(f"{OUT}/physrnn_hidden.npz", **d)
+    np.savez_compressed(f"{OUT}/{name}.npz", **d)
 
 
 if __name__ == "__main__":
     if not os.path.exists(ART):
         sys.exit("reference not present: golden fixtures can only be regenerated in the build container")
     main()
+    main(ART_B, "physrnn_hidden_b", ((8, 21),))

@@ -18,8 +18,8 @@ from oracle import physrnn_ref
 BLOCKS = [("out", c) for c in range(5)] + [("out_sfc", None), ("mem_out", None)]
 
 
-def _load():
-    g = np.load(os.path.join(GOLDEN, "physrnn_hidden.npz"))
+def _load(name="physrnn_hidden"):
+    g = np.load(os.path.join(GOLDEN, name + ".npz"))
     P = {k[2:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("w.")}
     return g, P
 
@@ -30,9 +30,13 @@ def _blocks(out, out_sfc, mem):
     return d
 
 
-def test_restatement_reproduces_the_artefact():
-    g, P = _load()
-    for i in range(2):
+FIXTURES = [("physrnn_hidden", 2), ("physrnn_hidden_b", 1)]       # two training runs of the same graph
+
+
+@pytest.mark.parametrize("fixture,ncase", FIXTURES)
+def test_restatement_reproduces_the_artefact(fixture, ncase):
+    g, P = _load(fixture)
+    for i in range(ncase):
         B, seed = (int(v) for v in g[f"case{i}.cfg"])
         xm, xs, mem, xd = inputs(P, B, seed)
         got = _blocks(*physrnn_ref.forward(P, xm, xs, mem, xd, torch.from_numpy(g[f"case{i}.hx2"])))
@@ -52,10 +56,11 @@ def _hip_model(P, max_batch):
 
 
 @pytest.mark.gpu
-def test_hip_physrnn_matches_the_artefact():
-    g, P = _load()
+@pytest.mark.parametrize("fixture,ncase", FIXTURES)
+def test_hip_physrnn_matches_the_artefact(fixture, ncase):
+    g, P = _load(fixture)
     m = _hip_model(P, 64)
-    for i in range(2):
+    for i in range(ncase):
         B, seed = (int(v) for v in g[f"case{i}.cfg"])
         xm, xs, mem, xd = inputs(P, B, seed)
         hx2 = torch.from_numpy(g[f"case{i}.hx2"])
