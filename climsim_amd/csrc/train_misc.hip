@@ -228,7 +228,7 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(
     const float *__restrict__ d_mem_out, const float *__restrict__ Z, const float *__restrict__ H2,
     float *__restrict__ dH2, float *__restrict__ part)
 {
-    extern __shared__ float smem[];
+    extern __shared__ __attribute__((aligned(16))) float smem[];
     const int L = m.cfg.nlev, ny = m.cfg.ny, nys = m.cfg.ny_sfc, nm = m.cfg.nh_mem, nh2 = m.cfg.nh2;
     float *dz = smem;                 // (L, nm)
     float *zs = dz + L * nm;          // (L, nm)
@@ -255,18 +255,48 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(
     for (int idx = tid; idx < L * nm; idx += 256) {
         const int l = idx / nm, j = idx - l * nm;
         float a = d_mem_out ? d_mem_out[((size_t)l * B + b) * nm + j] : 0.0f;
-        for (int v = 0; v < ny; ++v) a += dos[l * ny + v] * m.out_w[v * nm + j];
+        float w[8];
+#pragma unroll
+        for (int v = 0; v < 8; ++v) w[v] = m.out_w[min(v, ny - 1) * nm + j];      // ny <= 8 (launch check); clamped, weight 0 below
+#pragma unroll
+        for (int v = 0; v < 8; ++v) a += (v < ny ? dos[l * ny + min(v, ny - 1)] : 0.0f) * w[v];
         dz[idx] = a;
     }
     __syncthreads();
-    // dH2 = W_lat^T dz (+ W_sfo^T d_out_sfc on the last level)
-    for (int idx = tid; idx < L * nh2; idx += 256) {
-        const int l = idx / nh2, k = idx - l * nh2;
-        float a = 0.0f;
-        for (int j = 0; j < nm; ++j) a += dz[l * nm + j] * m.lat_wt[k * nm + j];
-        if (l == L - 1)
-            for (int v = 0; v < nys; ++v) a += d_out_sfc[(size_t)b * nys + v] * m.sfo_w[v * nh2 + k];
-        dH2[((size_t)l * B + b) * nh2 + k] = a;
+    // dH2 = W_lat^T dz (+ W_sfo^T d_out_sfc on the last level).  Thread -> hidden unit k is FIXED (k = tid mod nh2, 256 / nh2
+    // level groups), so the unit's W_lat column sits in registers for all levels; compile-time trip counts for nm = 16
+    // (with run-time bounds hipcc serialises every global load of the inner loop behind an s_waitcnt).
+    {
+        const int G = 256 / nh2 > 0 ? 256 / nh2 : 1, k = tid % nh2, g = tid / nh2;
+        if (nm == 16 && nh2 <= 256) {
+            if (g < G) {
+                float w[16];
+#pragma unroll
+                for (int j = 0; j < 16; ++j) w[j] = m.lat_wt[k * 16 + j];
+                for (int l = g; l < L; l += G) {
+                    const f32x4 *zr = (const f32x4 *)(dz + l * 16);
+                    float a0 = 0.0f, a1 = 0.0f;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const f32x4 z = zr[q];
+                        a0 += z.x * w[4 * q]; a1 += z.y * w[4 * q + 1]; a0 += z.z * w[4 * q + 2]; a1 += z.w * w[4 * q + 3];
+                    }
+                    float a = a0 + a1;
+                    if (l == L - 1)
+                        for (int v = 0; v < nys; ++v) a += d_out_sfc[(size_t)b * nys + v] * m.sfo_w[v * nh2 + k];
+                    dH2[((size_t)l * B + b) * nh2 + k] = a;
+                }
+            }
+        } else {
+            for (int idx = tid; idx < L * nh2; idx += 256) {
+                const int l = idx / nh2, kk = idx - l * nh2;
+                float a = 0.0f;
+                for (int j = 0; j < nm; ++j) a += dz[l * nm + j] * m.lat_wt[kk * nm + j];
+                if (l == L - 1)
+                    for (int v = 0; v < nys; ++v) a += d_out_sfc[(size_t)b * nys + v] * m.sfo_w[v * nh2 + kk];
+                dH2[((size_t)l * B + b) * nh2 + kk] = a;
+            }
+        }
     }
     // partial weight gradients of this column
     float *p = pp;
@@ -313,6 +343,7 @@ int launch_head_bwd(const DevModel &m, int B, const float *d_out, const float *d
 {
     const csa_config &c = m.cfg;
     if (c.nh_mem <= 0) { csa_set_error_msg("head_bwd: memory model required"); return CSA_ERR_UNSUPPORTED; }
+    if (c.ny > 8) { csa_set_error_msg("head_bwd: at most 8 level outputs"); return CSA_ERR_UNSUPPORTED; }
     const size_t shm = sizeof(float) * (size_t)c.nlev * (2 * c.nh_mem + c.ny + c.nh2);
     hipLaunchKernelGGL(head_bwd_kernel, dim3(B), dim3(256), shm, s, m, B, d_out, d_out_sfc, d_mem_out, Z, H2, dH2, part);
     CSA_HIP_CHECK(hipGetLastError());
@@ -325,18 +356,25 @@ int launch_head_bwd(const DevModel &m, int B, const float *d_out, const float *d
 //   d h0/c0 of rnn1), mlp_toa1/2 (from d h0/c0 of rnn2).
 // partial layout: [W_init nh1*nxp | b_init nh1 | W_s1 nh1*nxs | b_s1 nh1 | W_s2 nh1*nxs | b_s2 nh1 |
 //                  W_toa1 nh2*2 | b_toa1 nh2 | W_toa2 nh2*2 | b_toa2 nh2]
+#define PB_U 12
 __global__ __launch_bounds__(128) void prep_bwd_kernel(
     DevModel m, int B, const float *__restrict__ dX1, const float *__restrict__ X1, const float *__restrict__ X16,
     const float *__restrict__ xs_n, const float *__restrict__ hc0, const float *__restrict__ dhc1,
     const float *__restrict__ dhc2, float *__restrict__ d_mem_in, float *__restrict__ part)
 {
-    extern __shared__ float smem[];
+    extern __shared__ __attribute__((aligned(16))) float smem[];
     const int L = m.cfg.nlev, nxp = m.cfg.nx + 1, nxs = m.cfg.nx_sfc, nh1 = m.cfg.nh1, nh2 = m.cfg.nh2;
     const int nm = m.cfg.nh_mem, nin1 = nh1 + nm, nhm = nh1 > nh2 ? nh1 : nh2;
-    float *x16 = smem;                 // (L, nxp) level order
-    float *xs = x16 + L * nxp;         // (nxs)
+    // (L, 32) level order, rows ZERO-PADDED to 32: the accumulation loop below then has a compile-time trip count and
+    // no branch per element.  With "if (v < nxp)" inside it hipcc emitted a scalar branch + s_waitcnt per LDS read and
+    // serialised the two global loads of every level behind them: 80 us per launch, 3 launches per training step.
+    float *x16 = smem;
+    float *xs = x16 + L * 32;          // (nxs)
     const int b = blockIdx.x, tid = threadIdx.x;
-    for (int idx = tid; idx < L * nxp; idx += 128) x16[idx] = X16[(size_t)b * L * nxp + idx];
+    for (int idx = tid; idx < L * 32; idx += 128) {
+        const int l = idx >> 5, v = idx & 31;
+        x16[idx] = v < nxp ? X16[((size_t)b * L + l) * nxp + v] : 0.0f;
+    }
     for (int v = tid; v < nxs; v += 128) xs[v] = xs_n[(size_t)b * nxs + v];
     __syncthreads();
     float *p = part + (size_t)b * prep_bwd_partial_floats(m.cfg);
@@ -346,14 +384,25 @@ __global__ __launch_bounds__(128) void prep_bwd_kernel(
 #pragma unroll
         for (int v = 0; v < 32; ++v) gw[v] = 0.0f;
         float gb = 0.0f;
-        for (int t = 0; t < L; ++t) {
-            const size_t r = ((size_t)t * B + b) * nin1 + j;
-            const float a = X1[r];
-            const float dA = dX1[r] * (1.0f - a * a);
-            const float *xr = x16 + (L - 1 - t) * nxp;
-            gb += dA;
+        for (int t0 = 0; t0 < L; t0 += PB_U) {
+            float a[PB_U], dx[PB_U];
 #pragma unroll
-            for (int v = 0; v < 32; ++v) if (v < nxp) gw[v] += dA * xr[v];
+            for (int u = 0; u < PB_U; ++u) {           // 2 * PB_U independent loads in flight (clamped index on the tail, weight 0)
+                const size_t r = ((size_t)min(t0 + u, L - 1) * B + b) * nin1 + j;
+                a[u] = X1[r];
+                dx[u] = dX1[r];
+            }
+#pragma unroll
+            for (int u = 0; u < PB_U; ++u) {
+                const float dA = t0 + u < L ? dx[u] * (1.0f - a[u] * a[u]) : 0.0f;
+                const f32x4 *xr = (const f32x4 *)(x16 + (L - 1 - min(t0 + u, L - 1)) * 32);
+                gb += dA;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const f32x4 xv = xr[q];
+                    gw[4 * q] += dA * xv.x; gw[4 * q + 1] += dA * xv.y; gw[4 * q + 2] += dA * xv.z; gw[4 * q + 3] += dA * xv.w;
+                }
+            }
         }
 #pragma unroll
         for (int v = 0; v < 32; ++v) if (v < nxp) p[j * nxp + v] = gw[v];
@@ -392,7 +441,8 @@ __global__ __launch_bounds__(128) void prep_bwd_kernel(
 int launch_prep_bwd(const DevModel &m, int B, const float *dX1, const float *X1, const float *X16, const float *xs_n,
                     const float *hc0, const float *dhc1, const float *dhc2, float *d_mem_in, float *part, hipStream_t s)
 {
-    const size_t shm = sizeof(float) * ((size_t)m.cfg.nlev * (m.cfg.nx + 1) + m.cfg.nx_sfc);
+    if (m.cfg.nx + 1 > 32) { csa_set_error_msg("prep_bwd: at most 31 level inputs"); return CSA_ERR_UNSUPPORTED; }
+    const size_t shm = sizeof(float) * ((size_t)m.cfg.nlev * 32 + m.cfg.nx_sfc);
     hipLaunchKernelGGL(prep_bwd_kernel, dim3(B), dim3(128), shm, s, m, B, dX1, X1, X16, xs_n, hc0, dhc1, dhc2, d_mem_in, part);
     CSA_HIP_CHECK(hipGetLastError());
     return CSA_OK;
