@@ -90,7 +90,14 @@ __global__ __launch_bounds__(HEAD_THREADS) void head_kernel(
         for (int idx = tid; idx < L * ny; idx += HEAD_THREADS) {
             const int l = idx / ny, v = idx - l * ny;
             float a = m.out_b[v];
-            for (int q = 0; q < nm; ++q) a += zs[l * nm + q] * m.out_w[v * nm + q];
+            if (nm == 16) {        // compile-time trip count: the 16 weight loads are issued together (run-time bound: one s_waitcnt each)
+                float w[16];
+#pragma unroll
+                for (int q = 0; q < 16; ++q) w[q] = m.out_w[v * 16 + q];
+#pragma unroll
+                for (int q = 0; q < 16; ++q) a += zs[l * 16 + q] * w[q];
+            } else
+                for (int q = 0; q < nm; ++q) a += zs[l * nm + q] * m.out_w[v * nm + q];
             if (m.cfg.output_prune && l < 12 && v >= 1) a = 0.0f;
             os[idx] = a;
         }
