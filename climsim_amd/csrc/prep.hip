@@ -110,14 +110,26 @@ __global__ __launch_bounds__(PREP_THREADS) void prep_kernel(
     // ---- initial states (first slice only) ---------------------------------------------------
     if (blockIdx.y == 0) {
         for (int j = tid; j < nh1; j += PREP_THREADS) {
-            float a = m.s1_b[j];
-            for (int v = 0; v < nxs; ++v) a += m.s1_wt[v * nh1 + j] * xs[v];
-            hc0[((size_t)0 * B + b) * nhm + j] = tanhf(a);
-            if (m.cfg.use_lstm) {
-                float c = m.s2_b[j];
-                for (int v = 0; v < nxs; ++v) c += m.s2_wt[v * nh1 + j] * xs[v];
-                hc0[((size_t)1 * B + b) * nhm + j] = m.cfg.legacy ? tanhf(c) : c;
+            // chunks of 8 with a clamped weight index and a select on the input: compile-time trip counts, so the eight
+            // (sixteen) weight loads of a chunk are issued together instead of one s_waitcnt per element
+            float a = m.s1_b[j], c = m.cfg.use_lstm ? m.s2_b[j] : 0.0f;
+            for (int v0 = 0; v0 < nxs; v0 += 8) {
+                float w1[8], w2[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int v = min(v0 + u, nxs - 1);
+                    w1[u] = m.s1_wt[v * nh1 + j];
+                    w2[u] = m.cfg.use_lstm ? m.s2_wt[v * nh1 + j] : 0.0f;
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const float x = v0 + u < nxs ? xs[min(v0 + u, nxs - 1)] : 0.0f;
+                    a += w1[u] * x;
+                    c += w2[u] * x;
+                }
             }
+            hc0[((size_t)0 * B + b) * nhm + j] = tanhf(a);
+            if (m.cfg.use_lstm) hc0[((size_t)1 * B + b) * nhm + j] = m.cfg.legacy ? tanhf(c) : c;
         }
         if (!m.cfg.legacy) {
             const float t0 = xs[1], t1 = xs[6];
