@@ -63,31 +63,35 @@ __global__ __launch_bounds__(128) void phys_prep_kernel(PhysDev d, int B, const 
     __shared__ float xin[PH_L * 32];
     __shared__ float xs[64];
     const int b = blockIdx.x, j = threadIdx.x, nx1 = d.nx + 1, nh = d.nh, K1 = nh + 16;
+    // the levels are independent here: blockIdx.y takes one half of them (384 columns alone are 1.5 workgroups per CU)
+    const int lper = (PH_L + (int)gridDim.y - 1) / (int)gridDim.y, l0 = blockIdx.y * lper, l1 = min(PH_L, l0 + lper);
     for (int i = j; i < PH_L * 32; i += 128) xin[i] = 0.0f;
     if (j < 64) xs[j] = j < d.nx_sfc ? x_sfc[(size_t)b * d.nx_sfc + j] : 0.0f;
     __syncthreads();
-    for (int i = j; i < PH_L * d.nx; i += 128) {
+    for (int i = l0 * d.nx + j; i < l1 * d.nx; i += 128) {
         const int l = i / d.nx, v = i - l * d.nx;
         xin[l * 32 + v] = x_main[(size_t)b * PH_L * d.nx + i];
     }
     const float sp = xs[0] * d.xdiv_sca0 + d.xmean_sca0;
-    for (int l = j; l < PH_L; l += 128) xin[l * 32 + d.nx] = sqrtf(d.hyam[l] * 100000.0f + sp * d.hybm[l]) / 314.0f;
+    for (int l = l0 + j; l < l1; l += 128) xin[l * 32 + d.nx] = sqrtf(d.hyam[l] * 100000.0f + sp * d.hybm[l]) / 314.0f;
     __syncthreads();
     if (j < nh) {
-        float a = d.s1_b[j];
-        for (int k0 = 0; k0 < d.nx_sfc; k0 += 8) {
-            float t[8];
+        if (blockIdx.y == 0) {
+            float a = d.s1_b[j];
+            for (int k0 = 0; k0 < d.nx_sfc; k0 += 8) {
+                float t[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) t[u] = d.s1_wt[min(k0 + u, d.nx_sfc - 1) * nh + j];     // clamped index: xs is zero there
+                for (int u = 0; u < 8; ++u) t[u] = d.s1_wt[min(k0 + u, d.nx_sfc - 1) * nh + j];     // clamped index: xs is zero there
 #pragma unroll
-            for (int u = 0; u < 8; ++u) a = fmaf(xs[k0 + u], t[u], a);
+                for (int u = 0; u < 8; ++u) a = fmaf(xs[k0 + u], t[u], a);
+            }
+            hx[(size_t)b * nh + j] = tanhf(a);
         }
-        hx[(size_t)b * nh + j] = tanhf(a);
         float w[32];
         const float bj = d.init_b[j];
 #pragma unroll
         for (int k = 0; k < 32; ++k) w[k] = d.init_wt[min(k, nx1 - 1) * nh + j];                  // xin is zero for k >= nx + 1
-        for (int l = 0; l < PH_L; ++l) {
+        for (int l = l0; l < l1; ++l) {
             float acc = bj;
 #pragma unroll
             for (int k = 0; k < 32; ++k) acc = fmaf(xin[l * 32 + k], w[k], acc);
@@ -95,7 +99,7 @@ __global__ __launch_bounds__(128) void phys_prep_kernel(PhysDev d, int B, const 
         }
     }
     // memory channels (15 carried + zero pad to 16), zero above the CRM top
-    for (int i = j; i < PH_L * 16; i += 128) {
+    for (int i = l0 * 16 + j; i < l1 * 16; i += 128) {
         const int l = i >> 4, k = i & 15;
         const float v = (l >= d.ilev && k < d.nm0) ? mem[((size_t)b * d.Lc + (l - d.ilev)) * (d.nm0 + 1) + k] : 0.0f;
         X1[((size_t)(PH_L - 1 - l) * B + b) * K1 + nh + k] = v;
@@ -105,7 +109,8 @@ __global__ __launch_bounds__(128) void phys_prep_kernel(PhysDev d, int B, const 
 // head-GEMM column order
 enum { H_QV = 0, H_QN, H_T, H_AREA, H_FLUX, H_EDDY, H_QICE, H_SED, H_EVAP, H_COND, H_AA };
 
-__global__ __launch_bounds__(256) void phys_decode_kernel(PhysDev d, int B, const float *__restrict__ HD, const float *__restrict__ H2,
+#define PH_DT 512          // decoder workgroup: 800 (level, sub-column) cells in two passes
+__global__ __launch_bounds__(PH_DT) void phys_decode_kernel(PhysDev d, int B, const float *__restrict__ HD, const float *__restrict__ H2,
                                                           const float *__restrict__ x_sfc, const float *__restrict__ mem,
                                                           const float *__restrict__ x_denorm, int nxd,
                                                           float *__restrict__ out_lev, float *__restrict__ out_sfc, float *__restrict__ mem_out)
@@ -122,7 +127,7 @@ __global__ __launch_bounds__(256) void phys_decode_kernel(PhysDev d, int B, cons
     const float *last_h = H2 + ((size_t)(PH_L - 1) * B + b) * nh;
 
     // ---- phase A: latent memory -> mlp_output per level; level pressure thickness; surface heads ----
-    for (int l = tid; l < LC; l += 256) {
+    for (int l = tid; l < LC; l += PH_DT) {
         const float *hd = HD + ((size_t)(l + ilev) * B + b) * PH_HD + PH_NHEAD * NC;
         float lat[16];
 #pragma unroll
@@ -159,7 +164,7 @@ __global__ __launch_bounds__(256) void phys_decode_kernel(PhysDev d, int B, cons
     }
 
     // ---- phase B: sub-grid state and the fluxes at each level ----
-    for (int e0 = 0; e0 < LC * NC; e0 += 256) {
+    for (int e0 = 0; e0 < LC * NC; e0 += PH_DT) {
         const int e = e0 + tid, l = e >> 4, c = e & 15;
         const bool ok = l < LC;
         const int L = (ok ? l : 0) + ilev;
@@ -187,7 +192,7 @@ __global__ __launch_bounds__(256) void phys_decode_kernel(PhysDev d, int B, cons
     __syncthreads();
 
     // ---- phase C: flux divergences, clamps, tendencies, area-weighted means ----
-    for (int e0 = 0; e0 < LC * NC; e0 += 256) {
+    for (int e0 = 0; e0 < LC * NC; e0 += PH_DT) {
         const int e = e0 + tid, l = e >> 4, c = e & 15;
         const bool ok = l < LC;
         const int lc = ok ? l : 0, ec = ok ? e : c, L = lc + ilev;
@@ -228,7 +233,7 @@ __global__ __launch_bounds__(256) void phys_decode_kernel(PhysDev d, int B, cons
         }
     }
     // levels above the CRM top: only the radiative heating
-    for (int L = tid; L < ilev; L += 256) {
+    for (int L = tid; L < ilev; L += PH_DT) {
         float *o = out_lev + ((size_t)b * PH_L + L) * 5;
         o[0] = HD[((size_t)L * B + b) * PH_HD + PH_HD - 1];
         o[1] = 0.0f; o[2] = 0.0f; o[3] = 0.0f; o[4] = 0.0f;
@@ -258,7 +263,7 @@ __global__ __launch_bounds__(256) void phys_decode_kernel(PhysDev d, int B, cons
         }
     }
     __syncthreads();
-    for (int l = tid; l < LC; l += 256) mem_out[((size_t)b * LC + l) * (nm0 + 1) + nm0] = s_red[0];
+    for (int l = tid; l < LC; l += PH_DT) mem_out[((size_t)b * LC + l) * (nm0 + 1) + nm0] = s_red[0];
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -353,7 +358,7 @@ extern "C" int csa_phys_forward(csa_phys *h, int B, const float *x_main, const f
     const PhysDev &d = h->d;
     const int nh = d.nh, M = PH_L * B;
     int rc;
-    hipLaunchKernelGGL(phys_prep_kernel, dim3(B), dim3(128), 0, s, d, B, x_main, x_sfc, rnn_mem, h->X1, h->hx);
+    hipLaunchKernelGGL(phys_prep_kernel, dim3(B, B <= 1024 ? 2 : 1), dim3(128), 0, s, d, B, x_main, x_sfc, rnn_mem, h->X1, h->hx);
     CSA_HIP_CHECK(hipGetLastError());
     auto rec = [&](const float *whh, const float *bhn, const float *h0, float *Hout, int reverse) {
         return B <= 256 ? launch_rec1_gru(nh, whh, bhn, h->P, h0, Hout, B, PH_L, reverse, s)
@@ -364,7 +369,7 @@ extern "C" int csa_phys_forward(csa_phys *h, int B, const float *x_main, const f
     if ((rc = launch_proj_gemm(h->H1, h->wih2, h->bias2, h->P, M, 4 * nh, nh, s, 0))) return rc;
     if ((rc = rec(h->whh2p, h->bhn2, hx2, h->H2, 0))) return rc;
     if ((rc = launch_proj_gemm(h->H2, h->whead, h->bhead, h->HD, M, PH_HD, nh, s, 0))) return rc;
-    hipLaunchKernelGGL(phys_decode_kernel, dim3(B), dim3(256), 0, s, d, B, h->HD, h->H2, x_sfc, rnn_mem, x_denorm, nxd, out_lev, out_sfc, mem_out);
+    hipLaunchKernelGGL(phys_decode_kernel, dim3(B), dim3(PH_DT), 0, s, d, B, h->HD, h->H2, x_sfc, rnn_mem, x_denorm, nxd, out_lev, out_sfc, mem_out);
     CSA_HIP_CHECK(hipGetLastError());
     return CSA_OK;
 }
