@@ -44,3 +44,39 @@ def sharded_rollout(model, xlev, xsfc, world_size, rank, **kw):
     """This rank's contiguous block of columns of a global (ntime, ncol, ...) series; state stays on the rank."""
     lo, hi = shard_bounds(xlev.shape[1], world_size, rank)
     return rollout(model, xlev[:, lo:hi].contiguous(), xsfc[:, lo:hi].contiguous(), **kw), (lo, hi)
+
+
+def ensemble_window(model, x_lay, x_sfc, rnn_mem, ensemble_size, noise=None):
+    """Ensemble forward over one window, as the reference's stochastic training / validation loop runs it
+    (rnn/utils.py:1065-1075: every input is replicated `ensemble_size` times along the batch axis, member-major, and the
+    members differ only through the noise the stochastic model draws; :1200-1215: the window's outputs are concatenated
+    over time).  `model` is the model-level mirror (`wrappers.RNN_autoreg` built with add_stochastic_layer);
+    x_lay (T, B, nlev, nx) and x_sfc (T, B, nx_sfc) normalised, rnn_mem (nlev, E*B, nh_mem) or None (zeros).
+    noise: optional list over time of (hx0, cx0, eps) for the E*B replicated batch.
+    Returns (preds_lay (T*E*B, nlev, ny), preds_sfc (T*E*B, ny_sfc), rnn_mem) with rows ordered (time, member, column),
+    the layout `metrics.CRPS` / `compute_spread_skill_ratio` expect."""
+    T, B = x_lay.shape[0], x_lay.shape[1]
+    E = int(ensemble_size)
+    c = model.emulator.cfg
+    if rnn_mem is None:
+        rnn_mem = torch.zeros(c.nlev, E * B, c.nh_mem, device=x_lay.device)
+    lay, sfc = [], []
+    for j in range(T):
+        xl = x_lay[j].unsqueeze(0).expand(E, *x_lay[j].shape).reshape(E * B, *x_lay[j].shape[1:])   # repeat_interleave + flatten
+        xs = x_sfc[j].unsqueeze(0).expand(E, *x_sfc[j].shape).reshape(E * B, *x_sfc[j].shape[1:])
+        o, s, rnn_mem = model([xl, xs, rnn_mem], noise=None if noise is None else noise[j])
+        lay.append(o)
+        sfc.append(s)
+    return torch.cat(lay), torch.cat(sfc), rnn_mem
+
+
+def ensemble_scores(model, x_lay, x_sfc, targets_lay, targets_sfc, ensemble_size, rnn_mem=None, noise=None, beta=1, alpha=1.0):
+    """One validation window of the stochastic model: ensemble forward, then the scores the reference logs for it
+    (rnn/utils.py:1213-1215): CRPS (rnn/metrics.py:535-626) and the spread / skill pair (:509-533).
+    targets_lay (T*B, nlev, ny), targets_sfc (T*B, ny_sfc) normalised.  Returns dict(crps, spread, rmse, rnn_mem)."""
+    from . import metrics
+    T = x_lay.shape[0]
+    pl, ps, rnn_mem = ensemble_window(model, x_lay, x_sfc, rnn_mem, ensemble_size, noise=noise)
+    crps = metrics.CRPS(targets_lay, targets_sfc, pl, ps, T, beta=beta, alpha=alpha)
+    spread, rmse = metrics.compute_spread_skill_ratio(targets_lay, targets_sfc, pl, ps, T)
+    return {"crps": crps, "spread": spread, "rmse": rmse, "rnn_mem": rnn_mem, "preds_lay": pl, "preds_sfc": ps}

@@ -494,3 +494,44 @@ def test_overlap_path_is_bit_identical_to_sequential(memory):
             model.emulator.set_overlap(False)
         for y in ys:
             assert torch.equal(y, y_seq)
+
+
+def test_ensemble_window_replication_and_scores():
+    """Ensemble forward of the stochastic model (rnn/utils.py:1065-1075 replication, :1213-1215 scores): member e of the
+    replicated batch equals a single-member call fed member e's noise; the scores equal the metric kernels on the
+    concatenated outputs; rows are ordered (time, member, column)."""
+    import climsim_amd
+    from climsim_amd.rollout import ensemble_window, ensemble_scores
+    from climsim_amd import metrics
+    consts, weights, flags = load_npz_model("cur_stoch")
+    io = np.load(os.path.join(GOLDEN, "cur_stoch_io.npz"))
+    model = climsim_amd.RNN_autoreg(consts, weights, max_batch=16, use_lstm=True, output_prune=bool(flags["output_prune"]),
+                                    mp_mode=int(flags["mp_mode"]))
+    B, E, T = 3, 4, 2
+    c = model.emulator.cfg
+    x_lay = torch.stack([_dev(io[f"B3.t{t}.x_main_n"]) for t in range(T)])
+    x_sfc = torch.stack([_dev(io[f"B3.t{t}.x_sfc_n"]) for t in range(T)])
+    g = torch.Generator().manual_seed(5)
+    hx0, cx0, eps = (io["B3.t0." + k] for k in ("hx0", "cx0", "eps"))
+    noise = [tuple(torch.randn((E * B,) + a.shape[1:] if a.shape[0] == B else (a.shape[0], E * B) + a.shape[2:], generator=g).cuda()
+                   for a in (hx0, cx0, eps)) for _ in range(T)]
+    pl, ps, mem = ensemble_window(model, x_lay, x_sfc, None, E, noise=noise)
+    assert pl.shape == (T * E * B, c.nlev, c.ny) and ps.shape == (T * E * B, c.ny_sfc) and mem.shape == (c.nlev, E * B, c.nh_mem)
+    # member-by-member: carry each member's memory separately through single-member calls
+    def member_slice(a, e):
+        return a[e * B:(e + 1) * B] if a.shape[0] == E * B else a[:, e * B:(e + 1) * B]
+    for e in range(E):
+        m = torch.zeros(c.nlev, B, c.nh_mem, device="cuda")
+        for t in range(T):
+            o, s, m = model([x_lay[t], x_sfc[t], m], noise=tuple(member_slice(a, e).contiguous() for a in noise[t]))
+            rows = slice((t * E + e) * B, (t * E + e + 1) * B)
+            assert rel_err(pl[rows].cpu().numpy(), o.cpu().numpy()) <= 2e-6, (e, t)
+            assert rel_err(ps[rows].cpu().numpy(), s.cpu().numpy()) <= 2e-6, (e, t)
+        assert rel_err(mem[:, e * B:(e + 1) * B].cpu().numpy(), m.cpu().numpy()) <= 2e-6
+    tl = torch.randn(T * B, c.nlev, c.ny, generator=g).cuda()
+    ts = torch.randn(T * B, c.ny_sfc, generator=g).cuda()
+    sc = ensemble_scores(model, x_lay, x_sfc, tl, ts, E, noise=noise)
+    assert torch.equal(sc["preds_lay"], pl)
+    assert sc["crps"].item() == metrics.CRPS(tl, ts, pl, ps, T).item()
+    sp, rm = metrics.compute_spread_skill_ratio(tl, ts, pl, ps, T)
+    assert sc["spread"].item() == sp.item() and sc["rmse"].item() == rm.item() and sp.item() > 0
