@@ -173,6 +173,15 @@ int upload_params(csa_emulator *h, const csa_params *p, bool first)
         rec1_pack_weights(c.nh2, b_hh, packed.data());
         d.whh2q = U.up(packed);
     }
+    d.whh1g = d.whh2g = nullptr;
+    if (!c.use_lstm && c.nh1 <= 128 && c.nh2 <= 128) {    // second-generation two-column GRU kernel
+        packed.resize((size_t)3 * c.nh1 * c.nh1);
+        gru2_pack_weights(c.nh1, a_hh, packed.data());
+        d.whh1g = U.up(packed);
+        packed.resize((size_t)3 * c.nh2 * c.nh2);
+        gru2_pack_weights(c.nh2, b_hh, packed.data());
+        d.whh2g = U.up(packed);
+    }
     if (c.nh_mem > 0) {
         d.lat_wt = U.up(transposed(p->mlp_latent_w, c.nh_mem, c.nh2));
         d.lat_b = U.up(p->mlp_latent_b, c.nh_mem);
@@ -438,6 +447,9 @@ static int launch_rec_auto(const csa_emulator *h, int layer, const float *P, con
         return launch_rec1(nh, wq, P, h0, c0, Hout, B, L, reverse_out, s);
     if (!d.cfg.use_lstm && Bclass <= h->rec1_max_batch)
         return launch_rec1_gru(nh, layer == 1 ? d.whh1p : d.whh2p, layer == 1 ? d.bhn1 : d.bhn2, P, h0, Hout, B, L, reverse_out, s);
+    const float *wg = layer == 1 ? d.whh1g : d.whh2g;
+    if (!d.cfg.use_lstm && wg)
+        return launch_rec2_gru(nh, wg, layer == 1 ? d.bhn1 : d.bhn2, P, h0, Hout, B, L, reverse_out, s);
     return launch_rec(d.cfg.use_lstm, nh, layer == 1 ? d.whh1p : d.whh2p, layer == 1 ? d.bhn1 : d.bhn2, P, h0, c0, Hout, B, L,
                       reverse_out, s);
 }

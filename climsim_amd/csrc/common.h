@@ -33,6 +33,7 @@ struct DevModel {
     // recurrent weights packed for the register-stationary kernel (see rec.hip)
     const float *whh1p, *whh2p;
     const float *whh1q, *whh2q;         // the same matrices packed for the one-column kernel (lstm_rec1_kernel), LSTM only
+    const float *whh1g, *whh2g;         // GRU, nh <= 128: packed for the second-generation two-column kernel (gru_rec2_kernel)
     // W_ih in MFMA-operand order for the dual-pipe fused LSTM kernel (fused.hip); null if not built
     const float *wih1f, *wih2f;
     // heads
@@ -111,6 +112,10 @@ int launch_rec1_gru(int nh, const float *whh_packed, const float *bhn, const flo
                     int reverse_out, hipStream_t s);
 // one-column-per-workgroup LSTM kernel (small batches) and its weight packing
 void rec1_pack_weights(int nh, const float *w_hh, float *packed);
+// second-generation two-column GRU kernel (inference, nh in {64, 96, 128}) and its weight packing
+void gru2_pack_weights(int nh, const float *w_hh, float *packed);
+int launch_rec2_gru(int nh, const float *whh_g2, const float *bhn, const float *P, const float *h0, float *Hout, int B, int L,
+                    int reverse_out, hipStream_t s);
 int launch_rec1(int nh, const float *whh_packed1, const float *P, const float *h0, const float *c0, float *Hout, int B, int L,
                 int reverse_out, hipStream_t s);
 int launch_rec_train(int nh, const float *whh_packed, float *P, const float *h0, const float *c0, float *Hout,

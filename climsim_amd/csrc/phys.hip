@@ -36,7 +36,7 @@ struct PhysDev {
 struct csa_phys {
     PhysDev d;
     int max_batch;
-    float *wih1, *bias1, *bhn1, *whh1p, *wih2, *bias2, *bhn2, *whh2p, *whead, *bhead;
+    float *wih1, *bias1, *bhn1, *whh1p, *whh1g, *wih2, *bias2, *bhn2, *whh2p, *whh2g, *whead, *bhead;
     float *X1, *P, *H1, *H2, *hx, *HD;
     std::vector<void *> owned;
 };
@@ -314,6 +314,8 @@ extern "C" int csa_phys_create(int nx, int nx_sfc, int nh, int ilev_crm, int mp_
         std::vector<float> pk(rec_packed_floats(0, nh));
         rec_pack_weights(0, nh, w[W_R1_HH], pk.data()); h->whh1p = up(pk.data(), pk.size());
         rec_pack_weights(0, nh, w[W_R2_HH], pk.data()); h->whh2p = up(pk.data(), pk.size());
+        gru2_pack_weights(nh, w[W_R1_HH], pk.data()); h->whh1g = up(pk.data(), pk.size());   // two-column kernel (B > 256)
+        gru2_pack_weights(nh, w[W_R2_HH], pk.data()); h->whh2g = up(pk.data(), pk.size());
     }
     // head GEMM: 11 decoder heads (16 rows each), mlp_latent (15 rows), mlp_output_rad (1 row)
     {
@@ -360,14 +362,14 @@ extern "C" int csa_phys_forward(csa_phys *h, int B, const float *x_main, const f
     int rc;
     hipLaunchKernelGGL(phys_prep_kernel, dim3(B, B <= 1024 ? 2 : 1), dim3(128), 0, s, d, B, x_main, x_sfc, rnn_mem, h->X1, h->hx);
     CSA_HIP_CHECK(hipGetLastError());
-    auto rec = [&](const float *whh, const float *bhn, const float *h0, float *Hout, int reverse) {
+    auto rec = [&](const float *whh, const float *whg, const float *bhn, const float *h0, float *Hout, int reverse) {
         return B <= 256 ? launch_rec1_gru(nh, whh, bhn, h->P, h0, Hout, B, PH_L, reverse, s)
-                        : launch_rec(0, nh, whh, bhn, h->P, h0, nullptr, Hout, B, PH_L, reverse, s);
+                        : launch_rec2_gru(nh, whg, bhn, h->P, h0, Hout, B, PH_L, reverse, s);
     };
     if ((rc = launch_proj_gemm(h->X1, h->wih1, h->bias1, h->P, M, 4 * nh, nh + 16, s, 0))) return rc;
-    if ((rc = rec(h->whh1p, h->bhn1, h->hx, h->H1, 1))) return rc;
+    if ((rc = rec(h->whh1p, h->whh1g, h->bhn1, h->hx, h->H1, 1))) return rc;
     if ((rc = launch_proj_gemm(h->H1, h->wih2, h->bias2, h->P, M, 4 * nh, nh, s, 0))) return rc;
-    if ((rc = rec(h->whh2p, h->bhn2, hx2, h->H2, 0))) return rc;
+    if ((rc = rec(h->whh2p, h->whh2g, h->bhn2, hx2, h->H2, 0))) return rc;
     if ((rc = launch_proj_gemm(h->H2, h->whead, h->bhead, h->HD, M, PH_HD, nh, s, 0))) return rc;
     hipLaunchKernelGGL(phys_decode_kernel, dim3(B), dim3(PH_DT), 0, s, d, B, h->HD, h->H2, x_sfc, rnn_mem, x_denorm, nxd, out_lev, out_sfc, mem_out);
     CSA_HIP_CHECK(hipGetLastError());

@@ -402,6 +402,92 @@ __global__ __launch_bounds__(NH * 4, (NH / 16 + 3) / 4) void lstm_rec2_kernel(
 }
 
 // ------------------------------------------------------------------------------------------------
+// GRU kernel, second generation (inference): the lstm_rec2_kernel design with three accumulator slots.
+// Slot order per lane group (host packing, gru2_pack_weights): p<2 holds [r, hn, z], p>=2 holds [z, hn, r], so after
+//   r[s] = acc[s].x + xor1(acc[s].y);  v0 = r[0] + xor2(r[2]);  v1 = r[1] + xor2(r[1])
+// every lane has W_hn h (v1) and the (r,z)-gate sum of ITS group (v0): p<2 the reset gate, p>=2 the update gate.
+// 8 DPP adds per step (the all-reduce of rec_kernel<NH,3> needs 12 plus a select), 96 packed FMAs as before.
+// P rows are [r, z, n, 0] per unit: lane group g reads the 8-byte pair at offset g -> (r,z) or (z,n); the p>=2 lanes own
+// h_t: they receive r over one DPP move, form n = tanh(x_n + r (W_hn h + b_hn)) and h = (1-z) n + z h.
+template <int NH>
+__global__ __launch_bounds__(NH * 4, (NH / 16 + 3) / 4) void gru_rec2_kernel(
+    const f32x4 *__restrict__ Wp4, const float *__restrict__ bhn, const float *__restrict__ P,
+    const float *__restrict__ h0, float *__restrict__ Hout, int B, int L, int reverse_out)
+{
+    constexpr int NT = NH * 4;
+    constexpr int KC = NH / 4;
+    constexpr int CH = 2 * KC + 4;
+    constexpr int CPY = 4 * CH;
+    constexpr int KR = KC / 2;
+    static_assert(KC % 4 == 0, "nh must be a multiple of 16");
+    __shared__ __attribute__((aligned(16))) float hbuf[2][2 * CPY];
+
+    const int tid = threadIdx.x, u = tid >> 2, p = tid & 3, col = p & 1, grp = p >> 1;
+    int b = 2 * blockIdx.x + col;
+    const bool valid = b < B;
+    if (!valid) b = B - 1;
+    const bool owner = grp == 1;
+
+    f32x2 w[3][KR];
+#pragma unroll
+    for (int i = 0; i < 3 * KC / 4; ++i) {
+        const f32x4 v = Wp4[(size_t)i * NT + tid];
+        const int s = (4 * i) / KC, kk = (4 * i) % KC;
+        w[s][kk / 2] = f32x2{v.x, v.y};
+        w[s][kk / 2 + 1] = f32x2{v.z, v.w};
+    }
+    const float bn = bhn[u];
+    float h = h0[(size_t)b * NH + u];
+    const int slotN = 2 * u + col + 4 * (u / KC);
+    const int slotS = CPY + 2 * u + (1 - col) + 4 * (u / KC);
+    if (owner) { hbuf[0][slotN] = h; hbuf[0][slotS] = h; }
+
+    const float *Pb = P + (size_t)b * (4 * NH) + u * 4 + grp;
+    const size_t Pstep = (size_t)B * (4 * NH);
+    const int rdoff = col * CPY + p * CH;
+    f32x2 preA = f32x2{Pb[0], Pb[1]}, preB = preA;
+    __syncthreads();
+
+#define GRU2_STEP(T, CUR, NXT)                                                                     \
+    {                                                                                              \
+        const int t_ = (T);                                                                        \
+        if (t_ + 1 < L) {                                                                          \
+            const float *pn = Pb + (size_t)(t_ + 1) * Pstep;                                       \
+            asm volatile("global_load_dwordx2 %0, %1, off" : "=&v"(NXT) : "v"(pn) : "memory");     \
+        }                                                                                          \
+        const f32x4 *hp = (const f32x4 *)&hbuf[t_ & 1][rdoff];                                     \
+        f32x2 acc[3] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};                                       \
+        _Pragma("unroll") for (int j = 0; j < KR; ++j) {                                           \
+            const f32x4 hv = hp[j];                                                                \
+            const f32x2 ha = {hv.x, hv.y}, hb = {hv.z, hv.w};                                      \
+            _Pragma("unroll") for (int s = 0; s < 3; ++s) PK_FMA_LO(acc[s], w[s][j], ha);          \
+            _Pragma("unroll") for (int s = 0; s < 3; ++s) PK_FMA_HI(acc[s], w[s][j], hb);          \
+        }                                                                                          \
+        float r[3];                                                                                \
+        _Pragma("unroll") for (int s = 0; s < 3; ++s) r[s] = acc[s].x + dpp_xor1(acc[s].y);        \
+        if (t_ > 0) asm volatile("s_waitcnt vmcnt(1)" : "+v"(CUR));                                \
+        const float v0 = r[0] + dpp_xor2(r[2]) + CUR.x;                                            \
+        const float hn = r[1] + dpp_xor2(r[1]) + bn;                                               \
+        const float g0 = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504088896341f * v0)); \
+        const float rr = dpp_xor2(g0);                /* the reset gate arrives at the lane that owns h */ \
+        const float tn = fminf(__builtin_amdgcn_exp2f(-2.88539008177792681f * (CUR.y + rr * hn)), 1e30f); \
+        const float n = (1.0f - tn) * __builtin_amdgcn_rcpf(1.0f + tn);                            \
+        h = (1.0f - g0) * n + g0 * h;                                                              \
+        if (owner) {                                                                               \
+            hbuf[(t_ & 1) ^ 1][slotN] = h;                                                         \
+            hbuf[(t_ & 1) ^ 1][slotS] = h;                                                         \
+            if (valid) Hout[((size_t)(reverse_out ? L - 1 - t_ : t_) * B + b) * NH + u] = h;       \
+        }                                                                                          \
+        LDS_BARRIER();                                                                             \
+    }
+    for (int t = 0; t < L; t += 2) {
+        GRU2_STEP(t, preA, preB)
+        if (t + 1 < L) GRU2_STEP(t + 1, preB, preA)
+    }
+#undef GRU2_STEP
+}
+
+// ------------------------------------------------------------------------------------------------
 // LSTM kernel, ONE column per workgroup: the latency variant for small batches (B <= 256: every column gets its own
 // CU).  Same register-stationary weights (4 gate rows x nh/4 k-values per lane), but the packed FMA pairs two
 // consecutive k of the SAME column (acc.x + acc.y at the end), so a step costs 64 v_pk_fma_f32 per lane instead of
@@ -622,6 +708,37 @@ static void lstm2_pack_weights(int nh, const float *w_hh, float *packed)
             packed[((size_t)i * NT + tid) * 4 + e] = w_hh[(size_t)(g * nh + u) * nh + p * KC + kk];
         }
     }
+}
+
+// second-generation GRU kernel: slot s of lane group grp holds PyTorch gate kGru2Slot[grp][s] (r = 0, z = 1, n = 2)
+static const int kGru2Slot[2][3] = {{0, 2, 1}, {1, 2, 0}};
+void gru2_pack_weights(int nh, const float *w_hh, float *packed)
+{
+    const int NT = nh * 4, KC = nh / 4;
+    for (int tid = 0; tid < NT; ++tid) {
+        const int u = tid >> 2, p = tid & 3, grp = p >> 1;
+        for (int idx = 0; idx < 3 * KC; ++idx) {
+            const int s = idx / KC, kk = idx % KC, g = kGru2Slot[grp][s];
+            const int i = idx / 4, e = idx % 4;
+            packed[((size_t)i * NT + tid) * 4 + e] = w_hh[(size_t)(g * nh + u) * nh + p * KC + kk];
+        }
+    }
+}
+
+int launch_rec2_gru(int nh, const float *whh_g2, const float *bhn, const float *P, const float *h0, float *Hout, int B, int L,
+                    int reverse_out, hipStream_t s)
+{
+    const dim3 grid((B + 1) / 2), block(nh * 4);
+    switch (nh) {
+    case 64:  hipLaunchKernelGGL((gru_rec2_kernel<64>), grid, block, 0, s, (const f32x4 *)whh_g2, bhn, P, h0, Hout, B, L, reverse_out); break;
+    case 96:  hipLaunchKernelGGL((gru_rec2_kernel<96>), grid, block, 0, s, (const f32x4 *)whh_g2, bhn, P, h0, Hout, B, L, reverse_out); break;
+    case 128: hipLaunchKernelGGL((gru_rec2_kernel<128>), grid, block, 0, s, (const f32x4 *)whh_g2, bhn, P, h0, Hout, B, L, reverse_out); break;
+    default:
+        csa_set_error_msg("rec2(GRU): hidden size not supported (64, 96, 128)");
+        return CSA_ERR_UNSUPPORTED;
+    }
+    CSA_HIP_CHECK(hipGetLastError());
+    return CSA_OK;
 }
 
 size_t rec_packed_floats(int use_lstm, int nh) { return (size_t)(use_lstm ? 4 : 3) * nh * nh; }

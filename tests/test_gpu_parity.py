@@ -535,3 +535,32 @@ def test_ensemble_window_replication_and_scores():
     assert sc["crps"].item() == metrics.CRPS(tl, ts, pl, ps, T).item()
     sp, rm = metrics.compute_spread_skill_ratio(tl, ts, pl, ps, T)
     assert sc["spread"].item() == sp.item() and sc["rmse"].item() == rm.item() and sp.item() > 0
+
+
+def test_gru_two_column_kernel_vs_reference_class_and_one_column():
+    """gru_rec2_kernel (two columns per workgroup, chosen above 256 columns) forced at the golden batch sizes, against the
+    RNN_autoreg goldens; then against the one-column kernel on an odd batch (the last workgroup has one valid column)."""
+    import climsim_amd
+    consts, weights, flags = load_npz_model("cur_gru128")
+    io = np.load(os.path.join(GOLDEN, "cur_gru128_io.npz"))
+    model = climsim_amd.RNN_autoreg(consts, weights, max_batch=320, use_lstm=False, output_prune=bool(flags["output_prune"]))
+    try:
+        model.emulator.set_rec1_max_batch(0)
+        for B in (2, 16):
+            for t in range(int(io[f"B{B}.nsteps"])):
+                p = f"B{B}.t{t}."
+                out, out_sfc, mem_out = model([_dev(io[p + "x_main_n"]), _dev(io[p + "x_sfc_n"]), _dev(io[p + "mem_in"])])
+                assert rel_err(out.cpu().numpy(), io[p + "out"]) <= 1e-5
+                assert rel_err(out_sfc.cpu().numpy(), io[p + "out_sfc"]) <= 1e-5
+                assert rel_err(mem_out.cpu().numpy(), io[p + "mem_out"]) <= 1e-5
+        B = 301
+        g = torch.Generator().manual_seed(3)
+        xs = [0.8 * torch.randn(B, 60, model.emulator.cfg.nx, generator=g).cuda(), 0.8 * torch.randn(B, 19, generator=g).cuda(),
+              0.3 * torch.randn(60, B, 16, generator=g).cuda()]
+        two = [t.clone() for t in model(xs)]
+        model.emulator.set_rec1_max_batch(4096)
+        one = [t.clone() for t in model(xs)]
+    finally:
+        model.emulator.set_rec1_max_batch(256)
+    for a, b in zip(two, one):
+        assert rel_err(a.cpu().numpy(), b.cpu().numpy()) <= 2e-6
