@@ -174,7 +174,7 @@ int upload_params(csa_emulator *h, const csa_params *p, bool first)
         d.whh2q = U.up(packed);
     }
     d.whh1g = d.whh2g = nullptr;
-    if (!c.use_lstm && c.nh1 <= 128 && c.nh2 <= 128) {    // second-generation two-column GRU kernel
+    if (!c.use_lstm && c.nh1 <= 144 && c.nh2 <= 144) {    // second-generation two-column GRU kernel
         packed.resize((size_t)3 * c.nh1 * c.nh1);
         gru2_pack_weights(c.nh1, a_hh, packed.data());
         d.whh1g = U.up(packed);

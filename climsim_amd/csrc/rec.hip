@@ -733,8 +733,9 @@ int launch_rec2_gru(int nh, const float *whh_g2, const float *bhn, const float *
     case 64:  hipLaunchKernelGGL((gru_rec2_kernel<64>), grid, block, 0, s, (const f32x4 *)whh_g2, bhn, P, h0, Hout, B, L, reverse_out); break;
     case 96:  hipLaunchKernelGGL((gru_rec2_kernel<96>), grid, block, 0, s, (const f32x4 *)whh_g2, bhn, P, h0, Hout, B, L, reverse_out); break;
     case 128: hipLaunchKernelGGL((gru_rec2_kernel<128>), grid, block, 0, s, (const f32x4 *)whh_g2, bhn, P, h0, Hout, B, L, reverse_out); break;
+    case 144: hipLaunchKernelGGL((gru_rec2_kernel<144>), grid, block, 0, s, (const f32x4 *)whh_g2, bhn, P, h0, Hout, B, L, reverse_out); break;
     default:
-        csa_set_error_msg("rec2(GRU): hidden size not supported (64, 96, 128)");
+        csa_set_error_msg("rec2(GRU): hidden size not supported (64, 96, 128, 144)");
         return CSA_ERR_UNSUPPORTED;
     }
     CSA_HIP_CHECK(hipGetLastError());
