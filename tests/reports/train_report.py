@@ -3,7 +3,7 @@
 TBPTT optimiser step (GPU box)."""
 import os, sys, time
 import numpy as np, torch
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "tests", "golden")]
 from conftest import GOLDEN, load_npz_model, rel_err
 from oracle import torch_ref

@@ -54,7 +54,7 @@ def test_cnn_training_step_matches_autograd(depth, width, B, dropout):
 
     The gradient of a ReLU network is piecewise constant in the activations: a unit whose pre-activation is within
     fp32 rounding of zero can take a different branch in two correct fp32 evaluations (torch fp32 on two CPUs, or vs
-    torch fp64, differ the same way: tools/cnn_dbg.py), and with B*60 = 360 rows ONE flipped unit moves a
+    torch fp64, differ the same way: tests/reports/cnn_dbg.py), and with B*60 = 360 rows ONE flipped unit moves a
     weight-gradient row by ~1/sqrt(360) of its size.  The forward is therefore checked against the plain restatement,
     and the gradients against the restatement evaluated with the ReLU branch pattern of the HIP forward (read back
     through the csa_cnn_train_get_act tap); the patterns themselves must agree except at a handful of units."""
