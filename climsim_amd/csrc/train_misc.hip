@@ -211,8 +211,38 @@ int launch_reduce_partials_2stage(const float *part, int nsplit, int n, const in
     return launch_reduce_partials(tmp, chunks, n, map, map2, grad, s);
 }
 
+// the same reduction for SHORT vectors (biases, head / prep partials: n <= 16 K): with one thread per element the launch is
+// a handful of workgroups walking nsplit dependent-latency loads (6 us for 512 elements x 64 partials).  Here eight lanes
+// share an element: lane q sums partials q, q+8, ... (two interleaved chains), then three xor-shuffles combine the eight
+// sums in a fixed tree -> deterministic, ~3x shorter.
+__global__ __launch_bounds__(256) void reduce_partials_small_kernel(const float *__restrict__ part, int nsplit, int n,
+                                                                    const int *__restrict__ map, const int *__restrict__ map2,
+                                                                    float *__restrict__ grad)
+{
+    const int gid = blockIdx.x * 256 + threadIdx.x, i = gid >> 3, q = gid & 7;
+    const int ic = i < n ? i : n - 1;                       // all lanes take part in the shuffles
+    float a0 = 0.0f, a1 = 0.0f;
+    int s = q;
+    for (; s + 8 < nsplit; s += 16) {
+        a0 += part[(size_t)s * n + ic];
+        a1 += part[(size_t)(s + 8) * n + ic];
+    }
+    if (s < nsplit) a0 += part[(size_t)s * n + ic];
+    float a = a0 + a1;
+    a += __shfl_xor(a, 1); a += __shfl_xor(a, 2); a += __shfl_xor(a, 4);
+    if (i >= n || q != 0) return;
+    const int d = map ? map[i] : i;
+    if (d >= 0) grad[d] += a;
+    if (map2) { const int d2 = map2[i]; if (d2 >= 0) grad[d2] += a; }
+}
+
 int launch_reduce_partials(const float *part, int nsplit, int n, const int *map, const int *map2, float *grad, hipStream_t s)
 {
+    if (n <= 16384 && nsplit >= 16) {
+        hipLaunchKernelGGL(reduce_partials_small_kernel, dim3((8 * n + 255) / 256), dim3(256), 0, s, part, nsplit, n, map, map2, grad);
+        CSA_HIP_CHECK(hipGetLastError());
+        return CSA_OK;
+    }
     hipLaunchKernelGGL(reduce_partials_kernel, dim3((n + 255) / 256), dim3(256), 0, s, part, nsplit, n, map, map2, grad);
     CSA_HIP_CHECK(hipGetLastError());
     return CSA_OK;
