@@ -60,16 +60,42 @@ __device__ float gen_rh_to_q(float rh, float T, float p)
     return (float)((double)rh * qvs);
 }
 
-__global__ __launch_bounds__(256) void gen_batch_kernel(
+// One workgroup = GEN_T consecutive (sample, level) rows.  The row-major tensors are moved between HBM and LDS with
+// fully coalesced block copies (a thread-per-row access touches 64 different cache lines per wave instruction: 1.3 TB/s);
+// each thread then works on its own row in LDS (row stride 33 floats: conflict-free), which also replaces the
+// dynamically indexed register array the row used to live in.
+#define GEN_T 128
+#define GEN_SY 7
+__global__ __launch_bounds__(GEN_T) void gen_batch_kernel(
     GenDev g, int N, const float *__restrict__ x_lev, const float *__restrict__ x_sfc, const float *__restrict__ y_lev,
     const float *__restrict__ y_sfc, float *__restrict__ xo, float *__restrict__ xso, float *__restrict__ yo,
     float *__restrict__ yso, float *__restrict__ xd, float *__restrict__ yd, float *__restrict__ ysd)
 {
+    extern __shared__ float gsm[];             // sx[GEN_T][SX] | so[GEN_T][SX] | sy[GEN_T][7] | syo[GEN_T][7]
+    const int GEN_SX = g.nx_out <= 16 ? 17 : 33;   // odd row stride: conflict-free row-per-thread access
+    float *sx = gsm, *so = sx + GEN_T * GEN_SX, *sy = so + GEN_T * GEN_SX, *syo = sy + GEN_T * GEN_SY;
     const csa_gen_config &c = g.c;
-    const int L = c.nlev;
-    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (long)N * L) return;
-    const int n = (int)(i / L), l = (int)(i - (long)n * L);
+    const int L = c.nlev, tid = threadIdx.x;
+    const long total = (long)N * L, i0 = (long)blockIdx.x * GEN_T, i = i0 + tid;
+    const int rows = (int)(total - i0 < GEN_T ? total - i0 : GEN_T);
+    const bool valid = tid < rows;
+    const int n = valid ? (int)(i / L) : 0, l = valid ? (int)(i - (long)n * L) : 0;
+    const int nxi = c.nx_in, nxo = g.nx_out;
+    auto flush = [&](const float *src, int stride, float *dst, int width) {     // LDS rows -> contiguous global block
+        __syncthreads();
+        float *d = dst + (size_t)i0 * width;
+        const float inv = 1.0f / (float)width;      // (e + 0.5) / width is >= 0.5 / 33 away from an integer: the float quotient is exact
+        for (int e = tid; e < rows * width; e += GEN_T) { const int r = (int)(((float)e + 0.5f) * inv); d[e] = src[r * stride + (e - r * width)]; }
+        __syncthreads();
+    };
+    // ---- coalesced block loads ---------------------------------------------------------------------------------
+    {
+        const float *xb = x_lev + (size_t)i0 * nxi, *yb = y_lev + (size_t)i0 * 6;
+        const float invx = 1.0f / (float)nxi;
+        for (int e = tid; e < rows * nxi; e += GEN_T) { const int r = (int)(((float)e + 0.5f) * invx); sx[r * GEN_SX + (e - r * nxi)] = xb[e]; }
+        for (int e = tid; e < rows * 6; e += GEN_T) { const int r = e / 6; sy[r * GEN_SY + (e - r * 6)] = yb[e]; }
+    }
+    __syncthreads();
 
     // ---- scalars: every thread needs the raw surface pressure; level 0 writes the outputs ------------------
     const float *xs = x_sfc + (size_t)n * c.nx_sfc_in;
@@ -79,7 +105,7 @@ __global__ __launch_bounds__(256) void gen_batch_kernel(
         if (c.snowhice_fix && v > 1.0e10f) v = -1.0f;
         return v;
     };
-    if (l == 0) {
+    if (valid && l == 0) {
         for (int vo = 0; vo < g.nxs_out; ++vo) {
             const int vin = (c.remove_past_sfc_inputs && vo >= 17) ? vo + 5 : vo;
             float v = sfc_raw(vin);
@@ -95,69 +121,71 @@ __global__ __launch_bounds__(256) void gen_batch_kernel(
     }
 
     // ---- level inputs ------------------------------------------------------------------------------------------
-    float x[32];
-    const int nxi = c.nx_in, nxo = g.nx_out;
-    const float *xr = x_lev + ((size_t)n * L + l) * nxi;
-    for (int v = 0; v < nxi; ++v) {
-        float t = xr[v];
-        if (c.reverse_input_norm) t = add_nofma(mul_nofma(t, g.xref_div[l * nxi + v]), g.xref_mean[l * nxi + v]);
-        x[v] = t;
-    }
-    if (c.rh_prune) x[1] = fminf(fmaxf(x[1], 0.0f), 1.2f);       // np.clip: NaN propagates
+    float *x = sx + tid * GEN_SX, *o = so + tid * GEN_SX;
     int qcol = -1;
-    if (c.q_mode != 0) {
-        const float sp = sfc_raw(0);
-        const float pres = add_nofma(mul_nofma(sp, g.hybm[l]), mul_nofma(100000.0f, g.hyam[l]));
-        const float q = gen_rh_to_q(x[1], x[0], pres);
-        qcol = c.q_mode == 1 ? nxi : 1;
-        x[qcol] = q;
-    }
-    float *xdr = xd + ((size_t)n * L + l) * nxo;
-    for (int v = 0; v < nxo; ++v) xdr[v] = x[v];                  // x_lev_b_denorm (raw, q included)
-    const float T_b = x[0], ql_b = x[2], qi_b = x[3], qlast_b = x[nxo - 1];
-
-    if (c.v4_to_v5_inputs) {
-        float lf = mul_nofma(x[0] - 253.16f, 0.05f);
-        lf = fminf(fmaxf(lf, 0.0f), 1.0f);
-        float qn = x[2] + x[3];
-        if (c.qinput_prune && l < 15) qn = 0.0f;
-        if (c.cld_inp_transformation == 1) qn = 1.0f - expf(-qn * g.lbd_qn[l]);
-        else if (c.cld_inp_transformation == 2) qn = sqrtf(sqrtf(qn));
-        x[2] = qn; x[3] = lf;
-    } else {
-        if (c.cld_inp_transformation == 1) {
-            x[2] = 1.0f - expf(-x[2] * g.lbd_qc[l]);
-            x[3] = 1.0f - expf(-x[3] * g.lbd_qi[l]);
-        } else if (c.cld_inp_transformation == 2) {
-            x[2] = sqrtf(sqrtf(x[2]));
-            x[3] = sqrtf(sqrtf(x[3]));
+    float T_b = 0.f, ql_b = 0.f, qi_b = 0.f, qlast_b = 0.f;
+    if (valid) {
+        if (c.reverse_input_norm)
+            for (int v = 0; v < nxi; ++v) x[v] = add_nofma(mul_nofma(x[v], g.xref_div[l * nxi + v]), g.xref_mean[l * nxi + v]);
+        if (c.rh_prune) x[1] = fminf(fmaxf(x[1], 0.0f), 1.2f);       // np.clip: NaN propagates
+        if (c.q_mode != 0) {
+            const float sp = sfc_raw(0);
+            const float pres = add_nofma(mul_nofma(sp, g.hybm[l]), mul_nofma(100000.0f, g.hyam[l]));
+            const float q = gen_rh_to_q(x[1], x[0], pres);
+            qcol = c.q_mode == 1 ? nxi : 1;
+            x[qcol] = q;
         }
-        if (c.qinput_prune && l < 15) x[2] = 0.0f;
+        for (int v = 0; v < nxo; ++v) o[v] = x[v];                    // x_lev_b_denorm (raw, q included)
+        T_b = x[0]; ql_b = x[2]; qi_b = x[3]; qlast_b = x[nxo - 1];
     }
-    float *xor_ = xo + ((size_t)n * L + l) * nxo;
-    for (int v = 0; v < nxo; ++v) {
-        float t = x[v];
-        if (c.apply_new_input_scaling) {
-            t = (t - g.xmean_lev[l * nxo + v]) / g.xdiv_lev[l * nxo + v];
-            if (v == qcol && t < 0.0f) t = 0.0f;
+    flush(so, GEN_SX, xd, nxo);
+    if (valid) {
+        if (c.v4_to_v5_inputs) {
+            float lf = mul_nofma(x[0] - 253.16f, 0.05f);
+            lf = fminf(fmaxf(lf, 0.0f), 1.0f);
+            float qn = x[2] + x[3];
+            if (c.qinput_prune && l < 15) qn = 0.0f;
+            if (c.cld_inp_transformation == 1) qn = 1.0f - expf(-qn * g.lbd_qn[l]);
+            else if (c.cld_inp_transformation == 2) qn = sqrtf(sqrtf(qn));
+            x[2] = qn; x[3] = lf;
+        } else {
+            if (c.cld_inp_transformation == 1) {
+                x[2] = 1.0f - expf(-x[2] * g.lbd_qc[l]);
+                x[3] = 1.0f - expf(-x[3] * g.lbd_qi[l]);
+            } else if (c.cld_inp_transformation == 2) {
+                x[2] = sqrtf(sqrtf(x[2]));
+                x[3] = sqrtf(sqrtf(x[3]));
+            }
+            if (c.qinput_prune && l < 15) x[2] = 0.0f;
         }
-        if (isnan(t)) t = 0.0f;
-        xor_[v] = t;
+        for (int v = 0; v < nxo; ++v) {
+            float t = x[v];
+            if (c.apply_new_input_scaling) {
+                t = (t - g.xmean_lev[l * nxo + v]) / g.xdiv_lev[l * nxo + v];
+                if (v == qcol && t < 0.0f) t = 0.0f;
+            }
+            if (isnan(t)) t = 0.0f;
+            o[v] = t;
+        }
     }
+    flush(so, GEN_SX, xo, nxo);
 
     // ---- level targets -----------------------------------------------------------------------------------------
-    float y[6];
-    const float *yr = y_lev + ((size_t)n * L + l) * 6;
-    for (int v = 0; v < 6; ++v) {
-        float t = yr[v];
-        if (c.reverse_output_norm) t = t / g.yref_lev[l * 6 + v];
-        y[v] = t;
-        yd[((size_t)n * L + l) * 6 + v] = t;
+    float y[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (valid) {
+#pragma unroll
+        for (int v = 0; v < 6; ++v) {
+            float t = sy[tid * GEN_SY + v];
+            if (c.reverse_output_norm) t = t / g.yref_lev[l * 6 + v];
+            y[v] = t;
+            syo[tid * GEN_SY + v] = t;
+        }
     }
+    flush(syo, GEN_SY, yd, 6);
     float out[6];
     int ny = 6;
     if (c.mp_mode > 0) {                 // hu_mp_constraint: qn = qliq + qice replaces the two cloud tendencies
-        out[0] = y[0]; out[1] = y[1]; out[2] = y[2] + y[3]; out[3] = y[4]; out[4] = y[5];
+        out[0] = y[0]; out[1] = y[1]; out[2] = y[2] + y[3]; out[3] = y[4]; out[4] = y[5]; out[5] = 0.0f;
         ny = 5;
     } else if (c.mp_mode < 0) {          // pred_liq_frac (rnn/utils.py:2295-2343), float32 numpy arithmetic, unfused
         const float qn_b = add_nofma(ql_b, qi_b);
@@ -184,14 +212,18 @@ __global__ __launch_bounds__(256) void gen_batch_kernel(
             out[2] = tcf;
         }
     } else {
+#pragma unroll
         for (int v = 0; v < 6; ++v) out[v] = y[v];
     }
-    float *yor = yo + ((size_t)n * L + l) * ny;
-    for (int v = 0; v < ny; ++v) {
-        float t = out[v] * g.yscale_lev[l * ny + v];
-        if (c.output_prune && l < 12 && v >= 1) t = 0.0f;
-        yor[v] = t;
+    if (valid) {
+#pragma unroll
+        for (int v = 0; v < 6; ++v) {
+            float t = v < ny ? out[v] * g.yscale_lev[l * ny + (v < ny ? v : 0)] : 0.0f;
+            if (c.output_prune && l < 12 && v >= 1) t = 0.0f;
+            syo[tid * GEN_SY + v] = t;
+        }
     }
+    flush(syo, GEN_SY, yo, ny);
 }
 
 static const float *gen_up(csa_generator *h, const float *src, size_t n, int &rc)
@@ -269,7 +301,8 @@ extern "C" int csa_gen_batch(csa_generator *h, int N, const float *x_lev, const 
         return CSA_ERR_ARG;
     }
     const long tot = (long)N * h->d.c.nlev;
-    hipLaunchKernelGGL(gen_batch_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (hipStream_t)stream, h->d, N, x_lev, x_sfc, y_lev,
+    const size_t shm = sizeof(float) * GEN_T * (2 * (h->d.nx_out <= 16 ? 17 : 33) + 2 * GEN_SY);
+    hipLaunchKernelGGL(gen_batch_kernel, dim3((unsigned)((tot + GEN_T - 1) / GEN_T)), dim3(GEN_T), shm, (hipStream_t)stream, h->d, N, x_lev, x_sfc, y_lev,
                        y_sfc, x_lev_n, x_sfc_n, y_lev_n, y_sfc_n, x_lev_denorm, y_lev_denorm, y_sfc_denorm);
     CSA_HIP_CHECK(hipGetLastError());
     return CSA_OK;
