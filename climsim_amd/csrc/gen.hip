@@ -61,9 +61,11 @@ __device__ float gen_rh_to_q(float rh, float T, float p)
 }
 
 // One workgroup = GEN_T consecutive (sample, level) rows.  The row-major tensors are moved between HBM and LDS with
-// fully coalesced block copies (a thread-per-row access touches 64 different cache lines per wave instruction: 1.3 TB/s);
-// each thread then works on its own row in LDS (row stride 33 floats: conflict-free), which also replaces the
-// dynamically indexed register array the row used to live in.
+// fully coalesced block copies (a thread-per-row access touches 64 different cache lines per wave instruction), and
+// everything that is elementwise -- reversing the reference scaling, the new scaling with its per-(level, variable)
+// tables and IEEE divisions, the NaN scrub, the target scaling -- is done by those copy loops, one independent
+// iteration per element.  Only the operations that couple the variables of a row (RH clip and RH -> q, the cloud
+// transforms, the microphysics targets) run thread-per-row, on the row in LDS (odd stride 17 / 33: conflict-free).
 #define GEN_T 128
 #define GEN_SY 7
 __global__ __launch_bounds__(GEN_T) void gen_batch_kernel(
@@ -71,29 +73,38 @@ __global__ __launch_bounds__(GEN_T) void gen_batch_kernel(
     const float *__restrict__ y_sfc, float *__restrict__ xo, float *__restrict__ xso, float *__restrict__ yo,
     float *__restrict__ yso, float *__restrict__ xd, float *__restrict__ yd, float *__restrict__ ysd)
 {
-    extern __shared__ float gsm[];             // sx[GEN_T][SX] | so[GEN_T][SX] | sy[GEN_T][7] | syo[GEN_T][7]
-    const int GEN_SX = g.nx_out <= 16 ? 17 : 33;   // odd row stride: conflict-free row-per-thread access
-    float *sx = gsm, *so = sx + GEN_T * GEN_SX, *sy = so + GEN_T * GEN_SX, *syo = sy + GEN_T * GEN_SY;
+    extern __shared__ float gsm[];             // sx[GEN_T][SX] | sy[GEN_T][7] | level of each row
+    const int GEN_SX = g.nx_out <= 16 ? 17 : 33;
+    float *sx = gsm, *sy = sx + GEN_T * GEN_SX;
+    int *sl = (int *)(sy + GEN_T * GEN_SY);
     const csa_gen_config &c = g.c;
     const int L = c.nlev, tid = threadIdx.x;
     const long total = (long)N * L, i0 = (long)blockIdx.x * GEN_T, i = i0 + tid;
     const int rows = (int)(total - i0 < GEN_T ? total - i0 : GEN_T);
     const bool valid = tid < rows;
     const int n = valid ? (int)(i / L) : 0, l = valid ? (int)(i - (long)n * L) : 0;
-    const int nxi = c.nx_in, nxo = g.nx_out;
-    auto flush = [&](const float *src, int stride, float *dst, int width) {     // LDS rows -> contiguous global block
-        __syncthreads();
-        float *d = dst + (size_t)i0 * width;
-        const float inv = 1.0f / (float)width;      // (e + 0.5) / width is >= 0.5 / 33 away from an integer: the float quotient is exact
-        for (int e = tid; e < rows * width; e += GEN_T) { const int r = (int)(((float)e + 0.5f) * inv); d[e] = src[r * stride + (e - r * width)]; }
-        __syncthreads();
-    };
-    // ---- coalesced block loads ---------------------------------------------------------------------------------
+    const int nxi = c.nx_in, nxo = g.nx_out, ny = g.ny_out;
+    sl[tid] = l;
+    __syncthreads();
+    // (e + 0.5) / width is >= 0.5 / 33 away from an integer, so the float quotient gives the exact row index
+    // ---- coalesced block loads, reference scaling reversed on the way in ---------------------------------------------
     {
         const float *xb = x_lev + (size_t)i0 * nxi, *yb = y_lev + (size_t)i0 * 6;
         const float invx = 1.0f / (float)nxi;
-        for (int e = tid; e < rows * nxi; e += GEN_T) { const int r = (int)(((float)e + 0.5f) * invx); sx[r * GEN_SX + (e - r * nxi)] = xb[e]; }
-        for (int e = tid; e < rows * 6; e += GEN_T) { const int r = e / 6; sy[r * GEN_SY + (e - r * 6)] = yb[e]; }
+#pragma unroll 4
+        for (int e = tid; e < rows * nxi; e += GEN_T) {
+            const int r = (int)(((float)e + 0.5f) * invx), v = e - r * nxi;
+            float t = xb[e];
+            if (c.reverse_input_norm) { const int k = sl[r] * nxi + v; t = add_nofma(mul_nofma(t, g.xref_div[k]), g.xref_mean[k]); }
+            sx[r * GEN_SX + v] = t;
+        }
+#pragma unroll 4
+        for (int e = tid; e < rows * 6; e += GEN_T) {
+            const int r = e / 6, v = e - r * 6;
+            float t = yb[e];
+            if (c.reverse_output_norm) t = t / g.yref_lev[sl[r] * 6 + v];
+            sy[r * GEN_SY + v] = t;
+        }
     }
     __syncthreads();
 
@@ -120,25 +131,28 @@ __global__ __launch_bounds__(GEN_T) void gen_batch_kernel(
         }
     }
 
-    // ---- level inputs ------------------------------------------------------------------------------------------
-    float *x = sx + tid * GEN_SX, *o = so + tid * GEN_SX;
-    int qcol = -1;
+    // ---- level inputs: row-coupled part 1 (RH clip, RH -> q) -----------------------------------------------------
+    float *x = sx + tid * GEN_SX, *y = sy + tid * GEN_SY;
+    const int qcol = c.q_mode == 0 ? -1 : (c.q_mode == 1 ? nxi : 1);
     float T_b = 0.f, ql_b = 0.f, qi_b = 0.f, qlast_b = 0.f;
     if (valid) {
-        if (c.reverse_input_norm)
-            for (int v = 0; v < nxi; ++v) x[v] = add_nofma(mul_nofma(x[v], g.xref_div[l * nxi + v]), g.xref_mean[l * nxi + v]);
         if (c.rh_prune) x[1] = fminf(fmaxf(x[1], 0.0f), 1.2f);       // np.clip: NaN propagates
         if (c.q_mode != 0) {
             const float sp = sfc_raw(0);
             const float pres = add_nofma(mul_nofma(sp, g.hybm[l]), mul_nofma(100000.0f, g.hyam[l]));
-            const float q = gen_rh_to_q(x[1], x[0], pres);
-            qcol = c.q_mode == 1 ? nxi : 1;
-            x[qcol] = q;
+            x[qcol] = gen_rh_to_q(x[1], x[0], pres);
         }
-        for (int v = 0; v < nxo; ++v) o[v] = x[v];                    // x_lev_b_denorm (raw, q included)
         T_b = x[0]; ql_b = x[2]; qi_b = x[3]; qlast_b = x[nxo - 1];
     }
-    flush(so, GEN_SX, xd, nxo);
+    __syncthreads();
+    {   // x_lev_b_denorm (raw, q included): plain block copy
+        float *d = xd + (size_t)i0 * nxo;
+        const float inv = 1.0f / (float)nxo;
+#pragma unroll 4
+        for (int e = tid; e < rows * nxo; e += GEN_T) { const int r = (int)(((float)e + 0.5f) * inv); d[e] = sx[r * GEN_SX + (e - r * nxo)]; }
+    }
+    __syncthreads();
+    // ---- row-coupled part 2: cloud transforms ------------------------------------------------------------------------
     if (valid) {
         if (c.v4_to_v5_inputs) {
             float lf = mul_nofma(x[0] - 253.16f, 0.05f);
@@ -158,72 +172,73 @@ __global__ __launch_bounds__(GEN_T) void gen_batch_kernel(
             }
             if (c.qinput_prune && l < 15) x[2] = 0.0f;
         }
-        for (int v = 0; v < nxo; ++v) {
-            float t = x[v];
+    }
+    __syncthreads();
+    {   // new scaling, q >= 0, NaN -> 0: per element, straight to global memory
+        float *d = xo + (size_t)i0 * nxo;
+        const float inv = 1.0f / (float)nxo;
+#pragma unroll 4
+        for (int e = tid; e < rows * nxo; e += GEN_T) {
+            const int r = (int)(((float)e + 0.5f) * inv), v = e - r * nxo;
+            float t = sx[r * GEN_SX + v];
             if (c.apply_new_input_scaling) {
-                t = (t - g.xmean_lev[l * nxo + v]) / g.xdiv_lev[l * nxo + v];
+                const int k = sl[r] * nxo + v;
+                t = (t - g.xmean_lev[k]) / g.xdiv_lev[k];
                 if (v == qcol && t < 0.0f) t = 0.0f;
             }
             if (isnan(t)) t = 0.0f;
-            o[v] = t;
+            d[e] = t;
         }
     }
-    flush(so, GEN_SX, xo, nxo);
-
-    // ---- level targets -----------------------------------------------------------------------------------------
-    float y[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    // ---- level targets: raw copy, then the row-coupled microphysics targets, then scaling -------------------------
+    {
+        float *d = yd + (size_t)i0 * 6;
+#pragma unroll 4
+        for (int e = tid; e < rows * 6; e += GEN_T) { const int r = e / 6; d[e] = sy[r * GEN_SY + (e - r * 6)]; }
+    }
+    __syncthreads();
     if (valid) {
-#pragma unroll
-        for (int v = 0; v < 6; ++v) {
-            float t = sy[tid * GEN_SY + v];
-            if (c.reverse_output_norm) t = t / g.yref_lev[l * 6 + v];
-            y[v] = t;
-            syo[tid * GEN_SY + v] = t;
+        const float y0 = y[0], y1 = y[1], y2 = y[2], y3 = y[3], y4 = y[4], y5 = y[5];
+        if (c.mp_mode > 0) {                 // hu_mp_constraint: qn = qliq + qice replaces the two cloud tendencies
+            y[2] = y2 + y3; y[3] = y4; y[4] = y5;
+        } else if (c.mp_mode < 0) {          // pred_liq_frac (rnn/utils.py:2295-2343), float32 numpy arithmetic, unfused
+            const float qn_b = add_nofma(ql_b, qi_b);
+            const float dqn = add_nofma(y2, y3);
+            float qn_new = add_nofma(qn_b, mul_nofma(dqn, 1200.0f));
+            if (qn_new < 0.0f) qn_new = 0.0f;
+            const float ql_new = add_nofma(ql_b, mul_nofma(y2, 1200.0f));
+            const float T_new = add_nofma(T_b, mul_nofma(y0, 1200.0f));
+            float lf = (T_new - 253.16f) / 20.0f;
+            if (lf < 0.0f) lf = 0.0f;
+            if (lf > 1.0f) lf = 1.0f;
+            if (qn_new > 1e-20f && dqn > 1e-20f) lf = ql_new / qn_new;
+            if (lf < 0.0f) lf = 0.0f;
+            if (lf > 1.0f) lf = 1.0f;
+            y[2] = dqn; y[3] = lf;
+            if (c.mp_mode == -2) {
+                const float dqv = y1;
+                float qv_new = add_nofma(qlast_b, mul_nofma(dqv, 1200.0f));
+                if (qv_new < 0.0f) qv_new = 0.0f;
+                const float qtot_new = add_nofma(qv_new, qn_new);
+                float tcf = qtot_new > 0.0f ? qn_new / qtot_new : 0.0f;
+                tcf = sqrtf(sqrtf(tcf));
+                y[1] = add_nofma(dqv, dqn);
+                y[2] = tcf;
+            }
         }
     }
-    flush(syo, GEN_SY, yd, 6);
-    float out[6];
-    int ny = 6;
-    if (c.mp_mode > 0) {                 // hu_mp_constraint: qn = qliq + qice replaces the two cloud tendencies
-        out[0] = y[0]; out[1] = y[1]; out[2] = y[2] + y[3]; out[3] = y[4]; out[4] = y[5]; out[5] = 0.0f;
-        ny = 5;
-    } else if (c.mp_mode < 0) {          // pred_liq_frac (rnn/utils.py:2295-2343), float32 numpy arithmetic, unfused
-        const float qn_b = add_nofma(ql_b, qi_b);
-        const float dqn = add_nofma(y[2], y[3]);
-        float qn_new = add_nofma(qn_b, mul_nofma(dqn, 1200.0f));
-        if (qn_new < 0.0f) qn_new = 0.0f;
-        const float ql_new = add_nofma(ql_b, mul_nofma(y[2], 1200.0f));
-        const float T_new = add_nofma(T_b, mul_nofma(y[0], 1200.0f));
-        float lf = (T_new - 253.16f) / 20.0f;
-        if (lf < 0.0f) lf = 0.0f;
-        if (lf > 1.0f) lf = 1.0f;
-        if (qn_new > 1e-20f && dqn > 1e-20f) lf = ql_new / qn_new;
-        if (lf < 0.0f) lf = 0.0f;
-        if (lf > 1.0f) lf = 1.0f;
-        out[0] = y[0]; out[1] = y[1]; out[2] = dqn; out[3] = lf; out[4] = y[4]; out[5] = y[5];
-        if (c.mp_mode == -2) {
-            const float dqv = y[1];
-            float qv_new = add_nofma(qlast_b, mul_nofma(dqv, 1200.0f));
-            if (qv_new < 0.0f) qv_new = 0.0f;
-            const float qtot_new = add_nofma(qv_new, qn_new);
-            float tcf = qtot_new > 0.0f ? qn_new / qtot_new : 0.0f;
-            tcf = sqrtf(sqrtf(tcf));
-            out[1] = add_nofma(dqv, dqn);
-            out[2] = tcf;
-        }
-    } else {
-#pragma unroll
-        for (int v = 0; v < 6; ++v) out[v] = y[v];
-    }
-    if (valid) {
-#pragma unroll
-        for (int v = 0; v < 6; ++v) {
-            float t = v < ny ? out[v] * g.yscale_lev[l * ny + (v < ny ? v : 0)] : 0.0f;
-            if (c.output_prune && l < 12 && v >= 1) t = 0.0f;
-            syo[tid * GEN_SY + v] = t;
+    __syncthreads();
+    {
+        float *d = yo + (size_t)i0 * ny;
+        const float inv = 1.0f / (float)ny;
+#pragma unroll 4
+        for (int e = tid; e < rows * ny; e += GEN_T) {
+            const int r = (int)(((float)e + 0.5f) * inv), v = e - r * ny, lr = sl[r];
+            float t = sy[r * GEN_SY + v] * g.yscale_lev[lr * ny + v];
+            if (c.output_prune && lr < 12 && v >= 1) t = 0.0f;
+            d[e] = t;
         }
     }
-    flush(syo, GEN_SY, yo, ny);
 }
 
 static const float *gen_up(csa_generator *h, const float *src, size_t n, int &rc)
@@ -301,7 +316,7 @@ extern "C" int csa_gen_batch(csa_generator *h, int N, const float *x_lev, const 
         return CSA_ERR_ARG;
     }
     const long tot = (long)N * h->d.c.nlev;
-    const size_t shm = sizeof(float) * GEN_T * (2 * (h->d.nx_out <= 16 ? 17 : 33) + 2 * GEN_SY);
+    const size_t shm = sizeof(float) * GEN_T * ((h->d.nx_out <= 16 ? 17 : 33) + GEN_SY + 1);
     hipLaunchKernelGGL(gen_batch_kernel, dim3((unsigned)((tot + GEN_T - 1) / GEN_T)), dim3(GEN_T), shm, (hipStream_t)stream, h->d, N, x_lev, x_sfc, y_lev,
                        y_sfc, x_lev_n, x_sfc_n, y_lev_n, y_sfc_n, x_lev_denorm, y_lev_denorm, y_sfc_denorm);
     CSA_HIP_CHECK(hipGetLastError());
