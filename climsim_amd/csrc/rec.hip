@@ -402,6 +402,125 @@ __global__ __launch_bounds__(NH * 4, (NH / 16 + 3) / 4) void lstm_rec2_kernel(
 }
 
 // ------------------------------------------------------------------------------------------------
+// LSTM kernel for LARGE batches (inference): FOUR columns per workgroup = two column pairs that share the
+// register-stationary weights.  Per step the 128 packed FMAs are issued twice (once per pair, same weights, two LDS
+// reads per k-step instead of one), but the barrier, the reduce-scatter and the activation chains of the two pairs are
+// independent and interleave, so the ~900 non-FMA cycles of a lstm_rec2_kernel step are paid once per four columns
+// instead of once per two.  Every column sees exactly the arithmetic of lstm_rec2_kernel (same lane -> weight mapping,
+// same summation order), so results are bit-identical to it.  Used from 1,024 columns per call, where workgroups
+// outnumber the CUs anyway.
+template <int NH>
+__global__ __launch_bounds__(NH * 4, (NH / 16 + 3) / 4) void lstm_rec4_kernel(
+    const f32x4 *__restrict__ Wp4, const float *__restrict__ P,
+    const float *__restrict__ h0, const float *__restrict__ c0, float *__restrict__ Hout,
+    int B, int L, int reverse_out)
+{
+    constexpr int NT = NH * 4;
+    constexpr int KC = NH / 4;
+    constexpr int CH = 2 * KC + 4;
+    constexpr int CPY = 4 * CH;
+    constexpr int KR = KC / 2;
+    static_assert(KC % 4 == 0, "nh must be a multiple of 16");
+    __shared__ __attribute__((aligned(16))) float hbuf[2][2][2 * CPY];     // [parity][pair][two copies]
+
+    const int tid = threadIdx.x, u = tid >> 2, p = tid & 3, col = p & 1, grp = p >> 1;
+    int bA = 4 * blockIdx.x + col, bB = bA + 2;
+    const bool validA = bA < B, validB = bB < B;
+    if (!validA) bA = B - 1;
+    if (!validB) bB = B - 1;
+    const bool owner = grp == 1;
+
+    f32x2 w[4][KR];
+#pragma unroll
+    for (int i = 0; i < KC; ++i) {
+        const f32x4 v = Wp4[(size_t)i * NT + tid];
+        const int s = (4 * i) / KC, kk = (4 * i) % KC;
+        w[s][kk / 2] = f32x2{v.x, v.y};
+        w[s][kk / 2 + 1] = f32x2{v.z, v.w};
+    }
+    const float k1 = grp ? -1.44269504088896341f : -2.88539008177792681f;
+    const float nb1 = grp ? 0.0f : 1.0f;
+
+    float hA = h0[(size_t)bA * NH + u], cA = c0[(size_t)bA * NH + u];
+    float hB = h0[(size_t)bB * NH + u], cB = c0[(size_t)bB * NH + u];
+    const int slotN = 2 * u + col + 4 * (u / KC);
+    const int slotS = CPY + 2 * u + (1 - col) + 4 * (u / KC);
+    if (owner) {
+        hbuf[0][0][slotN] = hA; hbuf[0][0][slotS] = hA;
+        hbuf[0][1][slotN] = hB; hbuf[0][1][slotS] = hB;
+    }
+    const float *PbA = P + (size_t)bA * (4 * NH) + u * 4 + grp * 2;
+    const float *PbB = P + (size_t)bB * (4 * NH) + u * 4 + grp * 2;
+    const size_t Pstep = (size_t)B * (4 * NH);
+    const int rdoff = col * CPY + p * CH;
+    f32x2 preA0 = *(const f32x2 *)PbA, preA1 = preA0, preB0 = *(const f32x2 *)PbB, preB1 = preB0;
+    __syncthreads();
+
+#define LSTM4_GATES(R, CUR, C, H)                                                                  \
+    {                                                                                              \
+        const float v0 = R[0] + dpp_xor2(R[2]) + CUR.x;                                            \
+        const float v1 = R[1] + dpp_xor2(R[3]) + CUR.y;                                            \
+        const float g0 = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504088896341f * v0)); \
+        const float t1 = fminf(__builtin_amdgcn_exp2f(k1 * v1), 1e30f);                            \
+        const float g1 = (1.0f - nb1 * t1) * __builtin_amdgcn_rcpf(1.0f + t1);                     \
+        const float ig = dpp_xor2(g0 * g1);                                                        \
+        C = g0 * C + ig;                                                                           \
+        const float tc = fminf(__builtin_amdgcn_exp2f(-2.88539008177792681f * C), 1e30f);          \
+        const float th = (1.0f - tc) * __builtin_amdgcn_rcpf(1.0f + tc);                           \
+        H = g1 * th;                                                                               \
+    }
+#define LSTM4_STEP(T, CURA, NXTA, CURB, NXTB)                                                      \
+    {                                                                                              \
+        const int t_ = (T);                                                                        \
+        if (t_ + 1 < L) {                                                                          \
+            const float *pa = PbA + (size_t)(t_ + 1) * Pstep, *pb = PbB + (size_t)(t_ + 1) * Pstep; \
+            asm volatile("global_load_dwordx2 %0, %1, off" : "=&v"(NXTA) : "v"(pa) : "memory");    \
+            asm volatile("global_load_dwordx2 %0, %1, off" : "=&v"(NXTB) : "v"(pb) : "memory");    \
+        }                                                                                          \
+        const f32x4 *hpA = (const f32x4 *)&hbuf[t_ & 1][0][rdoff];                                 \
+        const f32x4 *hpB = (const f32x4 *)&hbuf[t_ & 1][1][rdoff];                                 \
+        f32x2 accA[4] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};                          \
+        f32x2 accB[4] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};                          \
+        _Pragma("unroll") for (int j = 0; j < KR; ++j) {                                           \
+            const f32x4 hvA = hpA[j], hvB = hpB[j];                                                \
+            const f32x2 haA = {hvA.x, hvA.y}, hbA = {hvA.z, hvA.w};                                \
+            const f32x2 haB = {hvB.x, hvB.y}, hbB = {hvB.z, hvB.w};                                \
+            _Pragma("unroll") for (int s = 0; s < 4; ++s) PK_FMA_LO(accA[s], w[s][j], haA);        \
+            _Pragma("unroll") for (int s = 0; s < 4; ++s) PK_FMA_LO(accB[s], w[s][j], haB);        \
+            _Pragma("unroll") for (int s = 0; s < 4; ++s) PK_FMA_HI(accA[s], w[s][j], hbA);        \
+            _Pragma("unroll") for (int s = 0; s < 4; ++s) PK_FMA_HI(accB[s], w[s][j], hbB);        \
+        }                                                                                          \
+        float rA[4], rB[4];                                                                        \
+        _Pragma("unroll") for (int s = 0; s < 4; ++s) {                                            \
+            rA[s] = accA[s].x + dpp_xor1(accA[s].y);                                               \
+            rB[s] = accB[s].x + dpp_xor1(accB[s].y);                                               \
+        }                                                                                          \
+        if (t_ > 0) {                                                                              \
+            if (t_ + 1 < L) asm volatile("s_waitcnt vmcnt(2)" : "+v"(CURA), "+v"(CURB));           \
+            else asm volatile("s_waitcnt vmcnt(0)" : "+v"(CURA), "+v"(CURB));                      \
+        }                                                                                          \
+        LSTM4_GATES(rA, CURA, cA, hA)                                                              \
+        LSTM4_GATES(rB, CURB, cB, hB)                                                              \
+        if (owner) {                                                                               \
+            hbuf[(t_ & 1) ^ 1][0][slotN] = hA;                                                     \
+            hbuf[(t_ & 1) ^ 1][0][slotS] = hA;                                                     \
+            hbuf[(t_ & 1) ^ 1][1][slotN] = hB;                                                     \
+            hbuf[(t_ & 1) ^ 1][1][slotS] = hB;                                                     \
+            const size_t lv = (size_t)(reverse_out ? L - 1 - t_ : t_) * B;                         \
+            if (validA) Hout[(lv + bA) * NH + u] = hA;                                             \
+            if (validB) Hout[(lv + bB) * NH + u] = hB;                                             \
+        }                                                                                          \
+        LDS_BARRIER();                                                                             \
+    }
+    for (int t = 0; t < L; t += 2) {
+        LSTM4_STEP(t, preA0, preA1, preB0, preB1)
+        if (t + 1 < L) LSTM4_STEP(t + 1, preA1, preA0, preB1, preB0)
+    }
+#undef LSTM4_STEP
+#undef LSTM4_GATES
+}
+
+// ------------------------------------------------------------------------------------------------
 // GRU kernel, second generation (inference): the lstm_rec2_kernel design with three accumulator slots.
 // Slot order per lane group (host packing, gru2_pack_weights): p<2 holds [r, hn, z], p>=2 holds [z, hn, r], so after
 //   r[s] = acc[s].x + xor1(acc[s].y);  v0 = r[0] + xor2(r[2]);  v1 = r[1] + xor2(r[1])
@@ -758,11 +877,25 @@ void rec_pack_weights(int use_lstm, int nh, const float *w_hh, float *packed)
     }
 }
 
+// smallest batch of a launch that uses the four-column kernel (env CSA_REC4_MIN_BATCH; 0 disables)
+static int rec4_min_batch()
+{
+    static const int v = getenv("CSA_REC4_MIN_BATCH") ? atoi(getenv("CSA_REC4_MIN_BATCH")) : 1024;
+    return v > 0 ? v : 0x7fffffff;
+}
+
 template <int NH>
 static int launch_rec_nh(int use_lstm, const float *whh, const float *bhn, const float *P, const float *h0,
                          const float *c0, float *Hout, int B, int L, int reverse_out, hipStream_t s)
 {
     const dim3 grid((B + 1) / 2), block(NH * 4);
+    if constexpr (NH <= 128) {
+        if (use_lstm && B >= rec4_min_batch()) {      // four columns per workgroup (bit-identical to the two-column kernel)
+            hipLaunchKernelGGL((lstm_rec4_kernel<NH>), dim3((B + 3) / 4), block, 0, s, (const f32x4 *)whh, P, h0, c0, Hout, B, L, reverse_out);
+            CSA_HIP_CHECK(hipGetLastError());
+            return CSA_OK;
+        }
+    }
     if (use_lstm) {
         constexpr int NL4 = NH > 128 ? 2 : 0;
         constexpr size_t shm = (size_t)4 * NL4 * NH * 4 * sizeof(f32x4);

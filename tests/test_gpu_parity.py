@@ -564,3 +564,29 @@ def test_gru_two_column_kernel_vs_reference_class_and_one_column():
         model.emulator.set_rec1_max_batch(256)
     for a, b in zip(two, one):
         assert rel_err(a.cpu().numpy(), b.cpu().numpy()) <= 2e-6
+
+
+@pytest.mark.parametrize("B", [1026, 1101, 2700])
+def test_four_column_kernel_is_bit_identical_to_two_column(memory, B):
+    """lstm_rec4_kernel (four columns per workgroup, from 1,024 columns per launch) gives every column exactly the
+    arithmetic of lstm_rec2_kernel: a large call equals, bit for bit, the same rows computed in sub-batches that are too
+    small for it (B = 1026 / 1101: a last workgroup with 2 / 1 valid columns), and the oracle tolerance holds."""
+    consts, weights, model = memory
+    xm, xs = synth_inputs(consts, B, 700 + B)
+    g = np.random.Generator(np.random.PCG64(B))
+    mem = (0.4 * g.standard_normal((B, 60, 16))).astype(np.float32)
+    hx, cx = g.standard_normal((2, B, 128)).astype(np.float32)
+    args = [_dev(a) for a in (xm, xs, mem, hx, cx)]
+    model.emulator.set_halves(False)
+    try:
+        y_full = model.emulator.forward_packed(*args).clone()
+        parts = []
+        for lo in range(0, B, 700):                                     # 700 < 1024: two-column kernel, same GEMM class
+            hi = min(B, lo + 700)
+            parts.append(model.emulator.forward_packed(*[a[lo:hi].contiguous() for a in args]).clone())
+    finally:
+        model.emulator.set_halves(None)
+    assert torch.equal(y_full, torch.cat(parts))
+    # and with the automatic two-stream halves (each half >= 1,024 columns only at B = 2,700)
+    y_auto = model.emulator.forward_packed(*args)
+    assert torch.equal(y_auto, y_full)
