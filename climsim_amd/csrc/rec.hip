@@ -472,8 +472,12 @@ __global__ __launch_bounds__(NH * 4, (NH / 16 + 3) / 4) void lstm_rec4_kernel(
 #define LSTM4_STEP(T, CURA, NXTA, CURB, NXTB)                                                      \
     {                                                                                              \
         const int t_ = (T);                                                                        \
-        if (t_ + 1 < L) {                                                                          \
-            const float *pa = PbA + (size_t)(t_ + 1) * Pstep, *pb = PbB + (size_t)(t_ + 1) * Pstep; \
+        {   /* UNCONDITIONAL prefetch (the last step re-reads its own row): the number of loads in flight is then the  \
+               same at every step and ONE wait statement serves all of them.  With a second, conditional wait        \
+               ("vmcnt(0)" on the last step) hipcc placed register copies of the in-flight values BEFORE that wait:  \
+               stale projections at t = L-1 whenever the load was late (seen only under memory contention). */      \
+            const int tn_ = t_ + 1 < L ? t_ + 1 : L - 1;                                           \
+            const float *pa = PbA + (size_t)tn_ * Pstep, *pb = PbB + (size_t)tn_ * Pstep;          \
             asm volatile("global_load_dwordx2 %0, %1, off" : "=&v"(NXTA) : "v"(pa) : "memory");    \
             asm volatile("global_load_dwordx2 %0, %1, off" : "=&v"(NXTB) : "v"(pb) : "memory");    \
         }                                                                                          \
@@ -495,10 +499,7 @@ __global__ __launch_bounds__(NH * 4, (NH / 16 + 3) / 4) void lstm_rec4_kernel(
             rA[s] = accA[s].x + dpp_xor1(accA[s].y);                                               \
             rB[s] = accB[s].x + dpp_xor1(accB[s].y);                                               \
         }                                                                                          \
-        if (t_ > 0) {                                                                              \
-            if (t_ + 1 < L) asm volatile("s_waitcnt vmcnt(2)" : "+v"(CURA), "+v"(CURB));           \
-            else asm volatile("s_waitcnt vmcnt(0)" : "+v"(CURA), "+v"(CURB));                      \
-        }                                                                                          \
+        if (t_ > 0) asm volatile("s_waitcnt vmcnt(2)" : "+v"(CURA), "+v"(CURB));                   \
         LSTM4_GATES(rA, CURA, cA, hA)                                                              \
         LSTM4_GATES(rB, CURB, cB, hB)                                                              \
         if (owner) {                                                                               \

@@ -590,3 +590,27 @@ def test_four_column_kernel_is_bit_identical_to_two_column(memory, B):
     # and with the automatic two-stream halves (each half >= 1,024 columns only at B = 2,700)
     y_auto = model.emulator.forward_packed(*args)
     assert torch.equal(y_auto, y_full)
+
+
+def test_large_batch_two_stream_call_matches_small_calls():
+    """10,800 columns in one call (two column halves of 5,400 on two streams, four-column recurrent kernel, projection
+    GEMMs of the other half contending for HBM) against the same rows computed 700 at a time on one stream: bit for bit,
+    three times over.  Regression guard: a first version of lstm_rec4_kernel read its prefetched projections of the
+    LAST level before the wait whenever the load was late, which only showed under this contention."""
+    import climsim_amd
+    consts, weights, _ = load_npz_model("v4_memory")
+    B = 10800
+    model = climsim_amd.NewModel_constraint(consts, weights, max_batch=B)
+    xm, xs = synth_inputs(consts, B, 3)
+    g = np.random.Generator(np.random.PCG64(1))
+    args = [_dev(a) for a in (xm, xs, (0.3 * g.standard_normal((B, 60, 16))).astype(np.float32),
+                              g.standard_normal((B, 128)).astype(np.float32), g.standard_normal((B, 128)).astype(np.float32))]
+    model.emulator.set_halves(False)
+    ref = torch.cat([model.emulator.forward_packed(*[a[lo:lo + 700].contiguous() for a in args]) for lo in range(0, B, 700)])
+    model.emulator.set_halves(True)
+    try:
+        for _ in range(3):
+            y = model.emulator.forward_packed(*args)
+            assert torch.equal(y, ref)
+    finally:
+        model.emulator.set_halves(None)
