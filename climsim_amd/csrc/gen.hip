@@ -91,7 +91,6 @@ __global__ __launch_bounds__(GEN_T) void gen_batch_kernel(
     {
         const float *xb = x_lev + (size_t)i0 * nxi, *yb = y_lev + (size_t)i0 * 6;
         const float invx = 1.0f / (float)nxi;
-#pragma unroll 4
         for (int e = tid; e < rows * nxi; e += GEN_T) {
             const int r = (int)(((float)e + 0.5f) * invx), v = e - r * nxi;
             float t = xb[e];
