@@ -1,33 +1,65 @@
 #!/usr/bin/env python3
-"""bench.py -- grid-columns/s of the emulator forward on N MI355X GPUs (one process per GPU).
+"""bench.py -- grid-columns/s of the emulator forward and column-timesteps/s of the TBPTT training step on N MI355X
+GPUs (one process per GPU).
 
-    python bench.py --gpus 1 --steps 200 --warmup 20
+    python bench.py --gpus N --steps K --warmup W        (N > 1: this process only SPAWNS the N ranks -- before it has
+                                                          made any GPU call -- as `python -m torch.distributed.run ...`)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-        --master-port P bench.py --gpus N --steps K --warmup W
+        --master-port P bench.py --gpus N --steps K --warmup W     (externally launched form, same result)
 
-Workload (BASELINE.json configs[1]): the v4 stateless wrapper (weights of
-rnn/v4_rnn_wrapper_constrained.pt, committed as data under tests/golden/), one 384-column batch
-of synthetic raw inputs per GPU per step, inputs resident in HBM.  Columns are independent, so
-ranks shard them with NO data-path collective (weak scaling: 384 columns per GPU).
-
-One JSON line on rank 0.  `roofline` is for the dominant kernel (the register-stationary
-recurrent kernel, two launches per step), timed with HIP events on the launch stream;
-`cpu_baseline` is the oracle's torch restatement (nn.LSTM on the host cores) on the same batch.
+Default invocation = ONE JSON line on rank 0 with both halves of BASELINE.json's metric:
+  * headline (`value`): BASELINE.json configs[1], the v4 stateless wrapper (weights of rnn/v4_rnn_wrapper_constrained.pt,
+    committed as data under tests/golden/), one 384-column batch of synthetic raw inputs per GPU per step, inputs
+    resident in HBM.  Columns are independent, so ranks shard them with NO data-path collective (weak scaling).
+  * `memory_wrapper`: the same measurement for the stateful v4 memory wrapper (configs[2]/[4]'s model, the north_star's
+    target), rnn1_mem fed back by the caller every step.
+  * `train`: one TBPTT optimiser step (window 3) of the current-generation LSTM-with-memory, 384 columns per GPU, ONE
+    flat-gradient all-reduce per step; column-timesteps/s, with the roofline of the BPTT recurrence kernel.
+`roofline` is for the dominant kernel (the register-stationary recurrent kernel, two launches per step), timed with HIP
+events on the launch stream; `cpu_baseline` is the oracle's torch restatement (nn.LSTM on the host cores), same batch.
 """
 import argparse
 import gc
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import numpy as np
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 for p in (ROOT, os.path.join(ROOT, "tests", "golden")):
     if p not in sys.path:
         sys.path.insert(0, p)
+
+
+def spawn_ranks(n, argv):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as children of a process that has not touched the
+    GPU (no torch import yet, no HIP call) and pass their output through.  Never a re-exec."""
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")    # dmabuf IPC: RCCL between processes needs it on this pool
+    env.setdefault("OMP_NUM_THREADS", "4")
+    return subprocess.call(cmd, env=env)
+
+
+def _early_spawn():
+    ap = argparse.ArgumentParser(add_help=False)
+    ap.add_argument("--gpus", type=int, default=1)
+    a, _ = ap.parse_known_args()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(a.gpus, sys.argv[1:]))
+
+
+if __name__ == "__main__":
+    _early_spawn()
+
+import numpy as np      # noqa: E402  (after the spawn decision: the parent of an N-rank run stays torch-free)
+import torch            # noqa: E402
 
 PEAK_FP32_TFLOPS = 157.3   # MI355X dense fp32 (vector == f32 MFMA), MI355X_MICROARCH.md
 WORKLOADS = {
@@ -105,12 +137,78 @@ def cpu_baseline(tag, consts, weights, xm, xs, mem, hx, cx, budget_s=12.0):
                       f"(torch {torch.__version__} CPU, {cores} threads), {el:.1f} s"}
 
 
-def train_workload(a, rank, local_rank, world, dist):
-    """Optional workload (BASELINE.json configs[2]): one TBPTT optimiser step of the current-generation
-    LSTM (window T_w = 3, 384 columns per GPU): 3 forwards with saved activations, loss, 3 backwards,
-    ONE flat-buffer RCCL all-reduce, Adam.  Unit: column-timesteps/s."""
+def _fence(dist):
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+
+
+def _timed(step, steps, warmup, dist, preheat_s=0.25):
+    """W untimed warm-up steps (plus an untimed pre-heat of the same step so that the timed region does not start on an
+    idle-clocked device), then EXACTLY `steps` steps between barrier + synchronize fences; MAX over ranks."""
+    from climsim_amd.sharding import max_over_ranks
+    gc.collect(); gc.disable()     # a generation-2 collection over the interpreter's heap costs tens of ms (and lets the device
+    for _ in range(warmup):        # clock down while the host is busy): done BEFORE the warm-up, never inside the timed steps
+        step()
+    torch.cuda.synchronize()
+    t0, pre = time.perf_counter(), 0
+    while time.perf_counter() - t0 < preheat_s:      # back-to-back launches (sustained load), one sync per chunk
+        for _ in range(25):
+            step()
+        torch.cuda.synchronize()
+        pre += 25
+    _fence(dist)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    _fence(dist)
+    el = time.perf_counter() - t0
+    gc.enable()
+    return max_over_ranks(el, device="cuda"), pre
+
+
+def cpu_train_baseline(consts, weights, grid, B, Tw, args_cpu, budget_s=8.0):
+    """CPU leg of the training metric: the oracle's torch restatement (nn.LSTM autograd + the metrics restatement + Adam),
+    the loop semantics of rnn/train_rnn_rollout.py:762-933, on this host's cores; a few optimiser steps, bounded."""
+    from oracle import torch_ref
+    xn, xsn, xr, t5, t8, y6, y8 = args_cpu
+    ref = torch_ref.EmulatorRef(consts, weights, legacy=False, use_lstm=True, output_prune=True, scrub_inf=True)
+    opt = torch.optim.Adam(ref.parameters(), lr=1e-3)
+    ncpu = os.cpu_count() or 1
+    cores = min(ncpu, 16)
+    torch.set_num_threads(cores)
+    mem = torch.zeros(60, B, 16)
+    cat = lambda t: torch.cat([t] * Tw, 0)
+
+    def one(mem):
+        outs, outs_sfc = [], []
+        for _ in range(Tw):
+            o, os_, mem = ref.model_forward(xn, xsn, mem)
+            outs.append(o); outs_sfc.append(os_)
+        loss, _ = torch_ref.window_loss(ref, torch.cat(outs, 0), torch.cat(outs_sfc, 0), cat(t5), cat(t8), cat(y6), cat(y8),
+                                        cat(xr), cat(xsn), grid["hyai"], grid["hybi"], Tw)
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        return mem.detach()
+    mem = one(mem)
+    t0, n = time.perf_counter(), 0
+    while True:
+        mem = one(mem)
+        n += 1
+        el = time.perf_counter() - t0
+        if (el > budget_s and n >= 2) or n >= 50:
+            break
+    return {"value": B * Tw * n / el, "unit": "column-timesteps/s", "cores": cores, "kind": "port",
+            "sample": f"{n} TBPTT optimiser steps (window {Tw}, {B} columns) through oracle/torch_ref.py autograd "
+                      f"(torch {torch.__version__} CPU, {cores} threads), {el:.1f} s"}
+
+
+def train_leg(a, rank, world, dist, steps, warmup, with_cpu):
+    """BASELINE.json configs[2]: one TBPTT optimiser step of the current-generation LSTM with memory (window T_w = 3, 384
+    columns per GPU): 3 forwards with saved activations, loss, 3 backwards, ONE flat-buffer RCCL all-reduce, Adam.
+    Unit: column-timesteps/s.  Returns the `train` object of the JSON line."""
     from climsim_amd.train import Trainer
-    from oracle import torch_ref          # cpu_baseline leg only (rank 0, N=1)
     from synth import synth_inputs
     consts, weights = load_model("cur_lstm128")
     grid = np.load(os.path.join(ROOT, "tests", "golden", "grid_consts.npz"))
@@ -129,32 +227,44 @@ def train_workload(a, rank, local_rank, world, dist):
     y8 = torch.rand(B, 8, generator=g) * 1e-7
     dv = lambda t: [t.contiguous().cuda()] * Tw
     args = (dv(xn), dv(xsn), dv(xmt), dv(t5), dv(t8), dv(y6), dv(y8))
-    mem = torch.zeros(60, B, 16, device="cuda")
+    state = {"mem": torch.zeros(60, B, 16, device="cuda"), "sc": None}
 
-    def fence():
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-    for _ in range(a.warmup):
-        sc, mem, _ = tr.window_step(*args, mem, world_size=world, global_columns=B * world)
-    fence()
-    gc.collect(); gc.disable()     # a generation-2 collection over the interpreter's heap costs tens of ms: keep it out of the timed steps
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        sc, mem, _ = tr.window_step(*args, mem, world_size=world, global_columns=B * world)
-    fence()
-    gc.enable()
-    from climsim_amd.sharding import max_over_ranks
-    el = max_over_ranks(time.perf_counter() - t0, device="cuda")
+    def step():
+        state["sc"], state["mem"], _ = tr.window_step(*args, state["mem"], world_size=world, global_columns=B * world)
+    el, pre = _timed(step, steps, warmup, dist)
+    # per-stage durations (HIP events on the launch stream), same step loop, outside the timed region
+    tr.set_profiling(True)
+    tr.reset_profile()
+    for _ in range(20):
+        step()
+    prof = tr.get_profile()
+    tr.set_profiling(False)
+    out = None
     if rank == 0:
-        print(json.dumps({
-            "metric": "train-step column-timesteps/sec (TBPTT window 3)", "value": world * B * Tw * a.steps / el,
-            "unit": "column-timesteps/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-            "ms_per_step": 1e3 * el / a.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
-            "config": {"workload": a.workload, "columns_per_gpu": B, "window": Tw, "model": "RNN_autoreg LSTM 128/128, nh_mem 16",
-                       "parallelism": f"columns sharded x{world}, one flat-gradient all-reduce per step"},
-            "loss": sc["loss"]}), flush=True)
+        bwd_ms, nb = prof["bwd_rec"]
+        flop = B * 60 * 2.0 * 4 * 128 * 128       # W_hh^T . d(gates): algorithmic FLOP of one BPTT recurrence launch
+        ach = flop / (bwd_ms * 1e-3) / 1e12 if bwd_ms > 0 else 0.0
+        value = world * B * Tw * steps / el
+        flop_step = 3 * 32.95e6                    # fwd + bwd ~ 3x forward FLOP per column-timestep
+        out = {"metric": "train-step column-timesteps/sec (TBPTT window 3)", "value": value, "unit": "column-timesteps/s",
+               "steps": steps, "warmup": warmup, "preheat_steps": pre, "ms_per_step": 1e3 * el / steps, "scaling": "weak", "dtype": "f32",
+               "config": {"workload": "train_tbptt3_384", "columns_per_gpu": B, "window": Tw,
+                          "model": "RNN_autoreg LSTM 128/128, nh_mem 16, mp_mode 1; huber + energy + water loss; Adam",
+                          "parallelism": f"columns sharded x{world}, one flat-gradient all-reduce per step"},
+               "roofline": {"bound": "fp32-vector (v_pk_fma_f32; same 157.3 TF peak as f32 MFMA)",
+                            "kernel": "lstm_bwd_rec_kernel<128> (one launch per LSTM per backward, 6 per step)",
+                            "achieved": ach, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_FP32_TFLOPS,
+                            "traffic": pmc_traffic("train_tbptt3_384", "lstm_bwd_rec_kernel"),
+                            "traffic_unit": "HBM bytes per launch (rocprofv3 PMC, profiles/)",
+                            "algorithmic_hbm_bytes_per_launch": B * 60 * (2 * 4 * 128 + 2 * 128) * 4.0,
+                            "flop_per_launch": flop, "avg_launch_ms": bwd_ms, "launches_timed": nb},
+               "whole_path": {"flop_per_column_timestep": flop_step, "achieved_tflops": value / world * flop_step / 1e12,
+                              "frac_fp32_peak": value / world * flop_step / 1e12 / PEAK_FP32_TFLOPS},
+               "stage_ms": {k: v[0] for k, v in prof.items()}, "loss": state["sc"]["loss"]}
+        if with_cpu:
+            out["cpu_baseline"] = cpu_train_baseline(consts, weights, grid, B, Tw, (xn, xsn, xmt, t5, t8, y6, y8))
+    tr.close()
+    return out
 
 
 def aux_workload(a, rank, world, dist):
@@ -250,21 +360,7 @@ def aux_workload(a, rank, world, dist):
             m(x)
         flop_col, what = 1.58e9, "Keras CNN (12 residual Conv1D blocks) forward, implicit-GEMM"
 
-    def fence():
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-    for _ in range(a.warmup):
-        step()
-    fence()
-    gc.collect(); gc.disable()     # see train_workload: no interpreter garbage collection inside the timed steps
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        step()
-    fence()
-    gc.enable()
-    from climsim_amd.sharding import max_over_ranks
-    el = max_over_ranks(time.perf_counter() - t0, device="cuda")
+    el, _ = _timed(step, a.steps, a.warmup, dist)
     if rank == 0:
         tf = B * flop_col * a.steps / el / 1e12
         print(json.dumps({
@@ -281,12 +377,81 @@ def aux_workload(a, rank, world, dist):
 AUX = ["cur_lstm144_384", "cur_lstm128_384", "cur_gru128_384", "mlp_384", "online_mlp_384", "physrnn_384", "cnn_384", "cnn_train_384"]
 
 
+def forward_leg(a, workload, rank, world, dist, steps, warmup, with_cpu):
+    """One forward workload: value (whole job), HIP-event kernel times, roofline of the recurrent kernel."""
+    import climsim_amd
+    from synth import synth_inputs
+    tag, B, flop_col, bytes_col = WORKLOADS[workload]
+    consts, weights = load_model(tag)
+    model = climsim_amd.NewModel_constraint(consts, weights, max_batch=B)
+    stateful = model.stateful
+    if a.halves >= 0:
+        model.emulator.set_halves(bool(a.halves))   # default: automatic (on from 640 columns per GPU)
+    # each rank owns its own shard of columns (different seed), resident in HBM
+    xm, xs = synth_inputs(consts, B, 9000 + rank)
+    rng = np.random.Generator(np.random.PCG64(100 + rank))
+    hx, cx = rng.standard_normal((2, B, 128)).astype(np.float32)
+    mem = np.zeros((B, 60, 16), np.float32) if stateful else None
+    d_xm, d_xs = torch.from_numpy(xm).cuda(), torch.from_numpy(xs).cuda()
+    d_hx, d_cx = torch.from_numpy(hx).cuda(), torch.from_numpy(cx).cuda()
+    st = {"mem": torch.from_numpy(mem).cuda() if stateful else None}
+    out = torch.empty(B, model.emulator.packed_width, device="cuda")
+
+    def step():
+        y = model.emulator.forward_packed(d_xm, d_xs, st["mem"], d_hx, d_cx, out=out)
+        if stateful:   # caller-owned state, fed back exactly like the reference harness
+            st["mem"] = y[:, 368:].reshape(B, 60, 16).contiguous()
+        return y
+
+    el, pre = _timed(step, steps, warmup, dist)
+    value = world * B * steps / el
+
+    # ---- per-kernel durations (HIP events on the launch stream), same step loop -------------------
+    em = model.emulator
+    em.set_profiling(True)
+    em.reset_profile()
+    for _ in range(100):
+        step()
+    prof, ncalls = em.get_profile()
+    em.set_profiling(False)
+    if rank != 0:
+        return None
+    rec_ms = 0.5 * (prof["rec_rnn1"] + prof["rec_rnn2"])
+    rec_flop = B * 60 * 2.0 * 4 * 128 * 128          # algorithmic FLOP of one recurrent launch
+    achieved = rec_flop / (rec_ms * 1e-3) / 1e12 if rec_ms > 0 else 0.0
+    rec_name = "lstm_rec1_kernel<128>" if B <= 256 else ("lstm_rec4_kernel<128>" if B >= 1024 else "lstm_rec2_kernel<128,false,0>")
+    leg = {
+        "value": value, "unit": "grid-columns/s", "steps": steps, "warmup": warmup, "preheat_steps": pre,
+        "ms_per_step": 1e3 * el / steps,
+        "config": {"workload": workload, "columns_per_gpu": B, "nlev": 60,
+                   "wrapper": "stateless v4 (rnn/v4_rnn_wrapper_constrained.pt weights)" if not stateful
+                   else "stateful v4 memory wrapper (rnn/v4_rnn-memory_wrapper_constrained_huber.pt weights), rnn1_mem fed back",
+                   "parallelism": f"columns sharded x{world}, no collective"},
+        "roofline": {"bound": "fp32-vector (v_pk_fma_f32; same 157.3 TF peak as f32 MFMA)",
+                     "kernel": rec_name + " (one launch per LSTM, 2 per step)",
+                     "achieved": achieved, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
+                     "frac": achieved / PEAK_FP32_TFLOPS, "traffic": pmc_traffic(workload, rec_name.split("<")[0]),
+                     "traffic_unit": "HBM bytes per launch (rocprofv3 PMC, profiles/)",
+                     "algorithmic_hbm_bytes_per_launch": B * 60 * (4 * 128 + 128) * 4.0,
+                     "flop_per_launch": rec_flop, "avg_launch_ms": rec_ms},
+        "whole_path": {"flop_per_column": flop_col, "achieved_tflops": value / world * flop_col / 1e12,
+                       "frac_fp32_peak": value / world * flop_col / 1e12 / PEAK_FP32_TFLOPS,
+                       "hbm_bytes_per_column": bytes_col,
+                       "achieved_hbm_gbs": value / world * bytes_col / 1e9},
+        "kernel_ms": prof, "kernel_profile_calls": ncalls,
+    }
+    if with_cpu:
+        leg["cpu_baseline"] = cpu_baseline(tag, consts, weights, xm, xs, mem, hx, cx)
+    model.emulator.close()
+    return leg
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--workload", default="v4_stateless_384", choices=sorted(WORKLOADS) + ["train_tbptt3_384"] + AUX)
+    ap.add_argument("--workload", default="default", choices=["default"] + sorted(WORKLOADS) + ["train_tbptt3_384"] + AUX)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--halves", type=int, default=-1, help="1/0: force the two-stream column-half path on/off (default: library default)")
     a = ap.parse_args()
@@ -294,8 +459,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if a.gpus > 1 and world != a.gpus:
-        sys.exit(f"--gpus {a.gpus} needs torch.distributed.run with WORLD_SIZE={a.gpus} (got {world})")
+    if a.gpus != world:
+        sys.exit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
     # one rank per GPU.  Rehearsal only (1-GPU box): CSA_BENCH_BACKEND=gloo lets several ranks share device 0 so that
     # the N>1 control flow (barriers, max-over-ranks, the gradient all-reduce) can be exercised without RCCL.
     backend = os.environ.get("CSA_BENCH_BACKEND", "nccl")
@@ -312,103 +477,35 @@ def main():
         else:
             dist.init_process_group(backend)
 
-    import climsim_amd
-    from synth import synth_inputs
+    def finish():
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
 
     if a.workload in AUX:
         aux_workload(a, rank, world, dist)
-        if dist is not None:
-            dist.barrier()
-            dist.destroy_process_group()
-        return
+        return finish()
+    with_cpu = not a.no_cpu_baseline and world == 1
+    common = {"n_gpus": world, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic"}
     if a.workload == "train_tbptt3_384":
-        train_workload(a, rank, local_rank, world, dist)
-        if dist is not None:
-            dist.barrier()
-            dist.destroy_process_group()
-        return
-    tag, B, flop_col, bytes_col = WORKLOADS[a.workload]
-    consts, weights = load_model(tag)
-    model = climsim_amd.NewModel_constraint(consts, weights, max_batch=B)
-    stateful = model.stateful
-    if a.halves >= 0:
-        model.emulator.set_halves(bool(a.halves))   # default: automatic (on from 640 columns per GPU)
-    # each rank owns its own shard of columns (different seed), resident in HBM
-    xm, xs = synth_inputs(consts, B, 9000 + rank)
-    rng = np.random.Generator(np.random.PCG64(100 + rank))
-    hx, cx = rng.standard_normal((2, B, 128)).astype(np.float32)
-    mem = np.zeros((B, 60, 16), np.float32) if stateful else None
-    d_xm, d_xs = torch.from_numpy(xm).cuda(), torch.from_numpy(xs).cuda()
-    d_hx, d_cx = torch.from_numpy(hx).cuda(), torch.from_numpy(cx).cuda()
-    d_mem = torch.from_numpy(mem).cuda() if stateful else None
-    out = torch.empty(B, model.emulator.packed_width, device="cuda")
-
-    def step():
-        nonlocal d_mem
-        y = model.emulator.forward_packed(d_xm, d_xs, d_mem, d_hx, d_cx, out=out)
-        if stateful:   # caller-owned state, fed back exactly like the reference harness
-            d_mem = y[:, 368:].reshape(B, 60, 16).contiguous()
-        return y
-
-    def fence():
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(a.warmup):
-        step()
-    fence()
-    gc.collect(); gc.disable()     # interpreter garbage collection (tens of ms for a full pass) stays outside the timed steps
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        step()
-    fence()
-    el = time.perf_counter() - t0
-    gc.enable()
-    from climsim_amd.sharding import max_over_ranks
-    el = max_over_ranks(el, device="cuda")     # whole-job time = the slowest rank's
-    value = world * B * a.steps / el
-
-    # ---- per-kernel durations (HIP events on the launch stream), same step loop -------------------
-    em = model.emulator
-    em.set_profiling(True)
-    em.reset_profile()
-    for _ in range(min(a.steps, 100)):
-        step()
-    prof, ncalls = em.get_profile()
-    em.set_profiling(False)
-    rec_ms = 0.5 * (prof["rec_rnn1"] + prof["rec_rnn2"])
-    rec_flop = B * 60 * 2.0 * 4 * 128 * 128          # algorithmic FLOP of one recurrent launch
-    achieved = rec_flop / (rec_ms * 1e-3) / 1e12 if rec_ms > 0 else 0.0
-
+        t = train_leg(a, rank, world, dist, a.steps, a.warmup, with_cpu)
+        if rank == 0:
+            print(json.dumps({**t, **common}), flush=True)
+        return finish()
+    head = forward_leg(a, "v4_stateless_384" if a.workload == "default" else a.workload, rank, world, dist, a.steps, a.warmup, with_cpu)
+    line = None
     if rank == 0:
-        line = {
-            "metric": "grid-columns/sec emulator fwd",
-            "value": value, "unit": "grid-columns/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-            "ms_per_step": 1e3 * el / a.steps, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": a.workload, "columns_per_gpu": B, "nlev": 60,
-                       "wrapper": "stateless v4 (rnn/v4_rnn_wrapper_constrained.pt weights)" if not stateful
-                       else "stateful v4 memory wrapper", "parallelism": f"columns sharded x{world}, no collective"},
-            "roofline": {"bound": "mfma", "kernel": ("lstm_rec1_kernel<128>" if B <= 256 else "lstm_rec2_kernel<128,false,0>") + " (one launch per LSTM, 2 per step)",
-                         "achieved": achieved, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_FP32_TFLOPS, "traffic": pmc_traffic(a.workload),
-                         "traffic_unit": "HBM bytes per launch (rocprofv3 PMC, profiles/)",
-                         "algorithmic_hbm_bytes_per_launch": B * 60 * (4 * 128 + 128) * 4.0,
-                         "flop_per_launch": rec_flop, "avg_launch_ms": rec_ms,
-                         "note": "fp32 packed-FMA vector pipe; same 157.3 TF peak as f32 MFMA"},
-            "whole_path": {"flop_per_column": flop_col, "achieved_tflops": value / world * flop_col / 1e12,
-                           "frac_fp32_peak": value / world * flop_col / 1e12 / PEAK_FP32_TFLOPS,
-                           "hbm_bytes_per_column": bytes_col,
-                           "achieved_hbm_gbs": value / world * bytes_col / 1e9},
-            "kernel_ms": prof, "kernel_profile_calls": ncalls,
-        }
-        if not a.no_cpu_baseline and world == 1:
-            line["cpu_baseline"] = cpu_baseline(tag, consts, weights, xm, xs, mem, hx, cx)
+        line = {"metric": "grid-columns/sec emulator fwd", **head, **common}
+    if a.workload == "default":
+        # the other half of BASELINE.json's metric and the north_star's target model, in the same line
+        memleg = forward_leg(a, "v4_memory_384", rank, world, dist, a.steps, a.warmup, False)
+        train = train_leg(a, rank, world, dist, max(3, min(a.steps, 30)), max(2, min(a.warmup, 5)), with_cpu)
+        if rank == 0:
+            line["memory_wrapper"] = {"metric": "grid-columns/sec emulator fwd", **memleg}
+            line["train"] = train
+    if rank == 0:
         print(json.dumps(line), flush=True)
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    finish()
 
 
 if __name__ == "__main__":

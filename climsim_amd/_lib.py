@@ -33,6 +33,7 @@ SYMBOLS = ["csa_create", "csa_destroy", "csa_set_params", "csa_packed_width", "c
            "csa_train_create", "csa_train_destroy", "csa_train_num_params", "csa_train_num_tensors",
            "csa_train_param_info", "csa_train_params", "csa_train_sync_params", "csa_train_copy_state", "csa_train_forward",
            "csa_train_backward", "csa_train_set_deferred", "csa_train_flush_wgrad", "csa_train_loss", "csa_train_adam",
+           "csa_train_set_profiling", "csa_train_reset_profile", "csa_train_get_profile", "csa_train_stage_name",
            "csa_mlp_create", "csa_mlp_destroy", "csa_mlp_forward",
            "csa_mlp_train_create", "csa_mlp_train_destroy", "csa_mlp_train_num_params", "csa_mlp_train_copy_params",
            "csa_mlp_train_forward", "csa_mlp_train_backward", "csa_mlp_train_adam",
@@ -129,6 +130,11 @@ def lib():
     L.csa_train_flush_wgrad.argtypes = [H, _F, ctypes.c_void_p]
     L.csa_train_loss.argtypes = [H, i, i, f, f] + [_F] * 11 + [ctypes.c_void_p]
     L.csa_train_adam.argtypes = [H, _F, f, f, f, f, f, i, ctypes.c_void_p]
+    L.csa_train_set_profiling.argtypes = [H, i]
+    L.csa_train_reset_profile.argtypes = [H]
+    L.csa_train_get_profile.argtypes = [H, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_long), i]
+    L.csa_train_stage_name.argtypes = [i]
+    L.csa_train_stage_name.restype = ctypes.c_char_p
     PP = ctypes.POINTER(ctypes.POINTER(ctypes.c_float))
     L.csa_mlp_create.argtypes = [i, ctypes.POINTER(i), PP, PP, f, i, i, ctypes.POINTER(H)]
     L.csa_mlp_destroy.argtypes = [H]

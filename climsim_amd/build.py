@@ -27,16 +27,23 @@ def _stale(target, deps):
 
 
 def build(force=False, verbose=False):
-    objs = []
+    objs, jobs = [], []
     for s in SOURCES:
         src = os.path.join(CSRC, s)
         obj = os.path.join(CSRC, s.replace(".hip", ".o"))
         if force or _stale(obj, [src] + HEADERS):
-            cmd = [HIPCC] + FLAGS + ["-c", src, "-o", obj]
+            jobs.append([HIPCC] + FLAGS + ["-c", src, "-o", obj])
+        objs.append(obj)
+    if jobs:      # independent translation units: compile them side by side (CSA_BUILD_JOBS, default = host cores, at most 8)
+        from concurrent.futures import ThreadPoolExecutor
+
+        def run(cmd):
             if verbose:
                 print(" ".join(cmd), flush=True)
             subprocess.check_call(cmd)
-        objs.append(obj)
+        nj = max(1, min(int(os.environ.get("CSA_BUILD_JOBS", os.cpu_count() or 1)), 8, len(jobs)))
+        with ThreadPoolExecutor(nj) as ex:
+            list(ex.map(run, jobs))
     if force or _stale(LIB, objs):
         cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
         if verbose:

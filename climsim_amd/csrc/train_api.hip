@@ -52,6 +52,14 @@ struct csa_trainer {
     bool defer = false;
     std::vector<int> pending;
     int pending_B = 0;
+    float sp_scale = 1.f, sp_shift = 0.f;     // xdiv_sca[0], xmean_sca[0]: surface pressure de-normalisation of the loss
+    // optional per-stage timing with HIP events on the call's own stream (csa_train_set_profiling; bench.py's roofline)
+    bool profiling = false;
+    struct EvPair { hipEvent_t a, b; int stage; };
+    std::vector<EvPair> ev_pending;
+    std::vector<hipEvent_t> ev_free;
+    double acc_ms[CSA_TRAIN_NSTAGE] = {};
+    long acc_n[CSA_TRAIN_NSTAGE] = {};
 };
 
 namespace {
@@ -94,6 +102,46 @@ std::vector<int> to_int(const std::vector<float> &f, int off)
     return v;
 }
 std::vector<float> index_values(size_t n) { std::vector<float> v(n); for (size_t i = 0; i < n; ++i) v[i] = (float)i; return v; }
+
+// ---- stage timing: event pairs around single launches, collected lazily (host sync only in csa_train_get_profile) ----
+hipEvent_t prof_event(csa_trainer *h)
+{
+    hipEvent_t e = nullptr;
+    if (!h->ev_free.empty()) { e = h->ev_free.back(); h->ev_free.pop_back(); return e; }
+    if (hipEventCreate(&e) != hipSuccess) return nullptr;
+    return e;
+}
+void prof_collect(csa_trainer *h)
+{
+    for (auto &p : h->ev_pending) {
+        float ms = 0.f;
+        if (hipEventSynchronize(p.b) == hipSuccess && hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
+            h->acc_ms[p.stage] += ms;
+            h->acc_n[p.stage] += 1;
+        }
+        h->ev_free.push_back(p.a);
+        h->ev_free.push_back(p.b);
+    }
+    h->ev_pending.clear();
+}
+struct StageTimer {     // brackets the launches issued during its lifetime when profiling is on
+    csa_trainer *h; hipStream_t s; int stage; hipEvent_t a = nullptr;
+    StageTimer(csa_trainer *h_, int stage_, hipStream_t s_) : h(h_), s(s_), stage(stage_)
+    {
+        if (!h->profiling) return;
+        if (h->ev_pending.size() >= 512) prof_collect(h);
+        a = prof_event(h);
+        if (a) (void)hipEventRecord(a, s);
+    }
+    ~StageTimer()
+    {
+        if (!a) return;
+        hipEvent_t b = prof_event(h);
+        if (!b) { h->ev_free.push_back(a); return; }
+        (void)hipEventRecord(b, s);
+        h->ev_pending.push_back({a, b, stage});
+    }
+};
 
 int repack(csa_trainer *h, hipStream_t s)
 {
@@ -183,6 +231,7 @@ extern "C" int csa_train_create(const csa_config *cfg, const csa_params *p, cons
     d.yscale_lev = upc(p->yscale_lev, (size_t)L * c.ny); d.yscale_sca = upc(p->yscale_sca, c.ny_sfc);
     d.hyam = upc(p->hyam, L); d.hybm = upc(p->hybm, L);
     h->hyai = upc(hyai, L + 1); h->hybi = upc(hybi, L + 1);
+    h->sp_scale = p->xdiv_sca[0]; h->sp_shift = p->xmean_sca[0];
 
     // ---- gathers: canonical flat -> kernel layouts -------------------------------------------------
     d.toa1_wt = add_gather(h, transposed_idx(O("mlp_toa1.weight"), nh2, 2), nullptr, rc);
@@ -361,6 +410,8 @@ extern "C" int csa_train_create(const csa_config *cfg, const csa_params *p, cons
 extern "C" int csa_train_destroy(csa_trainer *h)
 {
     if (!h) return CSA_ERR_ARG;
+    prof_collect(h);
+    for (hipEvent_t e : h->ev_free) (void)hipEventDestroy(e);
     for (void *q : h->owned) (void)hipFree(q);
     delete h;
     return CSA_OK;
@@ -403,20 +454,27 @@ extern "C" int csa_train_forward(csa_trainer *h, int slot, int B, const float *x
     Slot &S = h->slots[slot];
     int rc;
     if ((rc = launch_prep_train(h->dm, B, 1, x_main_n, x_sfc_n, mem_in, S.X1, S.hc0, S.X16, S.xs, s))) return rc;
-    if ((rc = launch_proj_gemm(S.X1, h->dm.wih1, h->dm.bias1, S.GP1, L * B, 4 * nh1, nh1 + nm, s))) return rc;
-    if (c.use_lstm) {
-        if ((rc = launch_rec_train(nh1, h->dm.whh1p, S.GP1, S.hc0, S.hc0 + (size_t)B * nhm, S.H1lev, B, L, 1, S.H1seq, S.C1, s))) return rc;
-    } else {
-        if ((rc = launch_rec_train_gru(nh1, h->dm.whh1p, h->dm.bhn1, S.GP1, S.hc0, S.H1lev, B, L, 1, S.H1seq, s))) return rc;
+    {
+        StageTimer tm(h, 2, s);
+        if ((rc = launch_proj_gemm(S.X1, h->dm.wih1, h->dm.bias1, S.GP1, L * B, 4 * nh1, nh1 + nm, s))) return rc;
     }
-    if ((rc = launch_proj_gemm(S.H1lev, h->dm.wih2, h->dm.bias2, S.GP2, L * B, 4 * nh2, nh1, s))) return rc;
-    // rnn2: level order == sequence order, so the hidden sequence itself carries the extra slot 0
-    if (c.use_lstm) {
-        if ((rc = launch_rec_train(nh2, h->dm.whh2p, S.GP2, S.hc0 + (size_t)2 * B * nhm, S.hc0 + (size_t)3 * B * nhm,
-                                   S.H2 + (size_t)B * nh2, B, L, 0, S.H2, S.C2, s))) return rc;
-    } else {
-        if ((rc = launch_rec_train_gru(nh2, h->dm.whh2p, h->dm.bhn2, S.GP2, S.hc0 + (size_t)2 * B * nhm, S.H2 + (size_t)B * nh2, B, L, 0,
-                                       S.H2, s))) return rc;
+    {
+        StageTimer tm(h, 0, s);
+        if (c.use_lstm) rc = launch_rec_train(nh1, h->dm.whh1p, S.GP1, S.hc0, S.hc0 + (size_t)B * nhm, S.H1lev, B, L, 1, S.H1seq, S.C1, s);
+        else rc = launch_rec_train_gru(nh1, h->dm.whh1p, h->dm.bhn1, S.GP1, S.hc0, S.H1lev, B, L, 1, S.H1seq, s);
+        if (rc) return rc;
+    }
+    {
+        StageTimer tm(h, 2, s);
+        if ((rc = launch_proj_gemm(S.H1lev, h->dm.wih2, h->dm.bias2, S.GP2, L * B, 4 * nh2, nh1, s))) return rc;
+    }
+    {   // rnn2: level order == sequence order, so the hidden sequence itself carries the extra slot 0
+        StageTimer tm(h, 0, s);
+        if (c.use_lstm) rc = launch_rec_train(nh2, h->dm.whh2p, S.GP2, S.hc0 + (size_t)2 * B * nhm, S.hc0 + (size_t)3 * B * nhm,
+                                              S.H2 + (size_t)B * nh2, B, L, 0, S.H2, S.C2, s);
+        else rc = launch_rec_train_gru(nh2, h->dm.whh2p, h->dm.bhn2, S.GP2, S.hc0 + (size_t)2 * B * nhm, S.H2 + (size_t)B * nh2, B, L, 0,
+                                       S.H2, s);
+        if (rc) return rc;
     }
     if ((rc = launch_head(h->dm, B, HEAD_RAW, S.H2 + (size_t)B * nh2, x_main_n, nullptr, out, out_sfc, S.Z, s))) return rc;
     CSA_HIP_CHECK(hipMemcpyAsync(mem_out, S.Z, sizeof(float) * (size_t)L * B * nm, hipMemcpyDeviceToDevice, s));
@@ -440,12 +498,14 @@ extern "C" int csa_train_backward(csa_trainer *h, int slot, int B, const float *
     if ((rc = launch_head_bwd(h->dm, B, d_out, d_out_sfc, d_mem_out, S.Z, S.H2 + (size_t)B * nh2, h->dH2, h->part, s))) return rc;
     if ((rc = launch_reduce_partials_2stage(h->part, B, head_bwd_partial_floats(c), h->map_head, nullptr, grads, h->rtmp, 32, s))) return rc;
     // rnn2 (downward): BPTT, then input / weight gradients from dP2 (stored in place in GP2)
+    { StageTimer tm(h, 1, s);
     if (c.use_lstm) {
         if ((rc = launch_bwd_rec(nh2, h->whh2Tp, S.GP2, S.C2, h->dH2, h->dhc2, h->dhc2 + (size_t)B * nhm, B, L, 0, s))) return rc;
     } else {
         if ((rc = launch_bwd_rec_gru(nh2, h->whh2Tp, S.GP2, S.H2, h->dH2, h->dhc2, B, L, 0, s))) return rc;
-    }
-    if ((rc = launch_proj_gemm(S.GP2, h->wih2T, nullptr, h->dH1, M, nh1, 4 * nh2, s))) return rc;
+    } }
+    { StageTimer tm(h, 3, s);
+    if ((rc = launch_proj_gemm(S.GP2, h->wih2T, nullptr, h->dH1, M, nh1, 4 * nh2, s))) return rc; }
     if (!h->defer) {
         if ((rc = launch_gemm_tn_partial(S.GP2, 4 * nh2, S.H1lev, nh1, h->part, M, 4 * nh2, nh1, ns, s))) return rc;
         if ((rc = launch_reduce_partials(h->part, ns, 4 * nh2 * nh1, h->map_wih2, nullptr, grads, s))) return rc;
@@ -455,12 +515,14 @@ extern "C" int csa_train_backward(csa_trainer *h, int slot, int B, const float *
     if ((rc = launch_colsum_partial(S.GP2, h->part, M, 4 * nh2, ns, s))) return rc;
     if ((rc = launch_reduce_partials(h->part, ns, 4 * nh2, h->map_b2a, h->map_b2b, grads, s))) return rc;
     // rnn1 (upward): dH1 is in level order, the recurrence runs in sequence order
+    { StageTimer tm(h, 1, s);
     if (c.use_lstm) {
         if ((rc = launch_bwd_rec(nh1, h->whh1Tp, S.GP1, S.C1, h->dH1, h->dhc1, h->dhc1 + (size_t)B * nhm, B, L, 1, s))) return rc;
     } else {
         if ((rc = launch_bwd_rec_gru(nh1, h->whh1Tp, S.GP1, S.H1seq, h->dH1, h->dhc1, B, L, 1, s))) return rc;
-    }
-    if ((rc = launch_proj_gemm(S.GP1, h->wih1T, nullptr, h->dX1, M, nin1, 4 * nh1, s))) return rc;
+    } }
+    { StageTimer tm(h, 3, s);
+    if ((rc = launch_proj_gemm(S.GP1, h->wih1T, nullptr, h->dX1, M, nin1, 4 * nh1, s))) return rc; }
     if (!h->defer) {
         if ((rc = launch_gemm_tn_partial(S.GP1, 4 * nh1, S.X1, nin1, h->part, M, 4 * nh1, nin1, ns, s))) return rc;
         if ((rc = launch_reduce_partials(h->part, ns, 4 * nh1 * nin1, h->map_wih1, nullptr, grads, s))) return rc;
@@ -498,6 +560,7 @@ extern "C" int csa_train_flush_wgrad(csa_trainer *h, float *grads, void *stream)
     const int nseg = (int)h->pending.size();
     const int ns = (h->nsplit / nseg) * nseg;      // same number of partials as one per-step call, shared by the segments
     int rc;
+    StageTimer tm(h, 4, s);
     auto run = [&](float *Slot::*a, float *Slot::*b, int N1, int N2, const int *map) {
         TnSegs g{};
         g.n = nseg;
@@ -530,10 +593,8 @@ extern "C" int csa_train_loss(csa_trainer *h, int B, int Tw, float w_h, float w_
     }
     hipStream_t s = (hipStream_t)stream;
     const int N = B * Tw;
-    // surface pressure de-normalised from the normalised x_sfc (rnn/utils.py:1248); host copies of the two scalars
-    float a, bc;
-    CSA_HIP_CHECK(hipMemcpy(&a, h->dm.xdiv_sca, sizeof(float), hipMemcpyDeviceToHost));
-    CSA_HIP_CHECK(hipMemcpy(&bc, h->dm.xmean_sca, sizeof(float), hipMemcpyDeviceToHost));
+    // surface pressure de-normalised from the normalised x_sfc (rnn/utils.py:1248); the two scalars were kept at create
+    const float a = h->sp_scale, bc = h->sp_shift;
     hipLaunchKernelGGL(sp_kernel, dim3((N + 255) / 256), dim3(256), 0, s, x_sfc_n, h->dm.cfg.nx_sfc, a, bc, h->sp, N);
     return launch_loss(h->dm, h->hyai, h->hybi, B, Tw, w_h, w_w, pred, pred_sfc, tgt, tgt_sfc, yto, yto_sfc, x_raw, h->sp,
                        h->samp, h->ecoef, scalars, d_pred, d_pred_sfc, s);
@@ -547,4 +608,32 @@ extern "C" int csa_train_adam(csa_trainer *h, const float *grads, float lr, floa
     int rc = launch_adam(h->params, grads, h->adam_m, h->adam_v, h->nparam, lr, beta1, beta2, eps, step, weight_decay, s);
     if (rc) return rc;
     return repack(h, s);
+}
+
+// ---- per-stage timing (HIP events on the caller's stream; measurement mode only) ----------------------------------------
+static const char *const kTrainStages[CSA_TRAIN_NSTAGE] = {"fwd_rec", "bwd_rec", "fwd_proj_gemm", "dx_gemm", "wgrad_flush"};
+extern "C" const char *csa_train_stage_name(int i) { return i >= 0 && i < CSA_TRAIN_NSTAGE ? kTrainStages[i] : ""; }
+extern "C" int csa_train_set_profiling(csa_trainer *h, int enable)
+{
+    if (!h) return CSA_ERR_ARG;
+    if (!enable) prof_collect(h);
+    h->profiling = enable != 0;
+    return CSA_OK;
+}
+extern "C" int csa_train_reset_profile(csa_trainer *h)
+{
+    if (!h) return CSA_ERR_ARG;
+    prof_collect(h);
+    for (int i = 0; i < CSA_TRAIN_NSTAGE; ++i) { h->acc_ms[i] = 0.0; h->acc_n[i] = 0; }
+    return CSA_OK;
+}
+extern "C" int csa_train_get_profile(csa_trainer *h, double *avg_ms, long *launches, int n)
+{
+    if (!h || !avg_ms || n < CSA_TRAIN_NSTAGE) return CSA_ERR_ARG;
+    prof_collect(h);
+    for (int i = 0; i < CSA_TRAIN_NSTAGE; ++i) {
+        avg_ms[i] = h->acc_n[i] ? h->acc_ms[i] / (double)h->acc_n[i] : 0.0;
+        if (launches) launches[i] = h->acc_n[i];
+    }
+    return CSA_OK;
 }

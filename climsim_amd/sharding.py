@@ -28,6 +28,12 @@ def shard_columns(t, world_size, rank, dim=0):
     return t.narrow(dim, lo, hi - lo)
 
 
+def shard_loss_scale(local_columns, global_columns):
+    """Factor that turns a batch-MEAN loss (or its gradient) over this rank's columns into this rank's share of the global
+    batch mean, so that a SUM all-reduce over the ranks yields the single-GPU value (ragged shards included)."""
+    return float(local_columns) / float(global_columns)
+
+
 def max_over_ranks(seconds, device=None):
     """Whole-job wall time = the slowest rank's (bench.py contract)."""
     import torch.distributed as dist

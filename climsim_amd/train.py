@@ -20,7 +20,7 @@ import torch
 
 from . import _lib
 from .emulator import CONST_KEYS, STATE_DICT_MAP, _check, _np32, _ptr
-from .sharding import allreduce_flat_
+from .sharding import allreduce_flat_, shard_loss_scale
 
 
 class Trainer:
@@ -129,6 +129,23 @@ class Trainer:
         if rc != 0:
             raise RuntimeError(f"{what} failed ({rc}): {_lib.last_error()}")
 
+    # ---- per-stage timing (HIP events on the launch stream; bench.py's roofline accounting) -------------
+    NSTAGE = 5
+
+    def set_profiling(self, enable):
+        self._rc(_lib.lib().csa_train_set_profiling(self._h, int(bool(enable))), "csa_train_set_profiling")
+
+    def reset_profile(self):
+        self._rc(_lib.lib().csa_train_reset_profile(self._h), "csa_train_reset_profile")
+
+    def get_profile(self):
+        """{stage: (average ms per bracketed launch group, number of groups)}"""
+        L = _lib.lib()
+        ms = (ctypes.c_double * self.NSTAGE)()
+        n = (ctypes.c_long * self.NSTAGE)()
+        self._rc(L.csa_train_get_profile(self._h, ms, n, self.NSTAGE), "csa_train_get_profile")
+        return {L.csa_train_stage_name(i).decode(): (ms[i], n[i]) for i in range(self.NSTAGE)}
+
     # ---- pieces ------------------------------------------------------------------------------------
     def forward(self, slot, x_main_n, x_sfc_n, rnn_mem):
         c = self.cfg
@@ -203,9 +220,11 @@ class Trainer:
                                        cat(yto_sfc), cat(x_raw), cat(x_sfc_n))
         if world_size > 1 and global_columns:
             # batch means were taken over the local shard: rescale so that SUM over ranks = global mean
-            scale = B / float(global_columns)
+            # (every loss term is a per-column quantity followed by a batch mean, rnn/metrics.py:142-315)
+            scale = shard_loss_scale(B, global_columns)
             d_pred.mul_(scale)
             d_pred_sfc.mul_(scale)
+            self.scalars.mul_(scale)
         self.grads.zero_()
         d_mem = None
         defer = Tw <= 8
@@ -217,6 +236,9 @@ class Trainer:
             self.flush_wgrad()
         if world_size > 1:
             allreduce_flat_(self.grads, world_size, average=not bool(global_columns))
+            # logged scalars: the same weighting, one 28-byte all-reduce (train_mlp_h5loader.py:470-473 reduces its
+            # logged loss likewise); without `global_columns` shards are equal and the plain average is the global mean
+            allreduce_flat_(self.scalars, world_size, average=not bool(global_columns))
         if optimise:
             self.adam_step()
         names = ["loss", "huber", "mse", "mae", "energy", "water", "precip_sum_mse"]

@@ -195,6 +195,15 @@ int csa_train_loss(csa_trainer *h, int B, int Tw, float w_energy, float w_water,
                    float *scalars, float *d_pred, float *d_pred_sfc, void *stream);
 int csa_train_adam(csa_trainer *h, const float *grads, float lr, float beta1, float beta2, float eps,
                    float weight_decay, int step, void *stream);
+/* Optional per-stage timing of the training step with HIP events recorded on the call's own stream (bench.py's roofline of
+ * the BPTT recurrence).  Stages (csa_train_stage_name): 0 fwd_rec (one launch per RNN per forward), 1 bwd_rec (one BPTT
+ * launch per RNN per backward), 2 fwd_proj_gemm, 3 dx_gemm, 4 wgrad_flush (the four deferred weight-gradient contractions).
+ * csa_train_get_profile synchronises with the recorded events: measurement mode only. */
+#define CSA_TRAIN_NSTAGE 5
+int csa_train_set_profiling(csa_trainer *h, int enable);
+int csa_train_reset_profile(csa_trainer *h);
+int csa_train_get_profile(csa_trainer *h, double *avg_ms /* [CSA_TRAIN_NSTAGE] */, long *launches /* nullable */, int n);
+const char *csa_train_stage_name(int i);
 
 /* ---- offline MLP baseline ------------------------------------------------------
  * baseline_models/MLP/training/HPO/baseline_v1/step2_retrain/step2_retrain.py:93-121: Dense stack with

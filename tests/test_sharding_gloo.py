@@ -77,3 +77,77 @@ def test_two_rank_sharded_forward_matches_unsharded():
     assert shape == (11, 1328)
     assert abs(t - 0.2) < 1e-12          # MAX over ranks
     assert abs(g - 1.5) < 1e-6           # (1 + 2) / 2
+
+
+def _grad_worker(rank, world, port, q):
+    """Data-parallel gradient property of SURVEY 8(e): every loss term is a per-column quantity followed by a batch mean,
+    so shard gradients of d(loss_local) * B_local / B_global, SUMMED by the one flat all-reduce, equal the unsharded
+    gradient.  Checked with the autograd oracle on a ragged 5 + 3 split of the golden TBPTT window."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.set_num_threads(2)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle import torch_ref
+        from test_train_golden import _golden, _window_inputs
+        consts, weights, flags, io, grid = _golden("cur_lstm128")
+        ref = torch_ref.EmulatorRef(consts, weights, legacy=False, use_lstm=True, output_prune=bool(flags["output_prune"]), scrub_inf=True)
+        B, Tw, xr, xs, xn, xsn, tgt, tgt_sfc, yto, yto_sfc = _window_inputs(ref, io)
+        lo, hi = sharding.shard_bounds(B, world, rank)
+        rows = lambda t: torch.cat([t[k * B + lo:k * B + hi] for k in range(Tw)], 0)     # (Tw*B, ...) window tensors
+        mem = torch.from_numpy(io["grad.mem0"])[:, lo:hi].contiguous()
+        outs, outs_sfc = [], []
+        for t in range(Tw):
+            o, os_, mem = ref.model_forward(xn[t][lo:hi], xsn[t][lo:hi], mem)
+            outs.append(o)
+            outs_sfc.append(os_)
+        loss, sc = torch_ref.window_loss(ref, torch.cat(outs, 0), torch.cat(outs_sfc, 0), rows(tgt), rows(tgt_sfc), rows(yto),
+                                         rows(yto_sfc), torch.cat([x[lo:hi] for x in xr], 0), torch.cat([x[lo:hi] for x in xsn], 0),
+                                         grid["hyai"], grid["hybi"], Tw)
+        (loss * sharding.shard_loss_scale(hi - lo, B)).backward()
+        names = [n for n, _ in ref.named_parameters()]
+        flat = torch.cat([p.grad.reshape(-1) for _, p in ref.named_parameters()])
+        scal = torch.tensor([float(sc["loss"])]) * sharding.shard_loss_scale(hi - lo, B)
+        sharding.allreduce_flat_(flat, world, average=False)        # THE collective of a training step
+        sharding.allreduce_flat_(scal, world, average=False)
+        if rank == 0:
+            gold = torch.cat([torch.from_numpy(io["grad.dw." + n]).reshape(-1) for n in names])
+            worst, off = 0.0, 0
+            for n, p in ref.named_parameters():
+                k = p.numel()
+                worst = max(worst, float((flat[off:off + k] - gold[off:off + k]).abs().max() / gold[off:off + k].abs().max()))
+                off += k
+            q.put((worst, float(scal[0]), float(io["grad.loss.loss"])))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_shard_gradients_sum_to_the_unsharded_gradient():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_grad_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    worst, loss, gold_loss = q.get(timeout=240)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert worst <= 2e-5, worst                       # summation order of the batch mean only (measured 2e-6)
+    assert abs(loss - gold_loss) <= 2e-6 * abs(gold_loss)
+
+
+def test_bench_spawns_its_own_ranks_before_touching_the_gpu():
+    """`python bench.py --gpus 2` with no launcher: the parent starts two ranks under torch.distributed.run.  On this
+    GPU-less container each rank stops at its device check, which proves the children ran as ranks 0 and 1 of 2."""
+    import subprocess
+    import sys
+    root = os.path.dirname(GOLDEN.rstrip("/")).rsplit("/tests", 1)[0]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, timeout=300, env=env)
+    if torch.cuda.is_available() and torch.cuda.device_count() >= 2:
+        assert r.returncode == 0 and '"n_gpus": 2' in r.stdout
+    else:
+        assert r.returncode != 0
+        assert "LOCAL_RANK 1 but only" in r.stderr or '"n_gpus": 2' in r.stdout, r.stderr[-2000:]

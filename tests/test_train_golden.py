@@ -12,6 +12,10 @@ from oracle import torch_ref
 
 torch.set_num_threads(4)
 
+# measured on MI355X (profiles/r1_train_parity_and_timing.txt): every gradient <= 7.5e-7 of its tensor's maximum, d(rnn_mem)
+# 4e-7, loss scalars to 7 digits; the asserted bounds are ~10x those
+GRAD_TOL = 8e-6
+
 
 def _golden(tag="cur_lstm128"):
     consts, weights, flags = load_npz_model(tag)
@@ -80,13 +84,13 @@ def test_hip_training_step_vs_reference_gradients(tag):
     assert rel_err(mem.cpu().numpy(), io["grad.mem_final"]) <= 1e-5
     for k in ("loss", "huber", "mse", "mae", "energy", "water", "precip_sum_mse"):
         g = float(io["grad.loss." + k])
-        assert abs(sc[k] - g) <= 5e-5 * abs(g) + 1e-30, (k, sc[k], g)
-    assert rel_err(d_mem0.cpu().numpy(), io["grad.d_mem0"]) <= 2e-4
+        assert abs(sc[k] - g) <= 5e-6 * abs(g) + 1e-30, (k, sc[k], g)
+    assert rel_err(d_mem0.cpu().numpy(), io["grad.d_mem0"]) <= GRAD_TOL
     worst = {}
     for name, g in tr.grad_dict().items():
         ref_g = io["grad.dw." + name]
         worst[name] = rel_err(g.cpu().numpy().reshape(ref_g.shape), ref_g)
-    bad = {k: v for k, v in worst.items() if v > 2e-4}
+    bad = {k: v for k, v in worst.items() if v > GRAD_TOL}
     assert not bad, bad
 
 
@@ -146,3 +150,74 @@ def test_checkpoint_resume_is_bit_identical():
     c = mk(weights)
     c.load_checkpoint(ck, only_load_model=True)
     assert c.step_count == 0 and torch.equal(c.flat_params(), torch.cat([ck["model_state_dict"][n].reshape(-1) for n in a.layout]).cuda())
+
+
+def _gpu_window(tr, B, Tw, xr, xn, xsn, tgt, tgt_sfc, yto, yto_sfc, mem0, lo, hi, **kw):
+    d = lambda t: t.contiguous().cuda()
+    cut = lambda seq: [d(a[lo:hi]) for a in seq]
+    rows = lambda t: [d(t[k * B + lo:k * B + hi]) for k in range(Tw)]
+    return tr.window_step(cut(xn), cut(xsn), cut(xr), rows(tgt), rows(tgt_sfc), rows(yto), rows(yto_sfc),
+                          d(mem0[:, lo:hi]), optimise=False, **kw)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag", ["cur_lstm128", "cur_gru128"])
+def test_column_shard_gradients_sum_to_the_single_gpu_gradient(tag):
+    """SURVEY 8(e) / train_mlp_h5loader.py:195-207,470-473: weights replicated, columns sharded, batch-mean losses divided
+    by the GLOBAL column count, ONE flat all-reduce (SUM).  The two shards of the golden window (ragged split)
+    run one after the other on this GPU with world_size=2, global_columns=B (no process group: the all-reduce is the
+    explicit sum below); flat gradients, d(rnn_mem) and the weighted scalars must add up to the unsharded step."""
+    from climsim_amd.train import Trainer
+    consts, weights, flags, io, grid = _golden(tag)
+    ref = torch_ref.EmulatorRef(consts, weights, legacy=False, use_lstm=bool(flags["use_lstm"]),
+                                output_prune=bool(flags["output_prune"]), scrub_inf=True)
+    B, Tw, xr, xs, xn, xsn, tgt, tgt_sfc, yto, yto_sfc = _window_inputs(ref, io)
+    mem0 = torch.from_numpy(io["grad.mem0"])
+    tr = Trainer(consts, weights, grid["hyai"], grid["hybi"], use_lstm=bool(flags["use_lstm"]),
+                 output_prune=bool(flags["output_prune"]), max_batch=8, max_window=3)
+    sc, mem, d_mem = _gpu_window(tr, B, Tw, xr, xn, xsn, tgt, tgt_sfc, yto, yto_sfc, mem0, 0, B)
+    g_full = tr.grads.clone()
+    g_sum, sc_sum, d_mem_parts, mem_parts = torch.zeros_like(g_full), {k: 0.0 for k in sc}, [], []
+    cutpt = B // 2 + 1                                  # ragged split
+    for lo, hi in ((0, cutpt), (cutpt, B)):
+        s, m, dm = _gpu_window(tr, B, Tw, xr, xn, xsn, tgt, tgt_sfc, yto, yto_sfc, mem0, lo, hi, world_size=2, global_columns=B)
+        g_sum += tr.grads
+        for k in s:
+            sc_sum[k] += s[k]
+        d_mem_parts.append(dm)
+        mem_parts.append(m)
+    for name, (o, r, c) in tr.layout.items():
+        a, b = g_sum[o:o + r * c], g_full[o:o + r * c]
+        assert float((a - b).abs().max()) <= 1e-6 * float(b.abs().max()) + 1e-30, name
+    assert torch.equal(torch.cat(mem_parts, 1), mem)                    # forward: columns are independent, bit for bit
+    dm = torch.cat(d_mem_parts, 1)
+    assert float((dm - d_mem).abs().max()) <= 1e-6 * float(d_mem.abs().max())
+    for k in sc:
+        assert abs(sc_sum[k] - sc[k]) <= 2e-6 * abs(sc[k]) + 1e-30, k
+    # and the sum is the reference's gradient (autograd of RNN_autoreg over the whole window)
+    for name, (o, r, c) in tr.layout.items():
+        ref_g = io["grad.dw." + name].reshape(-1)
+        assert rel_err(g_sum[o:o + r * c].cpu().numpy(), ref_g) <= GRAD_TOL, name
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_rehearsal_on_one_gpu():
+    """bench.py --gpus 2 started WITHOUT a launcher spawns its ranks itself; on a one-GPU box the two ranks share device 0
+    over gloo (CSA_BENCH_BACKEND) -- the control flow of the N > 1 line (barriers, MAX over ranks, the gradient and scalar
+    all-reduces) with n_gpus = 2 and both halves of the metric in ONE JSON line."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    if torch.cuda.device_count() < 2:
+        env["CSA_BENCH_BACKEND"] = "gloo"
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "2"],
+                       capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 5 and d["value"] > 0
+    assert d["memory_wrapper"]["value"] > 0 and d["train"]["value"] > 0 and d["train"]["roofline"]["avg_launch_ms"] > 0
+    assert np.isfinite(d["train"]["loss"])
