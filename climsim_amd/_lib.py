@@ -7,7 +7,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libclimsim_amd.so")
+# CSA_LIB_PATH: a diagnostic build of the same sources (e.g. tools/build_exact_gates.sh); never a different implementation
+LIB_PATH = os.environ.get("CSA_LIB_PATH") or os.path.join(_HERE, "libclimsim_amd.so")
 
 _F = ctypes.c_void_p   # device pointers travel as integers
 
@@ -29,7 +30,7 @@ SYMBOLS = ["csa_create", "csa_destroy", "csa_set_params", "csa_packed_width", "c
            "csa_forward_packed", "csa_forward_tuple", "csa_model_forward", "csa_forward_tuple_noise",
            "csa_model_forward_noise", "csa_tap_rnn1",
            "csa_tap_rnn2", "csa_last_error", "csa_version", "csa_set_profiling", "csa_reset_profile",
-           "csa_get_profile", "csa_stage_name", "csa_set_fused", "csa_set_overlap", "csa_set_halves", "csa_set_rec1_max_batch", "csa_set_graph", "csa_set_small_gemm_rows",
+           "csa_get_profile", "csa_stage_name", "csa_set_halves", "csa_set_rec1_max_batch", "csa_set_small_gemm_rows", "csa_debug_stage",
            "csa_train_create", "csa_train_destroy", "csa_train_num_params", "csa_train_num_tensors",
            "csa_train_param_info", "csa_train_params", "csa_train_sync_params", "csa_train_copy_state", "csa_train_forward",
            "csa_train_backward", "csa_train_set_deferred", "csa_train_flush_wgrad", "csa_train_loss", "csa_train_adam",
@@ -105,11 +106,9 @@ def lib():
     L.csa_set_profiling.argtypes = [H, i]
     L.csa_reset_profile.argtypes = [H]
     L.csa_get_profile.argtypes = [H, ctypes.POINTER(ctypes.c_double), i, ctypes.POINTER(ctypes.c_long)]
-    L.csa_set_fused.argtypes = [H, i]
-    L.csa_set_overlap.argtypes = [H, i]
     L.csa_set_halves.argtypes = [H, i]
     L.csa_set_rec1_max_batch.argtypes = [H, i]
-    L.csa_set_graph.argtypes = [H, i]
+    L.csa_debug_stage.argtypes = [H, i, i, _F, _F, _F, _F, _F, _F, _F, ctypes.c_void_p]
     L.csa_set_small_gemm_rows.argtypes = [i]
     L.csa_stage_name.argtypes = [i]
     L.csa_stage_name.restype = ctypes.c_char_p

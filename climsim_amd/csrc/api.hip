@@ -35,21 +35,11 @@ struct csa_emulator {
     double acc_ms[6] = {};
     long n_prof = 0;
     bool pending = false;
-    // level-split overlap (run_forward_overlap): side stream + events, second pre-activation buffer, cell state hand-over
-    bool overlap = false;        // off by default: measured slower (cross-queue event waits cost more than the GEMM time hidden)
+    // column halves on two streams (run_forward_halves): side stream + fork / join events
     hipStream_t side = nullptr;
-    hipEvent_t ov_ev[12] = {};
-    float *P2 = nullptr, *cstate = nullptr;
-    // hipGraph replay of the six launches of a call (csa_set_graph): one cached graph, keyed by every argument
-    int graph_mode = 0;          // 0 off, 1 on
-    hipGraphExec_t gexec = nullptr;
-    struct GKey { int B, normalised, mode; const void *p[8]; hipStream_t s; bool valid = false; } gkey;
+    hipEvent_t ov_ev[2] = {};
     int rec1_max_batch = 256;    // largest batch that uses the one-column-per-workgroup recurrent kernel (csa_set_rec1_max_batch)
     int halves = 2;              // two column halves on two streams (run_forward_halves): 0 off, 1 on, 2 auto (B >= 640)
-    bool fused = false;          // fused projection+recurrence layer kernel (csa_set_fused); off by default: measured slower
-                                 // than GEMM + recurrent kernel because W_ih is re-streamed from L2 per 8-level chunk
-    // slots of device weight buffers that csa_set_params refreshes
-    struct Slot { float **dst; size_t n; };
 };
 
 namespace {
@@ -145,19 +135,6 @@ int upload_params(csa_emulator *h, const csa_params *p, bool first)
     d.wih1 = U.up(w); d.bias1 = U.up(bias); d.bhn1 = U.up(bhn);
     pack_ih(c.use_lstm, c.nh2, c.nh1, b_ih, b_bi, b_bh, w, bias, bhn);
     d.wih2 = U.up(w); d.bias2 = U.up(bias); d.bhn2 = U.up(bhn);
-    // fused layer kernel (fused.hip, off by default): nh = 128, K in {128,144}
-    d.wih1f = d.wih2f = nullptr;
-    if (!st && c.use_lstm && c.nh1 == 128 && c.nh2 == 128 && (nin1 == 128 || nin1 == 144)) {
-        std::vector<float> wp, fp;
-        pack_ih(1, c.nh1, nin1, p->rnn1_w_ih, p->rnn1_b_ih, p->rnn1_b_hh, wp, bias, bhn);
-        fp.resize(fused_packed_floats(c.nh1, nin1));
-        fused_pack_wih(c.nh1, nin1, wp.data(), fp.data());
-        d.wih1f = U.up(fp);
-        pack_ih(1, c.nh2, c.nh1, p->rnn2_w_ih, p->rnn2_b_ih, p->rnn2_b_hh, wp, bias, bhn);
-        fp.resize(fused_packed_floats(c.nh2, c.nh1));
-        fused_pack_wih(c.nh2, c.nh1, wp.data(), fp.data());
-        d.wih2f = U.up(fp);
-    }
     packed.resize(rec_packed_floats(c.use_lstm, c.nh1));
     rec_pack_weights(c.use_lstm, c.nh1, a_hh, packed.data());
     d.whh1p = U.up(packed);
@@ -251,14 +228,12 @@ extern "C" int csa_create(const csa_config *cfg, const csa_params *hp, int max_b
         h->H1 = U.alloc(L * Bm * cfg->nh1);
         h->H2 = U.alloc(L * Bm * cfg->nh2);
         h->hc0 = U.alloc(4 * Bm * nhm);
-        h->P2 = U.alloc(L * Bm * 4 * nhm);
-        h->cstate = U.alloc(Bm * nhm);
         rc = U.rc;
         if (rc == CSA_OK && cfg->add_stochastic_layer)
             rc = csa_stoch_lstm4_create(cfg->nh1, cfg->nh2, hp->rnn2_weight_encoder, (int)(L * Bm), &h->stoch);
         if (rc == CSA_OK) {
             if (hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking) != hipSuccess) rc = CSA_ERR_HIP;
-            for (int i = 0; i < 12 && rc == CSA_OK; ++i)
+            for (int i = 0; i < 2 && rc == CSA_OK; ++i)
                 if (hipEventCreateWithFlags(&h->ov_ev[i], hipEventDisableTiming) != hipSuccess) rc = CSA_ERR_HIP;
         }
     }
@@ -276,11 +251,10 @@ extern "C" int csa_create(const csa_config *cfg, const csa_params *hp, int max_b
 extern "C" int csa_destroy(csa_emulator *h)
 {
     if (!h) return CSA_ERR_ARG;
-    if (h->gexec) (void)hipGraphExecDestroy(h->gexec);
     free_all(h);
     if (h->stoch) (void)csa_stoch_destroy(h->stoch);
     for (int i = 0; i < 7; ++i) if (h->ev[i]) (void)hipEventDestroy(h->ev[i]);
-    for (int i = 0; i < 12; ++i) if (h->ov_ev[i]) (void)hipEventDestroy(h->ov_ev[i]);
+    for (int i = 0; i < 2; ++i) if (h->ov_ev[i]) (void)hipEventDestroy(h->ov_ev[i]);
     if (h->side) (void)hipStreamDestroy(h->side);
     delete h;
     return CSA_OK;
@@ -354,83 +328,12 @@ extern "C" int csa_get_profile(csa_emulator *h, double *avg_ms, int n, long *cal
     return CSA_OK;
 }
 
-extern "C" int csa_set_fused(csa_emulator *h, int enable)
-{
-    if (!h) return CSA_ERR_ARG;
-    h->fused = enable != 0;
-    return (h->fused && h->dm.wih1f) ? 1 : 0;      // 1 = the fused path will be used
-}
-
 extern "C" const char *csa_stage_name(int i) { return (i >= 0 && i < 6) ? kStageNames[i] : ""; }
 
 #define PROF_MARK(i)                                                 \
     do {                                                             \
         if (h->profiling) CSA_HIP_CHECK(hipEventRecord(h->ev[i], s)); \
     } while (0)
-
-// Level-split overlap of the two LSTM layers (LSTM, nh = 128).  rnn1 runs as NS launches over
-// consecutive step ranges; on a side stream the projection GEMM of the NEXT piece (layer 1) and of the
-// levels the PREVIOUS piece has just produced (layer 2) run concurrently with the recurrence -- the
-// recurrent kernel occupies 2 of 3 wave slots worth of registers and none of the MFMA pipe, so the GEMM
-// workgroups co-reside on the same CUs.  Only launch-granular stream events are used (no in-kernel flags),
-// arithmetic and results are bit-identical to the sequential path.
-//   S: prep, GEMM1[0], rec1[0], (wait g1) rec1[1], ..., rec1[NS-1], GEMM2[NS-1], (wait T) rec2, head
-//   T: (wait prep) GEMM1[1..NS-1], then for i < NS-1: (wait rec1[i]) GEMM2[i]
-static int run_forward_overlap(csa_emulator *h, int B, int normalised, int mode,
-                               const float *x_main, const float *x_sfc, const float *mem_in,
-                               const float *hx2, const float *cx2, float *y0, float *y1, float *y2, hipStream_t S)
-{
-    const csa_config &c = h->dm.cfg;
-    const int L = c.nlev, nh = c.nh1, K1 = c.nh1 + c.nh_mem, NS = 3;
-    const size_t nhm = nh;
-    hipStream_t T = h->side;
-    int bnd[NS + 1];
-    for (int i = 0; i <= NS; ++i) bnd[i] = ((L * i / NS) + 1) & ~1;       // even piece boundaries
-    bnd[0] = 0; bnd[NS] = L;
-    hipEvent_t *ev = h->ov_ev;      // [0] prep done, [1..NS-1] g1[i], [4..4+NS-2] r1[i], [8] T done
-    int rc;
-    if ((rc = launch_prep(h->dm, B, normalised, x_main, x_sfc, mem_in, hx2, cx2, h->X1, h->hc0, S))) return rc;
-    CSA_HIP_CHECK(hipEventRecord(ev[0], S));
-    CSA_HIP_CHECK(hipStreamWaitEvent(T, ev[0], 0));
-    for (int i = 1; i < NS; ++i) {                               // T: layer-1 projection of the later pieces
-        const size_t r0 = (size_t)bnd[i] * B;
-        if ((rc = launch_proj_gemm(h->X1 + r0 * K1, h->dm.wih1, h->dm.bias1, h->P + r0 * 4 * nh, (bnd[i + 1] - bnd[i]) * B,
-                                   4 * nh, K1, T, L * B))) return rc;
-        CSA_HIP_CHECK(hipEventRecord(ev[i], T));
-    }
-    if ((rc = launch_proj_gemm(h->X1, h->dm.wih1, h->dm.bias1, h->P, bnd[1] * B, 4 * nh, K1, S, L * B))) return rc;
-    for (int i = 0; i < NS; ++i) {
-        if (i > 0) CSA_HIP_CHECK(hipStreamWaitEvent(S, ev[i], 0));
-        // state entering piece i: h of step bnd[i]-1 sits in H1 at level L - bnd[i]; c in cstate
-        const float *hin = i == 0 ? h->hc0 : h->H1 + (size_t)(L - bnd[i]) * B * nh;
-        const float *cin = i == 0 ? h->hc0 + (size_t)B * nhm : h->cstate;
-        if ((rc = launch_rec_range(nh, h->dm.whh1p, h->P, hin, cin, h->H1, B, L, /*reverse_out=*/1, bnd[i], bnd[i + 1],
-                                   i + 1 < NS ? h->cstate : nullptr, S))) return rc;
-        // levels produced by piece i: [L - bnd[i+1], L - bnd[i])
-        const size_t r0 = (size_t)(L - bnd[i + 1]) * B;
-        const int rows = (bnd[i + 1] - bnd[i]) * B;
-        if (i + 1 < NS) {
-            CSA_HIP_CHECK(hipEventRecord(ev[4 + i], S));
-            CSA_HIP_CHECK(hipStreamWaitEvent(T, ev[4 + i], 0));
-            if ((rc = launch_proj_gemm(h->H1 + r0 * nh, h->dm.wih2, h->dm.bias2, h->P2 + r0 * 4 * nh, rows, 4 * nh, nh, T, L * B))) return rc;
-        } else {
-            if ((rc = launch_proj_gemm(h->H1 + r0 * nh, h->dm.wih2, h->dm.bias2, h->P2 + r0 * 4 * nh, rows, 4 * nh, nh, S, L * B))) return rc;
-        }
-    }
-    CSA_HIP_CHECK(hipEventRecord(ev[8], T));
-    CSA_HIP_CHECK(hipStreamWaitEvent(S, ev[8], 0));
-    const float *h2 = c.legacy ? hx2 : h->hc0 + (size_t)2 * B * nhm;
-    const float *c2 = c.legacy ? cx2 : h->hc0 + (size_t)3 * B * nhm;
-    if ((rc = launch_rec(1, nh, h->dm.whh2p, nullptr, h->P2, h2, c2, h->H2, B, L, /*reverse_out=*/0, S))) return rc;
-    return launch_head(h->dm, B, mode, h->H2, x_main, x_sfc, y0, y1, y2, S);
-}
-
-extern "C" int csa_set_overlap(csa_emulator *h, int enable)
-{
-    if (!h) return CSA_ERR_ARG;
-    h->overlap = enable != 0;
-    return h->overlap ? 1 : 0;
-}
 
 // Recurrent layer `layer` (1 or 2): up to 256 columns every column gets its own workgroup / CU (lstm_rec1_kernel, ~1.6x
 // shorter steps); above that two columns share a workgroup (lstm_rec2_kernel), which is what saturates the chip.
@@ -452,14 +355,6 @@ static int launch_rec_auto(const csa_emulator *h, int layer, const float *P, con
         return launch_rec2_gru(nh, wg, layer == 1 ? d.bhn1 : d.bhn2, P, h0, Hout, B, L, reverse_out, s);
     return launch_rec(d.cfg.use_lstm, nh, layer == 1 ? d.whh1p : d.whh2p, layer == 1 ? d.bhn1 : d.bhn2, P, h0, c0, Hout, B, L,
                       reverse_out, s);
-}
-
-extern "C" int csa_set_graph(csa_emulator *h, int enable)
-{
-    if (!h) return CSA_ERR_ARG;
-    h->graph_mode = enable != 0;
-    if (!h->graph_mode && h->gexec) { (void)hipGraphExecDestroy(h->gexec); h->gexec = nullptr; h->gkey.valid = false; }
-    return h->graph_mode;
 }
 
 extern "C" int csa_set_rec1_max_batch(csa_emulator *h, int max_batch)
@@ -570,64 +465,23 @@ static int run_forward(csa_emulator *h, int B, int normalised, int mode,
     int rc;
     // measured (tools/halves_sweep.py, memory wrapper): 0.90x at 384 columns (the co-running GEMM slows the latency-bound
     // recurrence of the other half), 1.04-1.09x from 768 columns up -> automatic from 640
-    if ((h->halves == 1 || (h->halves == 2 && B >= 640)) && !h->profiling && !h->fused && B >= 64)
+    if ((h->halves == 1 || (h->halves == 2 && B >= 640)) && !h->profiling && B >= 64)
         return run_forward_halves(h, B, normalised, mode, x_main, x_sfc, mem_in, hx2, cx2, y0, y1, y2, s);
-    if (h->overlap && !h->profiling && !h->fused && c.use_lstm && c.nh1 == 128 && c.nh2 == 128 && L >= 8 && B > h->rec1_max_batch)
-        return run_forward_overlap(h, B, normalised, mode, x_main, x_sfc, mem_in, hx2, cx2, y0, y1, y2, s);
-    if (h->graph_mode && !h->profiling && !h->fused && s != nullptr) {
-        // Rollout loops call with the same buffers every step: replay the six launches as ONE graph launch (removes the
-        // inter-kernel dispatch gaps that matter at small batches).  Any change of an argument re-captures.
-        csa_emulator::GKey k;
-        k.B = B; k.normalised = normalised; k.mode = mode; k.s = s; k.valid = true;
-        const void *ps[8] = {x_main, x_sfc, mem_in, hx2, cx2, y0, y1, y2};
-        for (int i = 0; i < 8; ++i) k.p[i] = ps[i];
-        const csa_emulator::GKey &o = h->gkey;
-        bool same = o.valid && o.B == B && o.normalised == normalised && o.mode == mode && o.s == s;
-        for (int i = 0; same && i < 8; ++i) same = o.p[i] == k.p[i];
-        if (!same) {
-            if (h->gexec) { (void)hipGraphExecDestroy(h->gexec); h->gexec = nullptr; h->gkey.valid = false; }
-            hipGraph_t g = nullptr;
-            CSA_HIP_CHECK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
-            rc = run_chain(h, B, normalised, mode, x_main, x_sfc, mem_in, hx2, cx2, y0, y1, y2, h->X1, h->P, h->H1, h->H2, h->hc0, 0, 0, s, B);
-            const hipError_t e = hipStreamEndCapture(s, &g);
-            if (rc) { if (g) (void)hipGraphDestroy(g); return rc; }
-            if (e != hipSuccess) { csa_set_error("hipStreamEndCapture", e); return CSA_ERR_HIP; }
-            const hipError_t e2 = hipGraphInstantiate(&h->gexec, g, nullptr, nullptr, 0);
-            (void)hipGraphDestroy(g);
-            if (e2 != hipSuccess) { h->gexec = nullptr; csa_set_error("hipGraphInstantiate", e2); return CSA_ERR_HIP; }
-            h->gkey = k;
-        }
-        CSA_HIP_CHECK(hipGraphLaunch(h->gexec, s));
-        return CSA_OK;
-    }
     if (h->profiling) prof_collect(h);   // previous profiled call (host sync: profiling mode only)
     PROF_MARK(0);
     if ((rc = launch_prep(h->dm, B, normalised, x_main, x_sfc, mem_in, hx2, cx2, h->X1, h->hc0, s))) return rc;
     const float *h2 = c.legacy ? hx2 : h->hc0 + (size_t)2 * B * nhm;
     const float *c2 = c.legacy ? cx2 : h->hc0 + (size_t)3 * B * nhm;
-    if (h->fused && h->dm.wih1f) {
-        // fused path: each LSTM layer is ONE launch (projection by four MFMA waves, recurrence by eight vector waves on the
-        // VALU pipe of the same CUs); the two GEMM stages are empty
-        PROF_MARK(1);
-        PROF_MARK(2);
-        if ((rc = launch_fused_lstm(c.nh1, c.nh1 + c.nh_mem, h->dm.whh1p, h->dm.wih1f, h->dm.bias1, h->X1, h->hc0,
-                                    h->hc0 + (size_t)B * nhm, h->H1, B, L, /*reverse_out=*/1, s))) return rc;
-        PROF_MARK(3);
-        PROF_MARK(4);
-        if ((rc = launch_fused_lstm(c.nh2, c.nh1, h->dm.whh2p, h->dm.wih2f, h->dm.bias2, h->H1, h2, c2, h->H2, B, L,
-                                    /*reverse_out=*/0, s))) return rc;
-    } else {
-        PROF_MARK(1);
-        // rnn1: upward over the flipped sequence; hidden sequence stored back in level order
-        if ((rc = launch_proj_gemm(h->X1, h->dm.wih1, h->dm.bias1, h->P, L * B, 4 * c.nh1, c.nh1 + c.nh_mem, s))) return rc;
-        PROF_MARK(2);
-        if ((rc = launch_rec_auto(h, 1, h->P, h->hc0, h->hc0 + (size_t)B * nhm, h->H1, B, L, /*reverse_out=*/1, s))) return rc;
-        PROF_MARK(3);
-        // rnn2: downward in level order
-        if ((rc = launch_proj_gemm(h->H1, h->dm.wih2, h->dm.bias2, h->P, L * B, 4 * c.nh2, c.nh1, s))) return rc;
-        PROF_MARK(4);
-        if ((rc = launch_rec_auto(h, 2, h->P, h2, c2, h->H2, B, L, /*reverse_out=*/0, s))) return rc;
-    }
+    PROF_MARK(1);
+    // rnn1: upward over the flipped sequence; hidden sequence stored back in level order
+    if ((rc = launch_proj_gemm(h->X1, h->dm.wih1, h->dm.bias1, h->P, L * B, 4 * c.nh1, c.nh1 + c.nh_mem, s))) return rc;
+    PROF_MARK(2);
+    if ((rc = launch_rec_auto(h, 1, h->P, h->hc0, h->hc0 + (size_t)B * nhm, h->H1, B, L, /*reverse_out=*/1, s))) return rc;
+    PROF_MARK(3);
+    // rnn2: downward in level order
+    if ((rc = launch_proj_gemm(h->H1, h->dm.wih2, h->dm.bias2, h->P, L * B, 4 * c.nh2, c.nh1, s))) return rc;
+    PROF_MARK(4);
+    if ((rc = launch_rec_auto(h, 2, h->P, h2, c2, h->H2, B, L, /*reverse_out=*/0, s))) return rc;
     PROF_MARK(5);
     rc = launch_head(h->dm, B, mode, h->H2, x_main, x_sfc, y0, y1, y2, s);
     PROF_MARK(6);
@@ -680,4 +534,46 @@ extern "C" int csa_model_forward(csa_emulator *h, int B, const float *x_main_n, 
     if (!h) return CSA_ERR_ARG;
     if (!out_sfc || (h->dm.cfg.nh_mem > 0 && !mem_out)) { csa_set_error_msg("model_forward: null output"); return CSA_ERR_ARG; }
     return run_forward(h, B, 1, HEAD_RAW, x_main_n, x_sfc_n, mem_in, hx2, cx2, out, out_sfc, mem_out, (hipStream_t)stream);
+}
+
+// ---- stage-wise entry point (parity evidence, tests/test_stagewise_parity.py) ------------------------------------------------
+// Runs ONE stage of the six-launch path on caller-provided inputs in the library's internal layouts, so that every kernel can
+// be fed the reference's exact input for that stage (teacher forcing) and compared with the reference's output of it:
+//   0 prep      in0 x_main (B,L,nx) raw, in1 x_sfc (B,nx_sfc) raw, in2 mem_in (nullable), in3 hx2, in4 cx2 (legacy)
+//               -> out0 X1 (L,B,nh1+nh_mem) SEQUENCE order (t = 0 is the surface), out1 hc0 (4,B,nhm)
+//   1 / 3 proj  in0 X (L*B,K)            -> out0 P (L*B,4*nh), per unit [i,g~,f,o] (LSTM) / [r,z,n,0] (GRU), bias folded
+//   2 / 4 rec   in0 P, in1 h0, in2 c0    -> out0 H (L,B,nh) LEVEL order (rnn1 runs upward: reverse_out = 1)
+//   5 head      in0 H2 (L,B,nh2), in1 x_main raw, in2 x_sfc raw -> out0 packed (B,W)
+//   6 / 7 step  in0 P (L*B,4*nh), in1 h_{t-1} (L*B,nh), in2 c_{t-1} -> out0 h_t (L*B,nh): ONE cell step per row (rnn1 / rnn2
+//               weights), i.e. the recurrence kernel's arithmetic without the 60-step chain
+// The kernel class (one- / two- / four-column recurrence, small / large GEMM) is the one a full call with this B would use.
+extern "C" int csa_debug_stage(csa_emulator *h, int stage, int B, const float *in0, const float *in1, const float *in2,
+                               const float *in3, const float *in4, float *out0, float *out1, void *stream)
+{
+    if (!h || B <= 0 || B > h->max_batch || !in0 || !out0) { csa_set_error_msg("csa_debug_stage: bad argument"); return CSA_ERR_ARG; }
+    const csa_config &c = h->dm.cfg;
+    if (c.add_stochastic_layer) { csa_set_error_msg("csa_debug_stage: not for the stochastic variant"); return CSA_ERR_UNSUPPORTED; }
+    hipStream_t s = (hipStream_t)stream;
+    const int L = c.nlev;
+    switch (stage) {
+    case 0:
+        if (!in1 || !out1) { csa_set_error_msg("csa_debug_stage(prep): null tensor"); return CSA_ERR_ARG; }
+        return launch_prep(h->dm, B, 0, in0, in1, in2, in3, in4, out0, out1, s);
+    case 1: return launch_proj_gemm(in0, h->dm.wih1, h->dm.bias1, out0, L * B, 4 * c.nh1, c.nh1 + c.nh_mem, s);
+    case 3: return launch_proj_gemm(in0, h->dm.wih2, h->dm.bias2, out0, L * B, 4 * c.nh2, c.nh1, s);
+    case 2:
+    case 4:
+        if (!in1 || (c.use_lstm && !in2)) { csa_set_error_msg("csa_debug_stage(rec): null state"); return CSA_ERR_ARG; }
+        return launch_rec_auto(h, stage == 2 ? 1 : 2, in0, in1, in2, out0, B, L, stage == 2 ? 1 : 0, s);
+    case 6:
+    case 7:     // ONE cell step for every (level, column) pair: nlev*B independent columns, sequence length 1
+        if (!in1 || (c.use_lstm && !in2)) { csa_set_error_msg("csa_debug_stage(rec step): null state"); return CSA_ERR_ARG; }
+        return launch_rec_auto(h, stage == 6 ? 1 : 2, in0, in1, in2, out0, L * B, 1, 0, s, B);
+    case 5:
+        if (!in1 || !in2) { csa_set_error_msg("csa_debug_stage(head): null tensor"); return CSA_ERR_ARG; }
+        return launch_head(h->dm, B, HEAD_PACKED, in0, in1, in2, out0, nullptr, nullptr, s);
+    default:
+        csa_set_error_msg("csa_debug_stage: stage must be 0..7");
+        return CSA_ERR_ARG;
+    }
 }

@@ -34,8 +34,6 @@ struct DevModel {
     const float *whh1p, *whh2p;
     const float *whh1q, *whh2q;         // the same matrices packed for the one-column kernel (lstm_rec1_kernel), LSTM only
     const float *whh1g, *whh2g;         // GRU, nh <= 128: packed for the second-generation two-column kernel (gru_rec2_kernel)
-    // W_ih in MFMA-operand order for the dual-pipe fused LSTM kernel (fused.hip); null if not built
-    const float *wih1f, *wih2f;
     // heads
     const float *lat_wt, *lat_b;        // (nh2, nh_mem)
     const float *out_w, *out_b;         // (ny, nh_mem or nh2) row-major
@@ -122,18 +120,9 @@ int launch_rec_train(int nh, const float *whh_packed, float *P, const float *h0,
                      int B, int L, int reverse_out, float *Hseq, float *Cseq, hipStream_t s);
 int launch_rec_train_gru(int nh, const float *whh_packed, const float *bhn, float *P, const float *h0, float *Hout, int B, int L,
                          int reverse_out, float *Hseq, hipStream_t s);
-int launch_rec_range(int nh, const float *whh_packed, const float *P, const float *h0, const float *c0, float *Hout,
-                     int B, int L, int reverse_out, int t0, int t1, float *Cfin, hipStream_t s);
 size_t rec_packed_floats(int use_lstm, int nh);
 // host-side packer: W_hh (G*nh, nh) PyTorch layout -> register-stationary layout
 void rec_pack_weights(int use_lstm, int nh, const float *w_hh, float *packed);
-
-// fused.hip: whole LSTM layer (projection on the MFMA pipe + recurrence on the VALU pipe) in one launch
-size_t fused_packed_floats(int nh, int K);
-void fused_pack_wih(int nh, int K, const float *w_perm, float *packed);
-int launch_fused_lstm(int nh, int K, const float *whh_packed, const float *wih_packed, const float *bias,
-                      const float *X, const float *h0, const float *c0, float *Hout, int B, int L, int reverse_out,
-                      hipStream_t s);
 
 // head.hip: mlp_latent / mlp_output / surface head / de-normalisation / microphysics / packing
 int launch_head(const DevModel &m, int B, int mode, const float *H2, const float *x_main_raw, const float *x_sfc_raw,

@@ -22,6 +22,18 @@
 #define CSA_FAST_GATES 1
 #endif
 
+// The activation primitives of the second-generation kernels: 2^x and 1/x.  CSA_FAST_GATES=1 (default): v_exp_f32 and
+// v_rcp_f32 (1 ulp each); CSA_FAST_GATES=0 (diagnostic build, tools/build_exact_gates.sh): libm exp2f and IEEE division --
+// used once per round to show that the gate approximations are not what separates the HIP path from the reference
+// (profiles/r2_stagewise_parity.txt).
+#if CSA_FAST_GATES
+#define CSA_EXP2(x) __builtin_amdgcn_exp2f(x)
+#define CSA_RCP(x) __builtin_amdgcn_rcpf(x)
+#else
+#define CSA_EXP2(x) exp2f(x)
+#define CSA_RCP(x) (1.0f / (x))
+#endif
+
 __device__ __forceinline__ float sigmoid_f(float x)
 {
 #if CSA_FAST_GATES
@@ -228,13 +240,8 @@ template <int NH, bool TRAIN, int NL4 = 0>
 __global__ __launch_bounds__(NH * 4, (NH / 16 + 3) / 4) void lstm_rec2_kernel(
     const f32x4 *__restrict__ Wp4, float *__restrict__ P,
     const float *__restrict__ h0, const float *__restrict__ c0, float *__restrict__ Hout,
-    int B, int L, int reverse_out, float *__restrict__ Hseq, float *__restrict__ Cseq,
-    int t_begin, int t_end, float *__restrict__ Cfin)
+    int B, int L, int reverse_out, float *__restrict__ Hseq, float *__restrict__ Cseq)
 {
-    // [t_begin, t_end) = the steps of this launch (t_begin even): a layer may be split into several
-    // launches so that the next layer's projection GEMM on the levels already produced runs concurrently
-    // on another stream (api.hip); h0/c0 then point at the state left by the previous piece and the
-    // final c_t goes to Cfin.
     constexpr int NT = NH * 4;
     constexpr int KC = NH / 4;
     constexpr int CH = 2 * KC + 4;      // floats per k-quarter, padded by one 16-B slot
@@ -285,14 +292,18 @@ __global__ __launch_bounds__(NH * 4, (NH / 16 + 3) / 4) void lstm_rec2_kernel(
     const float *Pb = P + (size_t)b * (4 * NH) + u * 4 + grp * 2;
     const size_t Pstep = (size_t)B * (4 * NH);
     const int rdoff = col * CPY + p * CH;
-    f32x2 preA = *(const f32x2 *)(Pb + (size_t)t_begin * Pstep), preB = preA;
+    f32x2 preA = *(const f32x2 *)Pb, preB = preA;
     __syncthreads();
 
     // P(t+1) is fetched with an asm global_load at the top of step t and first touched behind an
     // explicit vmcnt(1) ("everything but the newest VMEM op") just before the gates of step t+1,
     // a whole step later; the h_t store of the previous step is older still.  hipcc inserts no
     // waits for loads issued inside asm, so nothing in the recurrence ever stalls on global
-    // memory; the "+v" operand of the wait orders the consumers behind it.  The LDS reads of
+    // memory; the "+v" operand of the wait orders the consumers behind it.  The prefetch is
+    // UNCONDITIONAL (the last step re-reads its own row) and so is the wait: every step has the
+    // same loads in flight and ONE wait statement with ONE count, so the compiler never sees a
+    // path on which a prefetch register is live without its wait (the hazard recorded at
+    // lstm_rec4_kernel; tools/check_asm_prefetch.py checks the emitted ISA of every such kernel).  The LDS reads of
     // h_{t-1} are left to the compiler (two ds_read_b128 in flight per wave).  Measured with the
     // in-kernel stamps of the REC_EXP_STAMP build: hand-pipelining them 4 deep changes nothing and
     // issuing all sixteen up front costs +170 cycles per step; the FMA phase is bound by the
@@ -309,8 +320,8 @@ __global__ __launch_bounds__(NH * 4, (NH / 16 + 3) / 4) void lstm_rec2_kernel(
 #define LSTM2_STEP(T, CUR, NXT)                                                                    \
     {                                                                                              \
         const int t_ = (T);                                                                        \
-        if (t_ + 1 < t_end) {                                                                      \
-            const float *pn = Pb + (size_t)(t_ + 1) * Pstep;                                       \
+        {                                                                                          \
+            const float *pn = Pb + (size_t)(t_ + 1 < L ? t_ + 1 : L - 1) * Pstep;                  \
             asm volatile("global_load_dwordx2 %0, %1, off" : "=&v"(NXT) : "v"(pn) : "memory");     \
         }                                                                                          \
         const f32x4 *hp = (const f32x4 *)&hbuf[t_ & 1][rdoff];                                     \
@@ -337,16 +348,16 @@ __global__ __launch_bounds__(NH * 4, (NH / 16 + 3) / 4) void lstm_rec2_kernel(
         STAMP(1, acc[0])                                                                           \
         float r[4];                                                                                \
         _Pragma("unroll") for (int s = 0; s < 4; ++s) r[s] = acc[s].x + dpp_xor1(acc[s].y);        \
-        if (t_ > t_begin) asm volatile("s_waitcnt vmcnt(1)" : "+v"(CUR));                                \
+        asm volatile("s_waitcnt vmcnt(1)" : "+v"(CUR));                                            \
         const float v0 = r[0] + dpp_xor2(r[2]) + CUR.x;                                            \
         const float v1 = r[1] + dpp_xor2(r[3]) + CUR.y;                                            \
-        const float g0 = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504088896341f * v0)); \
-        const float t1 = fminf(__builtin_amdgcn_exp2f(k1 * v1), 1e30f);                            \
-        const float g1 = (1.0f - nb1 * t1) * __builtin_amdgcn_rcpf(1.0f + t1);                     \
+        const float g0 = CSA_RCP(1.0f + CSA_EXP2(-1.44269504088896341f * v0)); \
+        const float t1 = fminf(CSA_EXP2(k1 * v1), 1e30f);                            \
+        const float g1 = (1.0f - nb1 * t1) * CSA_RCP(1.0f + t1);                     \
         const float ig = dpp_xor2(g0 * g1);           /* sigma(i)*tanh(g~) arrives at the (f,o) lane */ \
         c = g0 * c + ig;                                                                           \
-        const float tc = fminf(__builtin_amdgcn_exp2f(-2.88539008177792681f * c), 1e30f);          \
-        const float th = (1.0f - tc) * __builtin_amdgcn_rcpf(1.0f + tc);                           \
+        const float tc = fminf(CSA_EXP2(-2.88539008177792681f * c), 1e30f);          \
+        const float th = (1.0f - tc) * CSA_RCP(1.0f + tc);                           \
         h = g1 * th;                                                                               \
         STAMP(2, h)                                                                                \
         if (owner) {                                                                               \
@@ -380,11 +391,10 @@ __global__ __launch_bounds__(NH * 4, (NH / 16 + 3) / 4) void lstm_rec2_kernel(
 #define STAMP(K, DEP)
 #endif
 
-    for (int t = t_begin; t < t_end; t += 2) {
+    for (int t = 0; t < L; t += 2) {
         LSTM2_STEP(t, preA, preB)
-        if (t + 1 < t_end) LSTM2_STEP(t + 1, preB, preA)
+        if (t + 1 < L) LSTM2_STEP(t + 1, preB, preA)
     }
-    if (Cfin && owner && valid) Cfin[(size_t)b * NH + u] = c;
 #undef LSTM2_STEP
 #undef STAMP
 #ifdef REC_EXP_CLOCK
@@ -460,13 +470,13 @@ __global__ __launch_bounds__(NH * 4, (NH / 16 + 3) / 4) void lstm_rec4_kernel(
     {                                                                                              \
         const float v0 = R[0] + dpp_xor2(R[2]) + CUR.x;                                            \
         const float v1 = R[1] + dpp_xor2(R[3]) + CUR.y;                                            \
-        const float g0 = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504088896341f * v0)); \
-        const float t1 = fminf(__builtin_amdgcn_exp2f(k1 * v1), 1e30f);                            \
-        const float g1 = (1.0f - nb1 * t1) * __builtin_amdgcn_rcpf(1.0f + t1);                     \
+        const float g0 = CSA_RCP(1.0f + CSA_EXP2(-1.44269504088896341f * v0)); \
+        const float t1 = fminf(CSA_EXP2(k1 * v1), 1e30f);                            \
+        const float g1 = (1.0f - nb1 * t1) * CSA_RCP(1.0f + t1);                     \
         const float ig = dpp_xor2(g0 * g1);                                                        \
         C = g0 * C + ig;                                                                           \
-        const float tc = fminf(__builtin_amdgcn_exp2f(-2.88539008177792681f * C), 1e30f);          \
-        const float th = (1.0f - tc) * __builtin_amdgcn_rcpf(1.0f + tc);                           \
+        const float tc = fminf(CSA_EXP2(-2.88539008177792681f * C), 1e30f);          \
+        const float th = (1.0f - tc) * CSA_RCP(1.0f + tc);                           \
         H = g1 * th;                                                                               \
     }
 #define LSTM4_STEP(T, CURA, NXTA, CURB, NXTB)                                                      \
@@ -499,7 +509,7 @@ __global__ __launch_bounds__(NH * 4, (NH / 16 + 3) / 4) void lstm_rec4_kernel(
             rA[s] = accA[s].x + dpp_xor1(accA[s].y);                                               \
             rB[s] = accB[s].x + dpp_xor1(accB[s].y);                                               \
         }                                                                                          \
-        if (t_ > 0) asm volatile("s_waitcnt vmcnt(2)" : "+v"(CURA), "+v"(CURB));                   \
+        asm volatile("s_waitcnt vmcnt(2)" : "+v"(CURA), "+v"(CURB));                               \
         LSTM4_GATES(rA, CURA, cA, hA)                                                              \
         LSTM4_GATES(rB, CURB, cB, hB)                                                              \
         if (owner) {                                                                               \
@@ -571,8 +581,8 @@ __global__ __launch_bounds__(NH * 4, (NH / 16 + 3) / 4) void gru_rec2_kernel(
 #define GRU2_STEP(T, CUR, NXT)                                                                     \
     {                                                                                              \
         const int t_ = (T);                                                                        \
-        if (t_ + 1 < L) {                                                                          \
-            const float *pn = Pb + (size_t)(t_ + 1) * Pstep;                                       \
+        {   /* unconditional prefetch + unconditional wait: see lstm_rec2_kernel */                 \
+            const float *pn = Pb + (size_t)(t_ + 1 < L ? t_ + 1 : L - 1) * Pstep;                  \
             asm volatile("global_load_dwordx2 %0, %1, off" : "=&v"(NXT) : "v"(pn) : "memory");     \
         }                                                                                          \
         const f32x4 *hp = (const f32x4 *)&hbuf[t_ & 1][rdoff];                                     \
@@ -585,13 +595,13 @@ __global__ __launch_bounds__(NH * 4, (NH / 16 + 3) / 4) void gru_rec2_kernel(
         }                                                                                          \
         float r[3];                                                                                \
         _Pragma("unroll") for (int s = 0; s < 3; ++s) r[s] = acc[s].x + dpp_xor1(acc[s].y);        \
-        if (t_ > 0) asm volatile("s_waitcnt vmcnt(1)" : "+v"(CUR));                                \
+        asm volatile("s_waitcnt vmcnt(1)" : "+v"(CUR));                                            \
         const float v0 = r[0] + dpp_xor2(r[2]) + CUR.x;                                            \
         const float hn = r[1] + dpp_xor2(r[1]) + bn;                                               \
-        const float g0 = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504088896341f * v0)); \
+        const float g0 = CSA_RCP(1.0f + CSA_EXP2(-1.44269504088896341f * v0)); \
         const float rr = dpp_xor2(g0);                /* the reset gate arrives at the lane that owns h */ \
-        const float tn = fminf(__builtin_amdgcn_exp2f(-2.88539008177792681f * (CUR.y + rr * hn)), 1e30f); \
-        const float n = (1.0f - tn) * __builtin_amdgcn_rcpf(1.0f + tn);                            \
+        const float tn = fminf(CSA_EXP2(-2.88539008177792681f * (CUR.y + rr * hn)), 1e30f); \
+        const float n = (1.0f - tn) * CSA_RCP(1.0f + tn);                            \
         h = (1.0f - g0) * n + g0 * h;                                                              \
         if (owner) {                                                                               \
             hbuf[(t_ & 1) ^ 1][slotN] = h;                                                         \
@@ -656,8 +666,8 @@ __global__ __launch_bounds__(NH * 4, (NH / 16 + 3) / 4) void lstm_rec1_kernel(
 #define LSTM1_STEP(T, CUR, NXT)                                                                    \
     {                                                                                              \
         const int t_ = (T);                                                                        \
-        if (t_ + 1 < L) {                                                                          \
-            const float *pn = Pb + (size_t)(t_ + 1) * Pstep;                                       \
+        {   /* unconditional prefetch + unconditional wait: see lstm_rec2_kernel */                 \
+            const float *pn = Pb + (size_t)(t_ + 1 < L ? t_ + 1 : L - 1) * Pstep;                  \
             asm volatile("global_load_dword %0, %1, off" : "=&v"(NXT) : "v"(pn) : "memory");       \
         }                                                                                          \
         const f32x4 *hp = (const f32x4 *)&hbuf[t_ & 1][p * CH];                                    \
@@ -672,17 +682,17 @@ __global__ __launch_bounds__(NH * 4, (NH / 16 + 3) / 4) void lstm_rec1_kernel(
         _Pragma("unroll") for (int s = 0; s < 4; ++s) sm[s] = acc[s].x + acc[s].y;                 \
         const float r0 = sm[0] + dpp_xor1(sm[1]);                                                  \
         const float r1 = sm[2] + dpp_xor1(sm[3]);                                                  \
-        if (t_ > 0) asm volatile("s_waitcnt vmcnt(1)" : "+v"(CUR));                                \
+        asm volatile("s_waitcnt vmcnt(1)" : "+v"(CUR));                                            \
         const float v = r0 + dpp_xor2(r1) + CUR;                                                   \
-        const float te = fminf(__builtin_amdgcn_exp2f(kact * v), 1e30f);                           \
-        const float a = (1.0f - nb * te) * __builtin_amdgcn_rcpf(1.0f + te);     /* gate p of unit u */ \
+        const float te = fminf(CSA_EXP2(kact * v), 1e30f);                           \
+        const float a = (1.0f - nb * te) * CSA_RCP(1.0f + te);     /* gate p of unit u */ \
         const float ig = a * dpp_xor1(a);                                        /* lanes 0,1: i*g~ */ \
         const float igq = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, ig), 0x00, 0xF, 0xF, true)); \
         const float fq = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, a), 0xAA, 0xF, 0xF, true));  \
         const float oq = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, a), 0xFF, 0xF, 0xF, true));  \
         c = fq * c + igq;                                                                          \
-        const float tc = fminf(__builtin_amdgcn_exp2f(-2.88539008177792681f * c), 1e30f);          \
-        h = oq * ((1.0f - tc) * __builtin_amdgcn_rcpf(1.0f + tc));                                 \
+        const float tc = fminf(CSA_EXP2(-2.88539008177792681f * c), 1e30f);          \
+        h = oq * ((1.0f - tc) * CSA_RCP(1.0f + tc));                                 \
         if (p == 0) {                                                                              \
             hbuf[(t_ & 1) ^ 1][hslot] = h;                                                         \
             Hout[((size_t)(reverse_out ? L - 1 - t_ : t_) * B + b) * NH + u] = h;                  \
@@ -731,8 +741,8 @@ __global__ __launch_bounds__(NH * 4, (NH / 16 + 3) / 4) void gru_rec1_kernel(
 #define GRU1_STEP(T, CUR, NXT)                                                                     \
     {                                                                                              \
         const int t_ = (T);                                                                        \
-        if (t_ + 1 < L) {                                                                          \
-            const float *pn = Pb + (size_t)(t_ + 1) * Pstep;                                       \
+        {   /* unconditional prefetch + unconditional wait: see lstm_rec2_kernel */                 \
+            const float *pn = Pb + (size_t)(t_ + 1 < L ? t_ + 1 : L - 1) * Pstep;                  \
             asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(NXT) : "v"(pn) : "memory");     \
         }                                                                                          \
         const f32x4 *hp = (const f32x4 *)&hbuf[t_ & 1][p * CH];                                    \
@@ -745,7 +755,7 @@ __global__ __launch_bounds__(NH * 4, (NH / 16 + 3) / 4) void gru_rec1_kernel(
         }                                                                                          \
         const float sr = quad_sum(acc[0].x + acc[0].y), sz = quad_sum(acc[1].x + acc[1].y);        \
         const float sn = quad_sum(acc[2].x + acc[2].y);                                            \
-        if (t_ > 0) asm volatile("s_waitcnt vmcnt(1)" : "+v"(CUR));                                \
+        asm volatile("s_waitcnt vmcnt(1)" : "+v"(CUR));                                            \
         const float r = sigmoid_f(CUR.x + sr);                                                     \
         const float z = sigmoid_f(CUR.y + sz);                                                     \
         const float n = tanh_f(CUR.z + r * (sn + bn));                                             \
@@ -905,7 +915,7 @@ static int launch_rec_nh(int use_lstm, const float *whh, const float *bhn, const
             CSA_SET_DYN_LDS_ONCE(kern, shm);
         }
         hipLaunchKernelGGL(kern, grid, block, shm, s, (const f32x4 *)whh, (float *)P,
-                           h0, c0, Hout, B, L, reverse_out, (float *)nullptr, (float *)nullptr, 0, L, (float *)nullptr);
+                           h0, c0, Hout, B, L, reverse_out, (float *)nullptr, (float *)nullptr);
     }
     else   // GRU: 3*nh/4 weights per lane (108 at nh = 144) fit the 168-VGPR budget of a 9-wave workgroup as they are
         hipLaunchKernelGGL((rec_kernel<NH, 3>), grid, block, 0, s, (const f32x4 *)whh, bhn, P, h0, c0, Hout, B, L,
@@ -919,15 +929,15 @@ int launch_rec_train(int nh, const float *whh_packed, float *P, const float *h0,
 {
     const dim3 grid((B + 1) / 2), block(nh * 4);
     switch (nh) {
-    case 64:  hipLaunchKernelGGL((lstm_rec2_kernel<64, true>), grid, block, 0, s, (const f32x4 *)whh_packed, P, h0, c0, Hout, B, L, reverse_out, Hseq, Cseq, 0, L, (float *)nullptr); break;
-    case 96:  hipLaunchKernelGGL((lstm_rec2_kernel<96, true>), grid, block, 0, s, (const f32x4 *)whh_packed, P, h0, c0, Hout, B, L, reverse_out, Hseq, Cseq, 0, L, (float *)nullptr); break;
-    case 128: hipLaunchKernelGGL((lstm_rec2_kernel<128, true>), grid, block, 0, s, (const f32x4 *)whh_packed, P, h0, c0, Hout, B, L, reverse_out, Hseq, Cseq, 0, L, (float *)nullptr); break;
+    case 64:  hipLaunchKernelGGL((lstm_rec2_kernel<64, true>), grid, block, 0, s, (const f32x4 *)whh_packed, P, h0, c0, Hout, B, L, reverse_out, Hseq, Cseq); break;
+    case 96:  hipLaunchKernelGGL((lstm_rec2_kernel<96, true>), grid, block, 0, s, (const f32x4 *)whh_packed, P, h0, c0, Hout, B, L, reverse_out, Hseq, Cseq); break;
+    case 128: hipLaunchKernelGGL((lstm_rec2_kernel<128, true>), grid, block, 0, s, (const f32x4 *)whh_packed, P, h0, c0, Hout, B, L, reverse_out, Hseq, Cseq); break;
     case 144: {
         constexpr int NL4 = 3;   // the TRAIN variant carries more live state: one more float4 per slot in LDS
         constexpr size_t shm = (size_t)4 * NL4 * 144 * 4 * sizeof(f32x4);
         auto kern = lstm_rec2_kernel<144, true, NL4>;
         CSA_SET_DYN_LDS_ONCE(kern, shm);
-        hipLaunchKernelGGL(kern, grid, block, shm, s, (const f32x4 *)whh_packed, P, h0, c0, Hout, B, L, reverse_out, Hseq, Cseq, 0, L, (float *)nullptr);
+        hipLaunchKernelGGL(kern, grid, block, shm, s, (const f32x4 *)whh_packed, P, h0, c0, Hout, B, L, reverse_out, Hseq, Cseq);
         break;
     }
     default:
@@ -951,17 +961,6 @@ int launch_rec_train_gru(int nh, const float *whh_packed, const float *bhn, floa
         csa_set_error_msg("rec(train, GRU): hidden size not supported (64, 96, 128)");
         return CSA_ERR_UNSUPPORTED;
     }
-    CSA_HIP_CHECK(hipGetLastError());
-    return CSA_OK;
-}
-
-// LSTM, steps [t0, t1) only (t0 even); final cell state to Cfin.  nh = 128 (the split path of api.hip).
-int launch_rec_range(int nh, const float *whh_packed, const float *P, const float *h0, const float *c0, float *Hout,
-                     int B, int L, int reverse_out, int t0, int t1, float *Cfin, hipStream_t s)
-{
-    if (nh != 128 || (t0 & 1)) { csa_set_error_msg("rec_range: nh = 128 and an even first step are required"); return CSA_ERR_UNSUPPORTED; }
-    hipLaunchKernelGGL((lstm_rec2_kernel<128, false>), dim3((B + 1) / 2), dim3(512), 0, s, (const f32x4 *)whh_packed,
-                       (float *)P, h0, c0, Hout, B, L, reverse_out, (float *)nullptr, (float *)nullptr, t0, t1, Cfin);
     CSA_HIP_CHECK(hipGetLastError());
     return CSA_OK;
 }

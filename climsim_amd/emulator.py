@@ -233,28 +233,22 @@ class Emulator:
         self._rc(rc, "csa_model_forward")
         return out, out_sfc, mem_out
 
-    def set_fused(self, enable):
-        """Select the fused projection+recurrence layer kernel (fused.hip; off by default: measured slower, fp32 MFMA and
-        packed FMA do not co-execute on gfx950) instead of the six-launch path; returns True if fused is active."""
-        return bool(_lib.lib().csa_set_fused(self._h, int(bool(enable))))
-
     def set_halves(self, enable):
         """Two column halves on two streams (legacy models, B >= 64); bit-identical results.
         True / False force it, None restores the default (automatic from 640 columns)."""
         return _lib.lib().csa_set_halves(self._h, 2 if enable is None else int(bool(enable)))
 
-    def set_graph(self, enable):
-        """Replay the launches of a forward call as one hipGraph while all arguments stay the same (rollout loops over
-        persistent buffers, on a non-default stream)."""
-        return bool(_lib.lib().csa_set_graph(self._h, int(bool(enable))))
-
     def set_rec1_max_batch(self, max_batch):
         """Largest batch that uses the one-column-per-workgroup recurrent kernel (default 256); 0 disables it."""
         self._rc(_lib.lib().csa_set_rec1_max_batch(self._h, int(max_batch)), "csa_set_rec1_max_batch")
 
-    def set_overlap(self, enable):
-        """Level-split overlap of projection GEMMs with the recurrence on a side stream (off by default: measured slower)."""
-        return bool(_lib.lib().csa_set_overlap(self._h, int(bool(enable))))
+    def debug_stage(self, stage, B, ins, out_shapes):
+        """Run ONE launch of the forward path on given device inputs (csa_debug_stage; internal layouts, see the header)."""
+        ins = list(ins) + [None] * (5 - len(ins))
+        outs = [torch.empty(sh, device=self.device) for sh in out_shapes] + [None] * (2 - len(out_shapes))
+        self._rc(_lib.lib().csa_debug_stage(self._h, int(stage), int(B), *[_ptr(t) for t in ins], _ptr(outs[0]), _ptr(outs[1]),
+                                            self._stream()), "csa_debug_stage")
+        return outs[:len(out_shapes)]
 
     def set_profiling(self, enable):
         self._rc(_lib.lib().csa_set_profiling(self._h, int(bool(enable))), "csa_set_profiling")

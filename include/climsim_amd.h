@@ -17,7 +17,7 @@
  * by the caller and passed / returned on every call; the handle holds weights, constants and
  * scratch only.  Every data pointer is a DEVICE pointer; `stream` is a hipStream_t (NULL =
  * default stream).  Calls are asynchronous on `stream`, allocate nothing and are safe to
- * capture into a hipGraph.  All functions return 0 on success or a negative csa_status; no
+ * capture into a hipGraph (single-stream path: csa_set_halves(h, 0)).  All functions return 0 on success or a negative csa_status; no
  * exception crosses the boundary.  One call at a time per handle.
  *
  * The legacy generation (the shipped rnn/v4_rnn*_wrapper*.pt artefacts) draws
@@ -129,30 +129,29 @@ int csa_reset_profile(csa_emulator *h);
 int csa_get_profile(csa_emulator *h, double *avg_ms /* [6] */, int n, long *calls);
 const char *csa_stage_name(int i);
 
-/* Kernel selection: 0 (default) = the six-launch path (projection GEMM + recurrent kernel);
- * 1 = fused projection+recurrence LSTM layers (fused.hip; LSTM, nh = 128) -- parity-tested, slower (fp32 MFMA and packed FMA
- *     share the SIMD's FMA lanes on gfx950 and do not co-execute)
- * (DESIGN.md section 4.5).  Returns 1 if the fused path is in use. */
-int csa_set_fused(csa_emulator *h, int enable);
-/* 1 = level-split overlap: rnn1 runs in three launches and the projection GEMMs of the other pieces /
- * of the next layer run concurrently on an internal side stream (same results, bit for bit);
- * 0 (default) = strictly sequential six launches.  Measured on MI355X at 384 columns: 230 us vs 202 us
- * (the cross-queue event waits cost more than the GEMM time they hide), so it is opt-in. */
 /* Two column halves on two streams with one fork / one join event (B >= 64; not the stochastic variant); results are
  * bit-identical to the single-stream path.  enable: 0 off, 1 on, 2 automatic (default: on from 640 columns, where it
  * measures 4-9 % faster; slower below).  Returns the new state. */
 int csa_set_halves(csa_emulator *h, int enable);
-/* hipGraph replay (enable = 1): the six launches of a forward call are captured once and replayed as one graph launch while
- * every argument (batch, pointers, stream) stays the same, as in a rollout loop over persistent buffers; any change
- * re-captures.  Needs a non-default stream.  Off by default.  Returns the new state. */
-int csa_set_graph(csa_emulator *h, int enable);
 /* Process-wide: projections with at most `rows` rows (= nlev * B) use the small-M split-K GEMM (32x32 tiles; default
  * 11,520 = 192 columns, the measured crossover; also settable with CSA_SMALL_GEMM_ROWS before the first call). */
 int csa_set_small_gemm_rows(int rows);
 /* Largest batch that runs the recurrence with one column per workgroup (latency variant, LSTM nh <= 128; default 256 =
  * one column per CU).  0 forces the two-column kernel everywhere. */
 int csa_set_rec1_max_batch(csa_emulator *h, int max_batch);
-int csa_set_overlap(csa_emulator *h, int enable);
+
+/* Stage-wise execution for parity evidence: runs ONE of the six launches of a forward call (0 prep, 1 projection rnn1,
+ * 2 recurrence rnn1, 3 projection rnn2, 4 recurrence rnn2, 5 head + packing, 6 / 7 single cell step of rnn1 / rnn2) on caller-provided DEVICE inputs in the
+ * library's internal layouts, so that each kernel can be teacher-forced with the reference's input of that stage:
+ *   0: in0 x_main, in1 x_sfc, in2 mem_in (nullable), in3 / in4 hx2, cx2 (legacy) -> out0 X1 (nlev,B,nh1+nh_mem) sequence
+ *      order (t = 0 = surface), out1 (4,B,max(nh1,nh2)) initial states [h0,c0 of rnn1 | h0,c0 of rnn2]
+ *   1 / 3: in0 X (nlev*B,K) -> out0 pre-activations (nlev*B,4*nh), unit-major [i,g~,f,o] (GRU [r,z,n,0]), b_ih+b_hh folded
+ *   2 / 4: in0 pre-activations, in1 h0, in2 c0 -> out0 hidden sequence (nlev,B,nh) in LEVEL order
+ *   5: in0 rnn2 hidden sequence, in1 x_main, in2 x_sfc -> out0 packed output (B, csa_packed_width)
+ *   6 / 7: in0 pre-activations (nlev*B,4*nh), in1 h_{t-1}, in2 c_{t-1} (nlev*B,nh) -> out0 h_t (nlev*B,nh): ONE cell step of
+ *      rnn1 / rnn2 per row (the recurrent kernel's arithmetic without the chain of nlev dependent steps) */
+int csa_debug_stage(csa_emulator *h, int stage, int B, const float *in0, const float *in1, const float *in2,
+                    const float *in3, const float *in4, float *out0, float *out1, void *stream);
 
 /* ---- training step (e) ---------------------------------------------
  * Replaces, for the current-generation LSTM with memory (mp_mode 1):
