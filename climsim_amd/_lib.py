@@ -14,7 +14,7 @@ _F = ctypes.c_void_p   # device pointers travel as integers
 
 CONFIG_FIELDS = ["nlev", "nx", "nx_sfc", "ny", "ny_sfc", "nh1", "nh2", "nh_mem", "use_lstm", "legacy",
                  "output_prune", "mp_mode", "snowhice_fix", "qinput_prune", "rh_prune", "scrub_inf",
-                 "scrub_out_nan", "q_input_mode", "add_stochastic_layer"]
+                 "scrub_out_nan", "q_input_mode", "add_stochastic_layer", "v5_input"]
 PARAM_FIELDS = ["xmean_lev", "xdiv_lev", "xmean_sca", "xdiv_sca", "lbd_qc", "lbd_qi",
                 "yscale_lev", "yscale_sca", "hyam", "hybm",
                 "mlp_initial_w", "mlp_initial_b", "mlp_surface1_w", "mlp_surface1_b",
@@ -23,7 +23,7 @@ PARAM_FIELDS = ["xmean_lev", "xdiv_lev", "xmean_sca", "xdiv_sca", "lbd_qc", "lbd
                 "rnn2_w_ih", "rnn2_w_hh", "rnn2_b_ih", "rnn2_b_hh",
                 "mlp_latent_w", "mlp_latent_b", "mlp_output_w", "mlp_output_b",
                 "mlp_surface_output_w", "mlp_surface_output_b",
-                "rnn0_w_ih", "rnn0_w_hh", "rnn0_b_ih", "rnn0_b_hh", "rnn2_weight_encoder"]
+                "rnn0_w_ih", "rnn0_w_hh", "rnn0_b_ih", "rnn0_b_hh", "rnn2_weight_encoder", "lbd_qn"]
 
 # Every symbol include/climsim_amd.h declares (checked by tests/test_abi.py).
 SYMBOLS = ["csa_create", "csa_destroy", "csa_set_params", "csa_packed_width", "csa_max_batch",

@@ -104,6 +104,7 @@ int upload_params(csa_emulator *h, const csa_params *p, bool first)
     d.xdiv_sca = U.up(p->xdiv_sca, c.nx_sfc);
     d.lbd_qc = U.up(p->lbd_qc, L);
     d.lbd_qi = U.up(p->lbd_qi, L);
+    d.lbd_qn = c.v5_input ? U.up(p->lbd_qn, L) : nullptr;
     d.yscale_lev = U.up(p->yscale_lev, (size_t)L * c.ny);
     d.yscale_sca = U.up(p->yscale_sca, c.ny_sfc);
     d.hyam = U.up(p->hyam, L);
@@ -180,6 +181,7 @@ bool params_complete(const csa_config &c, const csa_params *p)
               p->mlp_surface1_w && p->mlp_surface1_b && p->rnn1_w_ih && p->rnn1_w_hh && p->rnn1_b_ih &&
               p->rnn1_b_hh && p->mlp_output_w &&
               p->mlp_output_b && p->mlp_surface_output_w && p->mlp_surface_output_b;
+    if (c.v5_input) ok = ok && p->lbd_qn;
     if (c.add_stochastic_layer) ok = ok && p->rnn0_w_ih && p->rnn0_w_hh && p->rnn0_b_ih && p->rnn0_b_hh && p->rnn2_weight_encoder;
     else ok = ok && p->rnn2_w_ih && p->rnn2_w_hh && p->rnn2_b_ih && p->rnn2_b_hh;
     if (c.use_lstm) ok = ok && p->mlp_surface2_w && p->mlp_surface2_b;

@@ -19,6 +19,7 @@ struct DevModel {
     int mem_B, mem_off;
     // constants
     const float *xmean_lev, *xdiv_lev, *xmean_sca, *xdiv_sca, *lbd_qc, *lbd_qi;
+    const float *lbd_qn;                // v5_input only
     const float *yscale_lev, *yscale_sca, *hyam, *hybm;
     // small MLPs, transposed to (in, out) so that thread j reads column j coalesced
     const float *init_wt, *init_b;      // (nx+1, nh1)

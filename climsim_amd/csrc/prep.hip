@@ -77,10 +77,19 @@ __global__ __launch_bounds__(PREP_THREADS) void prep_kernel(
             x = prep_rh_to_q(xrow[1], xrow[0], pres);
         }
         if (!normalised) {
-            if (v == 2) x = 1.0f - expf(-x * m.lbd_qc[l]);
-            if (v == 3) x = 1.0f - expf(-x * m.lbd_qi[l]);
+            if (m.cfg.v5_input) {      // rnn/utils.py:186-198: total cloud water with its own rate, liquid fraction from T
+                if (v == 2) {
+                    x = xrow[2] + xrow[3];
+                    if (m.cfg.qinput_prune && l < 15) x = 0.0f;      // pruned BEFORE the transform (:188-190)
+                    x = 1.0f - expf(-x * m.lbd_qn[l]);
+                }
+                if (v == 3) x = fminf(fmaxf((xrow[0] - 253.16f) * 0.05f, 0.0f), 1.0f);   // models.py:260-266
+            } else {
+                if (v == 2) x = 1.0f - expf(-x * m.lbd_qc[l]);
+                if (v == 3) x = 1.0f - expf(-x * m.lbd_qi[l]);
+            }
             x = (x - m.xmean_lev[gi]) / m.xdiv_lev[gi];
-            if (m.cfg.qinput_prune && v == 2 && l < 15) x = 0.0f;
+            if (!m.cfg.v5_input && m.cfg.qinput_prune && v == 2 && l < 15) x = 0.0f;
             if (m.cfg.rh_prune && v == 1 && !isnan(x)) x = fminf(fmaxf(x, 0.0f), 1.2f);
             if (isnan(x)) x = 0.0f;
             if (m.cfg.scrub_inf && isinf(x)) x = 0.0f;

@@ -57,7 +57,7 @@ def _ptr(t):
 class Emulator:
     def __init__(self, consts, state_dict, *, legacy, use_lstm=True, mp_mode=1, output_prune=False,
                  snowhice_fix=False, qinput_prune=False, rh_prune=False, scrub_inf=False,
-                 scrub_out_nan=False, q_input_mode=0, max_batch=4096, device=None):
+                 scrub_out_nan=False, q_input_mode=0, v5_input=False, max_batch=4096, device=None):
         self._h = None
         L = _lib.lib()
         if not torch.cuda.is_available():
@@ -68,6 +68,11 @@ class Emulator:
         for k in CONST_KEYS:
             self._host[k] = _np32(consts[k])
             setattr(params, k, self._host[k].ctypes.data_as(ctypes.POINTER(ctypes.c_float)))
+        if v5_input:
+            if "lbd_qn" not in consts:
+                raise RuntimeError("v5_input needs consts['lbd_qn'] (models.py:171)")
+            self._host["lbd_qn"] = _np32(consts["lbd_qn"])
+            params.lbd_qn = self._host["lbd_qn"].ctypes.data_as(ctypes.POINTER(ctypes.c_float))
         for sd, f in STATE_DICT_MAP.items():
             if sd in state_dict:
                 self._host[f] = _np32(state_dict[sd])
@@ -93,6 +98,7 @@ class Emulator:
         cfg.snowhice_fix, cfg.qinput_prune, cfg.rh_prune = int(snowhice_fix), int(qinput_prune), int(rh_prune)
         cfg.scrub_inf, cfg.scrub_out_nan = int(scrub_inf), int(scrub_out_nan)
         cfg.q_input_mode = int(q_input_mode)
+        cfg.v5_input = int(bool(v5_input))
         self.cfg = cfg
         self.max_batch = int(max_batch)
         h = ctypes.c_void_p()
@@ -106,7 +112,7 @@ class Emulator:
         """Replace the weights of this handle (same shapes): load_state_dict of the reference module.  Constants
         (normalisation, grid) are kept."""
         params = _lib.CsaParams()
-        for k in CONST_KEYS:
+        for k in CONST_KEYS + (["lbd_qn"] if "lbd_qn" in self._host else []):
             setattr(params, k, self._host[k].ctypes.data_as(ctypes.POINTER(ctypes.c_float)))
         for sd, f in STATE_DICT_MAP.items():
             if sd in state_dict:

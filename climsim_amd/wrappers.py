@@ -89,7 +89,7 @@ class RNN_autoreg(nn.Module):
 
 
 class model_wrapper(nn.Module):
-    """Tuple ("ftorch") wrapper of the current generation, rnn/utils.py:72-295 (v4 inputs).
+    """Tuple ("ftorch") wrapper of the current generation, rnn/utils.py:72-295 (v4 inputs, or v5_input=True: :186-198).
 
     forward(x_main0 (B,60,15), x_sfc0 (B,19), rnn1_mem (60,B,nh_mem)) ->
         (out_lev (B,60,6), out_sfc (B,8), rnn1_mem (60,B,nh_mem))
@@ -97,7 +97,7 @@ class model_wrapper(nn.Module):
 
     def __init__(self, consts, state_dict, *, use_lstm=True, output_prune=False, mp_mode=1,
                  qinput_prune=False, rh_prune=False, snowhice_fix=True, rh_to_q=False, include_q_input=None,
-                 max_batch=4096):
+                 v5_input=False, max_batch=4096):
         super().__init__()
         nx = np.asarray(consts["xmean_lev"]).shape[1]
         if include_q_input is None:          # rnn/utils.py:107-111: nx in [16, 21] means q was appended
@@ -106,7 +106,7 @@ class model_wrapper(nn.Module):
         self.emulator = Emulator(consts, state_dict, legacy=False, use_lstm=use_lstm, mp_mode=mp_mode,
                                  output_prune=output_prune, snowhice_fix=snowhice_fix,
                                  qinput_prune=qinput_prune, rh_prune=rh_prune, scrub_inf=True,
-                                 q_input_mode=q_mode, max_batch=max_batch)
+                                 q_input_mode=q_mode, v5_input=v5_input, max_batch=max_batch)
         c = self.emulator.cfg
         self.nx, self.nmem, self.nlev_mem = c.nx, c.nh_mem, c.nlev
 

@@ -55,6 +55,9 @@ typedef struct {
                                 2 rh_to_q: it replaces RH (input 1) */
     int32_t add_stochastic_layer;/* models.py:405-412,464-474,521-534: rnn0 (down, noise init) -> rnn1 (up) -> stochastic
                                 LSTM "rnn2" (MyStochasticLSTMLayer4, down).  LSTM, current generation, nh1 == nh2 */
+    int32_t v5_input;        /* model_wrapper.preprocessing, rnn/utils.py:186-198: level input 2 = 1 - exp(-(qliq+qice) lbd_qn)
+                                (qinput_prune zeroes qn of levels 0-14 BEFORE the transform), input 3 = the liquid fraction
+                                hardtanh((T - 253.16) * 0.05, 0, 1) (models.py:260-266); needs csa_params.lbd_qn */
 } csa_config;
 
 /* HOST pointers, PyTorch state_dict layout (out_features,in_features); copied by csa_create. */
@@ -72,6 +75,7 @@ typedef struct {
      * rnn2_weight_encoder (nh1+nh2, 5*nh2) in the reference's (in,out) layout; rnn2_w_* are unused */
     const float *rnn0_w_ih, *rnn0_w_hh, *rnn0_b_ih, *rnn0_b_hh;
     const float *rnn2_weight_encoder;
+    const float *lbd_qn;     /* (nlev) v5_input only (models.py:171) */
 } csa_params;
 
 typedef struct csa_emulator csa_emulator;

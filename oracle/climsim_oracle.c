@@ -246,10 +246,22 @@ int oracle_preprocess(const oracle_model *m, int B, const float *x_main, const f
                     const float pres = m->hyam[l] * 100000.0f + x_sfc[(size_t)b * m->nx_sfc] * m->hybm[l];
                     x = rh_to_q(xi[1], xi[0], pres);
                 }
-                if (v == 2) x = 1.0f - expf(-x * m->lbd_qc[l]);
-                if (v == 3) x = 1.0f - expf(-x * m->lbd_qi[l]);
+                if (m->v5_input) {          /* rnn/utils.py:186-198 */
+                    if (v == 2) {
+                        x = xi[2] + xi[3];
+                        if (m->qinput_prune && l < 15) x = 0.0f;
+                        x = 1.0f - expf(-x * m->lbd_qn[l]);
+                    }
+                    if (v == 3) {           /* temperature_scaling, models.py:260-266 */
+                        x = (xi[0] - 253.16f) * 0.05f;
+                        x = x < 0.0f ? 0.0f : (x > 1.0f ? 1.0f : x);
+                    }
+                } else {
+                    if (v == 2) x = 1.0f - expf(-x * m->lbd_qc[l]);
+                    if (v == 3) x = 1.0f - expf(-x * m->lbd_qi[l]);
+                }
                 x = (x - m->xmean_lev[l * nx + v]) / m->xdiv_lev[l * nx + v];
-                if (m->qinput_prune && v == 2 && l < 15) x = 0.0f;
+                if (!m->v5_input && m->qinput_prune && v == 2 && l < 15) x = 0.0f;
                 if (m->rh_prune && v == 1) {
                     /* torch.clamp propagates NaN */
                     if (!isnan(x)) x = x < 0.0f ? 0.0f : (x > 1.2f ? 1.2f : x);

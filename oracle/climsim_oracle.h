@@ -46,10 +46,13 @@ typedef struct {
     int scrub_inf;      /* Inf -> 0 after normalisation (current wrappers); legacy artefacts only scrub NaN */
     int scrub_out_nan;  /* NaN -> 0 on the packed output (save_wrapper_mem.py:539) */
     int q_input_mode;   /* rnn/utils.py:262-272: 0 none, 1 append q from (RH,T,p) as last input, 2 replace RH by q */
+    int v5_input;       /* rnn/utils.py:186-198: input 2 = 1-exp(-(qliq+qice) lbd_qn) (pruned BEFORE the transform), input 3 =
+                           hardtanh((T-253.16)*0.05, 0, 1) (models.py:260-266); then the usual normalisation */
     /* constants */
     const float *xmean_lev, *xdiv_lev;   /* (nlev,nx) */
     const float *xmean_sca, *xdiv_sca;   /* (nx_sfc) */
     const float *lbd_qc, *lbd_qi;        /* (nlev) */
+    const float *lbd_qn;                 /* (nlev), v5_input only */
     const float *yscale_lev;             /* (nlev,ny) */
     const float *yscale_sca;             /* (ny_sfc) */
     const float *hyam, *hybm;            /* (nlev) */

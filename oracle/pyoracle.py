@@ -16,8 +16,8 @@ _F = ctypes.POINTER(ctypes.c_float)
 
 _INT_FIELDS = ["nlev", "nx", "nx_sfc", "ny", "ny_sfc", "nh1", "nh2", "nh_mem",
                "use_lstm", "legacy", "output_prune", "mp_mode", "snowhice_fix",
-               "qinput_prune", "rh_prune", "scrub_inf", "scrub_out_nan", "q_input_mode"]
-_CONST_FIELDS = ["xmean_lev", "xdiv_lev", "xmean_sca", "xdiv_sca", "lbd_qc", "lbd_qi",
+               "qinput_prune", "rh_prune", "scrub_inf", "scrub_out_nan", "q_input_mode", "v5_input"]
+_CONST_FIELDS = ["xmean_lev", "xdiv_lev", "xmean_sca", "xdiv_sca", "lbd_qc", "lbd_qi", "lbd_qn",
                  "yscale_lev", "yscale_sca", "hyam", "hybm"]
 _W_FIELDS = ["mlp_initial_w", "mlp_initial_b", "mlp_surface1_w", "mlp_surface1_b",
              "mlp_surface2_w", "mlp_surface2_b", "mlp_toa1_w", "mlp_toa1_b",
@@ -89,12 +89,14 @@ class OracleModel:
 
     def __init__(self, consts, weights, *, legacy, use_lstm=True, nh_mem=None, mp_mode=1,
                  output_prune=False, snowhice_fix=False, qinput_prune=False, rh_prune=False,
-                 scrub_inf=False, scrub_out_nan=False, q_input_mode=0):
+                 scrub_inf=False, scrub_out_nan=False, q_input_mode=0, v5_input=False):
         self._keep = {}
         cm = _CModel()
         for k in _CONST_FIELDS:
-            self._keep[k] = _c(consts[k])
+            self._keep[k] = _c(consts.get(k))
             setattr(cm, k, _ptr(self._keep[k]))
+        if v5_input and self._keep["lbd_qn"] is None:
+            raise ValueError("v5_input needs the lbd_qn constants")
         for sd, f in _SD.items():
             a = _c(weights.get(sd))
             self._keep[f] = a
@@ -122,6 +124,7 @@ class OracleModel:
         cm.scrub_inf = int(scrub_inf)
         cm.scrub_out_nan = int(scrub_out_nan)
         cm.q_input_mode = int(q_input_mode)
+        cm.v5_input = int(v5_input)
         self.cm = cm
 
     @classmethod

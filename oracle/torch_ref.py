@@ -20,9 +20,10 @@ import torch.nn.functional as F
 class EmulatorRef(nn.Module):
     def __init__(self, consts, weights, *, legacy, use_lstm=True, mp_mode=1, output_prune=False,
                  snowhice_fix=False, qinput_prune=False, rh_prune=False, scrub_inf=False,
-                 scrub_out_nan=False, q_input_mode=0, dtype=torch.float32):
+                 scrub_out_nan=False, q_input_mode=0, v5_input=False, dtype=torch.float32):
         super().__init__()
         self.q_input_mode = q_input_mode
+        self.v5_input = v5_input
         self.legacy, self.use_lstm, self.mp_mode = legacy, use_lstm, mp_mode
         self.output_prune, self.snowhice_fix = output_prune, snowhice_fix
         self.qinput_prune, self.rh_prune = qinput_prune, rh_prune
@@ -159,11 +160,18 @@ class EmulatorRef(nn.Module):
         x_sfc = x_sfc.clone()
         if self.snowhice_fix:
             x_sfc = torch.where(x_sfc >= 1e10, torch.tensor(-1.0, dtype=x_sfc.dtype), x_sfc)
-        x_main[:, :, 2] = 1 - torch.exp(-x_main[:, :, 2] * self.lbd_qc)
-        x_main[:, :, 3] = 1 - torch.exp(-x_main[:, :, 3] * self.lbd_qi)
+        if self.v5_input:        # rnn/utils.py:186-198
+            qn = x_main[:, :, 2] + x_main[:, :, 3]
+            if self.qinput_prune:
+                qn[:, 0:15] = 0.0
+            x_main[:, :, 2] = 1 - torch.exp(-qn * self.lbd_qn)
+            x_main[:, :, 3] = F.hardtanh((x_main[:, :, 0] - 253.16) * 0.05, 0.0, 1.0)
+        else:
+            x_main[:, :, 2] = 1 - torch.exp(-x_main[:, :, 2] * self.lbd_qc)
+            x_main[:, :, 3] = 1 - torch.exp(-x_main[:, :, 3] * self.lbd_qi)
         x_main = (x_main - self.xmean_lev) / self.xdiv_lev
         x_sfc = (x_sfc - self.xmean_sca) / self.xdiv_sca
-        if self.qinput_prune:
+        if self.qinput_prune and not self.v5_input:
             x_main[:, 0:15, 2:3] = 0.0
         if self.rh_prune:
             x_main[:, :, 1] = torch.clamp(x_main[:, :, 1], 0, 1.2)
