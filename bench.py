@@ -274,7 +274,7 @@ def aux_workload(a, rank, world, dist):
     import climsim_amd
     from climsim_amd.baselines import MLPBaseline, CNNBaseline
     from synth import synth_inputs
-    B = 384
+    B = int(a.workload.rsplit("_", 1)[1])        # columns per GPU are the workload's suffix
     g = torch.Generator().manual_seed(100 + rank)
     if a.workload in ("cur_lstm144_384", "cur_gru128_384", "cur_lstm128_384"):
         tag = a.workload[:-4]
@@ -327,7 +327,7 @@ def aux_workload(a, rank, world, dist):
             m(x)
         dims = [n_in] + hidden + [368]
         flop_col, what = 2.0 * sum(dims[i] * dims[i + 1] for i in range(len(dims) - 1)), "online MLP_v2rh wrapper forward (B, 557) -> (B, 368)"
-    elif a.workload == "cnn_train_384":
+    elif a.workload.startswith("cnn_train_"):    # 384: low-res grid; 512: the reference batch (hpo_train.py:294); 2700: configs[3] shard
         from climsim_amd.baselines import CNNTrainer
         depth, width = 12, 406
         ws, bs = [], []
@@ -374,7 +374,8 @@ def aux_workload(a, rank, world, dist):
             flush=True)
 
 
-AUX = ["cur_lstm144_384", "cur_lstm128_384", "cur_gru128_384", "mlp_384", "online_mlp_384", "physrnn_384", "cnn_384", "cnn_train_384"]
+AUX = ["cur_lstm144_384", "cur_lstm128_384", "cur_gru128_384", "mlp_384", "online_mlp_384", "physrnn_384", "cnn_384", "cnn_train_384",
+       "cnn_train_512", "cnn_train_2700"]
 
 
 def forward_leg(a, workload, rank, world, dist, steps, warmup, with_cpu):

@@ -5,6 +5,6 @@ loudly when the HIP library or device is missing (there is no CPU fallback in th
 """
 from . import _lib  # noqa: F401
 from .emulator import Emulator  # noqa: F401
-from .wrappers import NewModel_constraint, RNN_autoreg, model_wrapper  # noqa: F401
+from .wrappers import NewModel_constraint, NewModel_constraint_ar, RNN_autoreg, model_wrapper  # noqa: F401
 
-__all__ = ["Emulator", "NewModel_constraint", "RNN_autoreg", "model_wrapper"]
+__all__ = ["Emulator", "NewModel_constraint", "NewModel_constraint_ar", "RNN_autoreg", "model_wrapper"]

@@ -28,7 +28,7 @@ PARAM_FIELDS = ["xmean_lev", "xdiv_lev", "xmean_sca", "xdiv_sca", "lbd_qc", "lbd
 # Every symbol include/climsim_amd.h declares (checked by tests/test_abi.py).
 SYMBOLS = ["csa_create", "csa_destroy", "csa_set_params", "csa_packed_width", "csa_max_batch",
            "csa_forward_packed", "csa_forward_tuple", "csa_model_forward", "csa_forward_tuple_noise",
-           "csa_model_forward_noise", "csa_tap_rnn1",
+           "csa_model_forward_noise", "csa_forward_packed_noise", "csa_postprocess", "csa_tap_rnn1",
            "csa_tap_rnn2", "csa_last_error", "csa_version", "csa_set_profiling", "csa_reset_profile",
            "csa_get_profile", "csa_stage_name", "csa_set_halves", "csa_set_rec1_max_batch", "csa_set_small_gemm_rows", "csa_debug_stage",
            "csa_train_create", "csa_train_destroy", "csa_train_num_params", "csa_train_num_tensors",
@@ -44,7 +44,7 @@ SYMBOLS = ["csa_create", "csa_destroy", "csa_set_params", "csa_packed_width", "c
            "csa_cnn_train_adam",
            "csa_gen_create", "csa_gen_destroy", "csa_gen_dims", "csa_gen_batch",
            "csa_crps", "csa_spread_skill",
-           "csa_eval_scratch_bytes", "csa_eval_metrics", "csa_eval_crps",
+           "csa_eval_scratch_bytes", "csa_eval_metrics", "csa_eval_crps", "csa_derive_inputs",
            "csa_phys_create", "csa_phys_destroy", "csa_phys_forward", "csa_phys_tap",
            "csa_online_create", "csa_online_destroy", "csa_online_dims", "csa_online_forward",
            "csa_stoch_gru5_create", "csa_stoch_lstm4_create", "csa_stoch_destroy", "csa_stoch_gru5_forward",
@@ -99,6 +99,8 @@ def lib():
     L.csa_model_forward.argtypes = [H, i, _F, _F, _F, _F, _F, _F, _F, _F, ctypes.c_void_p]
     L.csa_forward_tuple_noise.argtypes = [H, i] + [_F] * 9 + [ctypes.c_void_p]
     L.csa_model_forward_noise.argtypes = [H, i] + [_F] * 9 + [ctypes.c_void_p]
+    L.csa_forward_packed_noise.argtypes = [H, i] + [_F] * 7 + [ctypes.c_void_p]
+    L.csa_postprocess.argtypes = [H, i, _F, _F, _F, i, _F, _F, ctypes.c_void_p]
     L.csa_tap_rnn1.argtypes = [H]
     L.csa_tap_rnn1.restype = ctypes.c_void_p
     L.csa_tap_rnn2.argtypes = [H]
@@ -176,6 +178,7 @@ def lib():
     L.csa_eval_scratch_bytes.restype = ctypes.c_long
     L.csa_eval_metrics.argtypes = [i, i, i, _F, _F, i, ctypes.c_void_p, _F, ctypes.c_void_p]
     L.csa_eval_crps.argtypes = [i, i, i, i, _F, _F, i, ctypes.c_void_p, _F, ctypes.c_void_p]
+    L.csa_derive_inputs.argtypes = [ctypes.c_long] + [_F] * 8 + [ctypes.c_void_p]
     U8 = ctypes.POINTER(ctypes.c_ubyte)
     L.csa_online_create.argtypes = [i, i, ctypes.POINTER(i), PP, PP, _F, _F, _F, U8, fl, fl, _F, U8, i, i, ctypes.POINTER(H)]
     L.csa_phys_create.argtypes = [i, i, i, i, i, i, PP, i, ctypes.POINTER(H)]

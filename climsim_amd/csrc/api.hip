@@ -29,6 +29,7 @@ struct csa_emulator {
     // scratch
     float *X1, *P, *H1, *H2, *hc0;
     csa_stoch *stoch = nullptr;  // add_stochastic_layer: the MyStochasticLSTMLayer4 stage (stoch.hip)
+    float *ar_eps = nullptr, *ar_o6 = nullptr, *ar_sfc = nullptr, *ar_mem = nullptr, *ar_memT = nullptr;   // csa_forward_packed_noise scratch
     // optional per-kernel timing (csa_set_profiling): events bracket the 6 launches of a call
     bool profiling = false;
     hipEvent_t ev[7] = {};
@@ -231,6 +232,11 @@ extern "C" int csa_create(const csa_config *cfg, const csa_params *hp, int max_b
         h->H2 = U.alloc(L * Bm * cfg->nh2);
         h->hc0 = U.alloc(4 * Bm * nhm);
         rc = U.rc;
+        if (cfg->add_stochastic_layer) {
+            h->ar_eps = U.alloc(L * Bm * cfg->nh2); h->ar_o6 = U.alloc(L * Bm * 6); h->ar_sfc = U.alloc(Bm * cfg->ny_sfc);
+            h->ar_mem = U.alloc(L * Bm * cfg->nh_mem); h->ar_memT = U.alloc(L * Bm * cfg->nh_mem);
+            rc = U.rc;
+        }
         if (rc == CSA_OK && cfg->add_stochastic_layer)
             rc = csa_stoch_lstm4_create(cfg->nh1, cfg->nh2, hp->rnn2_weight_encoder, (int)(L * Bm), &h->stoch);
         if (rc == CSA_OK) {
@@ -519,6 +525,23 @@ extern "C" int csa_forward_tuple_noise(csa_emulator *h, int B, const float *x_ma
     return run_forward_stoch(h, B, 0, HEAD_TUPLE, x_main, x_sfc, mem_in, hx0, cx0, eps, out_lev, out_sfc, mem_out, (hipStream_t)stream);
 }
 
+extern "C" int csa_forward_packed_noise(csa_emulator *h, int B, const float *x_main, const float *x_sfc, const float *mem_in,
+                                        const float *hx0, const float *cx0, const float *eps_prev, float *yout, void *stream)
+{
+    if (!h) return CSA_ERR_ARG;
+    if (!h->stoch) { csa_set_error_msg("forward_packed_noise: handle was not created with add_stochastic_layer"); return CSA_ERR_ARG; }
+    if (h->dm.cfg.mp_mode != 1) { csa_set_error_msg("forward_packed_noise: only the mp_mode 1 wrapper is packed"); return CSA_ERR_UNSUPPORTED; }
+    if (!mem_in || !eps_prev || !yout || B <= 0 || B > h->max_batch) { csa_set_error_msg("forward_packed_noise: bad argument"); return CSA_ERR_ARG; }
+    const csa_config &c = h->dm.cfg;
+    hipStream_t s = (hipStream_t)stream;
+    int rc;
+    // the wrapper's two transposes (save_wrapper_mem.py:693 and the batch-first memory of the packed row)
+    if ((rc = launch_to_level_major(B, c.nlev, c.nh2, eps_prev, h->ar_eps, s))) return rc;
+    if ((rc = launch_to_level_major(B, c.nlev, c.nh_mem, mem_in, h->ar_memT, s))) return rc;
+    if ((rc = run_forward_stoch(h, B, 0, HEAD_TUPLE, x_main, x_sfc, h->ar_memT, hx0, cx0, h->ar_eps, h->ar_o6, h->ar_sfc, h->ar_mem, s))) return rc;
+    return launch_pack_ar(B, c.nlev, c.ny_sfc, c.nh_mem, c.nh2, h->ar_o6, h->ar_sfc, h->ar_mem, h->ar_eps, yout, s);
+}
+
 extern "C" int csa_model_forward_noise(csa_emulator *h, int B, const float *x_main_n, const float *x_sfc_n, const float *mem_in,
                                        const float *hx0, const float *cx0, const float *eps,
                                        float *out, float *out_sfc, float *mem_out, void *stream)
@@ -536,6 +559,14 @@ extern "C" int csa_model_forward(csa_emulator *h, int B, const float *x_main_n, 
     if (!h) return CSA_ERR_ARG;
     if (!out_sfc || (h->dm.cfg.nh_mem > 0 && !mem_out)) { csa_set_error_msg("model_forward: null output"); return CSA_ERR_ARG; }
     return run_forward(h, B, 1, HEAD_RAW, x_main_n, x_sfc_n, mem_in, hx2, cx2, out, out_sfc, mem_out, (hipStream_t)stream);
+}
+
+extern "C" int csa_postprocess(csa_emulator *h, int B, const float *out, const float *out_sfc, const float *x_denorm, int nxd,
+                               float *out_lev, float *out_sfc_denorm, void *stream)
+{
+    if (!h || B <= 0 || !out || !out_sfc || !x_denorm || !out_lev || !out_sfc_denorm) { csa_set_error_msg("csa_postprocess: bad argument"); return CSA_ERR_ARG; }
+    if (h->dm.cfg.mp_mode == 0) { csa_set_error_msg("csa_postprocess: mp_mode 0 returns its inputs unchanged (models.py:278-279)"); return CSA_ERR_UNSUPPORTED; }
+    return launch_postprocess(h->dm, B, out, out_sfc, x_denorm, nxd, out_lev, out_sfc_denorm, (hipStream_t)stream);
 }
 
 // ---- stage-wise entry point (parity evidence, tests/test_stagewise_parity.py) ------------------------------------------------

@@ -128,3 +128,10 @@ void rec_pack_weights(int use_lstm, int nh, const float *w_hh, float *packed);
 // head.hip: mlp_latent / mlp_output / surface head / de-normalisation / microphysics / packing
 int launch_head(const DevModel &m, int B, int mode, const float *H2, const float *x_main_raw, const float *x_sfc_raw,
                 float *y0, float *y1, float *y2, hipStream_t s);
+
+// head.hip: RNN_autoreg.postprocessing(out, out_sfc, x_denorm) on its own (models.py:273-339)
+int launch_postprocess(const DevModel &m, int B, const float *out, const float *out_sfc, const float *x_denorm, int nxd,
+                       float *out6, float *out_sfc_d, hipStream_t s);
+int launch_to_level_major(int B, int L, int n, const float *src, float *dst, hipStream_t s);
+int launch_pack_ar(int B, int L, int nys, int nm, int nh, const float *out6, const float *out_sfc, const float *mem,
+                   const float *eps, float *yout, hipStream_t s);

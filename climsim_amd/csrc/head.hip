@@ -14,6 +14,53 @@
 
 #define HEAD_THREADS 256
 
+// De-normalisation + microphysics partition of ONE level (models.py:273-339; wrapper twin save_wrapper_mem.py:470-483):
+// o = the ny normalised model outputs of level l, xr = the raw level inputs of that cell -> vals = [dT,dqv,dqliq,dqice,du,dv].
+__device__ __forceinline__ void postprocess_level(const DevModel &m, int l, int b, const float *o, const float *xr,
+                                                  const float *x_sfc_raw, float *vals)
+{
+    const int ny = m.cfg.ny, mp = m.cfg.mp_mode;
+    const float *ys = m.yscale_lev + l * ny;
+    const int nxr = m.cfg.nx - (m.cfg.q_input_mode == 1);
+    // mp_mode 1: [dT,dqv,dqn,du,dv]; -1: [dT,dqv,dqn,liq_frac,du,dv]; -2: [dT,dqtot,cld_frac,liq_frac,du,dv]
+    const int iu = mp == 1 ? 3 : 4;
+    const float dT = o[0] / ys[0];
+    float dqv = o[1] / ys[1], dqn = o[2] / ys[2];
+    const float du = o[iu] / ys[iu], dv = o[iu + 1] / ys[iu + 1];
+    const float T_old = xr[0], ql = xr[2], qi = xr[3];
+    if (mp == -2) {
+        // models.py:286-301: total-water tendency + cloud fraction of total water -> dqv, dqn.
+        // q_old is the LAST raw level input (the appended specific humidity when include_q_input)
+        float qv_old;
+        if (m.cfg.q_input_mode == 1) {
+            const float pres = m.hyam[l] * 100000.0f + x_sfc_raw[(size_t)b * m.cfg.nx_sfc] * m.hybm[l];
+            qv_old = prep_rh_to_q(xr[1], xr[0], pres);
+        } else {
+            qv_old = xr[nxr - 1];
+        }
+        float cf = dqn * dqn;
+        cf = cf * cf;
+        if (!isnan(cf)) cf = fminf(fmaxf(cf, 0.0f), 1.0f);
+        const float qn_old = ql + qi;
+        const float qtot_new = (qn_old + qv_old) + dqv * 1200.0f;
+        const float qv_new = (1.0f - cf) * qtot_new, qn_new2 = cf * qtot_new;
+        dqv = (qv_new - qv_old) * 0.0008333333333333334f;
+        dqn = (qn_new2 - qn_old) * 0.0008333333333333334f;
+    }
+    const float T_new = T_old + dT * 1200.0f;
+    float lf;
+    if (mp == 1) {
+        lf = (T_new - 253.16f) * 0.05f;
+        if (!isnan(lf)) lf = fminf(fmaxf(lf, 0.0f), 1.0f);
+    } else {
+        lf = o[3] / ys[3];      // models.py:319: the clamped value is overwritten by the raw prediction
+    }
+    const float qn_new = (ql + qi) + dqn * 1200.0f;
+    const float dql = (lf * qn_new - ql) * 0.0008333333333333334f;
+    const float dqi = ((1.0f - lf) * qn_new - qi) * 0.0008333333333333334f;
+    vals[0] = dT; vals[1] = dqv; vals[2] = dql; vals[3] = dqi; vals[4] = du; vals[5] = dv;
+}
+
 // First stage of the head: Z(l, j) = b1[j] + sum_k H2(l, k) * W1t(k, j), j < n1, where (W1t, n1) is
 // mlp_latent (n1 = nh_mem) for the memory models or mlp_output itself (n1 = ny) for the stateless
 // one.  Thread (lg, j): j = tid % n1p, lg = tid / n1p, n1p = n1 rounded up to a power of two;
@@ -106,7 +153,6 @@ __global__ __launch_bounds__(HEAD_THREADS) void head_kernel(
 
     // ---- de-normalise, microphysics, pack -------------------------------------------------------
     const bool post = (mode != HEAD_RAW) && m.cfg.mp_mode != 0;
-    const int mp = m.cfg.mp_mode;
     for (int l = tid; l < L; l += HEAD_THREADS) {
         const float *o = os + l * ny;
         if (mode == HEAD_RAW || m.cfg.mp_mode == 0) {
@@ -119,46 +165,9 @@ __global__ __launch_bounds__(HEAD_THREADS) void head_kernel(
                 dst[v] = val;
             }
         } else if (post) {
-            const float *ys = m.yscale_lev + l * ny;
             const int nxr = nx - (m.cfg.q_input_mode == 1);
-            const float *xr = x_raw + ((size_t)b * L + l) * nxr;
-            // mp_mode 1: [dT,dqv,dqn,du,dv]; -1: [dT,dqv,dqn,liq_frac,du,dv]; -2: [dT,dqtot,cld_frac,liq_frac,du,dv]
-            const int iu = mp == 1 ? 3 : 4;
-            const float dT = o[0] / ys[0];
-            float dqv = o[1] / ys[1], dqn = o[2] / ys[2];
-            const float du = o[iu] / ys[iu], dv = o[iu + 1] / ys[iu + 1];
-            const float T_old = xr[0], ql = xr[2], qi = xr[3];
-            if (mp == -2) {
-                // models.py:286-301: total-water tendency + cloud fraction of total water -> dqv, dqn.
-                // q_old is the LAST raw level input (the appended specific humidity when include_q_input)
-                float qv_old;
-                if (m.cfg.q_input_mode == 1) {
-                    const float pres = m.hyam[l] * 100000.0f + x_sfc_raw[(size_t)b * m.cfg.nx_sfc] * m.hybm[l];
-                    qv_old = prep_rh_to_q(xr[1], xr[0], pres);
-                } else {
-                    qv_old = xr[nxr - 1];
-                }
-                float cf = dqn * dqn;
-                cf = cf * cf;
-                if (!isnan(cf)) cf = fminf(fmaxf(cf, 0.0f), 1.0f);
-                const float qn_old = ql + qi;
-                const float qtot_new = (qn_old + qv_old) + dqv * 1200.0f;
-                const float qv_new = (1.0f - cf) * qtot_new, qn_new2 = cf * qtot_new;
-                dqv = (qv_new - qv_old) * 0.0008333333333333334f;
-                dqn = (qn_new2 - qn_old) * 0.0008333333333333334f;
-            }
-            const float T_new = T_old + dT * 1200.0f;
-            float lf;
-            if (mp == 1) {
-                lf = (T_new - 253.16f) * 0.05f;
-                if (!isnan(lf)) lf = fminf(fmaxf(lf, 0.0f), 1.0f);
-            } else {
-                lf = o[3] / ys[3];      // models.py:319: the clamped value is overwritten by the raw prediction
-            }
-            const float qn_new = (ql + qi) + dqn * 1200.0f;
-            const float dql = (lf * qn_new - ql) * 0.0008333333333333334f;
-            const float dqi = ((1.0f - lf) * qn_new - qi) * 0.0008333333333333334f;
-            float vals[6] = {dT, dqv, dql, dqi, du, dv};
+            float vals[6];
+            postprocess_level(m, l, b, o, x_raw + ((size_t)b * L + l) * nxr, x_sfc_raw, vals);
             if (mode == HEAD_PACKED) {
                 float *y = y0 + (size_t)b * W;
 #pragma unroll
@@ -215,6 +224,84 @@ int launch_head(const DevModel &m, int B, int mode, const float *H2, const float
         csa_set_error_msg("head: hidden size must be 64, 96, 128 or 144");
         return CSA_ERR_UNSUPPORTED;
     }
+    CSA_HIP_CHECK(hipGetLastError());
+    return CSA_OK;
+}
+
+// ---- RNN_autoreg.postprocessing(out, out_sfc, x_denorm) as its own entry (models.py:273-339) ---------------------------------
+// One thread per (column, level); HBM-bound: reads ny + 4 floats, writes 6 per cell.  mp_mode 0 returns its inputs unchanged
+// (:278-279), so the host mirror does not launch anything for it.
+__global__ __launch_bounds__(256) void post_kernel(DevModel m, int B, const float *__restrict__ out, const float *__restrict__ out_sfc,
+                                                   const float *__restrict__ x_denorm, int nxd, float *__restrict__ out6,
+                                                   float *__restrict__ out_sfc_d)
+{
+    const int L = m.cfg.nlev, ny = m.cfg.ny, nys = m.cfg.ny_sfc;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < B * L) {
+        const int b = i / L, l = i - b * L;
+        float o[8], vals[6];
+        for (int v = 0; v < ny; ++v) o[v] = out[(size_t)i * ny + v];
+        // x_denorm carries at least T, (RH), qliq, qice; mp_mode -2 reads its LAST column as the old specific humidity
+        const float *xr = x_denorm + (size_t)i * nxd;
+        DevModel mm = m;
+        mm.cfg.q_input_mode = 0;                 // the caller passes the tensor the model saw (q already appended)
+        mm.cfg.nx = nxd;
+        postprocess_level(mm, l, b, o, xr, nullptr, vals);
+        for (int v = 0; v < 6; ++v) out6[(size_t)i * 6 + v] = vals[v];
+    }
+    if (i < B * nys) out_sfc_d[i] = out_sfc[i] / m.yscale_sca[i % nys];
+}
+
+int launch_postprocess(const DevModel &m, int B, const float *out, const float *out_sfc, const float *x_denorm, int nxd,
+                       float *out6, float *out_sfc_d, hipStream_t s)
+{
+    if (m.cfg.ny > 8 || nxd < 4) { csa_set_error_msg("postprocess: ny <= 8 and x_denorm with at least 4 columns required"); return CSA_ERR_ARG; }
+    const int n = B * m.cfg.nlev;
+    hipLaunchKernelGGL(post_kernel, dim3((n + 255) / 256), dim3(256), 0, s, m, B, out, out_sfc, x_denorm, nxd, out6, out_sfc_d);
+    CSA_HIP_CHECK(hipGetLastError());
+    return CSA_OK;
+}
+
+// ---- packed row of the stateful + AR-noise wrapper (save_wrapper_mem.py:640-681 mp_postprocessing with eps_prev) ------------------
+// yout (B, 368 + nlev*nh_mem + nlev*nh) = [dT,dqv (120) | dqliq (60) | dqice (60) | du,dv (120) | sfc (8) | memory of the column
+// (nlev,nh_mem) | eps of the column (nlev,nh)], NaN -> 0 (:717).  Inputs are the tuple outputs of the model call: out6 (B,L,6),
+// out_sfc (B,8), mem (L,B,nm) level-major, eps (L,B,nh) level-major.  One workgroup per column; pure data movement.
+__global__ __launch_bounds__(256) void pack_ar_kernel(int B, int L, int nys, int nm, int nh, const float *__restrict__ out6,
+                                                      const float *__restrict__ out_sfc, const float *__restrict__ mem,
+                                                      const float *__restrict__ eps, float *__restrict__ yout)
+{
+    const int b = blockIdx.x, tid = threadIdx.x, W = 6 * L + nys + L * nm + L * nh;
+    float *y = yout + (size_t)b * W;
+    auto scrub = [](float v) { return isnan(v) ? 0.0f : v; };
+    for (int i = tid; i < 6 * L; i += 256) { const int v = i / L, l = i - v * L; y[i] = scrub(out6[((size_t)b * L + l) * 6 + v]); }
+    for (int i = tid; i < nys; i += 256) y[6 * L + i] = scrub(out_sfc[(size_t)b * nys + i]);
+    for (int i = tid; i < L * nm; i += 256) { const int l = i / nm, k = i - l * nm; y[6 * L + nys + i] = scrub(mem[((size_t)l * B + b) * nm + k]); }
+    for (int i = tid; i < L * nh; i += 256) { const int l = i / nh, k = i - l * nh; y[6 * L + nys + L * nm + i] = scrub(eps[((size_t)l * B + b) * nh + k]); }
+}
+// (B, L, n) batch-first -> (L, B, n) level-major (the wrapper's torch.transpose(eps_prev, 0, 1), :693)
+__global__ __launch_bounds__(256) void to_level_major_kernel(int B, int L, int n, const float *__restrict__ src, float *__restrict__ dst)
+{
+    const long total = (long)B * L * n;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int k = (int)(i % n);
+        const long r = i / n;
+        const int l = (int)(r % L), b = (int)(r / L);
+        dst[((size_t)l * B + b) * n + k] = src[i];
+    }
+}
+
+int launch_to_level_major(int B, int L, int n, const float *src, float *dst, hipStream_t s)
+{
+    const long total = (long)B * L * n, blocks = (total + 255) / 256;
+    hipLaunchKernelGGL(to_level_major_kernel, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, s, B, L, n, src, dst);
+    CSA_HIP_CHECK(hipGetLastError());
+    return CSA_OK;
+}
+
+int launch_pack_ar(int B, int L, int nys, int nm, int nh, const float *out6, const float *out_sfc, const float *mem,
+                   const float *eps, float *yout, hipStream_t s)
+{
+    hipLaunchKernelGGL(pack_ar_kernel, dim3(B), dim3(256), 0, s, B, L, nys, nm, nh, out6, out_sfc, mem, eps, yout);
     CSA_HIP_CHECK(hipGetLastError());
     return CSA_OK;
 }

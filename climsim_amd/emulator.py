@@ -248,6 +248,38 @@ class Emulator:
         """Largest batch that uses the one-column-per-workgroup recurrent kernel (default 256); 0 disables it."""
         self._rc(_lib.lib().csa_set_rec1_max_batch(self._h, int(max_batch)), "csa_set_rec1_max_batch")
 
+    def forward_packed_noise(self, x_main, x_sfc, rnn1_mem, eps_prev, hx0=None, cx0=None):
+        """Stateful + AR-noise packed wrapper (save_wrapper_mem.py:682-727) around the stochastic model; all state batch-first."""
+        c = self.cfg
+        B = x_main.shape[0]
+        x_main = _check(x_main, (B, c.nlev, c.nx), "x_main")
+        x_sfc = _check(x_sfc, (B, c.nx_sfc), "x_sfc")
+        rnn1_mem = _check(rnn1_mem, (B, c.nlev, c.nh_mem), "rnn1_mem")
+        eps_prev = _check(eps_prev, (B, c.nlev, c.nh2), "eps_prev")
+        hx0 = torch.randn(B, c.nh1, device=self.device) if hx0 is None else _check(hx0, (B, c.nh1), "hx0")
+        cx0 = torch.randn(B, c.nh1, device=self.device) if cx0 is None else _check(cx0, (B, c.nh1), "cx0")
+        y = torch.empty(B, 6 * c.nlev + c.ny_sfc + c.nlev * (c.nh_mem + c.nh2), device=self.device)
+        self._rc(_lib.lib().csa_forward_packed_noise(self._h, B, _ptr(x_main), _ptr(x_sfc), _ptr(rnn1_mem), _ptr(hx0), _ptr(cx0),
+                                                     _ptr(eps_prev), _ptr(y), self._stream()), "csa_forward_packed_noise")
+        return y
+
+    def postprocess(self, out, out_sfc, x_denorm):
+        """RNN_autoreg.postprocessing (models.py:273-339): (B,nlev,ny), (B,ny_sfc), raw (B,nlev,>=4) -> (B,nlev,6), (B,ny_sfc)."""
+        c = self.cfg
+        if c.mp_mode == 0:            # models.py:278-279: nothing is done
+            return out, out_sfc
+        B = out.shape[0]
+        out = _check(out, (B, c.nlev, c.ny), "out")
+        out_sfc = _check(out_sfc, (B, c.ny_sfc), "out_sfc")
+        if x_denorm.dim() != 3 or x_denorm.shape[:2] != (B, c.nlev) or x_denorm.shape[2] < 4:
+            raise RuntimeError(f"x_denorm: expected shape ({B}, {c.nlev}, >=4), got {tuple(x_denorm.shape)}")
+        x_denorm = _check(x_denorm, tuple(x_denorm.shape), "x_denorm")
+        o6 = torch.empty(B, c.nlev, 6, device=self.device)
+        osd = torch.empty(B, c.ny_sfc, device=self.device)
+        self._rc(_lib.lib().csa_postprocess(self._h, B, _ptr(out), _ptr(out_sfc), _ptr(x_denorm), int(x_denorm.shape[2]),
+                                            _ptr(o6), _ptr(osd), self._stream()), "csa_postprocess")
+        return o6, osd
+
     def debug_stage(self, stage, B, ins, out_shapes):
         """Run ONE launch of the forward path on given device inputs (csa_debug_stage; internal layouts, see the header)."""
         ins = list(ins) + [None] * (5 - len(ins))

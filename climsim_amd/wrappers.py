@@ -87,6 +87,11 @@ class RNN_autoreg(nn.Module):
         x_main, x_sfc, rnn_mem = inp_list[0], inp_list[1], inp_list[2]
         return self.emulator.model_forward(x_main, x_sfc, rnn_mem, noise=noise)
 
+    def postprocessing(self, out, out_sfc, x_denorm):
+        """models.py:273-339: de-normalise and (mp_mode != 0) partition the cloud-water tendency: (B,60,ny), (B,8), raw inputs
+        (B,60,nx) -> (B,60,6) [dT,dqv,dqliq,dqice,du,dv], (B,8).  mp_mode 0 returns its arguments unchanged, as upstream."""
+        return self.emulator.postprocess(out, out_sfc, x_denorm)
+
 
 class model_wrapper(nn.Module):
     """Tuple ("ftorch") wrapper of the current generation, rnn/utils.py:72-295 (v4 inputs, or v5_input=True: :186-198).
@@ -112,3 +117,26 @@ class model_wrapper(nn.Module):
 
     def forward(self, x_main0, x_sfc0, rnn1_mem, noise=None):
         return self.emulator.forward_tuple(x_main0, x_sfc0, rnn1_mem, noise=noise)
+
+
+class NewModel_constraint_ar(nn.Module):
+    """Stateful + AR-noise packed wrapper, rnn/save_wrapper_mem.py:682-727 (third row of SURVEY section 8b):
+
+        forward(x_main (B,60,15), x_sfc (B,19), rnn1_mem (B,60,nh_mem), eps_prev (B,60,nh)) -> (B, 368 + 60*nh_mem + 60*nh)
+
+    around the stochastic current-generation model (add_stochastic_layer).  The caller re-slices yout[:, 368:368+960] (memory)
+    and yout[:, 368+960:] (eps) and feeds both back.  The eps block is the eps that was used: the AR(1) model classes that
+    updated it are commented out upstream, so there is no update rule to restate."""
+
+    def __init__(self, consts, state_dict, *, output_prune=False, qinput_prune=False, rh_prune=False, snowhice_fix=True, max_batch=4096):
+        super().__init__()
+        if "rnn2.weight_encoder" not in state_dict:
+            raise RuntimeError("the AR-noise wrapper wraps a stochastic model (rnn2.weight_encoder missing)")
+        self.emulator = Emulator(consts, state_dict, legacy=False, use_lstm=True, mp_mode=1, output_prune=output_prune,
+                                 snowhice_fix=snowhice_fix, qinput_prune=qinput_prune, rh_prune=rh_prune, scrub_inf=True,
+                                 max_batch=max_batch)
+        self.nmem = self.emulator.cfg.nh_mem
+
+    def forward(self, x_main, x_sfc, rnn1_mem, eps_prev, noise=None):
+        hx0, cx0 = (None, None) if noise is None else noise
+        return self.emulator.forward_packed_noise(x_main, x_sfc, rnn1_mem, eps_prev, hx0, cx0)

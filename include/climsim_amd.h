@@ -110,6 +110,13 @@ int csa_model_forward(csa_emulator *h, int B,
                       const float *hx2, const float *cx2,
                       float *out, float *out_sfc, float *mem_out, void *stream);
 
+/* RNN_autoreg.postprocessing(out, out_sfc, x_denorm) (models.py:273-339) on its own: normalised model outputs (B,nlev,ny),
+ * (B,ny_sfc) and the raw level inputs x_denorm (B,nlev,nxd) (T first, qliq / qice at 2, 3; mp_mode -2 reads the LAST column
+ * as the old specific humidity) -> out_lev (B,nlev,6) = [dT,dqv,dqliq,dqice,du,dv], out_sfc_denorm (B,ny_sfc).  No NaN scrub
+ * (that is the wrapper's, rnn/utils.py:286).  mp_mode 0 is the identity upstream and is rejected here. */
+int csa_postprocess(csa_emulator *h, int B, const float *out, const float *out_sfc, const float *x_denorm, int nxd,
+                    float *out_lev, float *out_sfc_denorm, void *stream);
+
 /* Stochastic variant (cfg.add_stochastic_layer): same as csa_forward_tuple / csa_model_forward with the three
  * N(0,1) draws the reference makes inside forward passed explicitly, in its draw order (models.py:466-468 and
  * models_torch_kernels.py:1497): hx0, cx0 (B,nh1) initial state of rnn0, eps (nlev,B,nh2). */
@@ -119,6 +126,15 @@ int csa_forward_tuple_noise(csa_emulator *h, int B, const float *x_main, const f
 int csa_model_forward_noise(csa_emulator *h, int B, const float *x_main_n, const float *x_sfc_n, const float *mem_in,
                             const float *hx0, const float *cx0, const float *eps,
                             float *out, float *out_sfc, float *mem_out, void *stream);
+
+/* Stateful + AR-noise packed wrapper (rnn/save_wrapper_mem.py:640-727): forward(x_main, x_sfc, rnn1_mem (B,nlev,nh_mem),
+ * eps_prev (B,nlev,nh2)) -> yout (B, 6*nlev + ny_sfc + nlev*nh_mem + nlev*nh2) = [packed tendencies | surface | new memory of
+ * the column | eps of the column], NaN -> 0.  The wrapper hands eps_prev to the model as the noise of its stochastic layer and
+ * packs the eps the model returns; the AR(1) model classes that updated eps are commented out upstream
+ * (models_torch_kernels.py:1251-1444), so the eps block returned here is the eps that was used (pass-through).  Model: the
+ * add_stochastic_layer generation; hx0, cx0 (B,nh1) as in csa_forward_tuple_noise.  All state batch-first and caller-owned. */
+int csa_forward_packed_noise(csa_emulator *h, int B, const float *x_main, const float *x_sfc, const float *mem_in,
+                             const float *hx0, const float *cx0, const float *eps_prev, float *yout, void *stream);
 
 /* Debug taps of the last call: rnn1 / rnn2 hidden sequences, (nlev,B,nh) level order. */
 const float *csa_tap_rnn1(const csa_emulator *h);
@@ -327,6 +343,14 @@ int csa_eval_metrics(int T, int G, int L, const float *pred, const float *target
                      float *out, void *stream);
 int csa_eval_crps(int T, int G, int L, int S, const float *samplepreds, const float *target, int avg_grid,
                   void *scratch, float *out, void *stream);
+
+/* ---- derived loader inputs (climsim_utils/data_utils.py:654-707, get_xrdata) ------------------------------------------------------
+ * Variables a variable set names but the files do not store, computed from the stored state on read: state_rh = q / qvs(T, p)
+ * with the float64 saturation polynomials eliq / eice (:19-43, :662-673), liq_partition = clip((T - 253.16) / 20, 0, 1)
+ * (:684-690), state_qn = q0002 + q0003 (:692-707; the *_prvphy pairs likewise).  n cells, device pointers; every output is
+ * optional (NULL = not wanted) and only the inputs its formula reads are required. */
+int csa_derive_inputs(long n, const float *state_t, const float *state_q0001, const float *state_pmid, const float *q2,
+                      const float *q3, float *state_rh, float *liq_partition, float *state_qn, void *stream);
 
 /* ---- generic online wrapper (SURVEY section 8b "generic online": forward(x (B, n_in)) -> (B, 368)) ------------------
  * online_testing/model_postprocessing/v4_nn_wrapper.ipynb cell 5 (NewModel.preprocessing / forward / postprocessing)

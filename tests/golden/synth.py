@@ -29,3 +29,37 @@ def checksum(*arrays):
         with np.errstate(over="ignore"):
             acc = acc * np.uint64(1099511628211) + np.sum(bits * w, dtype=np.uint64)
     return np.array(acc, np.uint64)
+
+
+# ---- inputs of the data_utils goldens (make_golden_data_utils.py), regenerated from seeds by the tests --------------------------
+EVAL_CASES = {"A": (50, 60, 0.0), "B": (7, 0, 0.0), "C": (40, 60, 250.0)}      # tag: (T, L or 0 for scalars, offset)
+CRPS_CASES = {"A": (6, 60, 8), "B": (5, 0, 32)}                                # tag: (T, L, S)
+
+
+def eval_inputs(tag, ncol=384):
+    T, L, off = EVAL_CASES[tag]
+    r = np.random.Generator(np.random.PCG64(900 + ord(tag)))
+    shape = (T, ncol, L) if L else (T, ncol)
+    target = (r.standard_normal(shape) * r.uniform(0.1, 3.0, shape[1:]) + off).astype(np.float32)
+    pred = (target + r.standard_normal(shape) * 0.3 + 0.05).astype(np.float32)
+    return pred, target
+
+
+def crps_inputs(tag, ncol=384):
+    T, L, S = CRPS_CASES[tag]
+    r = np.random.Generator(np.random.PCG64(950 + ord(tag)))
+    shape = (T, ncol, L) if L else (T, ncol)
+    target = r.standard_normal(shape).astype(np.float32)
+    sp = (target[..., None] + 0.5 * r.standard_normal(shape + (S,))).astype(np.float32)
+    return sp, target
+
+
+def derived_inputs(hyam, hybm, N=500, nlev=60):
+    """(state_t, state_pmid, state_q0001, state_q0002, state_q0003) for the derived-input goldens."""
+    r = np.random.Generator(np.random.PCG64(977))
+    tair = r.uniform(180.0, 320.0, (N, nlev)).astype(np.float32)
+    pmid = (hyam * 1e5 + r.uniform(6e4, 1.05e5, (N, 1)) * hybm).astype(np.float32)
+    q1 = (r.uniform(0, 1, (N, nlev)) * 2e-2 * (pmid / 1e5)).astype(np.float32)
+    q2 = r.uniform(0, 1e-4, (N, nlev)).astype(np.float32)
+    q3 = r.uniform(0, 1e-4, (N, nlev)).astype(np.float32)
+    return tair, pmid, q1, q2, q3

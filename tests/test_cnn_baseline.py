@@ -133,3 +133,44 @@ def test_cnn_data_format_adapters():
     assert np.abs(back[:, 120:] - ref[:, 120:]).max() <= 2e-7        # level mean: summation order only
     # round trip: scalars repeated over the levels average back exactly
     assert np.abs(data_utils.reshape_target_from_cnn(data_utils.reshape_target_for_cnn(d(t))).cpu().numpy() - t).max() <= 1e-6 * np.abs(t).max()
+
+
+@pytest.mark.gpu
+def test_cnn_training_step_at_the_config3_shard_size():
+    """BASELINE.json configs[3]: the 21,600-column high-res grid sharded 8-way = 2,700 columns per GPU, full architecture
+    (12 blocks x 406 channels, Dropout 0.175).  Size-independent properties at full size: bitwise determinism, finite loss,
+    padding gradients exactly zero, and the data-parallel property (two half shards with grad_scale 1/2 each sum to the
+    unsharded flat gradient: one all-reduce is all a step needs)."""
+    from climsim_amd.baselines import CNNTrainer
+    B, depth, width = 2700, 12, 406
+    ws, bs = _arch(depth, width, seed=5)
+    tr = CNNTrainer([w.numpy() for w in ws], [b.numpy() for b in bs], depth=depth, width=width, dropout=0.175, max_batch=B)
+    g = torch.Generator().manual_seed(21)
+    x = torch.randn(B, 60, 6, generator=g).cuda()
+    yt = torch.randn(B, 60, 10, generator=g).cuda()
+    masks = tr.draw_masks(B)
+    y1 = tr.forward(x, masks).clone()
+    loss1, g1 = tr.backward(yt)
+    loss1, g1 = loss1.clone(), g1.clone()
+    y2 = tr.forward(x, masks)
+    loss2, g2 = tr.backward(yt)
+    assert torch.equal(y1, y2) and torch.equal(g1, g2) and torch.equal(loss1, loss2)          # no atomics anywhere
+    assert torch.isfinite(y1).all() and torch.isfinite(g1).all() and float(loss1) > 0
+    gw, gb = tr.unpack(g1)
+    assert int((g1 != 0).sum().item()) <= sum(a.numel() for a in gw) + sum(a.numel() for a in gb)
+    # data parallel: halves of the batch, each with grad_scale = its share of the global mean
+    h = B // 2
+    m3 = masks.view(2 * depth, B, 60, -1)
+    gsum, lsum = torch.zeros_like(g1), 0.0
+    for lo, hi in ((0, h), (h, B)):
+        tr.forward(x[lo:hi].contiguous(), m3[:, lo:hi].reshape(2 * depth, (hi - lo) * 60, -1).contiguous())
+        l, gpart = tr.backward(yt[lo:hi].contiguous(), (hi - lo) / B)
+        gsum += gpart
+        lsum += float(l)
+    assert float((gsum - g1).abs().max()) <= 2e-6 * float(g1.abs().max())
+    assert abs(lsum - float(loss1)) <= 1e-5 * float(loss1)
+    # one optimiser step changes the parameters and keeps them finite
+    p0 = tr.flat_params()
+    tr.adam(lr=1e-4)
+    p1 = tr.flat_params()
+    assert torch.isfinite(p1).all() and not torch.equal(p0, p1)

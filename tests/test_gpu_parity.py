@@ -106,6 +106,29 @@ def test_current_generation_vs_reference_class(tag):
             assert rel_err(mo.cpu().numpy(), io[p + "mem_out"]) <= 1e-5
 
 
+@pytest.mark.parametrize("tag", ["cur_lstm128", "cur_gru128", "cur_mpm1", "cur_mpm2"])
+def test_postprocessing_method_vs_reference_class(tag):
+    """RNN_autoreg.postprocessing(out, out_sfc, x_denorm) on the mirror (models.py:273-339), fed the reference's own normalised
+    outputs: mp_mode 1, -1 and -2 (the last reads q_old from the last raw column)."""
+    import climsim_amd
+    consts, weights, flags = load_npz_model(tag)
+    io = np.load(os.path.join(GOLDEN, f"{tag}_io.npz"))
+    mp = int(flags.get("mp_mode", 1))
+    model = climsim_amd.RNN_autoreg(consts, weights, max_batch=16, use_lstm=bool(flags.get("use_lstm", 1)),
+                                    output_prune=bool(flags["output_prune"]), mp_mode=mp)
+    for B in [int(k[1:].split(".")[0]) for k in io.files if k.endswith(".nsteps")]:
+        p = f"B{B}.t0."
+        xraw = io[p + "x_main"] if p + "x_raw" not in io.files else io[p + "x_raw"]
+        o6, osd = model.postprocessing(_dev(io[p + "out"]), _dev(io[p + "out_sfc"]), _dev(xraw))
+        o6 = o6.cpu().numpy()
+        for v in range(6):
+            tol = 5e-5 if (mp == -2 and v in (1, 2, 3)) else 1e-5      # mp -2: 1 - x^4 of a model output (see DESIGN section 2)
+            assert rel_err(o6[:, :, v], io[p + "post_lev"][:, :, v]) <= tol, (B, v)
+        assert rel_err(osd.cpu().numpy(), io[p + "post_sfc"]) <= 1e-6
+    with pytest.raises(RuntimeError):
+        model.postprocessing(_dev(io[p + "out"]), _dev(io[p + "out_sfc"]), _dev(xraw[:, :, :3]))
+
+
 @pytest.mark.parametrize("tag", ["cur_mpm1", "cur_mpm2", "cur_stoch"])
 def test_current_generation_variants_vs_reference_class(tag):
     """mp_mode -1 / -2 post-processing and the stochastic 3-RNN model against RNN_autoreg goldens
@@ -444,6 +467,33 @@ def test_column_halves_path_current_generation(tag):
     torch.cuda.synchronize()
     for x, y in zip(a, b):
         assert torch.equal(x, y)
+
+
+def test_ar_noise_packed_wrapper_is_the_tuple_wrapper_repacked():
+    """save_wrapper_mem.py:640-727: the stateful + AR-noise packed row = the tuple wrapper's outputs (pinned by the reference
+    class, cur_stoch goldens) in the packed order, the column's new memory and the column's eps, everything batch-first."""
+    import climsim_amd
+    consts, weights, flags = load_npz_model("cur_stoch")
+    io = np.load(os.path.join(GOLDEN, "cur_stoch_io.npz"))
+    kw = dict(output_prune=bool(flags["output_prune"]))
+    ar = climsim_amd.NewModel_constraint_ar(consts, weights, snowhice_fix=False, max_batch=16, **kw)
+    wrap = climsim_amd.model_wrapper(consts, weights, use_lstm=True, snowhice_fix=False, include_q_input=False, max_batch=16, **kw)
+    for B in (3, 10):
+        p = f"B{B}.t0."
+        hx0, cx0, eps = (_dev(io[p + k]) for k in ("hx0", "cx0", "eps"))          # eps (60,B,nh) as the reference drew it
+        xm, xs, mem = _dev(io[p + "x_main"]), _dev(io[p + "x_sfc"]), _dev(io[p + "mem_in"])
+        o6, osf, mo = wrap(xm, xs, mem, noise=(hx0, cx0, eps))
+        y = ar(xm, xs, mem.transpose(0, 1).contiguous(), eps.transpose(0, 1).contiguous(), noise=(hx0, cx0))
+        assert y.shape == (B, 368 + 60 * 16 + 60 * 128)
+        assert torch.equal(y[:, 0:120], o6[:, :, 0:2].transpose(1, 2).reshape(B, 120))
+        assert torch.equal(y[:, 120:180], o6[:, :, 2]) and torch.equal(y[:, 180:240], o6[:, :, 3])
+        assert torch.equal(y[:, 240:360], o6[:, :, 4:6].transpose(1, 2).reshape(B, 120))
+        assert torch.equal(y[:, 360:368], osf)
+        assert torch.equal(y[:, 368:368 + 960], mo.transpose(0, 1).reshape(B, 960))
+        assert torch.equal(y[:, 368 + 960:], eps.transpose(0, 1).reshape(B, 60 * 128))
+        # and against the reference class's own post-processed outputs
+        for v, (a, b) in enumerate(((0, 60), (60, 120), (120, 180), (180, 240), (240, 300), (300, 360))):
+            assert rel_err(y[:, a:b].cpu().numpy(), io[p + "post_lev"][:, :, v]) <= 1e-5, v
 
 
 def test_ensemble_window_replication_and_scores():
