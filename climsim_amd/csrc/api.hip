@@ -152,6 +152,15 @@ int upload_params(csa_emulator *h, const csa_params *p, bool first)
         rec1_pack_weights(c.nh2, b_hh, packed.data());
         d.whh2q = U.up(packed);
     }
+    d.whh1m = d.whh2m = nullptr;
+    if (c.use_lstm && c.nh1 <= 128 && c.nh2 <= 128) {     // matrix-pipe four-column kernel (large batches)
+        packed.resize((size_t)4 * c.nh1 * c.nh1);
+        rec4m_pack_weights(c.nh1, a_hh, packed.data());
+        d.whh1m = U.up(packed);
+        packed.resize((size_t)4 * c.nh2 * c.nh2);
+        rec4m_pack_weights(c.nh2, b_hh, packed.data());
+        d.whh2m = U.up(packed);
+    }
     d.whh1g = d.whh2g = nullptr;
     if (!c.use_lstm && c.nh1 <= 144 && c.nh2 <= 144) {    // second-generation two-column GRU kernel
         packed.resize((size_t)3 * c.nh1 * c.nh1);
@@ -356,6 +365,9 @@ static int launch_rec_auto(const csa_emulator *h, int layer, const float *P, con
     const float *wq = layer == 1 ? d.whh1q : d.whh2q;
     if (d.cfg.use_lstm && wq && Bclass <= h->rec1_max_batch)
         return launch_rec1(nh, wq, P, h0, c0, Hout, B, L, reverse_out, s);
+    const float *wm = layer == 1 ? d.whh1m : d.whh2m;
+    if (wm && rec4m_selected(d.cfg.use_lstm, nh, Bclass))     // by the whole call's batch: column halves stay bit-identical
+        return launch_rec4m(nh, wm, P, h0, c0, Hout, B, L, reverse_out, s);
     if (!d.cfg.use_lstm && Bclass <= h->rec1_max_batch)
         return launch_rec1_gru(nh, layer == 1 ? d.whh1p : d.whh2p, layer == 1 ? d.bhn1 : d.bhn2, P, h0, Hout, B, L, reverse_out, s);
     const float *wg = layer == 1 ? d.whh1g : d.whh2g;

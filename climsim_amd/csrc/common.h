@@ -35,6 +35,7 @@ struct DevModel {
     const float *whh1p, *whh2p;
     const float *whh1q, *whh2q;         // the same matrices packed for the one-column kernel (lstm_rec1_kernel), LSTM only
     const float *whh1g, *whh2g;         // GRU, nh <= 128: packed for the second-generation two-column kernel (gru_rec2_kernel)
+    const float *whh1m, *whh2m;         // LSTM, nh <= 128: k-major packing of the matrix-pipe four-column kernel (lstm_rec4m_kernel)
     // heads
     const float *lat_wt, *lat_b;        // (nh2, nh_mem)
     const float *out_w, *out_b;         // (ny, nh_mem or nh2) row-major
@@ -121,6 +122,11 @@ int launch_rec_train(int nh, const float *whh_packed, float *P, const float *h0,
                      int B, int L, int reverse_out, float *Hseq, float *Cseq, hipStream_t s);
 int launch_rec_train_gru(int nh, const float *whh_packed, const float *bhn, float *P, const float *h0, float *Hout, int B, int L,
                          int reverse_out, float *Hseq, hipStream_t s);
+// matrix-pipe four-column LSTM kernel (large batches): packing, selection (env CSA_REC4_KERNEL / CSA_REC4_MIN_BATCH), launch
+void rec4m_pack_weights(int nh, const float *w_hh, float *packed);
+bool rec4m_selected(int use_lstm, int nh, int B);
+int launch_rec4m(int nh, const float *whh_m, const float *P, const float *h0, const float *c0, float *Hout, int B, int L,
+                 int reverse_out, hipStream_t s);
 size_t rec_packed_floats(int use_lstm, int nh);
 // host-side packer: W_hh (G*nh, nh) PyTorch layout -> register-stationary layout
 void rec_pack_weights(int use_lstm, int nh, const float *w_hh, float *packed);

@@ -17,6 +17,7 @@
 // (packed FMA) -- MFMA would need >=4 (4x4x1) or 16 (16x16x4) columns per CU and leaves most of
 // the chip idle at the 384-column batch of BASELINE.json configs[1]; see DESIGN.md.
 #include "common.h"
+#include <cstring>
 
 #ifndef CSA_FAST_GATES
 #define CSA_FAST_GATES 1
@@ -532,6 +533,110 @@ __global__ __launch_bounds__(NH * 4, (NH / 16 + 3) / 4) void lstm_rec4_kernel(
 }
 
 // ------------------------------------------------------------------------------------------------
+// LSTM kernel for LARGE batches on the MATRIX pipe: four columns per workgroup through v_mfma_f32_4x4x1_16b_f32.
+// That instruction multiplies 16 independent (4x1)·(1x4) blocks per issue: block = hidden unit, the 4 rows of a block = the
+// unit's gate rows (i, f, g, o) at one k, the 4 columns = the workgroup's 4 grid columns.  So with
+//     lane = 4*unit_in_wave + x:   A operand  W_hh[gate x of the unit][k]      (128 registers per lane, stationary)
+//                                  B operand  h_{t-1}[k] of column x           (same for all 16 blocks)
+//                                  D (4 regs) the FOUR gate sums of (unit, column x)
+// a step is 128 MFMAs per wave (8 cycles each: the full fp32 rate, 64 FLOP/clk/SIMD, at FOUR columns per CU -- the packed-FMA
+// kernels need the VALU for that), the k-sum needs no cross-lane reduction at all and every lane ends the step holding all
+// four gate pre-activations of ITS (unit, column): no DPP exchange, c_t and h_t stay in that lane.
+// B operands come from LDS; with BLGP one ds_read_b128 feeds SIXTEEN MFMAs: each 16-lane group of the wave reads a different
+// k-quad of its column, and `blgp:4+g` makes the matrix pipe take B from lane group g for all four groups (16 KB of LDS
+// return traffic per wave and step instead of 64 KB).
+// Same arithmetic as the other LSTM kernels up to the order of the k-sum (four interleaved accumulator chains).
+template <int NH, bool BLGP>
+__global__ __launch_bounds__(NH * 4, (NH / 16 + 3) / 4) void lstm_rec4m_kernel(
+    const float *__restrict__ Wk, const float *__restrict__ P,
+    const float *__restrict__ h0, const float *__restrict__ c0, float *__restrict__ Hout,
+    int B, int L, int reverse_out)
+{
+    constexpr int NT = NH * 4;
+    constexpr int LDH = NH + 4;          // row stride: 4 rows start 4 banks apart -> the 4 addresses of a read never collide
+    static_assert(NH % 16 == 0, "nh must be a multiple of 16");
+    __shared__ __attribute__((aligned(16))) float hbuf[2][4][LDH];
+
+    const int tid = threadIdx.x, u = tid >> 2, x = tid & 3, lane = tid & 63;
+    int b = 4 * blockIdx.x + x;
+    const bool valid = b < B;
+    if (!valid) b = B - 1;
+
+    float w[NH];
+#pragma unroll
+    for (int k = 0; k < NH; ++k) w[k] = Wk[(size_t)k * NT + tid];
+
+    float h = h0[(size_t)b * NH + u], c = c0[(size_t)b * NH + u];
+    hbuf[0][x][u] = h;
+    const float *Pb = P + (size_t)b * (4 * NH) + u * 4;
+    const size_t Pstep = (size_t)B * (4 * NH);
+    f32x4 preA = *(const f32x4 *)Pb, preB = preA;
+    const int hoff = x * LDH + (BLGP ? 4 * (lane >> 4) : 0);
+    __syncthreads();
+
+#ifndef REC4M_EXP_MFMA_DIV      /* diagnostic builds (tools/rec_bench): 2 = half of the MFMAs, results are wrong */
+#define REC4M_EXP_MFMA_DIV 1
+#endif
+#ifdef REC4M_EXP_NOGATES        /* diagnostic: no transcendental work */
+#define REC4M_GATES c = 0.5f * c + 0.1f * (vi + vf); h = fminf(fmaxf(0.3f * (vg + vo) + c, -1.0f), 1.0f);
+#else
+#define REC4M_GATES                                                                                    \
+        const float ig = CSA_RCP(1.0f + CSA_EXP2(-1.44269504088896341f * vi));                         \
+        const float fg = CSA_RCP(1.0f + CSA_EXP2(-1.44269504088896341f * vf));                         \
+        const float og = CSA_RCP(1.0f + CSA_EXP2(-1.44269504088896341f * vo));                         \
+        const float tg = fminf(CSA_EXP2(-2.88539008177792681f * vg), 1e30f);                           \
+        const float gg = (1.0f - tg) * CSA_RCP(1.0f + tg);                                             \
+        c = fg * c + ig * gg;                                                                          \
+        const float tc = fminf(CSA_EXP2(-2.88539008177792681f * c), 1e30f);                            \
+        h = og * ((1.0f - tc) * CSA_RCP(1.0f + tc));
+#endif
+#define MF4(ACC, K, HV, G)                                                                             \
+    ACC = __builtin_amdgcn_mfma_f32_4x4x1f32(w[(K)], HV.x, ACC, 0, 0, G);                              \
+    ACC##b = __builtin_amdgcn_mfma_f32_4x4x1f32(w[(K) + 1], HV.y, ACC##b, 0, 0, G);                    \
+    ACC##c = __builtin_amdgcn_mfma_f32_4x4x1f32(w[(K) + 2], HV.z, ACC##c, 0, 0, G);                    \
+    ACC##d = __builtin_amdgcn_mfma_f32_4x4x1f32(w[(K) + 3], HV.w, ACC##d, 0, 0, G);
+#define LSTM4M_STEP(T, CUR, NXT)                                                                       \
+    {                                                                                                  \
+        const int t_ = (T);                                                                            \
+        {   /* unconditional prefetch + unconditional wait: see lstm_rec2_kernel */                     \
+            const float *pn = Pb + (size_t)(t_ + 1 < L ? t_ + 1 : L - 1) * Pstep;                      \
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(NXT) : "v"(pn) : "memory");         \
+        }                                                                                              \
+        const float *hb = &hbuf[t_ & 1][0][0] + hoff;                                                  \
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f}, accb = acc, accc = acc, accd = acc;                          \
+        if (BLGP) {                                                                                    \
+            _Pragma("unroll") for (int q = 0; q < NH / 16 / REC4M_EXP_MFMA_DIV; ++q) {                 \
+                const f32x4 hv = *(const f32x4 *)(hb + 16 * q);                                        \
+                MF4(acc, 16 * q, hv, 4)                                                                \
+                MF4(acc, 16 * q + 4, hv, 5)                                                            \
+                MF4(acc, 16 * q + 8, hv, 6)                                                            \
+                MF4(acc, 16 * q + 12, hv, 7)                                                           \
+            }                                                                                          \
+        } else {                                                                                       \
+            _Pragma("unroll") for (int q = 0; q < NH / 4; ++q) {                                       \
+                const f32x4 hv = *(const f32x4 *)(hb + 4 * q);                                         \
+                MF4(acc, 4 * q, hv, 0)                                                                 \
+            }                                                                                          \
+        }                                                                                              \
+        asm volatile("s_waitcnt vmcnt(1)" : "+v"(CUR));                                                \
+        /* D rows = gate rows (i, f, g, o); the projection row is stored [i, g~, f, o] */              \
+        acc = (acc + accb) + (accc + accd);            /* four interleaved k-chains: no dependent MFMA pair back to back */ \
+        const float vi = acc.x + CUR.x, vf = acc.y + CUR.z, vg = acc.z + CUR.y, vo = acc.w + CUR.w;    \
+        REC4M_GATES                                                                                    \
+        hbuf[(t_ & 1) ^ 1][x][u] = h;                                                                  \
+        if (valid) Hout[((size_t)(reverse_out ? L - 1 - t_ : t_) * B + b) * NH + u] = h;               \
+        LDS_BARRIER();                                                                                 \
+    }
+    for (int t = 0; t < L; t += 2) {
+        LSTM4M_STEP(t, preA, preB)
+        if (t + 1 < L) LSTM4M_STEP(t + 1, preB, preA)
+    }
+#undef LSTM4M_STEP
+#undef MF4
+#undef REC4M_GATES
+}
+
+// ------------------------------------------------------------------------------------------------
 // GRU kernel, second generation (inference): the lstm_rec2_kernel design with three accumulator slots.
 // Slot order per lane group (host packing, gru2_pack_weights): p<2 holds [r, hn, z], p>=2 holds [z, hn, r], so after
 //   r[s] = acc[s].x + xor1(acc[s].y);  v0 = r[0] + xor2(r[2]);  v1 = r[1] + xor2(r[1])
@@ -888,10 +993,56 @@ void rec_pack_weights(int use_lstm, int nh, const float *w_hh, float *packed)
     }
 }
 
+static int rec4_min_batch();
+// matrix-pipe kernel: Wk[k*NT + tid] = W_hh[gate (tid & 3) of unit (tid >> 2)][k], PyTorch gate rows (i, f, g, o)
+void rec4m_pack_weights(int nh, const float *w_hh, float *packed)
+{
+    const int NT = nh * 4;
+    for (int k = 0; k < nh; ++k)
+        for (int tid = 0; tid < NT; ++tid)
+            packed[(size_t)k * NT + tid] = w_hh[(size_t)((tid & 3) * nh + (tid >> 2)) * nh + k];
+}
+
+// which large-batch LSTM kernel: CSA_REC4_KERNEL = mfma (default: 4x4x1 matrix pipe, BLGP operand broadcast), mfma_noblgp,
+// valu (the packed-FMA four-column kernel)
+static int rec4_variant()
+{
+    static const int v = [] {
+        const char *e = getenv("CSA_REC4_KERNEL");
+        if (!e) return 2;
+        return !strcmp(e, "valu") ? 0 : (!strcmp(e, "mfma_noblgp") ? 1 : 2);
+    }();
+    return v;
+}
+
+int launch_rec4m(int nh, const float *whh_m, const float *P, const float *h0, const float *c0, float *Hout, int B, int L,
+                 int reverse_out, hipStream_t s)
+{
+    const dim3 grid((B + 3) / 4), block(nh * 4);
+    const bool blgp = rec4_variant() == 2;
+#define L4M(NHv)                                                                                                             \
+    if (blgp) hipLaunchKernelGGL((lstm_rec4m_kernel<NHv, true>), grid, block, 0, s, whh_m, P, h0, c0, Hout, B, L, reverse_out);   \
+    else hipLaunchKernelGGL((lstm_rec4m_kernel<NHv, false>), grid, block, 0, s, whh_m, P, h0, c0, Hout, B, L, reverse_out);
+    switch (nh) {
+    case 64: L4M(64) break;
+    case 96: L4M(96) break;
+    case 128: L4M(128) break;
+    default:
+        csa_set_error_msg("rec4m: hidden size not supported (64, 96, 128)");
+        return CSA_ERR_UNSUPPORTED;
+    }
+#undef L4M
+    CSA_HIP_CHECK(hipGetLastError());
+    return CSA_OK;
+}
+bool rec4m_selected(int use_lstm, int nh, int B) { return use_lstm && nh <= 128 && rec4_variant() != 0 && B >= rec4_min_batch(); }
+
 // smallest batch of a launch that uses the four-column kernel (env CSA_REC4_MIN_BATCH; 0 disables)
 static int rec4_min_batch()
 {
-    static const int v = getenv("CSA_REC4_MIN_BATCH") ? atoi(getenv("CSA_REC4_MIN_BATCH")) : 1024;
+    // measured (tools/rec_bench): one round of four-column workgroups costs 100 us (matrix pipe) / 130 us (packed FMA), one round of
+    // two-column workgroups 57 us: from 513 columns the two-column kernel needs a second round, so four columns win
+    static const int v = getenv("CSA_REC4_MIN_BATCH") ? atoi(getenv("CSA_REC4_MIN_BATCH")) : 544;
     return v > 0 ? v : 0x7fffffff;
 }
 

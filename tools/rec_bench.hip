@@ -16,7 +16,9 @@ int main(int argc, char **argv)
     for (auto &x : P) x = 2.0f * rnd();
     for (auto &x : h0) x = rnd();
     for (auto &x : c0) x = rnd();
-    rec_pack_weights(1, nh, w.data(), wp.data());
+    const bool mfma = argc > 3 && argv[3][0] == 'm';       // lstm_rec4m_kernel (matrix pipe; CSA_REC4_KERNEL picks BLGP or not)
+    if (mfma) rec4m_pack_weights(nh, w.data(), wp.data());
+    else rec_pack_weights(1, nh, w.data(), wp.data());
     float *dW, *dP, *dh, *dc, *dH;
     hipMalloc(&dW, wp.size() * 4); hipMalloc(&dP, P.size() * 4); hipMalloc(&dh, h0.size() * 4);
     hipMalloc(&dc, c0.size() * 4); hipMalloc(&dH, (size_t)L * B * nh * 4);
@@ -25,10 +27,11 @@ int main(int argc, char **argv)
     hipMemcpy(dh, h0.data(), h0.size() * 4, hipMemcpyHostToDevice);
     hipMemcpy(dc, c0.data(), c0.size() * 4, hipMemcpyHostToDevice);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    for (int i = 0; i < 5; ++i) launch_rec(1, nh, dW, nullptr, dP, dh, dc, dH, B, L, 0, 0);
+    auto run = [&] { return mfma ? launch_rec4m(nh, dW, dP, dh, dc, dH, B, L, 0, 0) : launch_rec(1, nh, dW, nullptr, dP, dh, dc, dH, B, L, 0, 0); };
+    for (int i = 0; i < 5; ++i) run();
     hipDeviceSynchronize();
     hipEventRecord(e0, 0);
-    for (int i = 0; i < iters; ++i) launch_rec(1, nh, dW, nullptr, dP, dh, dc, dH, B, L, 0, 0);
+    for (int i = 0; i < iters; ++i) run();
     hipEventRecord(e1, 0); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
     std::vector<float> H((size_t)L * B * nh);

@@ -12,18 +12,18 @@ P = os.path.join(ROOT, "profiles")
 os.makedirs(P, exist_ok=True)
 
 def agg(pattern, counter):
-    f = glob.glob(os.path.join(G, pattern))
+    f = sorted(glob.glob(os.path.join(G, pattern)), key=os.path.getmtime)      # newest run (gpurun_out/ keeps earlier ones)
     if not f:
         return {}
     d = collections.defaultdict(list)
-    for r in csv.DictReader(open(f[0])):
+    for r in csv.DictReader(open(f[-1])):
         if r["Counter_Name"] == counter:
             d[r["Kernel_Name"].split("(")[0].replace("void ", "")].append(float(r["Counter_Value"]))
     return {k: sum(v) / len(v) for k, v in d.items()}
 
-ks = glob.glob(os.path.join(G, f"prof_{w}", "*", "*kernel_stats.csv"))
+ks = sorted(glob.glob(os.path.join(G, f"prof_{w}", "*", "*kernel_stats.csv")), key=os.path.getmtime)
 if ks:
-    shutil.copy(ks[0], os.path.join(P, f"{tag}_{w}_kernel_stats.csv"))
+    shutil.copy(ks[-1], os.path.join(P, f"{tag}_{w}_kernel_stats.csv"))
 fetch = agg(f"pmc_fetch_{w}/*/*counter_collection.csv", "FETCH_SIZE")
 write = agg(f"pmc_write_{w}/*/*counter_collection.csv", "WRITE_SIZE")
 out = {"workload": w, "note": "bytes per launch; fetch = FETCH_SIZE(KB)*1024*2 (gfx950 correction), write = WRITE_SIZE(KB)*1024",
