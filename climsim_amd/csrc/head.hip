@@ -11,6 +11,7 @@
 // raw T/qliq/qice inputs, writes the packed row with level-contiguous (coalesced) stores.
 #include "common.h"
 #include "rh_to_q.h"
+#include <cstdlib>
 
 #define HEAD_THREADS 256
 
@@ -61,11 +62,9 @@ __device__ __forceinline__ void postprocess_level(const DevModel &m, int l, int 
     vals[0] = dT; vals[1] = dqv; vals[2] = dql; vals[3] = dqi; vals[4] = du; vals[5] = dv;
 }
 
-// First stage of the head: Z(l, j) = b1[j] + sum_k H2(l, k) * W1t(k, j), j < n1, where (W1t, n1) is
-// mlp_latent (n1 = nh_mem) for the memory models or mlp_output itself (n1 = ny) for the stateless
-// one.  Thread (lg, j): j = tid % n1p, lg = tid / n1p, n1p = n1 rounded up to a power of two;
-// it keeps column j of W1t in registers (NH2 VGPRs) and walks levels lg, lg + G, ...; the hidden
-// rows come from LDS as float4 broadcasts.
+// First stage of the head: Z(l, j) = b1[j] + sum_k H2(l, k) * W1t(k, j), j < n1 <= 16, where (W1t, n1) is
+// mlp_latent (n1 = nh_mem) for the memory models or mlp_output itself (n1 = ny) for the stateless one: a (60 x NH2) x
+// (NH2 x 16) product per column, done with 16x16x4 fp32 MFMAs on the hidden rows staged in LDS (see below).
 template <int NH2>
 __global__ __launch_bounds__(HEAD_THREADS) void head_kernel(
     DevModel m, int B, int mode, const float *__restrict__ H2, const float *__restrict__ x_raw,
@@ -75,76 +74,80 @@ __global__ __launch_bounds__(HEAD_THREADS) void head_kernel(
     const int L = m.cfg.nlev, nx = m.cfg.nx, ny = m.cfg.ny, nys = m.cfg.ny_sfc;
     const int nm = m.cfg.nh_mem;
     constexpr int ldh = NH2 + 4;            // float4-aligned rows, 16-B skew between rows
-    float *hs = smem;                       // (L, ldh)
-    float *zs = hs + L * ldh;               // (L, nm)
-    float *os = zs + L * (nm > 0 ? nm : 1); // (L, ny)
+    // a column's levels are cut into gridDim.y slices (one workgroup each): more, shorter workgroups in flight
+    const int Ls = (L + gridDim.y - 1) / gridDim.y, l0 = blockIdx.y * Ls, nl = min(L, l0 + Ls) - l0;
+    if (nl <= 0) return;
+    float *hs = smem;                        // (Ls, ldh)   rows of this slice
+    float *zs = hs + Ls * ldh;               // (Ls, nm)
+    float *os = zs + Ls * (nm > 0 ? nm : 1); // (Ls, ny)
     const int b = blockIdx.x, tid = threadIdx.x;
     const bool legacy = m.cfg.legacy != 0;
     const int W = 6 * L + nys + L * nm;     // packed row width
 
-    for (int idx = tid; idx < L * (NH2 / 4); idx += HEAD_THREADS) {
-        const int l = idx / (NH2 / 4), k4 = idx - l * (NH2 / 4);
-        *(f32x4 *)&hs[l * ldh + 4 * k4] = *(const f32x4 *)&H2[((size_t)l * B + b) * NH2 + 4 * k4];
+    for (int idx = tid; idx < nl * (NH2 / 4); idx += HEAD_THREADS) {
+        const int ll = idx / (NH2 / 4), k4 = idx - ll * (NH2 / 4);
+        *(f32x4 *)&hs[ll * ldh + 4 * k4] = *(const f32x4 *)&H2[((size_t)(l0 + ll) * B + b) * NH2 + 4 * k4];
     }
+    // ---- first stage on the matrix pipe: Z (L x n1) = H2 (L x NH2) . W1t (NH2 x n1) + b1, n1 <= 16 -------------------------------
+    // v_mfma_f32_16x16x4_f32: wave w takes the 16-level row block w (L = 60: four blocks, one per wave).  A = hidden rows from
+    // LDS (lane: row lane%16, k lane/16), B = the weight matrix itself, (NH2, n1) row-major: for n1 = 16 lane `lane` of k-step
+    // ks reads w1t[64*ks + lane] -- fully coalesced, 32 registers per lane instead of the NH2 a thread-per-output layout keeps
+    // (which limited the kernel to 3 workgroups per CU and re-read 128 KB of weights per column from L2).
     const int n1 = nm > 0 ? nm : ny;
-    int n1p = 1;
-    while (n1p < n1) n1p <<= 1;
-    const int j = tid & (n1p - 1), lg = tid / n1p, G = HEAD_THREADS / n1p;
     const float *w1t = nm > 0 ? m.lat_wt : m.out_wt;   // (NH2, n1)
-    float wreg[NH2];
-    float b1 = 0.0f;
-    if (j < n1) {
+    const int lane = tid & 63, wave = tid >> 6, col = lane & 15, kq = lane >> 4;
+    float wB[NH2 / 4];
 #pragma unroll
-        for (int k = 0; k < NH2; ++k) wreg[k] = w1t[k * n1 + j];
-        b1 = nm > 0 ? m.lat_b[j] : m.out_b[j];
-    }
+    for (int ks = 0; ks < NH2 / 4; ++ks) wB[ks] = col < n1 ? w1t[(4 * ks + kq) * n1 + col] : 0.0f;
+    const float b1 = col < n1 ? (nm > 0 ? m.lat_b[col] : m.out_b[col]) : 0.0f;
     __syncthreads();
-
-    if (j < n1) {
+    {
         float *mem_out = mode == HEAD_PACKED ? y0 + (size_t)b * W + 6 * L + nys : y2;
-        for (int l = lg; l < L; l += G) {
-            const f32x4 *hr = (const f32x4 *)(hs + l * ldh);
-            float a0 = b1, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
+        for (int r0 = 16 * wave; r0 < nl; r0 += 16 * (HEAD_THREADS / 64)) {
+            const float *arow = hs + min(r0 + col, nl - 1) * ldh + kq;     // rows beyond the slice: recompute the last one, discard
+            f32x4 d0 = {0.f, 0.f, 0.f, 0.f}, d1 = d0;
 #pragma unroll
-            for (int k4 = 0; k4 < NH2 / 4; ++k4) {
-                const f32x4 hv = hr[k4];
-                a0 += hv.x * wreg[4 * k4];
-                a1 += hv.y * wreg[4 * k4 + 1];
-                a2 += hv.z * wreg[4 * k4 + 2];
-                a3 += hv.w * wreg[4 * k4 + 3];
+            for (int ks = 0; ks < NH2 / 4; ks += 2) {
+                d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(arow[4 * ks], wB[ks], d0, 0, 0, 0);
+                d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(arow[4 * ks + 4], wB[ks + 1], d1, 0, 0, 0);
             }
-            const float a = (a0 + a1) + (a2 + a3);
-            if (nm > 0) {
-                zs[l * nm + j] = a;
-                float v = a;
-                if (mode == HEAD_PACKED) {
-                    if (m.cfg.scrub_out_nan && isnan(v)) v = 0.0f;
-                    // packed rows carry the model's memory block verbatim: legacy (L,nm), sequence order
-                    mem_out[(legacy ? (L - 1 - l) : l) * nm + j] = v;
-                } else if (legacy) {
-                    mem_out[((size_t)b * L + (L - 1 - l)) * nm + j] = v;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {                                   // D: row 4*(lane/16) + i, column lane%16
+                const int ll = r0 + 4 * kq + i, l = l0 + ll;
+                const float a = (d0[i] + d1[i]) + b1;
+                if (ll >= nl || col >= n1) continue;
+                if (nm > 0) {
+                    zs[ll * nm + col] = a;
+                    float v = a;
+                    if (mode == HEAD_PACKED) {
+                        if (m.cfg.scrub_out_nan && isnan(v)) v = 0.0f;
+                        // packed rows carry the model's memory block verbatim: legacy (L,nm), sequence order
+                        mem_out[(legacy ? (L - 1 - l) : l) * nm + col] = v;
+                    } else if (legacy) {
+                        mem_out[((size_t)b * L + (L - 1 - l)) * nm + col] = v;
+                    } else {
+                        mem_out[((size_t)l * (m.mem_B > 0 ? m.mem_B : B) + m.mem_off + b) * nm + col] = v;
+                    }
                 } else {
-                    mem_out[((size_t)l * (m.mem_B > 0 ? m.mem_B : B) + m.mem_off + b) * nm + j] = v;
+                    os[ll * ny + col] = (m.cfg.output_prune && l < 12 && col >= 1) ? 0.0f : a;
                 }
-            } else {
-                os[l * ny + j] = (m.cfg.output_prune && l < 12 && j >= 1) ? 0.0f : a;
             }
         }
     }
     __syncthreads();
     // ---- second stage for the memory models: out = mlp_output(latent) ---------------------------
     if (nm > 0) {
-        for (int idx = tid; idx < L * ny; idx += HEAD_THREADS) {
-            const int l = idx / ny, v = idx - l * ny;
+        for (int idx = tid; idx < nl * ny; idx += HEAD_THREADS) {
+            const int ll = idx / ny, v = idx - ll * ny, l = l0 + ll;
             float a = m.out_b[v];
             if (nm == 16) {        // compile-time trip count: the 16 weight loads are issued together (run-time bound: one s_waitcnt each)
                 float w[16];
 #pragma unroll
                 for (int q = 0; q < 16; ++q) w[q] = m.out_w[v * 16 + q];
 #pragma unroll
-                for (int q = 0; q < 16; ++q) a += zs[l * 16 + q] * w[q];
+                for (int q = 0; q < 16; ++q) a += zs[ll * 16 + q] * w[q];
             } else
-                for (int q = 0; q < nm; ++q) a += zs[l * nm + q] * m.out_w[v * nm + q];
+                for (int q = 0; q < nm; ++q) a += zs[ll * nm + q] * m.out_w[v * nm + q];
             if (m.cfg.output_prune && l < 12 && v >= 1) a = 0.0f;
             os[idx] = a;
         }
@@ -153,8 +156,9 @@ __global__ __launch_bounds__(HEAD_THREADS) void head_kernel(
 
     // ---- de-normalise, microphysics, pack -------------------------------------------------------
     const bool post = (mode != HEAD_RAW) && m.cfg.mp_mode != 0;
-    for (int l = tid; l < L; l += HEAD_THREADS) {
-        const float *o = os + l * ny;
+    for (int ll = tid; ll < nl; ll += HEAD_THREADS) {
+        const int l = l0 + ll;
+        const float *o = os + ll * ny;
         if (mode == HEAD_RAW || m.cfg.mp_mode == 0) {
             // RAW: model-level output; TUPLE with mp_mode 0 returns the UN-denormalised outputs
             // (models.py:278-279).  PACKED with mp_mode 0 is rejected on the host.
@@ -183,12 +187,13 @@ __global__ __launch_bounds__(HEAD_THREADS) void head_kernel(
             }
         }
     }
-    // ---- surface outputs: one wave, 8 lanes per output ---------------------------------------------
-    if (tid < 64) {
-        const int v = tid >> 3, part = tid & 7;
+    // ---- surface outputs: the slice that holds the last level; the SECOND wave (the first is busy with the loop above),
+    // 8 lanes per output
+    if (l0 + nl == L && tid >= 64 && tid < 128) {
+        const int v = (tid - 64) >> 3, part = tid & 7;
         float a = 0.0f;
         if (v < nys) {
-            const float *hr = hs + (L - 1) * ldh;     // last_h of the downward RNN
+            const float *hr = hs + (nl - 1) * ldh;    // last_h of the downward RNN
             for (int k = part; k < NH2; k += 8) a += hr[k] * m.sfo_w[v * NH2 + k];
         }
         a += __shfl_xor(a, 1); a += __shfl_xor(a, 2); a += __shfl_xor(a, 4);
@@ -210,16 +215,19 @@ int launch_head(const DevModel &m, int B, int mode, const float *H2, const float
                 const float *x_sfc_raw, float *y0, float *y1, float *y2, hipStream_t s)
 {
     const int L = m.cfg.nlev, nm = m.cfg.nh_mem;
-    const size_t shm = sizeof(float) * ((size_t)L * (m.cfg.nh2 + 4) + (size_t)L * (nm > 0 ? nm : 1) + (size_t)L * m.cfg.ny);
-    if (shm > 64 * 1024 || m.cfg.ny_sfc > 8 || (nm > 0 ? nm : m.cfg.ny) > 32) {
-        csa_set_error_msg("head: unsupported sizes (LDS > 64 KB, ny_sfc > 8 or first-stage width > 32)");
+    // level slices per column (CSA_HEAD_LSPLIT, default 2): measured at 384 / 2,700 columns, see DESIGN.md section 4.3
+    static const int lsplit = getenv("CSA_HEAD_LSPLIT") ? atoi(getenv("CSA_HEAD_LSPLIT")) : 2;
+    const int S = lsplit < 1 ? 1 : (lsplit > 4 ? 4 : lsplit), Ls = (L + S - 1) / S;
+    const size_t shm = sizeof(float) * ((size_t)Ls * (m.cfg.nh2 + 4) + (size_t)Ls * (nm > 0 ? nm : 1) + (size_t)Ls * m.cfg.ny);
+    if (shm > 64 * 1024 || m.cfg.ny_sfc > 8 || (nm > 0 ? nm : m.cfg.ny) > 16) {
+        csa_set_error_msg("head: unsupported sizes (LDS > 64 KB, ny_sfc > 8 or first-stage width > 16)");
         return CSA_ERR_UNSUPPORTED;
     }
     switch (m.cfg.nh2) {
-    case 64:  hipLaunchKernelGGL(head_kernel<64>, dim3(B), dim3(HEAD_THREADS), shm, s, m, B, mode, H2, x_main_raw, x_sfc_raw, y0, y1, y2); break;
-    case 96:  hipLaunchKernelGGL(head_kernel<96>, dim3(B), dim3(HEAD_THREADS), shm, s, m, B, mode, H2, x_main_raw, x_sfc_raw, y0, y1, y2); break;
-    case 128: hipLaunchKernelGGL(head_kernel<128>, dim3(B), dim3(HEAD_THREADS), shm, s, m, B, mode, H2, x_main_raw, x_sfc_raw, y0, y1, y2); break;
-    case 144: hipLaunchKernelGGL(head_kernel<144>, dim3(B), dim3(HEAD_THREADS), shm, s, m, B, mode, H2, x_main_raw, x_sfc_raw, y0, y1, y2); break;
+    case 64:  hipLaunchKernelGGL(head_kernel<64>, dim3(B, S), dim3(HEAD_THREADS), shm, s, m, B, mode, H2, x_main_raw, x_sfc_raw, y0, y1, y2); break;
+    case 96:  hipLaunchKernelGGL(head_kernel<96>, dim3(B, S), dim3(HEAD_THREADS), shm, s, m, B, mode, H2, x_main_raw, x_sfc_raw, y0, y1, y2); break;
+    case 128: hipLaunchKernelGGL(head_kernel<128>, dim3(B, S), dim3(HEAD_THREADS), shm, s, m, B, mode, H2, x_main_raw, x_sfc_raw, y0, y1, y2); break;
+    case 144: hipLaunchKernelGGL(head_kernel<144>, dim3(B, S), dim3(HEAD_THREADS), shm, s, m, B, mode, H2, x_main_raw, x_sfc_raw, y0, y1, y2); break;
     default:
         csa_set_error_msg("head: hidden size must be 64, 96, 128 or 144");
         return CSA_ERR_UNSUPPORTED;
