@@ -48,7 +48,8 @@ SYMBOLS = ["csa_create", "csa_destroy", "csa_set_params", "csa_packed_width", "c
            "csa_phys_create", "csa_phys_destroy", "csa_phys_forward", "csa_phys_tap",
            "csa_online_create", "csa_online_destroy", "csa_online_dims", "csa_online_forward",
            "csa_stoch_gru5_create", "csa_stoch_lstm4_create", "csa_stoch_destroy", "csa_stoch_gru5_forward",
-           "csa_stoch_lstm4_forward"]
+           "csa_stoch_lstm4_forward", "csa_stoch_enable_training", "csa_stoch_num_params", "csa_stoch_gru5_forward_train",
+           "csa_stoch_lstm4_forward_train", "csa_stoch_gru5_backward", "csa_stoch_lstm4_backward"]
 
 
 class CsaConfig(ctypes.Structure):
@@ -193,6 +194,13 @@ def lib():
     L.csa_stoch_destroy.argtypes = [H]
     L.csa_stoch_gru5_forward.argtypes = [H, i, i, _F, _F, _F, _F, ctypes.c_void_p]
     L.csa_stoch_lstm4_forward.argtypes = [H, i, i, _F, _F, _F, _F, _F, _F, _F, ctypes.c_void_p]
+    L.csa_stoch_enable_training.argtypes = [H]
+    L.csa_stoch_num_params.argtypes = [H]
+    L.csa_stoch_num_params.restype = ctypes.c_long
+    L.csa_stoch_gru5_forward_train.argtypes = L.csa_stoch_gru5_forward.argtypes
+    L.csa_stoch_lstm4_forward_train.argtypes = L.csa_stoch_lstm4_forward.argtypes
+    L.csa_stoch_gru5_backward.argtypes = [H, i, i] + [_F] * 7 + [ctypes.c_void_p]
+    L.csa_stoch_lstm4_backward.argtypes = [H, i, i] + [_F] * 10 + [ctypes.c_void_p]
     L.csa_last_error.restype = ctypes.c_char_p
     L.csa_version.restype = ctypes.c_char_p
     _lib = L

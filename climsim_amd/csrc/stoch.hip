@@ -13,6 +13,7 @@
 // of the reference's sequence loop become 2 launches.  eps (T,B,H) is an explicit input (the reference
 // draws it with torch.randn at the top of forward).
 #include "common.h"
+#include "stoch.h"
 #include <vector>
 
 #define PK_FMA_LO(acc, w, h) asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[0,1,1]" : "+v"(acc) : "v"(w), "v"(h))
@@ -78,11 +79,15 @@ __device__ __forceinline__ void load_rows(const f32x4 *Wp4, int NT, int tid, f32
 // GRU5: per level  pred = h W_enc -> (mean, logvar);  z = mean + eps*exp(logvar/2);  zr = z W_zh (+b);
 //   r = sig(r_u + z_r); zg = sig(zg_u + z_z); n = tanh(n_u + r*z_n); h' = n + zg*(h - n).
 // XP (T,B,3H) = x W_ih (+b_ih), gate-major.
-template <int NH>
+// TRAIN additionally saves what BPTT needs (stoch_bwd.hip): (r, zg, n) IN PLACE over the projections XP, z_n / z / exp(logvar/2)
+// into ZN / Zs / EX (T,B,H) and h_{t-1} into Hseq (T+1 slots, slot 0 = h0) -- the tensors the reference's C++ loop keeps
+// (all_r, all_zg, all_n, all_zn, all_z, all_exp, all_h; models_torch_kernels.py:141-174).
+template <int NH, bool TRAIN = false>
 __global__ __launch_bounds__(NH * 4, 2) void stoch_gru5_kernel(
     const f32x4 *__restrict__ Wenc4, const f32x4 *__restrict__ Wzh4, const float *__restrict__ bzh,
-    const float *__restrict__ XP, const float *__restrict__ eps, const float *__restrict__ h0,
-    float *__restrict__ out, int B, int T)
+    float *__restrict__ XP, const float *__restrict__ eps, const float *__restrict__ h0,
+    float *__restrict__ out, int B, int T, float *__restrict__ ZN = nullptr, float *__restrict__ Zs = nullptr,
+    float *__restrict__ EX = nullptr, float *__restrict__ Hseq = nullptr)
 {
     constexpr int NT = NH * 4, KC = NH / 4, CH = 2 * KC + 4;
     __shared__ __attribute__((aligned(16))) float hbuf[4 * CH];
@@ -99,6 +104,7 @@ __global__ __launch_bounds__(NH * 4, 2) void stoch_gru5_kernel(
     float h = h0[(size_t)b * NH + u];
     const int slot = 2 * u + col + 4 * (u / KC);
     if (p < 2) hbuf[slot] = h;
+    if (TRAIN && p < 2 && valid) Hseq[(size_t)b * NH + u] = h;
     asm volatile("" : "+v"(h));
     __syncthreads();
     for (int t = 0; t < T; ++t) {
@@ -110,7 +116,8 @@ __global__ __launch_bounds__(NH * 4, 2) void stoch_gru5_kernel(
         quarter_matvec<2, KC>(we, hbuf + p * CH, a2);
         const float mean = sq_pick(a2[0], col);
         const float logv = sq_pick(a2[1], col);
-        const float z = mean + e * s_exp(0.5f * logv);
+        const float ex = s_exp(0.5f * logv);
+        const float z = mean + e * ex;
         if (p < 2) zbuf[slot] = z;
         LDS_BARRIER();
         // phase B: (z_r, z_z, z_n) = z W_zh (+ b_zh)
@@ -126,6 +133,11 @@ __global__ __launch_bounds__(NH * 4, 2) void stoch_gru5_kernel(
         if (p < 2) {
             hbuf[slot] = h;
             if (valid) out[row * NH + u] = h;
+            if (TRAIN && valid) {
+                XP[row * 3 * NH + u] = r; XP[row * 3 * NH + NH + u] = zg; XP[row * 3 * NH + 2 * NH + u] = n;
+                ZN[row * NH + u] = z_n; Zs[row * NH + u] = z; EX[row * NH + u] = ex;
+                Hseq[((size_t)(t + 1) * B + b) * NH + u] = h;
+            }
         }
         LDS_BARRIER();
     }
@@ -134,11 +146,14 @@ __global__ __launch_bounds__(NH * 4, 2) void stoch_gru5_kernel(
 // ------------------------------------------------------------------------------------------------
 // LSTM4: per level  yy = [x, h] W_enc -> (mean, logvar, i, f, g);  o = sig(mean + eps*exp(logvar/2));
 //   c = sig(f) c + sig(i) tanh(g);  h = o tanh(c).     XP (T,B,5H) = x W_enc[:nx], gate-major.
-template <int NH>
+// TRAIN: the activated values [o, exp(logvar/2), sig(i), sig(f), tanh(g)] overwrite the projections XP in place, h_{t-1} and
+// c_{t-1} go to Hseq / Cseq (T+1 slots, slot 0 = the initial state).
+template <int NH, bool TRAIN = false>
 __global__ __launch_bounds__(NH * 4, 2) void stoch_lstm4_kernel(
-    const f32x4 *__restrict__ Wh4, const float *__restrict__ XP, const float *__restrict__ eps,
+    const f32x4 *__restrict__ Wh4, float *__restrict__ XP, const float *__restrict__ eps,
     const float *__restrict__ h0, const float *__restrict__ c0, float *__restrict__ out,
-    float *__restrict__ hT, float *__restrict__ cT, int B, int T)
+    float *__restrict__ hT, float *__restrict__ cT, int B, int T, float *__restrict__ Hseq = nullptr,
+    float *__restrict__ Cseq = nullptr)
 {
     constexpr int NT = NH * 4, KC = NH / 4, CH = 2 * KC + 4;
     __shared__ __attribute__((aligned(16))) float hbuf[2][4 * CH];
@@ -151,6 +166,7 @@ __global__ __launch_bounds__(NH * 4, 2) void stoch_lstm4_kernel(
     float h = h0[(size_t)b * NH + u], c = c0[(size_t)b * NH + u];
     const int slot = 2 * u + col + 4 * (u / KC);
     if (p < 2) hbuf[0][slot] = h;
+    if (TRAIN && p < 2 && valid) { Hseq[(size_t)b * NH + u] = h; Cseq[(size_t)b * NH + u] = c; }
     asm volatile("" : "+v"(h), "+v"(c));
     __syncthreads();
     for (int t = 0; t < T; ++t) {
@@ -164,12 +180,19 @@ __global__ __launch_bounds__(NH * 4, 2) void stoch_lstm4_kernel(
         float s[5];
 #pragma unroll
         for (int g = 0; g < 5; ++g) s[g] = sq_pick(a[g], col) + xp[g];
-        const float o = s_sigmoid(s[0] + e * s_exp(0.5f * s[1]));
-        c = s_sigmoid(s[3]) * c + s_sigmoid(s[2]) * s_tanh(s[4]);
+        const float ex = s_exp(0.5f * s[1]);
+        const float o = s_sigmoid(s[0] + e * ex), ig = s_sigmoid(s[2]), fg = s_sigmoid(s[3]), gg = s_tanh(s[4]);
+        c = fg * c + ig * gg;
         h = o * s_tanh(c);
         if (p < 2) {
             hbuf[(t & 1) ^ 1][slot] = h;
             if (valid) out[row * NH + u] = h;
+            if (TRAIN && valid) {
+                float *a = XP + row * 5 * NH + u;
+                a[0] = o; a[NH] = ex; a[2 * NH] = ig; a[3 * NH] = fg; a[4 * NH] = gg;
+                Hseq[((size_t)(t + 1) * B + b) * NH + u] = h;
+                Cseq[((size_t)(t + 1) * B + b) * NH + u] = c;
+            }
         }
         LDS_BARRIER();
     }
@@ -193,14 +216,6 @@ static void pack_rows(int nh, int R, const float *W, int ncols, int col0, float 
         }
     }
 }
-
-struct csa_stoch {
-    int kind, nx, nh, max_rows;       // kind 0: GRU5, 1: LSTM4
-    float *w_in_t, *b_in;             // (N, nx) transposed input weights for the NT GEMM, optional bias
-    float *wp_a, *wp_b, *b_zh;        // packed recurrent rows
-    float *XP;
-    std::vector<void *> owned;
-};
 
 static float *s_up(csa_stoch *h, const float *src, size_t n, int &rc)
 {
@@ -231,6 +246,10 @@ extern "C" int csa_stoch_gru5_create(int nx, int nh, const float *weight_ih, con
     pack_rows(nh, 3, weight_zh, 3 * nh, 0, pk.data());
     h->wp_b = s_up(h, pk.data(), (size_t)3 * nh * nh, rc);
     h->b_zh = bias_zh ? s_up(h, bias_zh, 3 * nh, rc) : nullptr;
+    h->has_bias = (bias_ih && bias_zh) ? 1 : 0;
+    h->host_a.assign(weight_zh, weight_zh + (size_t)nh * 3 * nh);            // kept for the BPTT packings (csa_stoch_enable_training)
+    h->host_b.assign(weight_encoder, weight_encoder + (size_t)nh * 2 * nh);
+    h->w_ref_in = s_up(h, weight_ih, (size_t)nx * 3 * nh, rc);
     h->XP = s_up(h, nullptr, (size_t)max_rows * 3 * nh, rc);
     if (rc) { for (void *p : h->owned) (void)hipFree(p); delete h; return rc; }
     *out = h;
@@ -253,6 +272,8 @@ extern "C" int csa_stoch_lstm4_create(int nx, int nh, const float *weight_encode
     pack_rows(nh, 5, weight_encoder + (size_t)nx * 5 * nh, 5 * nh, 0, pk.data());
     h->wp_a = s_up(h, pk.data(), pk.size(), rc);
     h->wp_b = nullptr; h->b_zh = nullptr;
+    h->host_a.assign(weight_encoder + (size_t)nx * 5 * nh, weight_encoder + (size_t)(nx + nh) * 5 * nh);
+    h->w_ref_in = s_up(h, weight_encoder, (size_t)nx * 5 * nh, rc);
     h->XP = s_up(h, nullptr, (size_t)max_rows * 5 * nh, rc);
     if (rc) { for (void *p : h->owned) (void)hipFree(p); delete h; return rc; }
     *out = h;
@@ -268,8 +289,8 @@ extern "C" int csa_stoch_destroy(csa_stoch *h)
 }
 
 // x (T,B,nx), h0 (B,H), eps (T,B,H) -> out (T,B,H)
-extern "C" int csa_stoch_gru5_forward(csa_stoch *h, int T, int B, const float *x, const float *h0, const float *eps,
-                                      float *out, void *stream)
+static int gru5_forward_impl(csa_stoch *h, int T, int B, const float *x, const float *h0, const float *eps, float *out, void *stream,
+                             bool train)
 {
     if (!h || h->kind != 0 || !x || !h0 || !eps || !out || T <= 0 || B <= 0 || (long)T * B > h->max_rows) { csa_set_error_msg("csa_stoch_gru5_forward: bad argument"); return CSA_ERR_ARG; }
     hipStream_t s = (hipStream_t)stream;
@@ -277,18 +298,32 @@ extern "C" int csa_stoch_gru5_forward(csa_stoch *h, int T, int B, const float *x
     int rc = launch_proj_gemm(x, h->w_in_t, h->b_in, h->XP, T * B, 3 * nh, h->nx, s);
     if (rc) return rc;
     const dim3 grid((B + 1) / 2), block(nh * 4);
+    if (train && !h->Hseq) { csa_set_error_msg("csa_stoch_gru5_forward_train: call csa_stoch_enable_training first"); return CSA_ERR_ARG; }
+#define G5(NHv, TR) hipLaunchKernelGGL((stoch_gru5_kernel<NHv, TR>), grid, block, 0, s, (const f32x4 *)h->wp_a, (const f32x4 *)h->wp_b, \
+                                       h->b_zh, h->XP, eps, h0, out, B, T, h->ZN, h->Zs, h->EX, h->Hseq)
     switch (nh) {
-    case 64:  hipLaunchKernelGGL((stoch_gru5_kernel<64>), grid, block, 0, s, (const f32x4 *)h->wp_a, (const f32x4 *)h->wp_b, h->b_zh, h->XP, eps, h0, out, B, T); break;
-    case 96:  hipLaunchKernelGGL((stoch_gru5_kernel<96>), grid, block, 0, s, (const f32x4 *)h->wp_a, (const f32x4 *)h->wp_b, h->b_zh, h->XP, eps, h0, out, B, T); break;
-    default:  hipLaunchKernelGGL((stoch_gru5_kernel<128>), grid, block, 0, s, (const f32x4 *)h->wp_a, (const f32x4 *)h->wp_b, h->b_zh, h->XP, eps, h0, out, B, T); break;
+    case 64:  if (train) G5(64, true); else G5(64, false); break;
+    case 96:  if (train) G5(96, true); else G5(96, false); break;
+    default:  if (train) G5(128, true); else G5(128, false); break;
     }
+#undef G5
     CSA_HIP_CHECK(hipGetLastError());
     return CSA_OK;
 }
+extern "C" int csa_stoch_gru5_forward(csa_stoch *h, int T, int B, const float *x, const float *h0, const float *eps,
+                                      float *out, void *stream)
+{
+    return gru5_forward_impl(h, T, B, x, h0, eps, out, stream, false);
+}
+extern "C" int csa_stoch_gru5_forward_train(csa_stoch *h, int T, int B, const float *x, const float *h0, const float *eps,
+                                            float *out, void *stream)
+{
+    return gru5_forward_impl(h, T, B, x, h0, eps, out, stream, true);
+}
 
 // x (T,B,nx), (h0,c0) (B,H), eps (T,B,H) -> out (T,B,H), hT, cT (B,H; nullable)
-extern "C" int csa_stoch_lstm4_forward(csa_stoch *h, int T, int B, const float *x, const float *h0, const float *c0,
-                                       const float *eps, float *out, float *hT, float *cT, void *stream)
+static int lstm4_forward_impl(csa_stoch *h, int T, int B, const float *x, const float *h0, const float *c0, const float *eps,
+                              float *out, float *hT, float *cT, void *stream, bool train)
 {
     if (!h || h->kind != 1 || !x || !h0 || !c0 || !eps || !out || T <= 0 || B <= 0 || (long)T * B > h->max_rows) { csa_set_error_msg("csa_stoch_lstm4_forward: bad argument"); return CSA_ERR_ARG; }
     hipStream_t s = (hipStream_t)stream;
@@ -296,11 +331,25 @@ extern "C" int csa_stoch_lstm4_forward(csa_stoch *h, int T, int B, const float *
     int rc = launch_proj_gemm(x, h->w_in_t, nullptr, h->XP, T * B, 5 * nh, h->nx, s);
     if (rc) return rc;
     const dim3 grid((B + 1) / 2), block(nh * 4);
+    if (train && !h->Hseq) { csa_set_error_msg("csa_stoch_lstm4_forward_train: call csa_stoch_enable_training first"); return CSA_ERR_ARG; }
+#define L4(NHv, TR) hipLaunchKernelGGL((stoch_lstm4_kernel<NHv, TR>), grid, block, 0, s, (const f32x4 *)h->wp_a, h->XP, eps, h0, c0, out, \
+                                       hT, cT, B, T, h->Hseq, h->Cseq)
     switch (nh) {
-    case 64:  hipLaunchKernelGGL((stoch_lstm4_kernel<64>), grid, block, 0, s, (const f32x4 *)h->wp_a, h->XP, eps, h0, c0, out, hT, cT, B, T); break;
-    case 96:  hipLaunchKernelGGL((stoch_lstm4_kernel<96>), grid, block, 0, s, (const f32x4 *)h->wp_a, h->XP, eps, h0, c0, out, hT, cT, B, T); break;
-    default:  hipLaunchKernelGGL((stoch_lstm4_kernel<128>), grid, block, 0, s, (const f32x4 *)h->wp_a, h->XP, eps, h0, c0, out, hT, cT, B, T); break;
+    case 64:  if (train) L4(64, true); else L4(64, false); break;
+    case 96:  if (train) L4(96, true); else L4(96, false); break;
+    default:  if (train) L4(128, true); else L4(128, false); break;
     }
+#undef L4
     CSA_HIP_CHECK(hipGetLastError());
     return CSA_OK;
+}
+extern "C" int csa_stoch_lstm4_forward(csa_stoch *h, int T, int B, const float *x, const float *h0, const float *c0,
+                                       const float *eps, float *out, float *hT, float *cT, void *stream)
+{
+    return lstm4_forward_impl(h, T, B, x, h0, c0, eps, out, hT, cT, stream, false);
+}
+extern "C" int csa_stoch_lstm4_forward_train(csa_stoch *h, int T, int B, const float *x, const float *h0, const float *c0,
+                                             const float *eps, float *out, float *hT, float *cT, void *stream)
+{
+    return lstm4_forward_impl(h, T, B, x, h0, c0, eps, out, hT, cT, stream, true);
 }

@@ -407,6 +407,25 @@ int csa_stoch_gru5_forward(csa_stoch *h, int T, int B, const float *x, const flo
                            float *out, void *stream);
 int csa_stoch_lstm4_forward(csa_stoch *h, int T, int B, const float *x, const float *h0, const float *c0,
                             const float *eps, float *out, float *hT, float *cT, void *stream);
+/* Backward of the two layers.  MyStochasticGRULayer5: the reference's hand-written backward, stochastic_gru_backward_elem_kernel
+ * rnn/models_torch_kernels.py:85-126 + the reverse sequence loop :176-232 + FusedCUDAStochasticGRUSequence.backward :826-841;
+ * MyStochasticLSTMLayer4: autograd through :1494-1531.  csa_stoch_enable_training allocates the saved-activation buffers (once);
+ * *_forward_train is *_forward that also saves them; *_backward consumes them: ONE launch walks the levels backwards with the
+ * transposed recurrent weights register-stationary, then one GEMM per weight / input gradient.  d_out (T,B,H) is the gradient of
+ * the output sequence (d_hT, d_cT (B,H): of the returned final state, nullable); d_x (T,B,nx), d_h0 / d_c0 (B,H), d_eps (T,B,H,
+ * nullable) are written; `grads` is a flat device buffer of csa_stoch_num_params floats, ACCUMULATED into, in the layout
+ * GRU5: weight_ih (nx,3H) | weight_zh (H,3H) | weight_encoder (H,2H) [| bias_ih (3H) | bias_zh (3H)], LSTM4: weight_encoder. */
+int csa_stoch_enable_training(csa_stoch *h);
+long csa_stoch_num_params(const csa_stoch *h);
+int csa_stoch_gru5_forward_train(csa_stoch *h, int T, int B, const float *x, const float *h0, const float *eps,
+                                 float *out, void *stream);
+int csa_stoch_lstm4_forward_train(csa_stoch *h, int T, int B, const float *x, const float *h0, const float *c0,
+                                  const float *eps, float *out, float *hT, float *cT, void *stream);
+int csa_stoch_gru5_backward(csa_stoch *h, int T, int B, const float *x, const float *eps, const float *d_out,
+                            float *d_x, float *d_h0, float *d_eps, float *grads, void *stream);
+int csa_stoch_lstm4_backward(csa_stoch *h, int T, int B, const float *x, const float *eps, const float *d_out,
+                             const float *d_hT, const float *d_cT, float *d_x, float *d_h0, float *d_c0, float *d_eps,
+                             float *grads, void *stream);
 
 const char *csa_last_error(void);
 const char *csa_version(void);

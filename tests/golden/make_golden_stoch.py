@@ -51,6 +51,41 @@ def main():
         print(B, float(out.abs().max()))
     np.savez_compressed(f"{OUT}/stoch_layers.npz", **d)
 
+    # ---- gradients: autograd through the reference layer classes (the GRU's CPU branch is plain torch; its CUDA branch is the
+    # hand-written backward of :85-126,:176-232 that the HIP BPTT kernels replace).  Loss = <out, dout> (+ <hT, dhT> + <cT, dcT>).
+    g = {}
+    for B, seed in ((6, 11), (3, 12)):
+        gen = torch.Generator().manual_seed(seed)
+        x = (torch.randn(T, B, nx, generator=gen) * 0.7).requires_grad_(True)
+        h0 = (torch.randn(B, H, generator=gen) * 0.5).requires_grad_(True)
+        c0 = (torch.randn(B, H, generator=gen) * 0.5).requires_grad_(True)
+        dout = torch.randn(T, B, H, generator=gen)
+        dhT, dcT = torch.randn(B, H, generator=gen), torch.randn(B, H, generator=gen)
+        g[f"B{B}.x"], g[f"B{B}.h0"], g[f"B{B}.c0"] = x.detach().numpy(), h0.detach().numpy(), c0.detach().numpy()
+        g[f"B{B}.dout"], g[f"B{B}.dhT"], g[f"B{B}.dcT"] = dout.numpy(), dhT.numpy(), dcT.numpy()
+        for tag, m in (("gru5", gru), ("gru5b", gru_b), ("lstm4", lstm)):
+            for t_ in (x, h0, c0):
+                t_.grad = None
+            m.zero_grad()
+            torch.manual_seed(300 + seed)
+            if tag == "lstm4":
+                out, (hT, cT) = m(x, (h0, c0))
+                loss = (out * dout).sum() + (hT * dhT).sum() + (cT * dcT).sum()
+            else:
+                out = m(x, h0)
+                loss = (out * dout).sum()
+            loss.backward()
+            torch.manual_seed(300 + seed)
+            g[f"B{B}.{tag}.eps"] = torch.randn(T, B, H).numpy()
+            g[f"B{B}.{tag}.out"] = out.detach().numpy()
+            g[f"B{B}.{tag}.dx"], g[f"B{B}.{tag}.dh0"] = x.grad.numpy().copy(), h0.grad.numpy().copy()
+            if tag == "lstm4":
+                g[f"B{B}.{tag}.dc0"] = c0.grad.numpy().copy()
+            for n, p_ in m.named_parameters():
+                g[f"B{B}.{tag}.dw.{n}"] = p_.grad.numpy().copy()
+            print("grad", B, tag, float(x.grad.abs().max()))
+    np.savez_compressed(f"{OUT}/stoch_grads.npz", **g)
+
 
 if __name__ == "__main__":
     if not os.path.isdir(REF):

@@ -49,3 +49,57 @@ def test_hip_stochastic_lstm4_vs_reference(B):
     assert rel_err(out.cpu().numpy(), G[f"B{B}.lstm4.out"]) <= 1e-5
     assert rel_err(hT.cpu().numpy(), G[f"B{B}.lstm4.hT"]) <= 1e-5
     assert rel_err(cT.cpu().numpy(), G[f"B{B}.lstm4.cT"]) <= 1e-5
+
+
+GR = np.load(os.path.join(GOLDEN, "stoch_grads.npz"))
+tg = lambda k: torch.from_numpy(GR[k])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B", [6, 3])
+@pytest.mark.parametrize("tag", ["gru5", "gru5b"])
+def test_hip_stochastic_gru5_backward_vs_reference_autograd(tag, B):
+    """The HIP BPTT of MyStochasticGRULayer5 (the reference's hand-written CUDA backward, :85-126, :176-232) against autograd
+    through the reference class (make_golden_stoch.py), through the same plugin interface: a torch.autograd.Function."""
+    from climsim_amd.layers import MyStochasticGRULayer5
+    w = {k: G[f"{tag}.w.{k}"] for k in ("weight_ih", "weight_zh", "weight_encoder")}
+    bi = G[f"{tag}.w.bias_ih"] if f"{tag}.w.bias_ih" in G.files else None
+    bz = G[f"{tag}.w.bias_zh"] if f"{tag}.w.bias_zh" in G.files else None
+    layer = MyStochasticGRULayer5(w["weight_ih"], w["weight_zh"], w["weight_encoder"], bi, bz, max_rows=60 * 8, requires_grad=True)
+    x = tg(f"B{B}.x").cuda().requires_grad_(True)
+    h0 = tg(f"B{B}.h0").cuda().requires_grad_(True)
+    out = layer(x, h0, eps=tg(f"B{B}.{tag}.eps").cuda())
+    assert rel_err(out.detach().cpu().numpy(), GR[f"B{B}.{tag}.out"]) <= 1e-5
+    (out * tg(f"B{B}.dout").cuda()).sum().backward()
+    assert rel_err(x.grad.cpu().numpy(), GR[f"B{B}.{tag}.dx"]) <= 2e-5
+    assert rel_err(h0.grad.cpu().numpy(), GR[f"B{B}.{tag}.dh0"]) <= 2e-5
+    for n, p in layer.named_parameters():
+        assert rel_err(p.grad.cpu().numpy(), GR[f"B{B}.{tag}.dw.{n}"]) <= 2e-5, n
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B", [6, 3])
+def test_hip_stochastic_lstm4_backward_vs_reference_autograd(B):
+    from climsim_amd.layers import MyStochasticLSTMLayer4
+    layer = MyStochasticLSTMLayer4(G["lstm4.w.weight_encoder"], 128, max_rows=60 * 8, requires_grad=True)
+    x = tg(f"B{B}.x").cuda().requires_grad_(True)
+    h0 = tg(f"B{B}.h0").cuda().requires_grad_(True)
+    c0 = tg(f"B{B}.c0").cuda().requires_grad_(True)
+    out, (hT, cT) = layer(x, (h0, c0), eps=tg(f"B{B}.lstm4.eps").cuda())
+    assert rel_err(out.detach().cpu().numpy(), GR[f"B{B}.lstm4.out"]) <= 1e-5
+    ((out * tg(f"B{B}.dout").cuda()).sum() + (hT * tg(f"B{B}.dhT").cuda()).sum() + (cT * tg(f"B{B}.dcT").cuda()).sum()).backward()
+    assert rel_err(x.grad.cpu().numpy(), GR[f"B{B}.lstm4.dx"]) <= 2e-5
+    assert rel_err(h0.grad.cpu().numpy(), GR[f"B{B}.lstm4.dh0"]) <= 2e-5
+    assert rel_err(c0.grad.cpu().numpy(), GR[f"B{B}.lstm4.dc0"]) <= 2e-5
+    assert rel_err(layer.weight_encoder.grad.cpu().numpy(), GR[f"B{B}.lstm4.dw.weight_encoder"]) <= 2e-5
+    # gradients accumulate over calls and a second identical pass is bit-identical (no atomics)
+    g1 = layer.weight_encoder.grad.clone()
+    layer.weight_encoder.grad = None
+    x.grad = None
+    out2, (hT2, cT2) = layer(x, (h0, c0), eps=tg(f"B{B}.lstm4.eps").cuda())
+    ((out2 * tg(f"B{B}.dout").cuda()).sum() + (hT2 * tg(f"B{B}.dhT").cuda()).sum() + (cT2 * tg(f"B{B}.dcT").cuda()).sum()).backward()
+    assert torch.equal(layer.weight_encoder.grad, g1)
+    # inference mode is unchanged by the training plumbing
+    with torch.no_grad():
+        out3, _ = layer(x, (h0, c0), eps=tg(f"B{B}.lstm4.eps").cuda())
+    assert torch.equal(out3, out.detach())
