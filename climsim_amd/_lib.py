@@ -43,7 +43,7 @@ SYMBOLS = ["csa_create", "csa_destroy", "csa_set_params", "csa_packed_width", "c
            "csa_cnn_train_params", "csa_cnn_train_get_params", "csa_cnn_train_set_params", "csa_cnn_train_get_act", "csa_cnn_train_layer_info", "csa_cnn_train_forward", "csa_cnn_train_backward",
            "csa_cnn_train_adam",
            "csa_gen_create", "csa_gen_destroy", "csa_gen_dims", "csa_gen_batch",
-           "csa_crps", "csa_spread_skill",
+           "csa_crps", "csa_crps_backward", "csa_spread_skill",
            "csa_eval_scratch_bytes", "csa_eval_metrics", "csa_eval_crps", "csa_derive_inputs",
            "csa_phys_create", "csa_phys_destroy", "csa_phys_forward", "csa_phys_tap",
            "csa_online_create", "csa_online_destroy", "csa_online_dims", "csa_online_forward",
@@ -174,6 +174,7 @@ def lib():
     L.csa_gen_dims.argtypes = [H, PI, PI, PI]
     L.csa_gen_batch.argtypes = [H, i] + [_F] * 11 + [ctypes.c_void_p]
     L.csa_crps.argtypes = [i, i, i, i, i, _F, _F, _F, _F, fl, fl, _F, _F, ctypes.c_void_p]
+    L.csa_crps_backward.argtypes = [i, i, i, i, i, _F, _F, _F, _F, fl, fl, fl, _F, _F, ctypes.c_void_p]
     L.csa_spread_skill.argtypes = [i, i, i, i, i, _F, _F, _F, _F, ctypes.c_void_p, _F, ctypes.c_void_p]
     L.csa_eval_scratch_bytes.argtypes = [i, i, i, i]
     L.csa_eval_scratch_bytes.restype = ctypes.c_long

@@ -1,4 +1,4 @@
-// crps.hip -- the ensemble score of the reference's probabilistic training, forward / evaluation:
+// crps.hip -- the ensemble score of the reference's probabilistic training, value and gradient:
 //   rnn/metrics.py:535-626  CRPS(y, y_sfc, y_pred, y_sfc_pred, timesteps, beta, alpha)
 // an energy-score form: with z = [level outputs | surface outputs] (D values per sample),
 //   skill  = mean over samples and members of ||z_true - z_e||_2 / sqrt(D)
@@ -79,6 +79,70 @@ extern "C" int csa_crps(int T, int B, int E, int D_lev, int D_sfc, const float *
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(crps_sample_kernel, dim3(N), dim3(256), shm, s, y, y_sfc, y_pred, y_sfc_pred, scratch, B, E, D_lev, D_sfc);
     hipLaunchKernelGGL(crps_final_kernel, dim3(1), dim3(256), 0, s, scratch, N, E, D, beta, alpha, out);
+    CSA_HIP_CHECK(hipGetLastError());
+    return CSA_OK;
+}
+
+// ---- gradient of the score w.r.t. the ensemble outputs (training with the score as loss, rnn/utils.py:1213) --------------------
+//   dCRPS/dz_e = 2 beta / (N E sqrt(D)) (z_e - z) / ||z - z_e||  -  2 (1 - eps) / (N E (E-1) sqrt(D)) sum_{f != e} (z_e - z_f) / ||z_e - z_f||
+// (each unordered pair appears twice in the reference's cdist(y_pred, y_pred) sum; a zero distance contributes 0, as
+// torch.cdist's backward does).  Same staging as the forward: one workgroup per (time, column) sample, distances by block
+// reductions, then every thread writes its features of all members.  gscale = dLoss/dCRPS.
+__global__ __launch_bounds__(256) void crps_backward_kernel(
+    const float *__restrict__ y, const float *__restrict__ ys, const float *__restrict__ yp, const float *__restrict__ yps,
+    float *__restrict__ d_yp, float *__restrict__ d_yps, int N, int B, int E, int D1, int D2, float beta, float alpha, float gscale)
+{
+    extern __shared__ float sm[];
+    const int D = D1 + D2, n = blockIdx.x, t = n / B, b = n - t * B, tid = threadIdx.x;
+    float *zt = sm, *ze = sm + D, *red = sm + (size_t)(E + 1) * D, *inv = red + 256;     // inv: E (skill) + E*E (pairs) reciprocals
+    for (int i = tid; i < D; i += 256) zt[i] = i < D1 ? y[(size_t)n * D1 + i] : ys[(size_t)n * D2 + (i - D1)];
+    for (int e = 0; e < E; ++e) {
+        const size_t r = ((size_t)t * E + e) * B + b;
+        for (int i = tid; i < D; i += 256) ze[(size_t)e * D + i] = i < D1 ? yp[r * D1 + i] : yps[r * D2 + (i - D1)];
+    }
+    __syncthreads();
+    for (int e = 0; e < E; ++e) {
+        float a = 0.0f;
+        for (int i = tid; i < D; i += 256) { const float d = zt[i] - ze[(size_t)e * D + i]; a += d * d; }
+        const float ds = sqrtf(crps_block_sum(a, red));
+        if (tid == 0) inv[e] = ds > 0.0f ? 1.0f / ds : 0.0f;
+        for (int f = e + 1; f < E; ++f) {
+            float c = 0.0f;
+            for (int i = tid; i < D; i += 256) { const float d = ze[(size_t)e * D + i] - ze[(size_t)f * D + i]; c += d * d; }
+            const float dp = sqrtf(crps_block_sum(c, red));
+            if (tid == 0) inv[E + e * E + f] = inv[E + f * E + e] = dp > 0.0f ? 1.0f / dp : 0.0f;
+        }
+    }
+    __syncthreads();
+    const float rs = rsqrtf((float)D), eps = (1.0f - alpha) / (float)E;
+    const float cs = gscale * 2.0f * beta * rs / ((float)N * (float)E);
+    const float cv = E > 1 ? gscale * 2.0f * (1.0f - eps) * rs / ((float)N * (float)E * (float)(E - 1)) : 0.0f;
+    for (int e = 0; e < E; ++e) {
+        const size_t r = ((size_t)t * E + e) * B + b;
+        for (int i = tid; i < D; i += 256) {
+            const float x = ze[(size_t)e * D + i];
+            float g = cs * (x - zt[i]) * inv[e];
+            for (int f = 0; f < E; ++f)
+                if (f != e) g -= cv * (x - ze[(size_t)f * D + i]) * inv[E + e * E + f];
+            if (i < D1) d_yp[r * D1 + i] = g; else d_yps[r * D2 + (i - D1)] = g;
+        }
+    }
+}
+
+extern "C" int csa_crps_backward(int T, int B, int E, int D_lev, int D_sfc, const float *y, const float *y_sfc, const float *y_pred,
+                                 const float *y_sfc_pred, float beta, float alpha, float gscale, float *d_y_pred,
+                                 float *d_y_sfc_pred, void *stream)
+{
+    if (T <= 0 || B <= 0 || E <= 0 || D_lev <= 0 || D_sfc < 0 || !y || !y_pred || !d_y_pred ||
+        (D_sfc > 0 && (!y_sfc || !y_sfc_pred || !d_y_sfc_pred))) {
+        csa_set_error_msg("csa_crps_backward: bad argument");
+        return CSA_ERR_ARG;
+    }
+    const int D = D_lev + D_sfc, N = T * B;
+    const size_t shm = sizeof(float) * ((size_t)(E + 1) * D + 256 + E + (size_t)E * E);
+    if (shm > 64 * 1024) { csa_set_error_msg("csa_crps_backward: ensemble x features exceed the 64 KB LDS staging (E*D too large)"); return CSA_ERR_UNSUPPORTED; }
+    hipLaunchKernelGGL(crps_backward_kernel, dim3(N), dim3(256), shm, (hipStream_t)stream, y, y_sfc, y_pred, y_sfc_pred, d_y_pred,
+                       d_y_sfc_pred, N, B, E, D_lev, D_sfc, beta, alpha, gscale);
     CSA_HIP_CHECK(hipGetLastError());
     return CSA_OK;
 }

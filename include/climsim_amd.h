@@ -326,6 +326,13 @@ int csa_gen_batch(csa_generator *h, int N, const float *x_lev, const float *x_sf
 int csa_crps(int T, int B, int E, int D_lev, int D_sfc, const float *y, const float *y_sfc, const float *y_pred,
              const float *y_sfc_pred, float beta, float alpha, float *scratch, float *out, void *stream);
 
+/* Gradient of csa_crps w.r.t. the ensemble outputs (the score as training loss, rnn/utils.py:1213; upstream: autograd through
+ * torch.cdist): d_y_pred (T*E*B, D_lev), d_y_sfc_pred (T*E*B, D_sfc) are WRITTEN; gscale = dLoss/dCRPS; zero distances
+ * contribute zero, as torch's cdist backward does. */
+int csa_crps_backward(int T, int B, int E, int D_lev, int D_sfc, const float *y, const float *y_sfc, const float *y_pred,
+                      const float *y_sfc_pred, float beta, float alpha, float gscale, float *d_y_pred, float *d_y_sfc_pred,
+                      void *stream);
+
 /* rnn/metrics.py:509-533 compute_spread_skill_ratio and rnn/metrics.py:628-699 CRPS_l1 on the same tensors as csa_crps.
  * scratch: 32 KB device; out: 4 device floats [spread (with the sqrt((E+1)/E) correction), RMSE of the member mean,
  * CRPS_l1 = mean|z_e - z| - 0.5 mean|z_0 - z_1|, its skill term]. */
