@@ -32,7 +32,7 @@ SYMBOLS = ["csa_create", "csa_destroy", "csa_set_params", "csa_packed_width", "c
            "csa_tap_rnn2", "csa_last_error", "csa_version", "csa_set_profiling", "csa_reset_profile",
            "csa_get_profile", "csa_stage_name", "csa_set_halves", "csa_set_rec1_max_batch", "csa_set_small_gemm_rows", "csa_debug_stage",
            "csa_train_create", "csa_train_destroy", "csa_train_num_params", "csa_train_num_tensors",
-           "csa_train_param_info", "csa_train_params", "csa_train_sync_params", "csa_train_copy_state", "csa_train_forward",
+           "csa_train_param_info", "csa_train_params", "csa_train_sync_params", "csa_train_copy_state", "csa_train_forward", "csa_train_forward_noise",
            "csa_train_backward", "csa_train_set_deferred", "csa_train_flush_wgrad", "csa_train_loss", "csa_train_adam",
            "csa_train_set_profiling", "csa_train_reset_profile", "csa_train_get_profile", "csa_train_stage_name",
            "csa_mlp_create", "csa_mlp_destroy", "csa_mlp_forward",
@@ -126,6 +126,7 @@ def lib():
     L.csa_train_params.restype = ctypes.c_void_p
     L.csa_train_sync_params.argtypes = [H, ctypes.c_void_p]
     L.csa_train_forward.argtypes = [H, i, i, _F, _F, _F, _F, _F, _F, ctypes.c_void_p]
+    L.csa_train_forward_noise.argtypes = [H, i, i] + [_F] * 9 + [ctypes.c_void_p]
     L.csa_train_backward.argtypes = [H, i, i, _F, _F, _F, _F, _F, ctypes.c_void_p]
     L.csa_train_copy_state.argtypes = [H, i, i, _F, ctypes.c_void_p]
     L.csa_train_set_deferred.argtypes = [H, i]

@@ -17,3 +17,7 @@ struct csa_stoch {
     std::vector<float> host_a, host_b;        // host copies of the recurrent matrices (reference layout) until training is enabled
     std::vector<void *> owned;
 };
+
+// host packers (index-map friendly: the trainer runs them on arrays whose values are their own indices)
+void stoch_pack_rows(int nh, int R, const float *W, int ncols, int col0, float *packed);     // stoch.hip
+void stoch_pack_t(int nh, int ncols, const float *W, float *packed);                          // stoch_bwd.hip

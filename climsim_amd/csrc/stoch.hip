@@ -205,7 +205,7 @@ __global__ __launch_bounds__(NH * 4, 2) void stoch_lstm4_kernel(
 // ---- host side ---------------------------------------------------------------------------------------------
 // pack R recurrent rows per unit from an (in=nh, out=ncols) matrix W (reference layout): row r of unit u is
 // column (r*nh + u) of W
-static void pack_rows(int nh, int R, const float *W, int ncols, int col0, float *packed)
+void stoch_pack_rows(int nh, int R, const float *W, int ncols, int col0, float *packed)
 {
     const int NT = nh * 4, KC = nh / 4;
     for (int tid = 0; tid < NT; ++tid) {
@@ -241,9 +241,9 @@ extern "C" int csa_stoch_gru5_create(int nx, int nh, const float *weight_ih, con
     h->w_in_t = s_up(h, t.data(), t.size(), rc);
     h->b_in = bias_ih ? s_up(h, bias_ih, 3 * nh, rc) : nullptr;
     std::vector<float> pk((size_t)3 * nh * nh);
-    pack_rows(nh, 2, weight_encoder, 2 * nh, 0, pk.data());
+    stoch_pack_rows(nh, 2, weight_encoder, 2 * nh, 0, pk.data());
     h->wp_a = s_up(h, pk.data(), (size_t)2 * nh * nh, rc);
-    pack_rows(nh, 3, weight_zh, 3 * nh, 0, pk.data());
+    stoch_pack_rows(nh, 3, weight_zh, 3 * nh, 0, pk.data());
     h->wp_b = s_up(h, pk.data(), (size_t)3 * nh * nh, rc);
     h->b_zh = bias_zh ? s_up(h, bias_zh, 3 * nh, rc) : nullptr;
     h->has_bias = (bias_ih && bias_zh) ? 1 : 0;
@@ -269,7 +269,7 @@ extern "C" int csa_stoch_lstm4_create(int nx, int nh, const float *weight_encode
     h->w_in_t = s_up(h, t.data(), t.size(), rc);
     h->b_in = nullptr;
     std::vector<float> pk((size_t)5 * nh * nh);
-    pack_rows(nh, 5, weight_encoder + (size_t)nx * 5 * nh, 5 * nh, 0, pk.data());
+    stoch_pack_rows(nh, 5, weight_encoder + (size_t)nx * 5 * nh, 5 * nh, 0, pk.data());
     h->wp_a = s_up(h, pk.data(), pk.size(), rc);
     h->wp_b = nullptr; h->b_zh = nullptr;
     h->host_a.assign(weight_encoder + (size_t)nx * 5 * nh, weight_encoder + (size_t)(nx + nh) * 5 * nh);

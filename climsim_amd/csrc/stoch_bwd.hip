@@ -204,8 +204,9 @@ __global__ __launch_bounds__(NH * 4, 2) void stoch_gru5_bwd_kernel(
     if (cell && valid) d_h0[(size_t)b * NH + k] = dh_rec;
 }
 
+}  // namespace
 // transposed packing: thread (k, p) holds W[k][p*RQ + j], j < RQ, W (nh, ncols) row-major in the reference's (in, out) layout
-void pack_t(int nh, int ncols, const float *W, float *packed)
+void stoch_pack_t(int nh, int ncols, const float *W, float *packed)
 {
     const int NT = nh * 4, RQ = ncols / 4;
     for (int tid = 0; tid < NT; ++tid) {
@@ -214,6 +215,7 @@ void pack_t(int nh, int ncols, const float *W, float *packed)
             packed[((size_t)(j / 4) * NT + tid) * 4 + (j % 4)] = W[(size_t)k * ncols + p * RQ + j];
     }
 }
+namespace {
 
 float *dev_alloc(csa_stoch *h, size_t n, const float *src, int &rc)
 {
@@ -252,15 +254,15 @@ extern "C" int csa_stoch_enable_training(csa_stoch *h)
     std::vector<float> pk;
     if (h->kind == 1) {
         pk.resize((size_t)nh * 5 * nh);
-        pack_t(nh, 5 * nh, h->host_a.data(), pk.data());
+        stoch_pack_t(nh, 5 * nh, h->host_a.data(), pk.data());
         h->wT_a = dev_alloc(h, pk.size(), pk.data(), rc);
         h->Cseq = dev_alloc(h, R1 * nh, nullptr, rc);
     } else {
         pk.resize((size_t)nh * 3 * nh);
-        pack_t(nh, 3 * nh, h->host_a.data(), pk.data());
+        stoch_pack_t(nh, 3 * nh, h->host_a.data(), pk.data());
         h->wT_a = dev_alloc(h, pk.size(), pk.data(), rc);
         pk.resize((size_t)nh * 2 * nh);
-        pack_t(nh, 2 * nh, h->host_b.data(), pk.data());
+        stoch_pack_t(nh, 2 * nh, h->host_b.data(), pk.data());
         h->wT_b = dev_alloc(h, pk.size(), pk.data(), rc);
         h->ZN = dev_alloc(h, R * nh, nullptr, rc);
         h->Zs = dev_alloc(h, R * nh, nullptr, rc);

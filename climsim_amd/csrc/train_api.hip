@@ -12,6 +12,7 @@
 #include "common.h"
 #include "pack.h"
 #include "train.h"
+#include "stoch.h"
 #include <algorithm>
 #include <string>
 #include <vector>
@@ -24,6 +25,11 @@ struct Gather { float *dst; int *idx; int *idx2; int n; };
 
 struct Slot {   // saved activations of one time step of the window
     float *X16, *xs, *X1, *GP1, *C1, *H1lev, *H1seq, *GP2, *C2, *H2, *Z, *hc0;
+    // add_stochastic_layer: layer "1" = rnn0 (down), layer "2" = rnn1 (up), then the stochastic LSTM (down)
+    float *Hb = nullptr;               // rnn1's hidden sequence in level order (input of the stochastic layer)
+    float *Zs = nullptr;               // the stochastic layer's output (L,B,nh), the head's input
+    float *sXP = nullptr, *sH = nullptr, *sC = nullptr;     // its saved activations (swapped into the csa_stoch handle per call)
+    const float *eps = nullptr;        // the caller's noise of this slot (kept alive by the caller until backward)
 };
 
 }  // namespace
@@ -52,6 +58,9 @@ struct csa_trainer {
     bool defer = false;
     std::vector<int> pending;
     int pending_B = 0;
+    csa_stoch *stoch = nullptr;       // add_stochastic_layer: MyStochasticLSTMLayer4 (weights are gathers of the flat parameters)
+    int off_enc = 0;                  // offset of rnn2.weight_encoder in the flat parameter / gradient buffers
+    float *dscr = nullptr;            // discarded gradients of the noise initial state of rnn0
     float sp_scale = 1.f, sp_shift = 0.f;     // xdiv_sca[0], xmean_sca[0]: surface pressure de-normalisation of the loss
     // optional per-stage timing with HIP events on the call's own stream (csa_train_set_profiling; bench.py's roofline)
     bool profiling = false;
@@ -164,8 +173,12 @@ extern "C" int csa_train_create(const csa_config *cfg, const csa_params *p, cons
 {
     if (!cfg || !p || !hyai || !hybi || !out || max_batch <= 0 || max_window <= 0) { csa_set_error_msg("csa_train_create: bad argument"); return CSA_ERR_ARG; }
     const csa_config &c = *cfg;
-    if (c.legacy || c.nh_mem <= 0 || c.mp_mode != 1 || c.add_stochastic_layer) {
+    if (c.legacy || c.nh_mem <= 0 || c.mp_mode != 1) {
         csa_set_error_msg("csa_train_create: the HIP training step covers the current-generation LSTM / GRU with memory, mp_mode 1");
+        return CSA_ERR_UNSUPPORTED;
+    }
+    if (c.add_stochastic_layer && (!c.use_lstm || c.nh1 != c.nh2 || c.nh1 > 128 || !p->rnn0_w_ih || !p->rnn2_weight_encoder)) {
+        csa_set_error_msg("csa_train_create: add_stochastic_layer needs the LSTM flavour with nh1 == nh2 <= 128 and rnn0 / rnn2.weight_encoder");
         return CSA_ERR_UNSUPPORTED;
     }
     if (!c.use_lstm && !((c.nh1 == 64 || c.nh1 == 128) && (c.nh2 == 64 || c.nh2 == 128))) {
@@ -195,11 +208,21 @@ extern "C" int csa_train_create(const csa_config *cfg, const csa_params *p, cons
     srcs.insert(srcs.end(), {{"mlp_initial.weight", p->mlp_initial_w, nh1, nxp}, {"mlp_initial.bias", p->mlp_initial_b, nh1, 1},
                              {"mlp_surface1.weight", p->mlp_surface1_w, nh1, nxs}, {"mlp_surface1.bias", p->mlp_surface1_b, nh1, 1}});
     if (lstm) { srcs.push_back({"mlp_surface2.weight", p->mlp_surface2_w, nh1, nxs}); srcs.push_back({"mlp_surface2.bias", p->mlp_surface2_b, nh1, 1}); }
+    const bool st = c.add_stochastic_layer != 0;
+    if (st)     // models.py:405-412: rnn0 (nh+nm -> nh), rnn1 (nh -> nh), rnn2 = MyStochasticLSTMLayer4(nh, nh)
+        srcs.insert(srcs.end(), {
+            {"rnn0.weight_ih_l0", p->rnn0_w_ih, G * nh1, nin1}, {"rnn0.weight_hh_l0", p->rnn0_w_hh, G * nh1, nh1},
+            {"rnn0.bias_ih_l0", p->rnn0_b_ih, G * nh1, 1}, {"rnn0.bias_hh_l0", p->rnn0_b_hh, G * nh1, 1},
+            {"rnn1.weight_ih_l0", p->rnn1_w_ih, G * nh2, nh1}, {"rnn1.weight_hh_l0", p->rnn1_w_hh, G * nh2, nh2},
+            {"rnn1.bias_ih_l0", p->rnn1_b_ih, G * nh2, 1}, {"rnn1.bias_hh_l0", p->rnn1_b_hh, G * nh2, 1},
+            {"rnn2.weight_encoder", p->rnn2_weight_encoder, nh1 + nh2, 5 * nh2}});
+    else
+        srcs.insert(srcs.end(), {
+            {"rnn1.weight_ih_l0", p->rnn1_w_ih, G * nh1, nin1}, {"rnn1.weight_hh_l0", p->rnn1_w_hh, G * nh1, nh1},
+            {"rnn1.bias_ih_l0", p->rnn1_b_ih, G * nh1, 1}, {"rnn1.bias_hh_l0", p->rnn1_b_hh, G * nh1, 1},
+            {"rnn2.weight_ih_l0", p->rnn2_w_ih, G * nh2, nh1}, {"rnn2.weight_hh_l0", p->rnn2_w_hh, G * nh2, nh2},
+            {"rnn2.bias_ih_l0", p->rnn2_b_ih, G * nh2, 1}, {"rnn2.bias_hh_l0", p->rnn2_b_hh, G * nh2, 1}});
     srcs.insert(srcs.end(), {
-        {"rnn1.weight_ih_l0", p->rnn1_w_ih, G * nh1, nin1}, {"rnn1.weight_hh_l0", p->rnn1_w_hh, G * nh1, nh1},
-        {"rnn1.bias_ih_l0", p->rnn1_b_ih, G * nh1, 1}, {"rnn1.bias_hh_l0", p->rnn1_b_hh, G * nh1, 1},
-        {"rnn2.weight_ih_l0", p->rnn2_w_ih, G * nh2, nh1}, {"rnn2.weight_hh_l0", p->rnn2_w_hh, G * nh2, nh2},
-        {"rnn2.bias_ih_l0", p->rnn2_b_ih, G * nh2, 1}, {"rnn2.bias_hh_l0", p->rnn2_b_hh, G * nh2, 1},
         {"mlp_latent.weight", p->mlp_latent_w, nm, nh2}, {"mlp_latent.bias", p->mlp_latent_b, nm, 1},
         {"mlp_output.weight", p->mlp_output_w, c.ny, nm}, {"mlp_output.bias", p->mlp_output_b, c.ny, 1},
         {"mlp_surface_output.weight", p->mlp_surface_output_w, c.ny_sfc, nh2},
@@ -309,10 +332,13 @@ extern "C" int csa_train_create(const csa_config *cfg, const csa_params *p, cons
         whhTp = (float *)add_gather(h, to_int(pkT, o_whh), nullptr, rc);
         wihT = (float *)add_gather(h, t, nullptr, rc);
     };
+    // the two deterministic layers in execution order: (rnn1, rnn2), or (rnn0, rnn1) for the stochastic variant
+    const std::string la = st ? "rnn0" : "rnn1", lb = st ? "rnn1" : "rnn2";
+    auto ON = [&](const std::string &n) { return O(n.c_str()); };
     if (lstm) {
-        lstm_pack(nh1, nin1, O("rnn1.weight_ih_l0"), O("rnn1.weight_hh_l0"), O("rnn1.bias_ih_l0"), O("rnn1.bias_hh_l0"),
+        lstm_pack(nh1, nin1, ON(la + ".weight_ih_l0"), ON(la + ".weight_hh_l0"), ON(la + ".bias_ih_l0"), ON(la + ".bias_hh_l0"),
                   d.wih1, d.bias1, d.whh1p, h->whh1Tp, h->wih1T, rowmap1);
-        lstm_pack(nh2, nh1, O("rnn2.weight_ih_l0"), O("rnn2.weight_hh_l0"), O("rnn2.bias_ih_l0"), O("rnn2.bias_hh_l0"),
+        lstm_pack(nh2, nh1, ON(lb + ".weight_ih_l0"), ON(lb + ".weight_hh_l0"), ON(lb + ".bias_ih_l0"), ON(lb + ".bias_hh_l0"),
                   d.wih2, d.bias2, d.whh2p, h->whh2Tp, h->wih2T, rowmap2);
     } else {
         gru_pack(nh1, nin1, O("rnn1.weight_ih_l0"), O("rnn1.weight_hh_l0"), O("rnn1.bias_ih_l0"), O("rnn1.bias_hh_l0"),
@@ -335,14 +361,14 @@ extern "C" int csa_train_create(const csa_config *cfg, const csa_params *p, cons
     };
     auto bmap = [&](const std::vector<int> &rowmap, int o) { std::vector<int> v(rowmap.size()); for (size_t n = 0; n < rowmap.size(); ++n) v[n] = o + rowmap[n]; return v; };
     if (lstm) {
-        h->map_wih1 = upload_idx(h, wmap(rowmap1, nin1, O("rnn1.weight_ih_l0")), rc);
-        h->map_whh1 = upload_idx(h, wmap(rowmap1, nh1, O("rnn1.weight_hh_l0")), rc);
-        h->map_b1a = upload_idx(h, bmap(rowmap1, O("rnn1.bias_ih_l0")), rc);
-        h->map_b1b = upload_idx(h, bmap(rowmap1, O("rnn1.bias_hh_l0")), rc);
-        h->map_wih2 = upload_idx(h, wmap(rowmap2, nh1, O("rnn2.weight_ih_l0")), rc);
-        h->map_whh2 = upload_idx(h, wmap(rowmap2, nh2, O("rnn2.weight_hh_l0")), rc);
-        h->map_b2a = upload_idx(h, bmap(rowmap2, O("rnn2.bias_ih_l0")), rc);
-        h->map_b2b = upload_idx(h, bmap(rowmap2, O("rnn2.bias_hh_l0")), rc);
+        h->map_wih1 = upload_idx(h, wmap(rowmap1, nin1, ON(la + ".weight_ih_l0")), rc);
+        h->map_whh1 = upload_idx(h, wmap(rowmap1, nh1, ON(la + ".weight_hh_l0")), rc);
+        h->map_b1a = upload_idx(h, bmap(rowmap1, ON(la + ".bias_ih_l0")), rc);
+        h->map_b1b = upload_idx(h, bmap(rowmap1, ON(la + ".bias_hh_l0")), rc);
+        h->map_wih2 = upload_idx(h, wmap(rowmap2, nh1, ON(lb + ".weight_ih_l0")), rc);
+        h->map_whh2 = upload_idx(h, wmap(rowmap2, nh2, ON(lb + ".weight_hh_l0")), rc);
+        h->map_b2a = upload_idx(h, bmap(rowmap2, ON(lb + ".bias_ih_l0")), rc);
+        h->map_b2b = upload_idx(h, bmap(rowmap2, ON(lb + ".bias_hh_l0")), rc);
     } else {
         h->map_wih1 = upload_idx(h, gm1.wih, rc); h->map_whh1 = upload_idx(h, gm1.whh, rc);
         h->map_b1a = upload_idx(h, gm1.ba, rc); h->map_b1b = upload_idx(h, gm1.bb, rc);
@@ -382,6 +408,34 @@ extern "C" int csa_train_create(const csa_config *cfg, const csa_params *p, cons
         s.Z = dalloc<float>(h, LB * nm, rc); s.hc0 = dalloc<float>(h, 4 * Bm * nhm, rc);
         h->slots.push_back(s);
     }
+    if (st && rc == CSA_OK) {
+        // the stochastic layer: ONE handle; its weight layouts become gathers of the flat parameters (so Adam's re-pack
+        // refreshes them too), its saved activations are per-slot buffers swapped in before every call
+        rc = csa_stoch_lstm4_create(nh1, nh2, p->rnn2_weight_encoder, (int)LB, &h->stoch);
+        if (rc == CSA_OK) rc = csa_stoch_enable_training(h->stoch);
+        if (rc == CSA_OK) {
+            const int oe = O("rnn2.weight_encoder"), W5 = 5 * nh2;
+            h->off_enc = oe;
+            auto reg = [&](float *dst, const std::vector<int> &idx) {
+                Gather g; g.n = (int)idx.size(); g.dst = dst; g.idx = upload_idx(h, idx, rc); g.idx2 = nullptr;
+                h->gathers.push_back(g);
+            };
+            std::vector<float> iv = index_values((size_t)nh2 * W5), pk((size_t)nh2 * W5);
+            stoch_pack_rows(nh2, 5, iv.data(), W5, 0, pk.data());                 // forward packing of the hidden half
+            reg(h->stoch->wp_a, to_int(pk, oe + nh1 * W5));
+            stoch_pack_t(nh2, W5, iv.data(), pk.data());                          // BPTT packing
+            reg(h->stoch->wT_a, to_int(pk, oe + nh1 * W5));
+            std::vector<int> t((size_t)W5 * nh1);                                 // (5H, nx) transposed input half for the NT GEMM
+            for (int k = 0; k < nh1; ++k) for (int n = 0; n < W5; ++n) t[(size_t)n * nh1 + k] = oe + k * W5 + n;
+            reg(h->stoch->w_in_t, t);
+            reg(h->stoch->w_ref_in, iota_off(oe, nh1 * W5));
+        }
+        for (Slot &S : h->slots) {
+            S.Hb = dalloc<float>(h, LB * nh2, rc); S.Zs = dalloc<float>(h, LB * nh2, rc);
+            S.sXP = dalloc<float>(h, LB * 5 * nh2, rc); S.sH = dalloc<float>(h, (LB + Bm) * nh2, rc); S.sC = dalloc<float>(h, (LB + Bm) * nh2, rc);
+        }
+        h->dscr = dalloc<float>(h, 2 * Bm * nhm, rc);
+    }
     h->dH2 = dalloc<float>(h, LB * nh2, rc); h->dH1 = dalloc<float>(h, LB * nh1, rc);
     h->dX1 = dalloc<float>(h, LB * nin1, rc);
     h->dhc1 = dalloc<float>(h, 2 * Bm * nhm, rc); h->dhc2 = dalloc<float>(h, 2 * Bm * nhm, rc);
@@ -399,6 +453,7 @@ extern "C" int csa_train_create(const csa_config *cfg, const csa_params *p, cons
     if (rc == CSA_OK) rc = repack(h, 0);
     if (rc == CSA_OK && hipDeviceSynchronize() != hipSuccess) rc = CSA_ERR_HIP;
     if (rc != CSA_OK) {
+        if (h->stoch) (void)csa_stoch_destroy(h->stoch);
         for (void *q : h->owned) (void)hipFree(q);
         delete h;
         return rc;
@@ -411,6 +466,7 @@ extern "C" int csa_train_destroy(csa_trainer *h)
 {
     if (!h) return CSA_ERR_ARG;
     prof_collect(h);
+    if (h->stoch) (void)csa_stoch_destroy(h->stoch);
     for (hipEvent_t e : h->ev_free) (void)hipEventDestroy(e);
     for (void *q : h->owned) (void)hipFree(q);
     delete h;
@@ -450,6 +506,7 @@ extern "C" int csa_train_forward(csa_trainer *h, int slot, int B, const float *x
     }
     hipStream_t s = (hipStream_t)stream;
     const csa_config &c = h->dm.cfg;
+    if (c.add_stochastic_layer) { csa_set_error_msg("csa_train_forward: the stochastic variant takes its noise explicitly (csa_train_forward_noise)"); return CSA_ERR_ARG; }
     const int L = c.nlev, nh1 = c.nh1, nh2 = c.nh2, nm = c.nh_mem, nhm = nh1 > nh2 ? nh1 : nh2;
     Slot &S = h->slots[slot];
     int rc;
@@ -481,6 +538,75 @@ extern "C" int csa_train_forward(csa_trainer *h, int slot, int B, const float *x
     return CSA_OK;
 }
 
+// ---- the stochastic variant (models.py:464-474,521-534): rnn0 down (noise init) -> rnn1 up (surface init) -> stochastic LSTM down
+// (TOA init).  Layer "1" of the trainer is rnn0 (X1 in LEVEL order), layer "2" is rnn1 (its input H1lev = rnn0's sequence flipped).
+extern "C" int csa_train_forward_noise(csa_trainer *h, int slot, int B, const float *x_main_n, const float *x_sfc_n, const float *mem_in,
+                                       const float *hx0, const float *cx0, const float *eps, float *out, float *out_sfc,
+                                       float *mem_out, void *stream)
+{
+    if (!h || !h->stoch || slot < 0 || slot >= h->max_window || B <= 0 || B > h->max_batch || !x_main_n || !x_sfc_n || !mem_in || !hx0 ||
+        !cx0 || !eps || !out || !out_sfc || !mem_out) {
+        csa_set_error_msg("csa_train_forward_noise: bad argument (or the trainer was not created with add_stochastic_layer)");
+        return CSA_ERR_ARG;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    const csa_config &c = h->dm.cfg;
+    const int L = c.nlev, nh = c.nh1, nm = c.nh_mem;
+    Slot &S = h->slots[slot];
+    int rc;
+    if ((rc = launch_prep_train(h->dm, B, 1, x_main_n, x_sfc_n, mem_in, S.X1, S.hc0, S.X16, S.xs, s))) return rc;
+    if ((rc = launch_proj_gemm(S.X1, h->dm.wih1, h->dm.bias1, S.GP1, L * B, 4 * nh, nh + nm, s))) return rc;
+    // rnn0 runs downward over the level-ordered rows; its output is stored flipped = the sequence order of the upward rnn1
+    if ((rc = launch_rec_train(nh, h->dm.whh1p, S.GP1, hx0, cx0, S.H1lev, B, L, 1, S.H1seq, S.C1, s))) return rc;
+    if ((rc = launch_proj_gemm(S.H1lev, h->dm.wih2, h->dm.bias2, S.GP2, L * B, 4 * nh, nh, s))) return rc;
+    if ((rc = launch_rec_train(nh, h->dm.whh2p, S.GP2, S.hc0, S.hc0 + (size_t)B * nh, S.Hb, B, L, 1, S.H2, S.C2, s))) return rc;
+    csa_stoch *st = h->stoch;
+    st->XP = S.sXP; st->Hseq = S.sH; st->Cseq = S.sC;
+    if ((rc = csa_stoch_lstm4_forward_train(st, L, B, S.Hb, S.hc0 + (size_t)2 * B * nh, S.hc0 + (size_t)3 * B * nh, eps, S.Zs, nullptr,
+                                            nullptr, s))) return rc;
+    S.eps = eps;
+    if ((rc = launch_head(h->dm, B, HEAD_RAW, S.Zs, x_main_n, nullptr, out, out_sfc, S.Z, s))) return rc;
+    CSA_HIP_CHECK(hipMemcpyAsync(mem_out, S.Z, sizeof(float) * (size_t)L * B * nm, hipMemcpyDeviceToDevice, s));
+    return CSA_OK;
+}
+
+static int train_backward_stoch(csa_trainer *h, int slot, int B, const float *d_out, const float *d_out_sfc, const float *d_mem_out,
+                                float *d_mem_in, float *grads, hipStream_t s)
+{
+    const csa_config &c = h->dm.cfg;
+    const int L = c.nlev, nh = c.nh1, nm = c.nh_mem, nin1 = nh + nm, M = L * B, ns = h->nsplit;
+    Slot &S = h->slots[slot];
+    if (!S.eps) { csa_set_error_msg("csa_train_backward: no forward_noise call recorded for this slot"); return CSA_ERR_ARG; }
+    int rc;
+    if ((rc = launch_head_bwd(h->dm, B, d_out, d_out_sfc, d_mem_out, S.Z, S.Zs, h->dH2, h->part, s))) return rc;
+    if ((rc = launch_reduce_partials_2stage(h->part, B, head_bwd_partial_floats(c), h->map_head, nullptr, grads, h->rtmp, 32, s))) return rc;
+    // stochastic LSTM: BPTT + its input / weight gradients; d(h0, c0) = the gradients of the TOA MLPs' outputs
+    csa_stoch *st = h->stoch;
+    st->XP = S.sXP; st->Hseq = S.sH; st->Cseq = S.sC;
+    if ((rc = csa_stoch_lstm4_backward(st, L, B, S.Hb, S.eps, h->dH2, nullptr, nullptr, h->dH1, h->dhc2, h->dhc2 + (size_t)B * nh, nullptr,
+                                       grads + h->off_enc, s))) return rc;
+    // rnn1 (upward; dH1 is in level order, the recurrence ran in sequence order); d(h0, c0) -> the surface MLPs
+    if ((rc = launch_bwd_rec(nh, h->whh2Tp, S.GP2, S.C2, h->dH1, h->dhc1, h->dhc1 + (size_t)B * nh, B, L, 1, s))) return rc;
+    if ((rc = launch_proj_gemm(S.GP2, h->wih2T, nullptr, h->dH2, M, nh, 4 * nh, s))) return rc;          // d(H1lev), rnn1's sequence order
+    if ((rc = launch_gemm_tn_partial(S.GP2, 4 * nh, S.H1lev, nh, h->part, M, 4 * nh, nh, ns, s))) return rc;
+    if ((rc = launch_reduce_partials(h->part, ns, 4 * nh * nh, h->map_wih2, nullptr, grads, s))) return rc;
+    if ((rc = launch_gemm_tn_partial(S.GP2, 4 * nh, S.H2, nh, h->part, M, 4 * nh, nh, ns, s))) return rc;
+    if ((rc = launch_reduce_partials(h->part, ns, 4 * nh * nh, h->map_whh2, nullptr, grads, s))) return rc;
+    if ((rc = launch_colsum_partial(S.GP2, h->part, M, 4 * nh, ns, s))) return rc;
+    if ((rc = launch_reduce_partials(h->part, ns, 4 * nh, h->map_b2a, h->map_b2b, grads, s))) return rc;
+    // rnn0 (downward; its output row of step t sits at flipped position L-1-t): initial state was noise, its gradient is dropped
+    if ((rc = launch_bwd_rec(nh, h->whh1Tp, S.GP1, S.C1, h->dH2, h->dscr, h->dscr + (size_t)B * nh, B, L, 1, s))) return rc;
+    if ((rc = launch_proj_gemm(S.GP1, h->wih1T, nullptr, h->dX1, M, nin1, 4 * nh, s))) return rc;
+    if ((rc = launch_gemm_tn_partial(S.GP1, 4 * nh, S.X1, nin1, h->part, M, 4 * nh, nin1, ns, s))) return rc;
+    if ((rc = launch_reduce_partials(h->part, ns, 4 * nh * nin1, h->map_wih1, nullptr, grads, s))) return rc;
+    if ((rc = launch_gemm_tn_partial(S.GP1, 4 * nh, S.H1seq, nh, h->part, M, 4 * nh, nh, ns, s))) return rc;
+    if ((rc = launch_reduce_partials(h->part, ns, 4 * nh * nh, h->map_whh1, nullptr, grads, s))) return rc;
+    if ((rc = launch_colsum_partial(S.GP1, h->part, M, 4 * nh, ns, s))) return rc;
+    if ((rc = launch_reduce_partials(h->part, ns, 4 * nh, h->map_b1a, h->map_b1b, grads, s))) return rc;
+    if ((rc = launch_prep_bwd(h->dm, B, h->dX1, S.X1, S.X16, S.xs, S.hc0, h->dhc1, h->dhc2, d_mem_in, h->part, s))) return rc;
+    return launch_reduce_partials_2stage(h->part, B, prep_bwd_partial_floats(c), h->map_prep, nullptr, grads, h->rtmp, 32, s);
+}
+
 extern "C" int csa_train_backward(csa_trainer *h, int slot, int B, const float *d_out, const float *d_out_sfc,
                                   const float *d_mem_out, float *d_mem_in, float *grads, void *stream)
 {
@@ -490,6 +616,7 @@ extern "C" int csa_train_backward(csa_trainer *h, int slot, int B, const float *
     }
     hipStream_t s = (hipStream_t)stream;
     const csa_config &c = h->dm.cfg;
+    if (c.add_stochastic_layer) return train_backward_stoch(h, slot, B, d_out, d_out_sfc, d_mem_out, d_mem_in, grads, s);
     const int L = c.nlev, nh1 = c.nh1, nh2 = c.nh2, nm = c.nh_mem, nin1 = nh1 + nm, M = L * B, ns = h->nsplit;
     const int nhm = nh1 > nh2 ? nh1 : nh2;
     Slot &S = h->slots[slot];
@@ -545,6 +672,7 @@ extern "C" int csa_train_set_deferred(csa_trainer *h, int enable)
 {
     if (!h) return CSA_ERR_ARG;
     if (!h->pending.empty()) { csa_set_error_msg("csa_train_set_deferred: flush pending gradients first"); return CSA_ERR_ARG; }
+    if (enable && h->stoch) { csa_set_error_msg("csa_train_set_deferred: not available for the stochastic variant"); return CSA_ERR_UNSUPPORTED; }
     h->defer = enable != 0;
     return CSA_OK;
 }

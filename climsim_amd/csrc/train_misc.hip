@@ -425,7 +425,10 @@ __global__ __launch_bounds__(128) void prep_bwd_kernel(
 #pragma unroll
             for (int u = 0; u < PB_U; ++u) {
                 const float dA = t0 + u < L ? dx[u] * (1.0f - a[u] * a[u]) : 0.0f;
-                const f32x4 *xr = (const f32x4 *)(x16 + (L - 1 - min(t0 + u, L - 1)) * 32);
+                // X1 row t is level L-1-t (rnn1 runs upward over the flipped sequence) or, for the stochastic variant whose
+                // first RNN runs downward, level t
+                const int tt = min(t0 + u, L - 1);
+                const f32x4 *xr = (const f32x4 *)(x16 + (m.cfg.add_stochastic_layer ? tt : L - 1 - tt) * 32);
                 gb += dA;
 #pragma unroll
                 for (int q = 0; q < 8; ++q) {
@@ -464,7 +467,7 @@ __global__ __launch_bounds__(128) void prep_bwd_kernel(
     if (d_mem_in)
         for (int idx = tid; idx < L * nm; idx += 128) {
             const int t = idx / nm, k = idx - t * nm;
-            d_mem_in[((size_t)(L - 1 - t) * B + b) * nm + k] = dX1[((size_t)t * B + b) * nin1 + nh1 + k];
+            d_mem_in[((size_t)(m.cfg.add_stochastic_layer ? t : L - 1 - t) * B + b) * nm + k] = dX1[((size_t)t * B + b) * nin1 + nh1 + k];
         }
 }
 

@@ -46,7 +46,10 @@ class Trainer:
         cfg.ny = host["mlp_output_w"].shape[0]
         cfg.ny_sfc = host["mlp_surface_output_w"].shape[0]
         cfg.nh1 = host["rnn1_w_hh"].shape[1]
-        cfg.nh2 = host["rnn2_w_hh"].shape[1]
+        # add_stochastic_layer (models.py:405-412) is recognised by its parameters: rnn0.* + rnn2.weight_encoder
+        self.stochastic = "rnn2_weight_encoder" in host
+        cfg.add_stochastic_layer = int(self.stochastic)
+        cfg.nh2 = host["rnn2_weight_encoder"].shape[1] // 5 if self.stochastic else host["rnn2_w_hh"].shape[1]
         cfg.nh_mem = host["mlp_latent_w"].shape[0]
         cfg.use_lstm, cfg.legacy, cfg.mp_mode = int(use_lstm), 0, 1
         cfg.output_prune, cfg.scrub_inf = int(output_prune), 1
@@ -161,6 +164,26 @@ class Trainer:
                  "csa_train_forward")
         return out, out_sfc, mem_out
 
+    def forward_noise(self, slot, x_main_n, x_sfc_n, rnn_mem, hx0, cx0, eps):
+        """Stochastic variant: forward of one window step with the reference's three randn draws given (hx0, cx0 (B,nh), eps
+        (nlev,B,nh)); eps is kept referenced until the slot's backward."""
+        c = self.cfg
+        B = x_main_n.shape[0]
+        x_main_n = _check(x_main_n, (B, c.nlev, c.nx), "x_main")
+        x_sfc_n = _check(x_sfc_n, (B, c.nx_sfc), "x_sfc")
+        rnn_mem = _check(rnn_mem, (c.nlev, B, c.nh_mem), "rnn_mem")
+        hx0, cx0 = _check(hx0, (B, c.nh1), "hx0"), _check(cx0, (B, c.nh1), "cx0")
+        eps = _check(eps, (c.nlev, B, c.nh2), "eps")
+        out = torch.empty(B, c.nlev, c.ny, device=self.device)
+        out_sfc = torch.empty(B, c.ny_sfc, device=self.device)
+        mem_out = torch.empty(c.nlev, B, c.nh_mem, device=self.device)
+        self._rc(_lib.lib().csa_train_forward_noise(self._h, int(slot), B, _ptr(x_main_n), _ptr(x_sfc_n), _ptr(rnn_mem), _ptr(hx0),
+                                                    _ptr(cx0), _ptr(eps), _ptr(out), _ptr(out_sfc), _ptr(mem_out), self._stream()),
+                 "csa_train_forward_noise")
+        self._keep_eps = getattr(self, "_keep_eps", {})
+        self._keep_eps[int(slot)] = eps
+        return out, out_sfc, mem_out
+
     def backward(self, slot, d_out, d_out_sfc, d_mem_out=None, want_d_mem_in=True):
         c = self.cfg
         B = d_out.shape[0]
@@ -243,3 +266,51 @@ class Trainer:
             self.adam_step()
         names = ["loss", "huber", "mse", "mae", "energy", "water", "precip_sum_mse"]
         return dict(zip(names, self.scalars.tolist())), mem.detach(), d_mem
+
+    # ---- ensemble / CRPS training of the stochastic variant (rnn/utils.py:1065-1075, 1213, 1363-1377) ------------------------
+    def ensemble_window_step(self, x_main_n, x_sfc_n, tgt, tgt_sfc, rnn_mem, ensemble_size, *, noise=None, beta=1.0, alpha=1.0,
+                             world_size=1, global_columns=None, optimise=True):
+        """One optimiser step on the ensemble score: every step of the window runs E = ensemble_size members per column
+        (inputs replicated member-major, one noise draw per member: `noise[t] = (hx0, cx0 (E*B,nh), eps (nlev,E*B,nh))`, drawn
+        here when omitted), loss = CRPS(targets, ensemble outputs) over the window (rnn/metrics.py:535-626), its gradient comes
+        from csa_crps_backward, BPTT runs through the slots with d(rnn_mem) chained.  rnn_mem: (nlev, E*B, nh_mem).
+        Returns ({"loss": CRPS, "skill": ..., "spread": ...}, new rnn_mem (detached), d(rnn_mem at window start))."""
+        if not self.stochastic:
+            raise RuntimeError("ensemble_window_step needs a model with add_stochastic_layer")
+        c, L = self.cfg, _lib.lib()
+        Tw, B, E = len(x_main_n), x_main_n[0].shape[0], int(ensemble_size)
+        BE = B * E
+        rep = lambda t: torch.repeat_interleave(t.unsqueeze(0), E, dim=0).flatten(0, 1).contiguous()
+        preds, preds_sfc, mem = [], [], rnn_mem
+        for t in range(Tw):
+            if noise is None:
+                nz = (torch.randn(BE, c.nh1, device=self.device), torch.randn(BE, c.nh1, device=self.device),
+                      torch.randn(c.nlev, BE, c.nh2, device=self.device))
+            else:
+                nz = noise[t]
+            o, os_, mem = self.forward_noise(t, rep(x_main_n[t]), rep(x_sfc_n[t]), mem, *nz)
+            preds.append(o)
+            preds_sfc.append(os_)
+        yp, yps = torch.cat(preds, 0).contiguous(), torch.cat(preds_sfc, 0).contiguous()
+        y = _check(torch.cat(list(tgt), 0).contiguous(), (Tw * B, c.nlev, c.ny), "tgt")
+        ys = _check(torch.cat(list(tgt_sfc), 0).contiguous(), (Tw * B, c.ny_sfc), "tgt_sfc")
+        D1, D2 = c.nlev * c.ny, c.ny_sfc
+        scratch, out3 = torch.empty(2 * Tw * B, device=self.device), torch.empty(3, device=self.device)
+        self._rc(L.csa_crps(Tw, B, E, D1, D2, _ptr(y), _ptr(ys), _ptr(yp), _ptr(yps), float(beta), float(alpha), _ptr(scratch),
+                            _ptr(out3), self._stream()), "csa_crps")
+        share = shard_loss_scale(B, global_columns) if (world_size > 1 and global_columns) else 1.0
+        d_p, d_s = torch.empty_like(yp), torch.empty_like(yps)
+        self._rc(L.csa_crps_backward(Tw, B, E, D1, D2, _ptr(y), _ptr(ys), _ptr(yp), _ptr(yps), float(beta), float(alpha), float(share),
+                                     _ptr(d_p), _ptr(d_s), self._stream()), "csa_crps_backward")
+        self.grads.zero_()
+        d_mem = None
+        for t in reversed(range(Tw)):
+            d_mem = self.backward(t, d_p[t * BE:(t + 1) * BE], d_s[t * BE:(t + 1) * BE], d_mem)
+        sc = out3 * share
+        if world_size > 1:
+            allreduce_flat_(self.grads, world_size, average=not bool(global_columns))
+            allreduce_flat_(sc, world_size, average=not bool(global_columns))
+        if optimise:
+            self.adam_step()
+        v = sc.tolist()
+        return {"loss": v[0], "skill": v[1], "spread": v[2]}, mem.detach(), d_mem

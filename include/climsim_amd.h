@@ -198,6 +198,15 @@ int csa_train_sync_params(csa_trainer *h, void *stream);     /* re-pack after wr
 int csa_train_copy_state(csa_trainer *h, int which, int dir, float *buf, void *stream);
 int csa_train_forward(csa_trainer *h, int slot, int B, const float *x_main_n, const float *x_sfc_n,
                       const float *mem_in, float *out, float *out_sfc, float *mem_out, void *stream);
+/* The stochastic variant (cfg.add_stochastic_layer; models.py:464-474,521-534: rnn0 down with noise initial state -> rnn1 up ->
+ * MyStochasticLSTMLayer4 down): forward with the three N(0,1) draws of the reference passed explicitly, as in
+ * csa_model_forward_noise: hx0, cx0 (B,nh1), eps (nlev,B,nh2).  `eps` is read again by csa_train_backward of the same slot:
+ * the caller keeps it alive until then.  csa_train_backward / _adam / _copy_state work unchanged (the flat layout carries
+ * rnn0.*, rnn1.*, rnn2.weight_encoder in state_dict order); the deferred weight-gradient mode is not available.  Ensemble
+ * training (rnn/utils.py:1065-1075,1213) = B * E columns per call (inputs replicated member-major), d_out from csa_crps_backward. */
+int csa_train_forward_noise(csa_trainer *h, int slot, int B, const float *x_main_n, const float *x_sfc_n, const float *mem_in,
+                            const float *hx0, const float *cx0, const float *eps, float *out, float *out_sfc, float *mem_out,
+                            void *stream);
 int csa_train_backward(csa_trainer *h, int slot, int B, const float *d_out, const float *d_out_sfc,
                        const float *d_mem_out /* nullable */, float *d_mem_in /* nullable */, float *grads, void *stream);
 /* Deferred weight gradients: with enable = 1 the backward calls skip the W_ih / W_hh gradient GEMMs and

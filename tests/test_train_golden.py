@@ -221,3 +221,44 @@ def test_bench_two_ranks_rehearsal_on_one_gpu():
     assert d["n_gpus"] == 2 and d["steps"] == 5 and d["value"] > 0
     assert d["memory_wrapper"]["value"] > 0 and d["train"]["value"] > 0 and d["train"]["roofline"]["avg_launch_ms"] > 0
     assert np.isfinite(d["train"]["loss"])
+
+
+@pytest.mark.gpu
+def test_hip_ensemble_crps_training_step_vs_reference_autograd():
+    """Training of the stochastic model (add_stochastic_layer: rnn0 down -> rnn1 up -> MyStochasticLSTMLayer4 down) on the
+    ensemble score: the HIP window step (E = 2 members, T_w = 2, BPTT through all three RNNs, csa_crps_backward) against
+    autograd through the reference's own RNN_autoreg + metrics.CRPS with the same noise draws
+    (tests/golden/make_golden_stoch_train.py): score, every parameter gradient, d(rnn_mem)."""
+    from climsim_amd.train import Trainer
+    consts, weights, flags = load_npz_model("cur_stoch")
+    io = np.load(os.path.join(GOLDEN, "cur_stoch_train.npz"))
+    grid = np.load(os.path.join(GOLDEN, "grid_consts.npz"))
+    B, E, Tw = int(io["B"]), int(io["E"]), int(io["T_w"])
+    tr = Trainer(consts, weights, grid["hyai"], grid["hybi"], use_lstm=True, output_prune=bool(flags["output_prune"]),
+                 max_batch=B * E, max_window=Tw)
+    assert tr.stochastic and "rnn2.weight_encoder" in tr.layout and "rnn0.weight_ih_l0" in tr.layout
+    d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    noise = [(d(io[f"t{t}.hx0"]), d(io[f"t{t}.cx0"]), d(io[f"t{t}.eps"])) for t in range(Tw)]
+    tgt, tgt_sfc = d(io["tgt"]), d(io["tgt_sfc"])
+    sc, mem, d_mem0 = tr.ensemble_window_step([d(io[f"t{t}.x_main_n"]) for t in range(Tw)], [d(io[f"t{t}.x_sfc_n"]) for t in range(Tw)],
+                                              [tgt[t * B:(t + 1) * B] for t in range(Tw)], [tgt_sfc[t * B:(t + 1) * B] for t in range(Tw)],
+                                              d(io["mem0"]), E, noise=noise, optimise=False)
+    assert rel_err(mem.cpu().numpy(), io["mem_final"]) <= 1e-5
+    assert abs(sc["loss"] - float(io["loss"])) <= 1e-5 * abs(float(io["loss"]))
+    assert rel_err(d_mem0.cpu().numpy(), io["d_mem0"]) <= 2e-5
+    worst = {}
+    for name, g in tr.grad_dict().items():
+        ref_g = io["dw." + name]
+        worst[name] = rel_err(g.cpu().numpy().reshape(ref_g.shape), ref_g)
+    bad = {k: v for k, v in worst.items() if v > 2e-5}
+    assert not bad, bad
+    # a few optimiser steps on fresh noise lower the score of a fixed evaluation ensemble
+    ev = lambda: tr.ensemble_window_step([d(io[f"t{t}.x_main_n"]) for t in range(Tw)], [d(io[f"t{t}.x_sfc_n"]) for t in range(Tw)],
+                                         [tgt[t * B:(t + 1) * B] for t in range(Tw)], [tgt_sfc[t * B:(t + 1) * B] for t in range(Tw)],
+                                         d(io["mem0"]), E, noise=noise, optimise=False)[0]["loss"]
+    before = ev()
+    for _ in range(10):
+        tr.ensemble_window_step([d(io[f"t{t}.x_main_n"]) for t in range(Tw)], [d(io[f"t{t}.x_sfc_n"]) for t in range(Tw)],
+                                [tgt[t * B:(t + 1) * B] for t in range(Tw)], [tgt_sfc[t * B:(t + 1) * B] for t in range(Tw)],
+                                d(io["mem0"]), E)
+    assert ev() < before
