@@ -501,6 +501,15 @@ __device__ __forceinline__ void mp_post(float T, float ql, float qi, float dT, f
     dqi = ((1.0f - lf) * qn_new - qi) * 0.0008333333333333334f;
 }
 
+// mp_mode -1 (models.py:303-329): the liquid fraction is the model's 4th output itself (de-normalised; the clamped diagnosed value
+// is overwritten, :319), so d lf / d dT = 0 and d(dql, dqi) / d lf = +- qn_new / 1200
+__device__ __forceinline__ void mp_post_pred(float ql, float qi, float dqn, float lf, float &dql, float &dqi, float &qn_new)
+{
+    qn_new = (ql + qi) + dqn * 1200.0f;
+    dql = (lf * qn_new - ql) * 0.0008333333333333334f;
+    dqi = ((1.0f - lf) * qn_new - qi) * 0.0008333333333333334f;
+}
+
 __device__ __forceinline__ float block_sum(float v, float *red)
 {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
@@ -540,7 +549,8 @@ __global__ __launch_bounds__(128) void loss_pass1_kernel(
         const float *xr = x_raw + ((size_t)n * L + l) * nx, *yt = yto + ((size_t)n * L + l) * 6;
         float dql, dqi, lf, qn; bool in;
         const float dT = o[0] / ys[0], dqv = o[1] / ys[1];
-        mp_post(xr[0], xr[2], xr[3], dT, o[2] / ys[2], dql, dqi, lf, qn, in);
+        if (m.cfg.mp_mode == 1) mp_post(xr[0], xr[2], xr[3], dT, o[2] / ys[2], dql, dqi, lf, qn, in);
+        else mp_post_pred(xr[2], xr[3], o[2] / ys[2], o[3] / ys[3], dql, dqi, qn);
         const float dhyb = hybi[l + 1] - hybi[l], dhya = hyai[l + 1] - hyai[l];
         const float th_e = k.ginv_e * (spn * dhyb + 100000.0f * dhya);
         const float th_w = k.ginv_w * (spn * dhyb + 100000.0f * dhya);
@@ -622,8 +632,10 @@ __global__ __launch_bounds__(128) void loss_pass3_kernel(
             const float d = o[v] - tg[v];
             g[v] = fminf(fmaxf(d, -1.0f), 1.0f) * inv_ntot;
         }
-        float dql, dqi, lf, qn; bool in;
-        mp_post(xr[0], xr[2], xr[3], o[0] / ys[0], o[2] / ys[2], dql, dqi, lf, qn, in);
+        float dql, dqi, lf, qn; bool in = false;
+        const bool diag = m.cfg.mp_mode == 1;
+        if (diag) mp_post(xr[0], xr[2], xr[3], o[0] / ys[0], o[2] / ys[2], dql, dqi, lf, qn, in);
+        else { lf = o[3] / ys[3]; mp_post_pred(xr[2], xr[3], o[2] / ys[2], lf, dql, dqi, qn); }
         const float dhyb = hybi[l + 1] - hybi[l], dhya = hyai[l + 1] - hyai[l];
         const float th_e = k.ginv_e * (spn * dhyb + 100000.0f * dhya);
         const float th_w = k.ginv_w * (spn * dhyb + 100000.0f * dhya);
@@ -640,6 +652,7 @@ __global__ __launch_bounds__(128) void loss_pass3_kernel(
         g[0] += ddT / ys[0];
         g[1] += g_dqv / ys[1];
         g[2] += ddqn / ys[2];
+        if (!diag) g[3] += (g_dql - g_dqi) * qn * s1200 / ys[3];                   // through the predicted liquid fraction
         float *dp = d_pred + ((size_t)n * L + l) * ny;
         for (int v = 0; v < ny; ++v) dp[v] = g[v];
     }
@@ -658,7 +671,7 @@ int launch_loss(const DevModel &m, const float *hyai, const float *hybi, int B, 
                 const float *yto_sfc, const float *x_raw, const float *sp, float *samp, float *ecoef, float *scal,
                 float *d_pred, float *d_pred_sfc, hipStream_t s)
 {
-    if (m.cfg.mp_mode != 1 || m.cfg.ny > 8) { csa_set_error_msg("loss: mp_mode 1 only"); return CSA_ERR_UNSUPPORTED; }
+    if ((m.cfg.mp_mode != 1 && m.cfg.mp_mode != -1) || m.cfg.ny > 8) { csa_set_error_msg("loss: mp_mode 1 and -1"); return CSA_ERR_UNSUPPORTED; }
     const int N = B * Tw;
     hipLaunchKernelGGL(loss_pass1_kernel, dim3(N), dim3(128), 0, s, m, hyai, hybi, N, pred, pred_sfc, tgt, tgt_sfc, yto, yto_sfc, x_raw, sp, samp);
     hipLaunchKernelGGL(loss_pass2_kernel, dim3(1), dim3(256), 0, s, m, B, Tw, w_h, w_w, samp, scal, ecoef);

@@ -24,7 +24,7 @@ from .sharding import allreduce_flat_, shard_loss_scale
 
 
 class Trainer:
-    def __init__(self, consts, state_dict, hyai, hybi, *, use_lstm=True, output_prune=False, max_batch=384, max_window=3,
+    def __init__(self, consts, state_dict, hyai, hybi, *, use_lstm=True, output_prune=False, mp_mode=1, max_batch=384, max_window=3,
                  w_energy=6.0e-6, w_water=6.0e7, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
         self._h = None
         L = _lib.lib()
@@ -51,7 +51,7 @@ class Trainer:
         cfg.add_stochastic_layer = int(self.stochastic)
         cfg.nh2 = host["rnn2_weight_encoder"].shape[1] // 5 if self.stochastic else host["rnn2_w_hh"].shape[1]
         cfg.nh_mem = host["mlp_latent_w"].shape[0]
-        cfg.use_lstm, cfg.legacy, cfg.mp_mode = int(use_lstm), 0, 1
+        cfg.use_lstm, cfg.legacy, cfg.mp_mode = int(use_lstm), 0, int(mp_mode)
         cfg.output_prune, cfg.scrub_inf = int(output_prune), 1
         self.cfg = cfg
         hyai, hybi = _np32(hyai), _np32(hybi)

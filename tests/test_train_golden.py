@@ -262,3 +262,39 @@ def test_hip_ensemble_crps_training_step_vs_reference_autograd():
                                 [tgt[t * B:(t + 1) * B] for t in range(Tw)], [tgt_sfc[t * B:(t + 1) * B] for t in range(Tw)],
                                 d(io["mem0"]), E)
     assert ev() < before
+
+
+@pytest.mark.gpu
+def test_hip_training_step_mp_mode_minus1_vs_reference_gradients():
+    """mp_mode -1 (the model predicts the liquid fraction, models.py:303-329; ny = 6, hidden size 64): loss scalars, every
+    parameter gradient and d(rnn_mem) of a T_w = 3 window against the reference's own autograd
+    (tests/golden/make_golden_train_mp.py)."""
+    from climsim_amd.train import Trainer
+    consts, weights, flags = load_npz_model("cur_mpm1")
+    io = np.load(os.path.join(GOLDEN, "cur_mpm1_train.npz"))
+    grid = np.load(os.path.join(GOLDEN, "grid_consts.npz"))
+    ref = torch_ref.EmulatorRef(consts, weights, legacy=False, use_lstm=True, output_prune=bool(flags["output_prune"]), mp_mode=-1,
+                                scrub_inf=True)
+    B, Tw = int(io["grad.B"]), int(io["grad.T_w"])
+    xr = [torch.from_numpy(io[f"grad.t{t}.x_main"]) for t in range(Tw)]
+    xs = [torch.from_numpy(io[f"grad.t{t}.x_sfc"]) for t in range(Tw)]
+    with torch.no_grad():
+        pre = [ref.preprocess(a, b) for a, b in zip(xr, xs)]
+    tr = Trainer(consts, weights, grid["hyai"], grid["hybi"], use_lstm=True, output_prune=bool(flags["output_prune"]), mp_mode=-1,
+                 max_batch=B, max_window=Tw)
+    d = lambda t: torch.as_tensor(t).contiguous().cuda()
+    cut = lambda a: [d(a[t * B:(t + 1) * B]) for t in range(Tw)]
+    sc, mem, d_mem0 = tr.window_step([d(p[0]) for p in pre], [d(p[1]) for p in pre], [d(a) for a in xr], cut(io["grad.tgt"]),
+                                     cut(io["grad.tgt_sfc"]), cut(io["grad.yto"]), cut(io["grad.yto_sfc"]), d(io["grad.mem0"]), optimise=False)
+    assert rel_err(mem.cpu().numpy(), io["grad.mem_final"]) <= 1e-5
+    for k in ("loss", "huber", "mse", "mae", "energy", "water", "precip_sum_mse"):
+        g = float(io["grad.loss." + k])
+        assert abs(sc[k] - g) <= 1e-5 * abs(g) + 1e-30, (k, sc[k], g)
+    assert rel_err(d_mem0.cpu().numpy(), io["grad.d_mem0"]) <= 2e-5
+    bad = {}
+    for name, g in tr.grad_dict().items():
+        ref_g = io["grad.dw." + name]
+        e = rel_err(g.cpu().numpy().reshape(ref_g.shape), ref_g)
+        if e > 2e-5:
+            bad[name] = e
+    assert not bad, bad
