@@ -553,9 +553,11 @@ __global__ __launch_bounds__(NH * 4, (NH / 16 + 3) / 4) void lstm_rec4m_kernel(
     int B, int L, int reverse_out)
 {
     constexpr int NT = NH * 4;
-    constexpr int LDH = NH + 4;          // row stride: 4 rows start 4 banks apart -> the 4 addresses of a read never collide
     static_assert(NH % 16 == 0, "nh must be a multiple of 16");
-    __shared__ __attribute__((aligned(16))) float hbuf[2][4][LDH];
+    // h_{t-1} in LDS as [k / 16][(k % 16) / 4][column][k % 4]: the sixteen 16-byte chunks one ds_read_b128 of a wave touches
+    // (4 lane groups x 4 columns) are 256 CONTIGUOUS bytes -> conflict-free however the hardware splits the wave
+    // (a [column][k] layout with padded rows measured 50 % SQ_LDS_BANK_CONFLICT, profiles/r2_v4_memory_2700_sq_pmc.json)
+    __shared__ __attribute__((aligned(16))) float hbuf[2][4 * NH];
 
     const int tid = threadIdx.x, u = tid >> 2, x = tid & 3, lane = tid & 63;
     int b = 4 * blockIdx.x + x;
@@ -567,11 +569,12 @@ __global__ __launch_bounds__(NH * 4, (NH / 16 + 3) / 4) void lstm_rec4m_kernel(
     for (int k = 0; k < NH; ++k) w[k] = Wk[(size_t)k * NT + tid];
 
     float h = h0[(size_t)b * NH + u], c = c0[(size_t)b * NH + u];
-    hbuf[0][x][u] = h;
+    const int hslot = (u >> 4) * 64 + ((((u & 15) >> 2) * 4 + x) << 2) + (u & 3);      // where (k = u, column x) lives
+    hbuf[0][hslot] = h;
     const float *Pb = P + (size_t)b * (4 * NH) + u * 4;
     const size_t Pstep = (size_t)B * (4 * NH);
     f32x4 preA = *(const f32x4 *)Pb, preB = preA;
-    const int hoff = x * LDH + (BLGP ? 4 * (lane >> 4) : 0);
+    const int hoff = BLGP ? (((lane >> 4) * 4 + x) << 2) : (x << 2);                       // this lane's chunk of a 16-k block
     __syncthreads();
 
 #ifndef REC4M_EXP_MFMA_DIV      /* diagnostic builds (tools/rec_bench): 2 = half of the MFMAs, results are wrong */
@@ -602,11 +605,11 @@ __global__ __launch_bounds__(NH * 4, (NH / 16 + 3) / 4) void lstm_rec4m_kernel(
             const float *pn = Pb + (size_t)(t_ + 1 < L ? t_ + 1 : L - 1) * Pstep;                      \
             asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(NXT) : "v"(pn) : "memory");         \
         }                                                                                              \
-        const float *hb = &hbuf[t_ & 1][0][0] + hoff;                                                  \
+        const float *hb = &hbuf[t_ & 1][0] + hoff;                                                     \
         f32x4 acc = {0.f, 0.f, 0.f, 0.f}, accb = acc, accc = acc, accd = acc;                          \
         if (BLGP) {                                                                                    \
             _Pragma("unroll") for (int q = 0; q < NH / 16 / REC4M_EXP_MFMA_DIV; ++q) {                 \
-                const f32x4 hv = *(const f32x4 *)(hb + 16 * q);                                        \
+                const f32x4 hv = *(const f32x4 *)(hb + 64 * q);                                        \
                 MF4(acc, 16 * q, hv, 4)                                                                \
                 MF4(acc, 16 * q + 4, hv, 5)                                                            \
                 MF4(acc, 16 * q + 8, hv, 6)                                                            \
@@ -614,7 +617,7 @@ __global__ __launch_bounds__(NH * 4, (NH / 16 + 3) / 4) void lstm_rec4m_kernel(
             }                                                                                          \
         } else {                                                                                       \
             _Pragma("unroll") for (int q = 0; q < NH / 4; ++q) {                                       \
-                const f32x4 hv = *(const f32x4 *)(hb + 4 * q);                                         \
+                const f32x4 hv = *(const f32x4 *)(hb + 64 * (q >> 2) + 16 * (q & 3));                   \
                 MF4(acc, 4 * q, hv, 0)                                                                 \
             }                                                                                          \
         }                                                                                              \
@@ -623,7 +626,7 @@ __global__ __launch_bounds__(NH * 4, (NH / 16 + 3) / 4) void lstm_rec4m_kernel(
         acc = (acc + accb) + (accc + accd);            /* four interleaved k-chains: no dependent MFMA pair back to back */ \
         const float vi = acc.x + CUR.x, vf = acc.y + CUR.z, vg = acc.z + CUR.y, vo = acc.w + CUR.w;    \
         REC4M_GATES                                                                                    \
-        hbuf[(t_ & 1) ^ 1][x][u] = h;                                                                  \
+        hbuf[(t_ & 1) ^ 1][hslot] = h;                                                                 \
         if (valid) Hout[((size_t)(reverse_out ? L - 1 - t_ : t_) * B + b) * NH + u] = h;               \
         LDS_BARRIER();                                                                                 \
     }
