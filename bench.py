@@ -315,6 +315,25 @@ def aux_workload(a, rank, world, dist):
             o, osfc, state["mem"] = m([xs_[0], xs_[1], state["mem"], xs_[3]], hx2=hx2)
         flop_col = 60 * (2.0 * 22 * 128 + 2.0 * 384 * (143 + 128) + 2.0 * 384 * 256 + 2.0 * 192 * 128) + 50 * 16 * 150.0
         what = "physRNN-Hidden (BiGRU 128/128 + microphysics decoder), weights of the shipped artefact"
+    elif a.workload == "physrnn_rad_384":
+        import numpy as np
+        sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests", "golden"))
+        from make_golden_physrnn import inputs_rad
+        from climsim_amd.physrnn import physical_RNN_autoreg
+        gz = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests", "golden", "physrnn_rad.npz"))
+        Pw = {k[2:]: torch.from_numpy(gz[k]) for k in gz.files if k.startswith("w.")}
+        m = physical_RNN_autoreg(Pw, max_batch=B)
+        xs_ = [t.cuda() for t in inputs_rad(Pw, B, 300 + rank)]
+        hx2 = torch.randn(B, 128, generator=g).cuda()
+        state = {"mem": xs_[2]}
+
+        def step():
+            o, osfc, state["mem"] = m([xs_[0], xs_[1], state["mem"], xs_[3]], hx2=hx2)
+        # 50-level BiGRU + 59-wide head GEMM + decoder; radiation: gas optics 18-64-64-256, 2 x (128 -> 16), SW head 24-32-48
+        # on 60 levels, ~250 flop per (level, g-point) cell of the two-stream / adding / LW sweeps
+        flop_col = (50 * (2.0 * 20 * 128 + 2.0 * 384 * (143 + 128) + 2.0 * 384 * 256 + 2.0 * 60 * 128) + 50 * 4 * 150.0
+                    + 60 * 2.0 * (18 * 64 + 64 * 64 + 64 * 256 + 2 * 128 * 16 + 24 * 32 + 32 * 48) + 60 * 16 * 250.0)
+        what = "physRNN-Hidden radiation graph (BiGRU 128/128 over 50 levels + decoder + physical LW/SW scheme), weights of num4050"
     elif a.workload == "online_mlp_384":
         from climsim_amd.online import MLP, NewModel
         n_in, hidden = 557, [384, 1024, 640]              # v2_rh input vector, slurm/v2rh_mlp_*_3l_lr1em3.sbatch widths
@@ -374,7 +393,7 @@ def aux_workload(a, rank, world, dist):
             flush=True)
 
 
-AUX = ["cur_lstm144_384", "cur_lstm128_384", "cur_gru128_384", "mlp_384", "online_mlp_384", "physrnn_384", "cnn_384", "cnn_train_384",
+AUX = ["cur_lstm144_384", "cur_lstm128_384", "cur_gru128_384", "mlp_384", "online_mlp_384", "physrnn_384", "physrnn_rad_384", "cnn_384", "cnn_train_384",
        "cnn_train_512", "cnn_train_2700"]
 
 

@@ -1,0 +1,47 @@
+// phys.h -- shared state of the physRNN "Hidden" path (phys.hip: core + decoder, phys_rad.hip: radiation scheme)
+#pragma once
+#include "common.h"
+#include "pack.h"
+#include <vector>
+
+#define PH_L 60
+#define PH_NHEAD 11
+#define PH_NG 16            // g-points of the radiation scheme (ng_lw = ng_sw = 16 in every shipped artefact)
+#define PH_NRETAB 138
+
+struct PhysDev {
+    int nx;                 // columns of x_main
+    int nfeat;              // leading columns of x_main that feed mlp_initial (the layer-pressure feature follows them)
+    int naux;               // columns of x_sfc
+    int nx_sfc;             // inputs of mlp_surface1: aux columns [0, sfc_cut) and [sfc_cut + sfc_skip, naux)
+    int sfc_cut, sfc_skip;
+    int nh, ilev, nm0, Lc;
+    int ltop, Lr;           // first level the GRUs see and their sequence length (0 / 60, or ilev / 50)
+    int ncol, hdw;          // mp_ncol; width of the head GEMM
+    int rad;                // 1: physical radiation scheme (no mlp_output_rad / mlp_surface_output_rad heads)
+    const float *hyam, *hybm, *hyai, *hybi, *yscale_lev, *yscale_sca;
+    float xdiv_sca0, xmean_sca0;
+    const float *init_wt, *init_b, *s1_wt, *s1_b;   // (nfeat+1, nh), (nx_sfc, nh) transposed
+    const float *out_w, *out_b;                     // mlp_output (5, nm0)
+    const float *sfo_w, *sfo_b;                     // mlp_surface_output_rad (6, nh)            (rad == 0)
+    const float *rel_w, *rel_b;                     // mlp_precip_release (1, nh)
+    // radiation scheme (rad == 1)
+    const float *xmean_sca, *xdiv_sca, *lbd_qn, *g_xmin, *g_xmax, *g_ymean, *g_ystd, *ys_rad, *toa_spec, *retab;
+};
+
+struct csa_phys {
+    PhysDev d;
+    int max_batch;
+    float *wih1, *bias1, *bhn1, *whh1p, *whh1g, *wih2, *bias2, *bhn2, *whh2p, *whh2g, *whead, *bhead;
+    float *X1, *P, *H1, *H2, *hx, *HD;
+    // radiation scheme: MLP weights (row-major (out, in), K padded to a multiple of 4) and per-call work arrays
+    float *g_w1, *g_b1, *g_w2, *g_b2, *g_w3, *g_b3, *r1_w, *r1_b, *r2_w, *r2_b, *s1_w, *s1_b, *s2_w, *s2_b;
+    float *XG, *XR, *RS, *CL, *A1, *A2, *A3, *TP, *S1, *S2;
+    std::vector<void *> owned;
+};
+
+#define PH_XG_K 20          // 18 gas-optics inputs, zero-padded
+#define PH_XR_K 24
+
+// phys_rad.hip
+int launch_phys_radiation(csa_phys *h, int B, const float *x_sfc, float *out_lev, float *out_sfc, hipStream_t s);

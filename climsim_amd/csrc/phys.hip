@@ -14,42 +14,25 @@
 // GRU recurrence -> ONE head GEMM (192 = 11 x 16 decoder heads + 15 latent + 1 radiative heating columns, K = nh) ->
 // phys_decode_kernel (one workgroup per grid column: all vertical differences, level softmax and column sums in LDS).
 // Activations are level-major (level, column, channel) as in the rest of the library.
-#include "common.h"
-#include "pack.h"
-#include <vector>
-
-#define PH_L 60
-#define PH_NCOL 16
-#define PH_NHEAD 11
-#define PH_HD 192          // 11*16 + 15 + 1
-
-struct PhysDev {
-    int nx, nx_sfc, nh, ilev, nm0, Lc;
-    const float *hyam, *hybm, *hyai, *hybi, *yscale_lev, *yscale_sca;
-    float xdiv_sca0, xmean_sca0;
-    const float *init_wt, *init_b, *s1_wt, *s1_b;   // (nx+1, nh), (nx_sfc, nh) transposed
-    const float *out_w, *out_b;                     // mlp_output (5, nm0)
-    const float *sfo_w, *sfo_b;                     // mlp_surface_output_rad (6, nh)
-    const float *rel_w, *rel_b;                     // mlp_precip_release (1, nh)
-};
-
-struct csa_phys {
-    PhysDev d;
-    int max_batch;
-    float *wih1, *bias1, *bhn1, *whh1p, *whh1g, *wih2, *bias2, *bhn2, *whh2p, *whh2g, *whead, *bhead;
-    float *X1, *P, *H1, *H2, *hx, *HD;
-    std::vector<void *> owned;
-};
-
+//
+// Two serialised geometries (csa_phys_create / csa_phys_rad_create):
+//   "mp16": 21 level inputs (+ pressure) on all 60 levels, 19 surface inputs, mp_ncol 16, radiative heating from two
+//           Linear heads (num14564, num49672)
+//   "rad" : 21 level inputs of which the first 18 (+ pressure) feed mlp_initial, both GRUs over the 50 CRM levels only,
+//           surface inputs 0:6 and 11:19, mp_ncol 4, and the physical radiation scheme of phys_rad.hip after the
+//           decoder (num4050)
+#include "phys.h"
 __device__ __forceinline__ float ph_softplus(float x) { return x > 20.0f ? x : log1pf(expf(x)); }   // torch.softplus(beta 1, threshold 20)
-__device__ __forceinline__ float ph_sum16(float v)
+template <int N> __device__ __forceinline__ float ph_sum(float v)
 {
-    v += __shfl_xor(v, 8); v += __shfl_xor(v, 4); v += __shfl_xor(v, 2); v += __shfl_xor(v, 1);
+#pragma unroll
+    for (int o = N / 2; o > 0; o >>= 1) v += __shfl_xor(v, o);
     return v;
 }
-__device__ __forceinline__ float ph_max16(float v)
+template <int N> __device__ __forceinline__ float ph_max(float v)
 {
-    v = fmaxf(v, __shfl_xor(v, 8)); v = fmaxf(v, __shfl_xor(v, 4)); v = fmaxf(v, __shfl_xor(v, 2)); v = fmaxf(v, __shfl_xor(v, 1));
+#pragma unroll
+    for (int o = N / 2; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
     return v;
 }
 
@@ -62,18 +45,18 @@ __global__ __launch_bounds__(128) void phys_prep_kernel(PhysDev d, int B, const 
     // (nx + 1 = 22) the compiler emitted one scalar branch and one s_waitcnt per LDS read -- 80 us instead of 13.
     __shared__ float xin[PH_L * 32];
     __shared__ float xs[64];
-    const int b = blockIdx.x, j = threadIdx.x, nx1 = d.nx + 1, nh = d.nh, K1 = nh + 16;
+    const int b = blockIdx.x, j = threadIdx.x, nf1 = d.nfeat + 1, nh = d.nh, K1 = nh + 16;
     // the levels are independent here: blockIdx.y takes one half of them (384 columns alone are 1.5 workgroups per CU)
-    const int lper = (PH_L + (int)gridDim.y - 1) / (int)gridDim.y, l0 = blockIdx.y * lper, l1 = min(PH_L, l0 + lper);
+    const int lper = (d.Lr + (int)gridDim.y - 1) / (int)gridDim.y, l0 = d.ltop + blockIdx.y * lper, l1 = min(PH_L, l0 + lper);
     for (int i = j; i < PH_L * 32; i += 128) xin[i] = 0.0f;
-    if (j < 64) xs[j] = j < d.nx_sfc ? x_sfc[(size_t)b * d.nx_sfc + j] : 0.0f;
+    if (j < 64) xs[j] = j < d.nx_sfc ? x_sfc[(size_t)b * d.naux + (j < d.sfc_cut ? j : j + d.sfc_skip)] : 0.0f;
+    const float sp = x_sfc[(size_t)b * d.naux] * d.xdiv_sca0 + d.xmean_sca0;
     __syncthreads();
     for (int i = l0 * d.nx + j; i < l1 * d.nx; i += 128) {
         const int l = i / d.nx, v = i - l * d.nx;
-        xin[l * 32 + v] = x_main[(size_t)b * PH_L * d.nx + i];
+        if (v < d.nfeat) xin[l * 32 + v] = x_main[(size_t)b * PH_L * d.nx + i];
     }
-    const float sp = xs[0] * d.xdiv_sca0 + d.xmean_sca0;
-    for (int l = l0 + j; l < l1; l += 128) xin[l * 32 + d.nx] = sqrtf(d.hyam[l] * 100000.0f + sp * d.hybm[l]) / 314.0f;
+    for (int l = l0 + j; l < l1; l += 128) xin[l * 32 + d.nfeat] = sqrtf(d.hyam[l] * 100000.0f + sp * d.hybm[l]) / 314.0f;
     __syncthreads();
     if (j < nh) {
         if (blockIdx.y == 0) {
@@ -90,7 +73,7 @@ __global__ __launch_bounds__(128) void phys_prep_kernel(PhysDev d, int B, const 
         float w[32];
         const float bj = d.init_b[j];
 #pragma unroll
-        for (int k = 0; k < 32; ++k) w[k] = d.init_wt[min(k, nx1 - 1) * nh + j];                  // xin is zero for k >= nx + 1
+        for (int k = 0; k < 32; ++k) w[k] = d.init_wt[min(k, nf1 - 1) * nh + j];                  // xin is zero for k >= nfeat + 1
         for (int l = l0; l < l1; ++l) {
             float acc = bj;
 #pragma unroll
@@ -109,26 +92,53 @@ __global__ __launch_bounds__(128) void phys_prep_kernel(PhysDev d, int B, const 
 // head-GEMM column order
 enum { H_QV = 0, H_QN, H_T, H_AREA, H_FLUX, H_EDDY, H_QICE, H_SED, H_EVAP, H_COND, H_AA };
 
-#define PH_DT 512          // decoder workgroup: 800 (level, sub-column) cells in two passes
-__global__ __launch_bounds__(PH_DT) void phys_decode_kernel(PhysDev d, int B, const float *__restrict__ HD, const float *__restrict__ H2,
-                                                          const float *__restrict__ x_sfc, const float *__restrict__ mem,
-                                                          const float *__restrict__ x_denorm, int nxd,
-                                                          float *__restrict__ out_lev, float *__restrict__ out_sfc, float *__restrict__ mem_out)
+// E3SM's ice effective radius table and liquid effective radius rule (rnn/models/physics_rad_e3sm.py:13, :62)
+__device__ __forceinline__ float ph_reitab(const float *__restrict__ tab, float t)
 {
-    constexpr int LC = 50, NC = PH_NCOL;
+    const int i = min(max((int)(t - 136.0f), 1), PH_NRETAB - 2);
+    const float w = t - floorf(t);
+    return tab[i] * (1.0f - w) + tab[i + 1] * w;
+}
+__device__ __forceinline__ float ph_reltab(float t, float landfrac, float icefrac, float snowh)
+{
+    float rel = 8.0f + 6.0f * fminf(fmaxf((273.15f - t) * 0.05f, 0.0f), 1.0f);
+    rel = rel + (14.0f - rel) * fminf(fmaxf(snowh * 10.0f, 0.0f), 1.0f);
+    rel = rel + (14.0f - rel) * fminf(fmaxf(1.0f - landfrac, 0.0f), 1.0f);
+    return rel + (14.0f - rel) * fminf(fmaxf(icefrac, 0.0f), 1.0f);
+}
+
+// Radiation work arrays written by the decoder when RAD (consumed by phys_rad.hip); rows are (level, column), level-major
+struct PhysRadOut {
+    const float *x_main;
+    float *XG, *XR, *RS, *CL;
+};
+
+// decoder workgroup: DT threads over the LC * NC (level, sub-column) cells -- 800 cells in two passes of 512 for
+// mp_ncol 16, 200 cells in one pass of 256 for mp_ncol 4
+template <int NC, int DT, bool RAD>
+__global__ __launch_bounds__(DT) void phys_decode_kernel(PhysDev d, int B, const float *__restrict__ HD, const float *__restrict__ H2,
+                                                         const float *__restrict__ x_sfc, const float *__restrict__ mem,
+                                                         const float *__restrict__ x_denorm, int nxd,
+                                                         float *__restrict__ out_lev, float *__restrict__ out_sfc, float *__restrict__ mem_out,
+                                                         PhysRadOut ro)
+{
+    constexpr int LC = 50, SH = NC == 16 ? 4 : 2;
+    static_assert(NC == 16 || NC == 4, "mp_ncol");
     __shared__ float s_out[LC][5], s_pv[LC], s_pd[LC], s_dprec[LC], s_red[8];
     __shared__ float s_area[LC * NC], s_qv[LC * NC], s_qn[LC * NC], s_fH[LC * NC], s_fqv[LC * NC], s_fqn[LC * NC], s_sed[LC * NC];
+    __shared__ float s_T[LC * NC];                    // sub-column temperature (RAD: overwritten with its updated value)
+    __shared__ float s_o01[PH_L][2];                  // RAD: the decoder's dT, dqv of every level (zero above the CRM top)
     __shared__ float s_scal[16];
     constexpr int nh = 128, nm0 = 15;                 // enforced by csa_phys_create: compile-time trip counts (see phys_prep_kernel)
-    const int b = blockIdx.x, tid = threadIdx.x, ilev = d.ilev;
+    const int b = blockIdx.x, tid = threadIdx.x, ilev = d.ilev, hd0 = ilev - d.ltop, HDW = d.hdw;
     const float CP = 1004.64f, G = 9.80665f, LV = 2510400.0f, LS = 2844000.0f, OOG = 0.1019716213f;
-    const float sp = x_sfc[(size_t)b * d.nx_sfc] * d.xdiv_sca0 + d.xmean_sca0;
+    const float sp = x_sfc[(size_t)b * d.naux] * d.xdiv_sca0 + d.xmean_sca0;
     const float P_old = mem[((size_t)b * LC + (LC - 1)) * (nm0 + 1) + nm0];
-    const float *last_h = H2 + ((size_t)(PH_L - 1) * B + b) * nh;
+    const float *last_h = H2 + ((size_t)(d.Lr - 1) * B + b) * nh;
 
     // ---- phase A: latent memory -> mlp_output per level; level pressure thickness; surface heads ----
-    for (int l = tid; l < LC; l += PH_DT) {
-        const float *hd = HD + ((size_t)(l + ilev) * B + b) * PH_HD + PH_NHEAD * NC;
+    for (int l = tid; l < LC; l += DT) {
+        const float *hd = HD + ((size_t)(l + hd0) * B + b) * HDW + PH_NHEAD * NC;
         float lat[16];
 #pragma unroll
         for (int k = 0; k < nm0; ++k) { lat[k] = hd[k]; mem_out[((size_t)b * LC + l) * (nm0 + 1) + k] = lat[k]; }
@@ -144,12 +154,14 @@ __global__ __launch_bounds__(PH_DT) void phys_decode_kernel(PhysDev d, int B, co
     }
     if (tid >= 64 && tid < 64 + 7 * 8) {              // 6 radiative surface outputs + the precipitation release logit: 8 lanes each
         const int o = (tid - 64) >> 3, part = tid & 7;
-        const float *w = o < 6 ? d.sfo_w + o * nh : d.rel_w;
-        float a = 0.0f;
+        if (!RAD || o == 6) {
+            const float *w = o < 6 ? d.sfo_w + o * nh : d.rel_w;
+            float a = 0.0f;
 #pragma unroll
-        for (int k = 0; k < nh / 8; ++k) a = fmaf(last_h[part + 8 * k], w[part + 8 * k], a);
-        a += __shfl_xor(a, 4); a += __shfl_xor(a, 2); a += __shfl_xor(a, 1);
-        if (part == 0) s_scal[o] = a + (o < 6 ? d.sfo_b[o] : d.rel_b[0]);
+            for (int k = 0; k < nh / 8; ++k) a = fmaf(last_h[part + 8 * k], w[part + 8 * k], a);
+            a += __shfl_xor(a, 4); a += __shfl_xor(a, 2); a += __shfl_xor(a, 1);
+            if (part == 0) s_scal[o] = a + (o < 6 ? d.sfo_b[o] : d.rel_b[0]);
+        }
     }
     __syncthreads();
     // softmax over the 50 levels of out[:, :, 2], times the stored water  (first wave)
@@ -164,27 +176,27 @@ __global__ __launch_bounds__(PH_DT) void phys_decode_kernel(PhysDev d, int B, co
     }
 
     // ---- phase B: sub-grid state and the fluxes at each level ----
-    for (int e0 = 0; e0 < LC * NC; e0 += PH_DT) {
-        const int e = e0 + tid, l = e >> 4, c = e & 15;
+    for (int e0 = 0; e0 < LC * NC; e0 += DT) {
+        const int e = e0 + tid, l = e >> SH, c = e & (NC - 1);
         const bool ok = l < LC;
         const int L = (ok ? l : 0) + ilev;
-        const float *hd = HD + ((size_t)L * B + b) * PH_HD + c;
+        const float *hd = HD + ((size_t)(L - d.ltop) * B + b) * HDW + c;
         const float *xd = x_denorm + ((size_t)b * PH_L + L) * nxd;
         const float a_raw = hd[H_AREA * NC];
-        const float am = ph_max16(a_raw), ae = expf(a_raw - am), area = ae / ph_sum16(ae);
+        const float am = ph_max<NC>(a_raw), ae = expf(a_raw - am), area = ae / ph_sum<NC>(ae);
         float qv = ph_softplus(hd[H_QV * NC]), qn = ph_softplus(hd[H_QN * NC]), qi = ph_softplus(hd[H_QICE * NC]);
-        const float mqv = ph_sum16(qv * area), mqn = ph_sum16(qn * area), mqi = ph_sum16(qi * area);
+        const float mqv = ph_sum<NC>(qv * area), mqn = ph_sum<NC>(qn * area), mqi = ph_sum<NC>(qi * area);
         qv *= mqv == 0.0f ? 1.0f : xd[nxd - 1] / mqv;
         qn *= mqn == 0.0f ? 1.0f : (xd[2] + xd[3]) / mqn;
         qi *= mqi == 0.0f ? 1.0f : xd[3] / mqi;
         const float dT = hd[H_T * NC];
-        const float T_crm = xd[0] + (dT - ph_sum16(dT * area));
+        const float T_crm = xd[0] + (dT - ph_sum<NC>(dT * area));
         const float play = d.hyam[L] * 100000.0f + sp * d.hybm[L], play_up = d.hyam[L - 1] * 100000.0f + sp * d.hybm[L - 1];
         float fH = hd[H_EDDY * NC] * (CP / G) * T_crm * (play - play_up);
         if (l == LC - 1) fH = -fmaxf(fH, 0.0f);
         const float flux1 = hd[H_FLUX * NC] * 300000.0f;
         if (ok) {
-            s_area[e] = area; s_qv[e] = qv; s_qn[e] = qn; s_fH[e] = fH;
+            s_area[e] = area; s_qv[e] = qv; s_qn[e] = qn; s_fH[e] = fH; s_T[e] = T_crm;
             s_fqv[e] = flux1 * qv; s_fqn[e] = flux1 * qn;
             s_sed[e] = fmaxf(hd[H_SED * NC], 0.0f) * G * qi * d.yscale_lev[L * 5 + 2];
         }
@@ -192,11 +204,11 @@ __global__ __launch_bounds__(PH_DT) void phys_decode_kernel(PhysDev d, int B, co
     __syncthreads();
 
     // ---- phase C: flux divergences, clamps, tendencies, area-weighted means ----
-    for (int e0 = 0; e0 < LC * NC; e0 += PH_DT) {
-        const int e = e0 + tid, l = e >> 4, c = e & 15;
+    for (int e0 = 0; e0 < LC * NC; e0 += DT) {
+        const int e = e0 + tid, l = e >> SH, c = e & (NC - 1);
         const bool ok = l < LC;
         const int lc = ok ? l : 0, ec = ok ? e : c, L = lc + ilev;
-        const float *hd = HD + ((size_t)L * B + b) * PH_HD + c;
+        const float *hd = HD + ((size_t)(L - d.ltop) * B + b) * HDW + c;
         const float *ys = d.yscale_lev + L * 5;
         const float pd = s_pd[lc], area = s_area[ec], qv = s_qv[ec], qn = s_qn[ec];
         const bool up = lc > 0, last = lc == LC - 1;
@@ -213,17 +225,26 @@ __global__ __launch_bounds__(PH_DT) void phys_decode_kernel(PhysDev d, int B, co
         const float dqv = (flux_qv_dp - cond) + evap;
         const float dqn = ((flux_qn_dp + cond) - aa) + sed_qn_dp;
         const float *xd = x_denorm + ((size_t)b * PH_L + L) * nxd;
-        const float temp = xd[0] + (ph_sum16(area * flux_t_dp) / ys[0]) * 1200.0f;
+        const float temp = xd[0] + (ph_sum<NC>(area * flux_t_dp) / ys[0]) * 1200.0f;
         const float liq = fminf(fmaxf((temp - 253.16f) * 0.05f, 0.0f), 1.0f);
         const float net = ((liq * LV + (1.0f - liq) * LS) * cond - evap * LV) * (1.0f / CP);
         const float dT_crm = flux_t_dp + net / ys[1] * ys[0];
-        const float sT = ph_sum16(area * dT_crm), sqv = ph_sum16(area * dqv), sqn = ph_sum16(area * dqn);
-        const float sprec = ph_sum16(area * (aa - evap));
-        const float ssed = ph_sum16(area * s_sed[ec]);
+        const float sT = ph_sum<NC>(area * dT_crm), sqv = ph_sum<NC>(area * dqv), sqn = ph_sum<NC>(area * dqn);
+        const float sprec = ph_sum<NC>(area * (aa - evap));
+        const float ssed = ph_sum<NC>(area * s_sed[ec]);
+        if (RAD && ok) {                              // sub-column state after the step, as the radiation scheme sees it
+            s_T[e] = fmaxf(s_T[e] + dT_crm * 1200.0f / ys[0], 0.0f);
+            s_qn[e] = fmaxf(qn + dqn * 1200.0f / ys[2], 0.0f);
+        }
         if (ok && c == 0) {
-            const float dT_rad = HD[((size_t)L * B + b) * PH_HD + PH_HD - 1];
             float *o = out_lev + ((size_t)b * PH_L + L) * 5;
-            o[0] = ((l >= 2 ? s_out[l][0] : 0.0f) + sT) + dT_rad;
+            if (RAD) {
+                o[0] = sT;
+                s_o01[L][0] = sT; s_o01[L][1] = sqv;
+            } else {
+                const float dT_rad = HD[((size_t)L * B + b) * HDW + HDW - 1];
+                o[0] = ((l >= 2 ? s_out[l][0] : 0.0f) + sT) + dT_rad;
+            }
             o[1] = sqv;
             o[2] = sqn;
             o[3] = l >= 2 ? s_out[l][3] : 0.0f;
@@ -233,10 +254,11 @@ __global__ __launch_bounds__(PH_DT) void phys_decode_kernel(PhysDev d, int B, co
         }
     }
     // levels above the CRM top: only the radiative heating
-    for (int L = tid; L < ilev; L += PH_DT) {
+    for (int L = tid; L < ilev; L += DT) {
         float *o = out_lev + ((size_t)b * PH_L + L) * 5;
-        o[0] = HD[((size_t)L * B + b) * PH_HD + PH_HD - 1];
+        o[0] = RAD ? 0.0f : HD[((size_t)L * B + b) * HDW + HDW - 1];
         o[1] = 0.0f; o[2] = 0.0f; o[3] = 0.0f; o[4] = 0.0f;
+        if (RAD) { s_o01[L][0] = 0.0f; s_o01[L][1] = 0.0f; }
     }
     __syncthreads();
 
@@ -256,25 +278,120 @@ __global__ __launch_bounds__(PH_DT) void phys_decode_kernel(PhysDev d, int B, co
             const float precc = ((s_scal[8] + released) + excess) / 1000.0f;
             const float snowfrac = fminf(fmaxf((-Tsfc + 283.3f) / 14.6f, 0.0f), 1.0f);
             float *os = out_sfc + (size_t)b * 8;
-            os[0] = fmaxf(s_scal[0], 0.0f); os[1] = fmaxf(s_scal[1], 0.0f);
             os[2] = snowfrac * precc; os[3] = precc;
-            for (int k = 2; k < 6; ++k) os[2 + k] = fmaxf(s_scal[k], 0.0f);
+            if (!RAD) {
+                os[0] = fmaxf(s_scal[0], 0.0f); os[1] = fmaxf(s_scal[1], 0.0f);
+                for (int k = 2; k < 6; ++k) os[2 + k] = fmaxf(s_scal[k], 0.0f);
+            }
             s_red[0] = stored;
         }
     }
     __syncthreads();
-    for (int l = tid; l < LC; l += PH_DT) mem_out[((size_t)b * LC + l) * (nm0 + 1) + nm0] = s_red[0];
+    for (int l = tid; l < LC; l += DT) mem_out[((size_t)b * LC + l) * (nm0 + 1) + nm0] = s_red[0];
+
+    // ---- phase E (RAD): inputs of the radiation scheme -- the artefact's radiative_transfer up to its three MLPs ----
+    if constexpr (RAD) {
+        const float *aux = x_sfc + (size_t)b * d.naux;
+        for (int L = tid; L < PH_L; L += DT) {
+            const size_t row = (size_t)L * B + b;
+            const float *xd = x_denorm + ((size_t)b * PH_L + L) * nxd;
+            const float *ys = d.yscale_lev + L * 5;
+            const float T_new = fmaxf(xd[0] + s_o01[L][0] / ys[0] * 1200.0f, 0.0f);
+            const float qv_new = fmaxf(xd[nxd - 1] + s_o01[L][1] / ys[1] * 1200.0f, 0.0f);
+            const float vmr = qv_new * 1.608079364f, fact = 1.0f / (1.0f + vmr), m_air = (vmr + 0.04698f) * fact;
+            const float pd = sp * (d.hybi[L + 1] - d.hybi[L]) + (d.hyai[L + 1] - d.hyai[L]) * 100000.0f;
+            const float col_dry = (pd * 10.0f * 6.02214076e23f * fact) / (m_air * 1000.0f * 100.0f * 9.80665f);
+            const float play = d.hyam[L] * 100000.0f + sp * d.hybm[L], lp = logf(play), v4 = sqrtf(sqrtf(vmr));
+            ro.RS[row * 2] = col_dry; ro.RS[row * 2 + 1] = T_new;
+            float f[PH_XG_K];
+#pragma unroll
+            for (int k = 0; k < PH_XG_K; ++k) f[k] = 0.0f;
+            f[0] = T_new; f[1] = lp; f[2] = v4; f[3] = sqrtf(sqrtf(xd[12])); f[4] = 0.0003887f; f[5] = xd[13]; f[6] = xd[14];
+            float *xg = ro.XG + row * PH_XG_K;
+#pragma unroll
+            for (int k = 0; k < PH_XG_K; ++k)
+                xg[k] = k < 18 ? fmaxf((f[k] - d.g_xmin[k]) / (d.g_xmax[k] - d.g_xmin[k]), 0.0f) : 0.0f;
+            float *xr = ro.XR + row * PH_XR_K;
+            const float *xm = ro.x_main + ((size_t)b * PH_L + L) * d.nx;
+            xr[0] = (lp - 0.00515f) / 11.59485f;
+            xr[1] = (T_new - 160.0f) / 180.0f;
+            xr[2] = v4 / 0.497653f;
+            xr[3] = 1.0f - expf(-(xd[2] + xd[3]) * d.lbd_qn[L]);
+            xr[4] = xm[12]; xr[5] = xm[13]; xr[6] = xm[14];
+            float rel = 0.0f, rei = 0.0f;
+            if (L >= ilev) {
+                rel = ph_reltab(T_new, aux[13] * d.xdiv_sca[13] + d.xmean_sca[13], aux[12] * d.xdiv_sca[12] + d.xmean_sca[12],
+                                aux[15] * d.xdiv_sca[15] + d.xmean_sca[15]) / 13.5f;
+                rei = ph_reitab(d.retab, T_new) / 250.0f;
+            }
+            xr[7] = rel; xr[8] = rei;
+            const float *lat = HD + ((size_t)(L - d.ltop) * B + b) * HDW + PH_NHEAD * NC;
+#pragma unroll
+            for (int k = 0; k < nm0; ++k) xr[9 + k] = L >= ilev ? lat[k] : 0.0f;
+        }
+        // cloud optical depth per (CRM level, g-point): every g-point sees one sub-column (physics_rad.py:533)
+        for (int e = tid; e < LC * PH_NG; e += DT) {
+            const int l = e >> 4, g = e & 15, L = l + ilev;
+            float p[NC], rem[NC], cnt[NC], tot = 0.0f;
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                p[c] = s_area[l * NC + c] * (float)PH_NG;
+                cnt[c] = floorf(p[c]);
+                rem[c] = p[c] - cnt[c];
+                tot += cnt[c];
+            }
+            const float deficit = (float)PH_NG - tot;
+            int sub = 0;
+            float edge = 0.0f;
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                int rank = 0;
+#pragma unroll
+                for (int i = 0; i < NC; ++i) rank += (rem[i] > rem[c] || (rem[i] == rem[c] && i < c)) ? 1 : 0;
+                edge += cnt[c] + ((float)rank < deficit ? 1.0f : 0.0f);
+                sub += edge <= (float)g ? 1 : 0;
+            }
+            sub = min(sub, NC - 1);
+            const float T_g = s_T[l * NC + sub], qn_g = s_qn[l * NC + sub];
+            const float liq = fminf(fmaxf((T_g - 253.16f) * 0.05f, 0.0f), 1.0f);
+            const float cwp = s_pd[l] / G * qn_g * 1000.0f, cwp_ice = (1.0f - liq) * cwp;
+            const float ifr = cwp_ice / fmaxf(cwp, 1e-8f);
+            const float *xd = x_denorm + ((size_t)b * PH_L + L) * nxd;
+            const float *ys = d.yscale_lev + L * 5;
+            const float T_new = fmaxf(xd[0] + s_o01[L][0] / ys[0] * 1200.0f, 0.0f);
+            const float rei = fminf(fmaxf(ph_reitab(d.retab, T_new), 13.0f), 130.0f);
+            ro.CL[((size_t)l * B + b) * PH_NG + g] = cwp * 0.090361f * (1.0f - ifr) + cwp * ifr * (1.0f / rei + 0.005f);
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-extern "C" int csa_phys_create(int nx, int nx_sfc, int nh, int ilev_crm, int mp_ncol, int nh_mem0,
-                               const float *const *w /* see include/climsim_amd.h for the order */, int max_batch, csa_phys **out)
+struct PhysHostW {           // host pointers of one state_dict, by role
+    const float *hyam, *hybm, *hyai, *hybi, *ysl, *yss, *xds, *xms, *init_w, *init_b, *s1_w, *s1_b;
+    const float *r1_ih, *r1_hh, *r1_bih, *r1_bhh, *r2_ih, *r2_hh, *r2_bih, *r2_bhh;
+    const float *lat_w, *lat_b, *out_w, *out_b, *sfo_w, *sfo_b, *rad_w, *rad_b, *rel_w, *rel_b;
+    const float *const *heads;    // 11 x (weight (mp_ncol, nh), bias) in head-GEMM column order
+    // radiation scheme
+    const float *lbd_qn, *ys_rad, *solar_w, *g_xmin, *g_xmax, *g_ymean, *g_ystd;
+    const float *g_w1, *g_b1, *g_w2, *g_b2, *g_w3, *g_b3, *r1_w, *r1_b, *r2_w, *r2_b, *sw1_w, *sw1_b, *sw2_w, *sw2_b;
+};
+
+// ice effective radius (micron) against temperature, 137 K ... : E3SM's table as listed in rnn/models/physics_rad_e3sm.py:13-59
+static const float kRetab[PH_NRETAB] = {
+    0.05f, 0.05f, 0.05f, 0.05f, 0.05f, 0.05f, 0.055f, 0.06f, 0.07f, 0.08f, 0.09f, 0.1f, 0.2f, 0.3f, 0.4f, 0.5f, 0.6f, 0.7f, 0.8f, 0.9f, 1.0f,
+    1.1f, 1.2f, 1.3f, 1.4f, 1.5f, 1.6f, 1.8f, 2.0f, 2.2f, 2.4f, 2.6f, 2.8f, 3.0f, 3.2f, 3.5f, 3.8f, 4.1f, 4.4f, 4.7f, 5.0f, 5.3f, 5.6f, 5.92779f,
+    6.26422f, 6.61973f, 6.99539f, 7.39234f, 7.81177f, 8.25496f, 8.72323f, 9.218f, 9.74075f, 10.293f, 10.8765f, 11.4929f, 12.144f,
+    12.8317f, 13.5581f, 14.2319f, 15.0351f, 15.8799f, 16.7674f, 17.6986f, 18.6744f, 19.6955f, 20.7623f, 21.8757f, 23.0364f, 24.2452f,
+    25.5034f, 26.8125f, 27.7895f, 28.645f, 29.4167f, 30.1088f, 30.7306f, 31.2943f, 31.8151f, 32.3077f, 32.787f, 33.2657f, 33.754f,
+    34.2601f, 34.7892f, 35.3442f, 35.9255f, 36.5316f, 37.1602f, 37.8078f, 38.472f, 39.1508f, 39.8442f, 40.5552f, 41.2912f, 42.0635f,
+    42.8876f, 43.7863f, 44.7853f, 45.917f, 47.2165f, 48.7221f, 50.471f, 52.498f, 54.8315f, 57.4898f, 60.4785f, 63.7898f, 65.5604f,
+    71.2885f, 75.4113f, 79.7368f, 84.2351f, 88.8833f, 93.6658f, 98.5739f, 103.603f, 108.752f, 114.025f, 119.424f, 124.954f, 130.63f,
+    136.457f, 142.446f, 148.608f, 154.956f, 161.503f, 168.262f, 175.248f, 182.473f, 189.952f, 197.699f, 205.728f, 214.055f, 222.694f,
+    231.661f, 240.971f, 250.639f};
+
+static int phys_build(int nx, int nfeat, int naux, int nx_sfc, int sfc_cut, int nh, int ilev_crm, int mp_ncol, int nh_mem0, int rad,
+                      const PhysHostW &w, int max_batch, csa_phys **out)
 {
-    if (!w || !out || max_batch <= 0) { csa_set_error_msg("csa_phys_create: bad argument"); return CSA_ERR_ARG; }
-    if (nh != 128 || mp_ncol != PH_NCOL || nh_mem0 != 15 || ilev_crm != 10 || nx + 1 > 32 || nx_sfc > 64) {
-        csa_set_error_msg("csa_phys_create: built for the shipped physRNN-Hidden geometry (GRU 128/128, mp_ncol 16, 15+1 memory channels, ilev_crm 10)");
-        return CSA_ERR_UNSUPPORTED;
-    }
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) { csa_set_error_msg("csa_phys_create: no HIP device"); return CSA_ERR_HIP; }
     csa_phys *h = new csa_phys();
@@ -287,55 +404,131 @@ extern "C" int csa_phys_create(int nx, int nx_sfc, int nh, int ilev_crm, int mp_
         if (src && hipMemcpy(p, src, sizeof(float) * n, hipMemcpyHostToDevice) != hipSuccess) rc = CSA_ERR_HIP;
         return (float *)p;
     };
-    enum { W_HYAM, W_HYBM, W_HYAI, W_HYBI, W_YSL, W_YSS, W_XDS, W_XMS, W_INIT_W, W_INIT_B, W_S1_W, W_S1_B, W_R1_IH, W_R1_HH, W_R1_BIH,
-           W_R1_BHH, W_R2_IH, W_R2_HH, W_R2_BIH, W_R2_BHH, W_LAT_W, W_LAT_B, W_OUT_W, W_OUT_B, W_SFO_W, W_SFO_B, W_RAD_W, W_RAD_B,
-           W_REL_W, W_REL_B, W_HEADS /* 11 x (weight, bias) in head-GEMM column order */ };
     PhysDev &d = h->d;
-    d.nx = nx; d.nx_sfc = nx_sfc; d.nh = nh; d.ilev = ilev_crm; d.nm0 = nh_mem0; d.Lc = PH_L - ilev_crm;
-    d.hyam = up(w[W_HYAM], 60); d.hybm = up(w[W_HYBM], 60); d.hyai = up(w[W_HYAI], 61); d.hybi = up(w[W_HYBI], 61);
-    d.yscale_lev = up(w[W_YSL], 60 * 5); d.yscale_sca = up(w[W_YSS], 8);
-    d.xdiv_sca0 = w[W_XDS][0]; d.xmean_sca0 = w[W_XMS][0];
-    { auto t = transposed(w[W_INIT_W], nh, nx + 1); d.init_wt = up(t.data(), t.size()); }
-    d.init_b = up(w[W_INIT_B], nh);
-    { auto t = transposed(w[W_S1_W], nh, nx_sfc); d.s1_wt = up(t.data(), t.size()); }
-    d.s1_b = up(w[W_S1_B], nh);
-    d.out_w = up(w[W_OUT_W], 5 * nh_mem0); d.out_b = up(w[W_OUT_B], 5);
-    d.sfo_w = up(w[W_SFO_W], 6 * nh); d.sfo_b = up(w[W_SFO_B], 6);
-    d.rel_w = up(w[W_REL_W], nh); d.rel_b = up(w[W_REL_B], 1);
+    d.nx = nx; d.nfeat = nfeat; d.naux = naux; d.nx_sfc = nx_sfc; d.sfc_cut = sfc_cut; d.sfc_skip = naux - nx_sfc;
+    d.nh = nh; d.ilev = ilev_crm; d.nm0 = nh_mem0; d.Lc = PH_L - ilev_crm;
+    d.ltop = rad ? ilev_crm : 0; d.Lr = PH_L - d.ltop;
+    d.ncol = mp_ncol; d.rad = rad;
+    d.hdw = rad ? ((PH_NHEAD * mp_ncol + nh_mem0 + 3) / 4) * 4 : PH_NHEAD * mp_ncol + nh_mem0 + 1;
+    d.hyam = up(w.hyam, 60); d.hybm = up(w.hybm, 60); d.hyai = up(w.hyai, 61); d.hybi = up(w.hybi, 61);
+    d.yscale_lev = up(w.ysl, 60 * 5); d.yscale_sca = up(w.yss, 8);
+    d.xdiv_sca0 = w.xds[0]; d.xmean_sca0 = w.xms[0];
+    { auto t = transposed(w.init_w, nh, nfeat + 1); d.init_wt = up(t.data(), t.size()); }
+    d.init_b = up(w.init_b, nh);
+    { auto t = transposed(w.s1_w, nh, nx_sfc); d.s1_wt = up(t.data(), t.size()); }
+    d.s1_b = up(w.s1_b, nh);
+    d.out_w = up(w.out_w, 5 * nh_mem0); d.out_b = up(w.out_b, 5);
+    if (!rad) { d.sfo_w = up(w.sfo_w, 6 * nh); d.sfo_b = up(w.sfo_b, 6); }
+    d.rel_w = up(w.rel_w, nh); d.rel_b = up(w.rel_b, 1);
     // GRU layers: W_ih rows to unit-major [r, z, n, 0]; rnn1's K = nh + 15 padded to nh + 16 with a zero column
     {
         const int Kin = nh + nh_mem0, K1 = nh + 16;
         std::vector<float> wpad((size_t)3 * nh * K1, 0.0f), wp, bp, bhn;
-        for (int r = 0; r < 3 * nh; ++r) memcpy(&wpad[(size_t)r * K1], &w[W_R1_IH][(size_t)r * Kin], sizeof(float) * Kin);
-        pack_ih(0, nh, K1, wpad.data(), w[W_R1_BIH], w[W_R1_BHH], wp, bp, bhn);
+        for (int r = 0; r < 3 * nh; ++r) memcpy(&wpad[(size_t)r * K1], &w.r1_ih[(size_t)r * Kin], sizeof(float) * Kin);
+        pack_ih(0, nh, K1, wpad.data(), w.r1_bih, w.r1_bhh, wp, bp, bhn);
         h->wih1 = up(wp.data(), wp.size()); h->bias1 = up(bp.data(), bp.size()); h->bhn1 = up(bhn.data(), bhn.size());
-        pack_ih(0, nh, nh, w[W_R2_IH], w[W_R2_BIH], w[W_R2_BHH], wp, bp, bhn);
+        pack_ih(0, nh, nh, w.r2_ih, w.r2_bih, w.r2_bhh, wp, bp, bhn);
         h->wih2 = up(wp.data(), wp.size()); h->bias2 = up(bp.data(), bp.size()); h->bhn2 = up(bhn.data(), bhn.size());
         std::vector<float> pk(rec_packed_floats(0, nh));
-        rec_pack_weights(0, nh, w[W_R1_HH], pk.data()); h->whh1p = up(pk.data(), pk.size());
-        rec_pack_weights(0, nh, w[W_R2_HH], pk.data()); h->whh2p = up(pk.data(), pk.size());
-        gru2_pack_weights(nh, w[W_R1_HH], pk.data()); h->whh1g = up(pk.data(), pk.size());   // two-column kernel (B > 256)
-        gru2_pack_weights(nh, w[W_R2_HH], pk.data()); h->whh2g = up(pk.data(), pk.size());
+        rec_pack_weights(0, nh, w.r1_hh, pk.data()); h->whh1p = up(pk.data(), pk.size());
+        rec_pack_weights(0, nh, w.r2_hh, pk.data()); h->whh2p = up(pk.data(), pk.size());
+        gru2_pack_weights(nh, w.r1_hh, pk.data()); h->whh1g = up(pk.data(), pk.size());   // two-column kernel (B > 256)
+        gru2_pack_weights(nh, w.r2_hh, pk.data()); h->whh2g = up(pk.data(), pk.size());
     }
-    // head GEMM: 11 decoder heads (16 rows each), mlp_latent (15 rows), mlp_output_rad (1 row)
+    // head GEMM: 11 decoder heads (mp_ncol rows each), mlp_latent (15 rows), then mlp_output_rad (1 row) or zero padding
     {
-        std::vector<float> wh((size_t)PH_HD * nh), bh(PH_HD);
+        const int HDW = d.hdw;
+        std::vector<float> wh((size_t)HDW * nh, 0.0f), bh(HDW, 0.0f);
         for (int k = 0; k < PH_NHEAD; ++k) {
-            memcpy(&wh[(size_t)k * PH_NCOL * nh], w[W_HEADS + 2 * k], sizeof(float) * PH_NCOL * nh);
-            memcpy(&bh[k * PH_NCOL], w[W_HEADS + 2 * k + 1], sizeof(float) * PH_NCOL);
+            memcpy(&wh[(size_t)k * mp_ncol * nh], w.heads[2 * k], sizeof(float) * mp_ncol * nh);
+            memcpy(&bh[k * mp_ncol], w.heads[2 * k + 1], sizeof(float) * mp_ncol);
         }
-        memcpy(&wh[(size_t)PH_NHEAD * PH_NCOL * nh], w[W_LAT_W], sizeof(float) * nh_mem0 * nh);
-        memcpy(&bh[PH_NHEAD * PH_NCOL], w[W_LAT_B], sizeof(float) * nh_mem0);
-        memcpy(&wh[(size_t)(PH_HD - 1) * nh], w[W_RAD_W], sizeof(float) * nh);
-        bh[PH_HD - 1] = w[W_RAD_B][0];
+        memcpy(&wh[(size_t)PH_NHEAD * mp_ncol * nh], w.lat_w, sizeof(float) * nh_mem0 * nh);
+        memcpy(&bh[PH_NHEAD * mp_ncol], w.lat_b, sizeof(float) * nh_mem0);
+        if (!rad) {
+            memcpy(&wh[(size_t)(HDW - 1) * nh], w.rad_w, sizeof(float) * nh);
+            bh[HDW - 1] = w.rad_b[0];
+        }
         h->whead = up(wh.data(), wh.size()); h->bhead = up(bh.data(), bh.size());
     }
-    const size_t rows = (size_t)PH_L * max_batch;
+    const size_t rows = (size_t)d.Lr * max_batch;
     h->X1 = up(nullptr, rows * (nh + 16)); h->P = up(nullptr, rows * 4 * nh); h->H1 = up(nullptr, rows * nh);
-    h->H2 = up(nullptr, rows * nh); h->hx = up(nullptr, (size_t)max_batch * nh); h->HD = up(nullptr, rows * PH_HD);
+    h->H2 = up(nullptr, rows * nh); h->hx = up(nullptr, (size_t)max_batch * nh); h->HD = up(nullptr, rows * d.hdw);
+    if (rad) {
+        d.xmean_sca = up(w.xms, naux); d.xdiv_sca = up(w.xds, naux); d.lbd_qn = up(w.lbd_qn, 60);
+        d.g_xmin = up(w.g_xmin, 18); d.g_xmax = up(w.g_xmax, 18); d.g_ymean = up(w.g_ymean, 128); d.g_ystd = up(w.g_ystd, 128);
+        d.ys_rad = up(w.ys_rad, 6); d.retab = up(kRetab, PH_NRETAB);
+        {   // incoming spectral weights: softmax of the squared learned weights (float arithmetic as in the reference)
+            float sq[PH_NG], m = -3.0e38f, sum = 0.0f, e[PH_NG];
+            for (int g = 0; g < PH_NG; ++g) { sq[g] = w.solar_w[g] * w.solar_w[g]; m = sq[g] > m ? sq[g] : m; }
+            for (int g = 0; g < PH_NG; ++g) { e[g] = expf(sq[g] - m); sum += e[g]; }
+            for (int g = 0; g < PH_NG; ++g) e[g] /= sum;
+            d.toa_spec = up(e, PH_NG);
+        }
+        auto padK = [&](const float *src, int n, int k, int kp) {
+            std::vector<float> t((size_t)n * kp, 0.0f);
+            for (int r = 0; r < n; ++r) memcpy(&t[(size_t)r * kp], &src[(size_t)r * k], sizeof(float) * k);
+            return up(t.data(), t.size());
+        };
+        h->g_w1 = padK(w.g_w1, 64, 18, PH_XG_K); h->g_b1 = up(w.g_b1, 64);
+        h->g_w2 = up(w.g_w2, 64 * 64); h->g_b2 = up(w.g_b2, 64);
+        h->g_w3 = up(w.g_w3, 256 * 64); h->g_b3 = up(w.g_b3, 256);
+        h->r1_w = up(w.r1_w, 16 * 128); h->r1_b = up(w.r1_b, 16);
+        h->r2_w = up(w.r2_w, 16 * 128); h->r2_b = up(w.r2_b, 16);
+        h->s1_w = up(w.sw1_w, 32 * PH_XR_K); h->s1_b = up(w.sw1_b, 32);
+        h->s2_w = up(w.sw2_w, 48 * 32); h->s2_b = up(w.sw2_b, 48);
+        const size_t M = (size_t)PH_L * max_batch;
+        h->XG = up(nullptr, M * PH_XG_K); h->XR = up(nullptr, M * PH_XR_K); h->RS = up(nullptr, M * 2);
+        h->CL = up(nullptr, (size_t)d.Lc * max_batch * PH_NG);
+        h->A1 = up(nullptr, M * 64); h->A2 = up(nullptr, M * 64); h->A3 = up(nullptr, M * 256); h->TP = up(nullptr, M * 32);
+        h->S1 = up(nullptr, M * 32); h->S2 = up(nullptr, M * 48);
+    }
     if (rc != CSA_OK) { for (void *p : h->owned) (void)hipFree(p); delete h; return rc; }
     *out = h;
     return CSA_OK;
+}
+
+extern "C" int csa_phys_create(int nx, int nx_sfc, int nh, int ilev_crm, int mp_ncol, int nh_mem0,
+                               const float *const *w /* see include/climsim_amd.h for the order */, int max_batch, csa_phys **out)
+{
+    if (!w || !out || max_batch <= 0) { csa_set_error_msg("csa_phys_create: bad argument"); return CSA_ERR_ARG; }
+    if (nh != 128 || mp_ncol != 16 || nh_mem0 != 15 || ilev_crm != 10 || nx + 1 > 32 || nx_sfc > 64) {
+        csa_set_error_msg("csa_phys_create: built for the shipped physRNN-Hidden geometry (GRU 128/128, mp_ncol 16, 15+1 memory channels, ilev_crm 10)");
+        return CSA_ERR_UNSUPPORTED;
+    }
+    PhysHostW v{};
+    const float *const *p = w;
+    v.hyam = *p++; v.hybm = *p++; v.hyai = *p++; v.hybi = *p++; v.ysl = *p++; v.yss = *p++; v.xds = *p++; v.xms = *p++;
+    v.init_w = *p++; v.init_b = *p++; v.s1_w = *p++; v.s1_b = *p++;
+    v.r1_ih = *p++; v.r1_hh = *p++; v.r1_bih = *p++; v.r1_bhh = *p++; v.r2_ih = *p++; v.r2_hh = *p++; v.r2_bih = *p++; v.r2_bhh = *p++;
+    v.lat_w = *p++; v.lat_b = *p++; v.out_w = *p++; v.out_b = *p++; v.sfo_w = *p++; v.sfo_b = *p++; v.rad_w = *p++; v.rad_b = *p++;
+    v.rel_w = *p++; v.rel_b = *p++;
+    v.heads = p;
+    return phys_build(nx, nx, nx_sfc, nx_sfc, nx_sfc, nh, ilev_crm, mp_ncol, nh_mem0, 0, v, max_batch, out);
+}
+
+// The radiation graphs (num4050): see include/climsim_amd.h for the pointer order
+extern "C" int csa_phys_rad_create(int nx, int naux, int nh, int ilev_crm, int mp_ncol, int nh_mem0, int ng,
+                                   const float *const *w, int max_batch, csa_phys **out)
+{
+    if (!w || !out || max_batch <= 0) { csa_set_error_msg("csa_phys_rad_create: bad argument"); return CSA_ERR_ARG; }
+    if (nh != 128 || mp_ncol != 4 || nh_mem0 != 15 || ilev_crm != 10 || nx != 21 || naux != 19 || ng != PH_NG) {
+        csa_set_error_msg("csa_phys_rad_create: built for the shipped geometry (21 level inputs, 19 surface inputs, GRU 128/128 over 50 levels, "
+                          "mp_ncol 4, 15+1 memory channels, 16 g-points)");
+        return CSA_ERR_UNSUPPORTED;
+    }
+    PhysHostW v{};
+    const float *const *p = w;
+    v.hyam = *p++; v.hybm = *p++; v.hyai = *p++; v.hybi = *p++; v.ysl = *p++; v.yss = *p++; v.xds = *p++; v.xms = *p++;
+    v.init_w = *p++; v.init_b = *p++; v.s1_w = *p++; v.s1_b = *p++;
+    v.r1_ih = *p++; v.r1_hh = *p++; v.r1_bih = *p++; v.r1_bhh = *p++; v.r2_ih = *p++; v.r2_hh = *p++; v.r2_bih = *p++; v.r2_bhh = *p++;
+    v.lat_w = *p++; v.lat_b = *p++; v.out_w = *p++; v.out_b = *p++; v.rel_w = *p++; v.rel_b = *p++;
+    v.heads = p; p += 2 * PH_NHEAD;
+    v.lbd_qn = *p++; v.ys_rad = *p++; v.solar_w = *p++; v.g_xmin = *p++; v.g_xmax = *p++; v.g_ymean = *p++; v.g_ystd = *p++;
+    v.g_w1 = *p++; v.g_b1 = *p++; v.g_w2 = *p++; v.g_b2 = *p++; v.g_w3 = *p++; v.g_b3 = *p++;
+    v.r1_w = *p++; v.r1_b = *p++; v.r2_w = *p++; v.r2_b = *p++; v.sw1_w = *p++; v.sw1_b = *p++; v.sw2_w = *p++; v.sw2_b = *p++;
+    // mlp_initial sees x_main[:, :, 0:nx-3] and the layer pressure; mlp_surface1 sees aux 0:6 and 11:naux
+    return phys_build(nx, nx - 3, naux, naux - 5, 6, nh, ilev_crm, mp_ncol, nh_mem0, 1, v, max_batch, out);
 }
 
 extern "C" int csa_phys_destroy(csa_phys *h)
@@ -346,41 +539,50 @@ extern "C" int csa_phys_destroy(csa_phys *h)
     return CSA_OK;
 }
 
-// x_main (B,60,nx) normalised, x_sfc (B,nx_sfc) normalised, rnn_mem (B,50,16), x_denorm (B,60,nxd) raw (T, ., qliq, qice, ..., qv last),
+// x_main (B,60,nx) normalised, x_sfc (B,naux) normalised, rnn_mem (B,50,16), x_denorm (B,60,nxd) raw (T, ., qliq, qice, ..., qv last),
 // hx2 (B,nh): the N(0,1) draw the reference makes for rnn2's initial state.  -> out_lev (B,60,5), out_sfc (B,8), mem_out (B,50,16)
 extern "C" int csa_phys_forward(csa_phys *h, int B, const float *x_main, const float *x_sfc, const float *rnn_mem,
                                 const float *x_denorm, int nxd, const float *hx2, float *out_lev, float *out_sfc, float *mem_out,
                                 void *stream)
 {
-    if (!h || !x_main || !x_sfc || !rnn_mem || !x_denorm || !hx2 || !out_lev || !out_sfc || !mem_out || B <= 0 || B > h->max_batch || nxd < 5) {
+    if (!h || !x_main || !x_sfc || !rnn_mem || !x_denorm || !hx2 || !out_lev || !out_sfc || !mem_out || B <= 0 || B > h->max_batch || nxd < 5 ||
+        (h->d.rad && nxd < 16)) {
         csa_set_error_msg("csa_phys_forward: bad argument");
         return CSA_ERR_ARG;
     }
     hipStream_t s = (hipStream_t)stream;
     const PhysDev &d = h->d;
-    const int nh = d.nh, M = PH_L * B;
+    const int nh = d.nh, L = d.Lr, M = L * B;
     int rc;
     hipLaunchKernelGGL(phys_prep_kernel, dim3(B, B <= 1024 ? 2 : 1), dim3(128), 0, s, d, B, x_main, x_sfc, rnn_mem, h->X1, h->hx);
     CSA_HIP_CHECK(hipGetLastError());
     auto rec = [&](const float *whh, const float *whg, const float *bhn, const float *h0, float *Hout, int reverse) {
-        return B <= 256 ? launch_rec1_gru(nh, whh, bhn, h->P, h0, Hout, B, PH_L, reverse, s)
-                        : launch_rec2_gru(nh, whg, bhn, h->P, h0, Hout, B, PH_L, reverse, s);
+        return B <= 256 ? launch_rec1_gru(nh, whh, bhn, h->P, h0, Hout, B, L, reverse, s)
+                        : launch_rec2_gru(nh, whg, bhn, h->P, h0, Hout, B, L, reverse, s);
     };
     if ((rc = launch_proj_gemm(h->X1, h->wih1, h->bias1, h->P, M, 4 * nh, nh + 16, s, 0))) return rc;
     if ((rc = rec(h->whh1p, h->whh1g, h->bhn1, h->hx, h->H1, 1))) return rc;
     if ((rc = launch_proj_gemm(h->H1, h->wih2, h->bias2, h->P, M, 4 * nh, nh, s, 0))) return rc;
     if ((rc = rec(h->whh2p, h->whh2g, h->bhn2, hx2, h->H2, 0))) return rc;
-    if ((rc = launch_proj_gemm(h->H2, h->whead, h->bhead, h->HD, M, PH_HD, nh, s, 0))) return rc;
-    hipLaunchKernelGGL(phys_decode_kernel, dim3(B), dim3(PH_DT), 0, s, d, B, h->HD, h->H2, x_sfc, rnn_mem, x_denorm, nxd, out_lev, out_sfc, mem_out);
+    if ((rc = launch_proj_gemm(h->H2, h->whead, h->bhead, h->HD, M, d.hdw, nh, s, 0))) return rc;
+    if (d.rad) {
+        PhysRadOut ro{x_main, h->XG, h->XR, h->RS, h->CL};
+        hipLaunchKernelGGL((phys_decode_kernel<4, 256, true>), dim3(B), dim3(256), 0, s, d, B, h->HD, h->H2, x_sfc, rnn_mem, x_denorm, nxd,
+                           out_lev, out_sfc, mem_out, ro);
+        CSA_HIP_CHECK(hipGetLastError());
+        return launch_phys_radiation(h, B, x_sfc, out_lev, out_sfc, s);
+    }
+    hipLaunchKernelGGL((phys_decode_kernel<16, 512, false>), dim3(B), dim3(512), 0, s, d, B, h->HD, h->H2, x_sfc, rnn_mem, x_denorm, nxd,
+                       out_lev, out_sfc, mem_out, PhysRadOut{});
     CSA_HIP_CHECK(hipGetLastError());
     return CSA_OK;
 }
 
-// taps for tests: level-major (60, B, nh) outputs of rnn1 (level order) and rnn2 of the last call
+// taps for tests: level-major (Lr, B, nh) outputs of rnn1 (level order) and rnn2 of the last call
 extern "C" int csa_phys_tap(csa_phys *h, int which, int B, float *dst, void *stream)
 {
     if (!h || !dst || B <= 0 || B > h->max_batch || which < 1 || which > 2) return CSA_ERR_ARG;
-    CSA_HIP_CHECK(hipMemcpyAsync(dst, which == 1 ? h->H1 : h->H2, sizeof(float) * (size_t)PH_L * B * h->d.nh, hipMemcpyDeviceToDevice,
+    CSA_HIP_CHECK(hipMemcpyAsync(dst, which == 1 ? h->H1 : h->H2, sizeof(float) * (size_t)h->d.Lr * B * h->d.nh, hipMemcpyDeviceToDevice,
                                  (hipStream_t)stream));
     return CSA_OK;
 }

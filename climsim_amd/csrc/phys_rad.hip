@@ -1,0 +1,229 @@
+// phys_rad.hip -- the physical radiation scheme of the physRNN "Hidden" radiation graphs, as
+// serialised in rnn/saved_models/physRNN-Hidden_*_num4050_BEST_script_cpu.pt (`radiative_transfer`; the current source
+// splits it differently, rnn/models/models_phys.py:1272-1584).  Helpers restated from rnn/models/physics_rad.py:
+//   :34 interpolate_tlev_batchlast   :51 outgoing_lw   :60 reftrans_lw   :96 lw_solver_noscat_batchlast
+//   :139 calc_ref_trans_sw           :332 adding_ica_sw_inference
+// and rnn/layers.py gasopt_mlp (LW gas optics 18 -> 64 -> 64 -> 256, reduced to 16 g-points by two Linear(128, 16)).
+//
+// After phys_decode_kernel<.., RAD> has written the MLP inputs (XG, XR), the per-level scalars (RS: dry-air column, updated
+// temperature) and the MCICA cloud optical depth (CL), one call runs
+//   3 GEMMs (gas optics, Softsign fused) -> rad_gas_post_kernel ((ystd x + ymean)^8 * col_dry | x^2, in place)
+//   -> 2 GEMMs (k-distribution 128 -> 16: optical depth, Planck fraction) -> 2 GEMMs (SW optical-property head)
+//   -> phys_rad_solve_kernel: one workgroup per grid column; two-stream coefficients for its 60 x 16 (level, g-point)
+//      cells in parallel, then the level recurrences (LW no-scattering sweep on wave 0, SW adding method on wave 1, one
+//      lane per g-point), flux sums, heating rate added onto out_lev[:, :, 0], six surface fluxes into out_sfc.
+// The LW downward source equals the upward source, as in the serialised graph.
+#include "phys.h"
+
+template <int N> __device__ __forceinline__ float pr_sum(float v)
+{
+#pragma unroll
+    for (int o = N / 2; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+template <int N> __device__ __forceinline__ float pr_max(float v)
+{
+#pragma unroll
+    for (int o = N / 2; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+}
+__device__ __forceinline__ float pr_pow8(float x) { x *= x; x *= x; return x * x; }
+__device__ __forceinline__ float pr_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
+__device__ __forceinline__ float pr_softplus(float x) { return x > 20.0f ? x : log1pf(expf(x)); }
+
+// A3 (M, 256) in place: first half -> col_dry * (ystd x + ymean)^8 (k-point optical depths), second half -> x^2
+__global__ __launch_bounds__(256) void rad_gas_post_kernel(float *__restrict__ A3, const float *__restrict__ RS,
+                                                           const float *__restrict__ ystd, const float *__restrict__ ymean, size_t M)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;        // one float4 of a row
+    if (i >= M * 64) return;
+    const size_t row = i >> 6;
+    const int c = (int)(i & 63) * 4;
+    f32x4 v = *(f32x4 *)(A3 + row * 256 + c);
+    if (c < 128) {
+        const float cd = RS[row * 2];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = cd * pr_pow8(ystd[c + u] * v[u] + ymean[c + u]);
+    } else {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = v[u] * v[u];
+    }
+    *(f32x4 *)(A3 + row * 256 + c) = v;
+}
+
+#define RS_T 256
+__global__ __launch_bounds__(RS_T) void phys_rad_solve_kernel(PhysDev d, int B, const float *__restrict__ x_sfc, const float *__restrict__ TP,
+                                                            const float *__restrict__ CL, const float *__restrict__ S2,
+                                                            const float *__restrict__ RS, float *__restrict__ out_lev, float *__restrict__ out_sfc)
+{
+    constexpr int L = PH_L, NG = PH_NG, NC = L * NG, NI = (L + 1) * NG;
+    __shared__ float s_tr[NC], s_su[NC], s_pf[NC];                               // LW: transmittance, source, Planck fraction
+    __shared__ float s_R[NC], s_T[NC], s_Rd[NC], s_Td[NC], s_Tdir[NC];           // SW layer properties
+    __shared__ float s_A[NI], s_Ad[NI];                                          // SW: albedo of everything below an interface
+    __shared__ float s_ldn[NI], s_lup[NI], s_sup[NI], s_sdf[NI], s_sdr[NI];      // per g-point fluxes at the interfaces
+    __shared__ float s_tl[L], s_pl[L], s_cd[L], s_ph[L + 1], s_bl[L + 1], s_net[L + 1], s_aux[32];
+    const int b = blockIdx.x, tid = threadIdx.x, ilev = d.ilev;
+    if (tid < d.naux) s_aux[tid] = x_sfc[(size_t)b * d.naux + tid] * d.xdiv_sca[tid] + d.xmean_sca[tid];
+    __syncthreads();
+    const float sp = s_aux[0];
+    if (tid < L) {
+        const size_t row = (size_t)tid * B + b;
+        s_cd[tid] = RS[row * 2]; s_tl[tid] = RS[row * 2 + 1];
+        s_pl[tid] = d.hyam[tid] * 100000.0f + sp * d.hybm[tid];
+    }
+    if (tid <= L) s_ph[tid] = sp * d.hybi[tid] + d.hyai[tid] * 100000.0f;
+    __syncthreads();
+    if (tid <= L) {                                   // interface temperatures (physics_rad.py:34) and their black-body flux
+        const int j = tid;
+        float t;
+        if (j == 0) t = s_tl[0] + (s_ph[0] - s_pl[0]) * (s_tl[1] - s_tl[0]) / (s_pl[1] - s_pl[0]);
+        else if (j == L) t = s_tl[L - 1] + (s_ph[L] - s_pl[L - 1]) * (s_tl[L - 1] - s_tl[L - 2]) / (s_pl[L - 1] - s_pl[L - 2]);
+        else t = (s_pl[j - 1] * s_tl[j - 1] * (s_ph[j] - s_pl[j]) + s_pl[j] * s_tl[j] * (s_pl[j - 1] - s_ph[j])) / (s_ph[j] * (s_pl[j - 1] - s_pl[j]));
+        const float t2 = t * t;
+        s_bl[j] = t2 * t2 * 5.670374419e-8f;
+    }
+    const float mu0 = fmaxf(s_aux[6], 1e-6f);
+    // ---- per (level, g-point) cell: LW optical depth + Planck fraction, SW two-stream coefficients ----
+    for (int e0 = 0; e0 < NC; e0 += RS_T) {
+        const int e = e0 + tid, lv = min(e >> 4, L - 1), g = e & 15;
+        const bool ok = e < NC;
+        const size_t row = (size_t)lv * B + b;
+        const float *tp = TP + row * 32;
+        const float logit = tp[16 + g], m = pr_max<NG>(logit), ex = expf(logit - m), pf = ex / pr_sum<NG>(ex);
+        const float tau = pr_softplus(tp[g]) * 0.01f + (lv >= ilev ? CL[((size_t)(lv - ilev) * B + b) * NG + g] : 0.0f);
+        const float od_lw = tau * 1.66f;
+        const float *o = S2 + row * 48;
+        const float od = fminf(fmaxf(pr_pow8(o[g]) * (s_cd[lv] * 1e-23f), 1e-6f), 40.0f);
+        const float ssa = pr_sigmoid(o[16 + g]), asy = pr_sigmoid(o[32 + g]);
+        // two-stream coefficients (physics_rad.py:139)
+        const float t_dir = expf(-od / mu0);
+        const float g1 = (8.0f - ssa * (5.0f + 3.0f * asy)) * 0.25f, g2 = 3.0f * (ssa * (1.0f - asy)) * 0.25f;
+        const float g3 = (2.0f - 3.0f * mu0 * asy) * 0.25f, g4 = 1.0f - g3;
+        const float a1 = g1 * g4 + g2 * g3, a2 = g1 * g3 + g2 * g4;
+        const float k = sqrtf(fmaxf((g1 - g2) * (g1 + g2), 1e-4f));
+        const float ek = expf(-k * od), e2 = ek * ek, k2e = 2.0f * k * ek;
+        float rf = 1.0f / (k + g1 + (k - g1) * e2);
+        const float r_dif = g2 * (1.0f - e2) * rf;
+        const float t_dif = fmaxf(fminf(fmaxf(k2e * rf, 0.0f), 1.0f - r_dif), 0.0f);
+        const float kmu = k * mu0;
+        float den = 1.0f - kmu * kmu;
+        den = fabsf(den) > 1e-7f ? den : 1e-7f;
+        rf = ssa * rf / den;
+        const float kg3 = k * g3, kg4 = k * g4;
+        float r_dir = rf * (((1.0f - kmu) * (a2 + kg3) - (1.0f + kmu) * (a2 - kg3) * e2) - k2e * (g3 - a2 * mu0) * t_dir);
+        float t_dd = rf * (k2e * (g4 + a1 * mu0) - t_dir * ((1.0f + kmu) * (a1 + kg4) - (1.0f - kmu) * (a1 - kg4) * e2));
+        const float room = 1.0f - t_dir;
+        r_dir = fminf(fmaxf(r_dir, 0.0f), room);
+        t_dd = fminf(fmaxf(t_dd, 0.0f), room - r_dir);
+        if (ok) {
+            s_pf[e] = pf; s_tr[e] = expf(-od_lw); s_su[e] = od_lw;
+            s_R[e] = r_dif; s_T[e] = t_dif; s_Rd[e] = r_dir; s_Td[e] = t_dd; s_Tdir[e] = t_dir;
+        }
+    }
+    __syncthreads();
+    // LW layer sources (physics_rad.py:60): Planck flux of a g-point at the layer's top and bottom interfaces
+    for (int e = tid; e < NC; e += RS_T) {
+        const int lv = e >> 4;
+        const float top = s_pf[e] * s_bl[lv];
+        const float bot = lv < L - 1 ? s_pf[e + NG] * s_bl[lv + 1] : s_pf[e] * s_bl[L];
+        const float c = s_su[e] * 0.2f;
+        s_su[e] = (1.0f - s_tr[e]) * ((top + bot) * 0.5f + c * top) / (c + 1.0f);
+    }
+    __syncthreads();
+    // ---- level recurrences, one lane per g-point: LW on wave 0, SW on wave 1 ----
+    if (tid < NG) {
+        const int g = tid;
+        float f = 0.0f;
+        s_ldn[g] = 0.0f;
+        for (int j = 0; j < L; ++j) {
+            f = s_tr[j * NG + g] * f + s_su[j * NG + g];
+            s_ldn[(j + 1) * NG + g] = f;
+        }
+        f = s_pf[(L - 1) * NG + g] * s_aux[11];       // surface emission (emissivity 1)
+        s_lup[L * NG + g] = f;
+        for (int j = L - 1; j >= 0; --j) {
+            f = s_tr[j * NG + g] * f + s_su[j * NG + g];
+            s_lup[j * NG + g] = f;
+        }
+    } else if (tid >= 64 && tid < 64 + NG) {
+        const int g = tid - 64;
+        const int n_ir = 11, n_mix = 13;              // round(0.7143 * 16), round(0.7946 * 16): near-IR | mixed | visible g-points
+        const float toa = s_aux[1] * d.toa_spec[g];
+        float A = g < n_ir ? s_aux[7] : g < n_mix ? (s_aux[7] + s_aux[9]) * 0.5f : s_aux[9];
+        float Ad = g < n_ir ? s_aux[8] : g < n_mix ? (s_aux[8] + s_aux[10]) * 0.5f : s_aux[10];
+        s_A[L * NG + g] = A; s_Ad[L * NG + g] = Ad;
+        for (int j = L - 1; j >= 0; --j) {
+            const int e = j * NG + g;
+            const float inv = 1.0f / (1.0f - A * s_R[e]);
+            Ad = s_Rd[e] + (s_Tdir[e] * Ad + s_Td[e] * A) * s_T[e] * inv;
+            A = s_R[e] + s_T[e] * s_T[e] * A * inv;
+            s_A[e] = A; s_Ad[e] = Ad;
+        }
+        float dif = 0.0f, dr = toa;
+        s_sup[g] = fmaxf(toa * Ad, 0.0f); s_sdf[g] = 0.0f; s_sdr[g] = fmaxf(toa, 0.0f);
+        for (int j = 0; j < L; ++j) {
+            const int e = j * NG + g;
+            const float Ab = s_A[e + NG], Adb = s_Ad[e + NG];
+            const float inv = 1.0f / (1.0f - s_R[e] * Ab);
+            dif = (s_T[e] * dif + dr * (s_T[e] * Adb * s_R[e] + s_Td[e])) * inv;
+            dr = dr * s_Tdir[e];
+            s_sup[e + NG] = fmaxf(dr * Adb + dif * Ab, 0.0f);
+            s_sdf[e + NG] = fmaxf(dif, 0.0f);
+            s_sdr[e + NG] = fmaxf(dr, 0.0f);
+        }
+    }
+    __syncthreads();
+    // ---- spectral sums, net flux per interface, surface diagnostics ----
+    const float day = s_aux[6] < 1e-6f ? 0.0f : 1.0f;
+    if (tid <= L) {
+        const int j = tid;
+        float ldn = 0.0f, lup = 0.0f, up = 0.0f, df = 0.0f, dr = 0.0f;
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            ldn += s_ldn[j * NG + g]; lup += s_lup[j * NG + g];
+            up += s_sup[j * NG + g]; df += s_sdf[j * NG + g]; dr += s_sdr[j * NG + g];
+        }
+        const float sw_dn = df + dr;
+        s_net[j] = (ldn - lup) + day * (sw_dn - up);
+        if (j == L) {
+            float dir_ir = 0.0f, dir_mix = 0.0f, dir_vis = 0.0f, dif_ir = 0.0f, dif_mix = 0.0f, dif_vis = 0.0f;
+            for (int g = 0; g < NG; ++g) {
+                const float a = s_sdr[L * NG + g], c = s_sdf[L * NG + g];
+                if (g < 11) { dir_ir += a; dif_ir += c; } else if (g < 13) { dir_mix += a; dif_mix += c; } else { dir_vis += a; dif_vis += c; }
+            }
+            float *os = out_sfc + (size_t)b * 8;
+            os[0] = day * sw_dn * d.ys_rad[0];
+            os[1] = ldn * d.ys_rad[1];
+            os[4] = day * (dir_vis + 0.5f * dir_mix) * d.ys_rad[2];      // SOLS
+            os[5] = day * (dir_ir + 0.5f * dir_mix) * d.ys_rad[3];       // SOLL
+            os[6] = day * (dif_vis + 0.5f * dif_mix) * d.ys_rad[4];      // SOLSD
+            os[7] = day * (dif_ir + 0.5f * dif_mix) * d.ys_rad[5];       // SOLLD
+        }
+    }
+    __syncthreads();
+    if (tid < L) {
+        const int j = tid;
+        const float pd = sp * (d.hybi[j + 1] - d.hybi[j]) + (d.hyai[j + 1] - d.hyai[j]) * 100000.0f;
+        const float dT = -((s_net[j + 1] - s_net[j]) / pd) * 0.009761357302f * d.yscale_lev[j * 5];
+        out_lev[((size_t)b * L + j) * 5] += dT;
+    }
+}
+
+int launch_phys_radiation(csa_phys *h, int B, const float *x_sfc, float *out_lev, float *out_sfc, hipStream_t s)
+{
+    const PhysDev &d = h->d;
+    const int M = PH_L * B;
+    int rc;
+    if ((rc = launch_gemm_act(h->XG, h->g_w1, h->g_b1, h->A1, M, 64, PH_XG_K, 4, 0.0f, 0, s))) return rc;
+    if ((rc = launch_gemm_act(h->A1, h->g_w2, h->g_b2, h->A2, M, 64, 64, 4, 0.0f, 0, s))) return rc;
+    if ((rc = launch_gemm_act(h->A2, h->g_w3, h->g_b3, h->A3, M, 256, 64, 0, 0.0f, 0, s))) return rc;
+    hipLaunchKernelGGL(rad_gas_post_kernel, dim3((unsigned)(((size_t)M * 64 + 255) / 256)), dim3(256), 0, s, h->A3, h->RS, d.g_ystd, d.g_ymean, (size_t)M);
+    CSA_HIP_CHECK(hipGetLastError());
+    if ((rc = launch_gemm_ex(h->A3, h->r1_w, h->r1_b, h->TP, M, 16, 128, 0, 0.0f, 0, 256, 32, 0, 0, 0, s))) return rc;
+    if ((rc = launch_gemm_ex(h->A3 + 128, h->r2_w, h->r2_b, h->TP + 16, M, 16, 128, 0, 0.0f, 0, 256, 32, 0, 0, 0, s))) return rc;
+    if ((rc = launch_gemm_act(h->XR, h->s1_w, h->s1_b, h->S1, M, 32, PH_XR_K, 4, 0.0f, 0, s))) return rc;
+    if ((rc = launch_gemm_act(h->S1, h->s2_w, h->s2_b, h->S2, M, 48, 32, 0, 0.0f, 0, s))) return rc;
+    hipLaunchKernelGGL(phys_rad_solve_kernel, dim3(B), dim3(RS_T), 0, s, d, B, x_sfc, h->TP, h->CL, h->S2, h->RS, out_lev, out_sfc);
+    CSA_HIP_CHECK(hipGetLastError());
+    return CSA_OK;
+}

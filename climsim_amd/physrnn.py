@@ -21,13 +21,29 @@ _ORDER = (["hyam", "hybm", "hyai", "hybi", "yscale_lev", "yscale_sca", "xdiv_sca
           + [f"{m}.{n}" for m in _HEADS for n in ("weight", "bias")])
 
 
+# the radiation graphs (use_physrad, e.g. ..._num4050_BEST_script_cpu.pt): no radiative Linear heads, and the weights of the
+# serialised radiative_transfer after the decoder heads (order of include/climsim_amd.h::csa_phys_rad_create)
+_ORDER_RAD = ([k for k in _ORDER if not k.startswith(("mlp_surface_output_rad", "mlp_output_rad"))]
+              + ["lbd_qn", "yscale_sca_rad", "sw_solar_weights", "gas_optics_model_lw.xmin", "gas_optics_model_lw.xmax",
+                 "gas_optics_model_lw.ymean", "gas_optics_model_lw.ystd"]
+              + [f"{m}.{n}" for m in ("gas_optics_model_lw.mlp1", "gas_optics_model_lw.mlp2", "gas_optics_model_lw.mlp3",
+                                      "gas_optics_lw_reduce1", "gas_optics_lw_reduce2", "mlp_sw_optprops1", "mlp_sw_optprops2")
+                 for n in ("weight", "bias")])
+
+
 class physical_RNN_autoreg(torch.nn.Module):
-    def __init__(self, state_dict, *, ilev_crm=10, mp_ncol=16, nh_mem0=15, max_batch=4096):
+    def __init__(self, state_dict, *, ilev_crm=10, mp_ncol=None, nh_mem0=15, max_batch=4096):
         super().__init__()
         self._h = None
         if not torch.cuda.is_available():
             raise RuntimeError("climsim_amd needs a HIP device: the product path has no CPU fallback")
         self.device = torch.device("cuda", torch.cuda.current_device())
+        self.use_physrad = "gas_optics_model_lw.mlp1.weight" in state_dict
+        if mp_ncol is None:
+            mp_ncol = int(state_dict["mlp_qv_crm.weight"].shape[0]) if "mlp_qv_crm.weight" in state_dict else 16
+        if self.use_physrad:
+            self._init_rad(state_dict, ilev_crm, mp_ncol, nh_mem0, max_batch)
+            return
         arrs = []
         for k in _ORDER:
             if k not in state_dict:
@@ -49,6 +65,29 @@ class physical_RNN_autoreg(torch.nn.Module):
             raise RuntimeError(f"csa_phys_create failed ({rc}): {_lib.last_error()}")
         self._h, self.max_batch = h, max_batch
 
+    def _init_rad(self, state_dict, ilev_crm, mp_ncol, nh_mem0, max_batch):
+        arrs = []
+        for k in _ORDER_RAD:
+            if k not in state_dict:
+                raise RuntimeError(f"physRNN (radiation graph) state_dict lacks {k}")
+            v = state_dict[k]
+            v = v.detach().cpu().numpy() if isinstance(v, torch.Tensor) else np.asarray(v)
+            arrs.append(np.ascontiguousarray(v, np.float32))
+        sd = dict(zip(_ORDER_RAD, arrs))
+        self.nh = sd["mlp_initial.weight"].shape[0]
+        self.nx = sd["mlp_initial.weight"].shape[1] + 2             # x_main columns: 3 of them bypass mlp_initial, which also sees pressure
+        self.nx_sfc = sd["xmean_sca"].shape[0]                      # x_sfc columns (5 of them bypass mlp_surface1)
+        self.nlev, self.nlev_mem, self.nh_mem = 60, 60 - ilev_crm, nh_mem0 + 1
+        ng = sd["gas_optics_lw_reduce1.weight"].shape[0]
+        FP = ctypes.POINTER(ctypes.c_float)
+        warr = (FP * len(arrs))(*[a.ctypes.data_as(FP) for a in arrs])
+        h = ctypes.c_void_p()
+        rc = _lib.lib().csa_phys_rad_create(self.nx, self.nx_sfc, self.nh, int(ilev_crm), int(mp_ncol), int(nh_mem0), int(ng), warr,
+                                            int(max_batch), ctypes.byref(h))
+        if rc != 0:
+            raise RuntimeError(f"csa_phys_rad_create failed ({rc}): {_lib.last_error()}")
+        self._h, self.max_batch = h, max_batch
+
     def forward(self, inp_list, hx2=None):
         x_main, x_sfc, rnn_mem, x_denorm = inp_list[0], inp_list[1], inp_list[2], inp_list[3]
         B = x_main.shape[0]
@@ -68,7 +107,7 @@ class physical_RNN_autoreg(torch.nn.Module):
         return out, out_sfc, mem_out
 
     def tap(self, which, B):
-        t = torch.empty(60, B, self.nh, device=self.device)
+        t = torch.empty(self.nlev_mem if self.use_physrad else 60, B, self.nh, device=self.device)
         rc = _lib.lib().csa_phys_tap(self._h, which, B, _ptr(t), ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream))
         if rc != 0:
             raise RuntimeError(f"csa_phys_tap failed ({rc})")

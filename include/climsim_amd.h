@@ -408,6 +408,21 @@ int csa_phys_forward(csa_phys *h, int B, const float *x_main, const float *x_sfc
                      void *stream);
 int csa_phys_tap(csa_phys *h, int which, int B, float *dst, void *stream);
 
+/* The radiation graphs of the same model family (physRNN-Hidden_*_num4050_BEST_script_cpu.pt: `use_physrad`): 21 level
+ * inputs of which the first 18 and the layer pressure feed mlp_initial, both GRUs over the 50 CRM levels, surface inputs
+ * aux[0:6] and aux[11:19], mp_ncol 4, and instead of the two radiative Linear heads the serialised `radiative_transfer`
+ * (LW gas-optics MLP rnn/layers.py gasopt_mlp + no-scattering solver rnn/models/physics_rad.py:96, learned SW optical
+ * properties + two-stream :139 + adding :332, MCICA sub-column sampling :533, E3SM effective radii
+ * rnn/models/physics_rad_e3sm.py:13,:62).  Same handle type: csa_phys_forward / _tap (50 levels) / _destroy apply;
+ * x_sfc is (B, naux = 19), x_denorm needs columns 12..14 = O3, CH4, N2O.
+ * w (HOST pointers): the first 24 of csa_phys_create's list (hyam ... mlp_output.b), mlp_precip_release.{w, b}, the 11
+ * decoder heads {weight (4,nh), bias}, then lbd_qn (60), yscale_sca_rad (6), sw_solar_weights (16),
+ * gas_optics_model_lw.{xmin (18), xmax (18), ymean (128), ystd (128), mlp1.{w (64,18), b}, mlp2.{w (64,64), b},
+ * mlp3.{w (256,64), b}}, gas_optics_lw_reduce1.{w (16,128), b}, gas_optics_lw_reduce2.{w, b},
+ * mlp_sw_optprops1.{w (32,24), b}, mlp_sw_optprops2.{w (48,32), b}                                   (69 pointers) */
+int csa_phys_rad_create(int nx, int naux, int nh, int ilev_crm, int mp_ncol, int nh_mem0, int ng, const float *const *w,
+                        int max_batch, csa_phys **out);
+
 /* ---- stochastic recurrent layers ---------------------------------------------------
  * MyStochasticGRULayer5  rnn/models_torch_kernels.py:834-891 (its GPU path = the repo's inline CUDA, :29-252)
  * MyStochasticLSTMLayer4 rnn/models_torch_kernels.py:1474-1531

@@ -1,0 +1,265 @@
+"""TEST INFRASTRUCTURE ONLY (never imported by climsim_amd/): CPU restatement of the physRNN "Hidden" graphs that carry the
+physical radiation scheme (second slice) -- the architecture serialised in
+`rnn/saved_models/physRNN-Hidden_*_num4050_BEST_script_cpu.pt` (and num71535 / num83000 / num5730 / num62104, which add
+a stochastic third RNN or a liquid-fraction head on top of the same graph):
+
+  forward              the artefact's own TorchScript (an earlier revision of rnn/models/models_phys.py:1586-1823):
+                       21 input columns of which 18 (+ layer pressure) feed mlp_initial, RNNs over the 50 CRM levels only,
+                       14 surface inputs (aux 0:6 and 11:19), mp_ncol = 4, nh_mem = 15 + 1 stored-water channel
+  microphysics_decode  rnn/models/models_phys.py:414-748 (oracle/physrnn_ref.py, copy_dT = False)
+  radiative_transfer   serialised in the artefact (the current source, models_phys.py:1272-1584, has since been split into an
+                       optics step and a solver step); helpers: rnn/models/physics_rad.py:34 interpolate_tlev_batchlast,
+                       :51 outgoing_lw, :60 reftrans_lw, :96 lw_solver_noscat_batchlast, :139 calc_ref_trans_sw,
+                       :332 adding_ica_sw_inference, :533 stratified_sample; rnn/models/physics_rad_e3sm.py:13 reitab,
+                       :62 reltab; rnn/layers.py gasopt_mlp
+
+Two behaviours of the serialised graph that look accidental are kept because parity is against the artefact: the LW
+downward source equals the upward source (the artefact views `source_up` twice), and the cloud water handed to the
+gas/aerosol input vector is the un-updated q_liq + q_ice.
+
+PINNED: tests/golden/make_golden_physrnn.py runs the artefact (torch.jit.load, CPU) on seeded inputs and stores its outputs;
+tests/test_physrnn_rad.py checks this restatement against them.  Arrays here are (B, nlev, g) -- batch first."""
+import torch
+import torch.nn.functional as F
+
+from .physrnn_ref import _gru, _lin, microphysics_decode, G
+
+SIGMA = 5.670374419e-8
+# ice effective radius against temperature, E3SM's table (rnn/models/physics_rad_e3sm.py:13-59); index 0 = 137 K
+RETAB = [0.05, 0.05, 0.05, 0.05, 0.05, 0.05, 0.055, 0.06, 0.07, 0.08, 0.09, 0.1, 0.2, 0.3, 0.4, 0.5, 0.6, 0.7, 0.8, 0.9, 1.0,
+         1.1, 1.2, 1.3, 1.4, 1.5, 1.6, 1.8, 2.0, 2.2, 2.4, 2.6, 2.8, 3.0, 3.2, 3.5, 3.8, 4.1, 4.4, 4.7, 5.0, 5.3, 5.6, 5.92779,
+         6.26422, 6.61973, 6.99539, 7.39234, 7.81177, 8.25496, 8.72323, 9.218, 9.74075, 10.293, 10.8765, 11.4929, 12.144,
+         12.8317, 13.5581, 14.2319, 15.0351, 15.8799, 16.7674, 17.6986, 18.6744, 19.6955, 20.7623, 21.8757, 23.0364, 24.2452,
+         25.5034, 26.8125, 27.7895, 28.645, 29.4167, 30.1088, 30.7306, 31.2943, 31.8151, 32.3077, 32.787, 33.2657, 33.754,
+         34.2601, 34.7892, 35.3442, 35.9255, 36.5316, 37.1602, 37.8078, 38.472, 39.1508, 39.8442, 40.5552, 41.2912, 42.0635,
+         42.8876, 43.7863, 44.7853, 45.917, 47.2165, 48.7221, 50.471, 52.498, 54.8315, 57.4898, 60.4785, 63.7898, 65.5604,
+         71.2885, 75.4113, 79.7368, 84.2351, 88.8833, 93.6658, 98.5739, 103.603, 108.752, 114.025, 119.424, 124.954, 130.63,
+         136.457, 142.446, 148.608, 154.956, 161.503, 168.262, 175.248, 182.473, 189.952, 197.699, 205.728, 214.055, 222.694,
+         231.661, 240.971, 250.639]
+
+
+def reitab(t):
+    tab = torch.tensor(RETAB, dtype=t.dtype)
+    i = (t - 136.0).to(torch.int32).clamp(1, len(RETAB) - 2).long()
+    w = t - torch.floor(t)
+    return tab[i] * (1.0 - w) + tab[i + 1] * w
+
+
+def reltab(t, landfrac, icefrac, snowh):
+    rel = 8.0 + 6.0 * ((273.15 - t) * 0.05).clamp(0.0, 1.0)
+    rel = rel + (14.0 - rel) * (snowh * 10.0).clamp(0.0, 1.0)
+    rel = rel + (14.0 - rel) * (1.0 - landfrac).clamp(0.0, 1.0)
+    return rel + (14.0 - rel) * icefrac.clamp(0.0, 1.0)
+
+
+def subcolumn_of_gpoint(p, ng):
+    """physics_rad.py:533: p (..., n) area fractions -> (..., ng) sub-column index of every g-point: sub-column j owns
+    round-to-largest-remainder(p_j * ng) consecutive g-points."""
+    exact = p * ng
+    fl = torch.floor(exact)
+    rem = exact - fl
+    deficit = ng - fl.sum(-1, keepdim=True)
+    n = p.shape[-1]
+    ri, rj = rem.unsqueeze(-1), rem.unsqueeze(-2)               # rank_j = #{i : r_i > r_j, or equal and i before j}
+    idx = torch.arange(n)
+    before = (rj > ri) | ((rj == ri) & (idx.view(1, -1) < idx.view(-1, 1)))
+    rank = before.sum(-1).to(p.dtype)
+    count = fl + (rank < deficit).to(p.dtype)
+    edge = torch.cumsum(count, -1)                              # (..., n)
+    g = torch.arange(ng, dtype=p.dtype)
+    return (edge.unsqueeze(-2) <= g.view(-1, 1)).sum(-1)        # (..., ng)
+
+
+def pow8(x):
+    x = x * x
+    x = x * x
+    return x * x
+
+
+def two_stream_sw(mu0, od, ssa, asy):
+    """physics_rad.py:139 (Meador-Weaver / Zdunkowski coefficients as coded there)."""
+    t_dir = torch.exp(-od / mu0)
+    g1 = (8.0 - ssa * (5.0 + 3.0 * asy)) * 0.25
+    g2 = 3.0 * (ssa * (1.0 - asy)) * 0.25
+    g3 = (2.0 - 3.0 * mu0 * asy) * 0.25
+    g4 = 1.0 - g3
+    a1 = g1 * g4 + g2 * g3
+    a2 = g1 * g3 + g2 * g4
+    k = torch.sqrt(((g1 - g2) * (g1 + g2)).clamp(min=1e-4))
+    e = torch.exp(-k * od)
+    e2 = e * e
+    k2e = 2.0 * k * e
+    rf = 1.0 / (k + g1 + (k - g1) * e2)
+    r_dif = g2 * (1.0 - e2) * rf
+    t_dif = torch.minimum(torch.maximum(k2e * rf, torch.zeros_like(rf)), 1.0 - r_dif).clamp(min=0.0)
+    kmu = k * mu0
+    den = 1.0 - kmu * kmu
+    den = torch.where(den.abs() > 1e-7, den, torch.full_like(den, 1e-7))
+    rf = ssa * rf / den
+    kg3, kg4 = k * g3, k * g4
+    r_dir = rf * ((1.0 - kmu) * (a2 + kg3) - (1.0 + kmu) * (a2 - kg3) * e2 - k2e * (g3 - a2 * mu0) * t_dir)
+    t_dd = rf * (k2e * (g4 + a1 * mu0) - t_dir * ((1.0 + kmu) * (a1 + kg4) - (1.0 - kmu) * (a1 - kg4) * e2))
+    room = 1.0 - t_dir
+    r_dir = torch.minimum(torch.maximum(r_dir, torch.zeros_like(room)), room)
+    t_dd = torch.minimum(torch.maximum(t_dd, torch.zeros_like(room)), room - r_dir)
+    return r_dif, t_dif, r_dir, t_dd, t_dir
+
+
+def adding_sw(toa, alb_dif, alb_dir, R, T, Rdir, Tdd, Tdir):
+    """physics_rad.py:332: level axis 1; toa / albedos (B, g); layer props (B, nlev, g) -> up, dn_diffuse, dn_direct
+    (B, nlev+1, g)."""
+    nlev = R.shape[1]
+    A, Ad = [None] * (nlev + 1), [None] * (nlev + 1)            # albedo of everything below interface j
+    A[nlev], Ad[nlev] = alb_dif, alb_dir
+    for j in range(nlev - 1, -1, -1):
+        inv = 1.0 / (1.0 - A[j + 1] * R[:, j])
+        Ad[j] = Rdir[:, j] + (Tdir[:, j] * Ad[j + 1] + Tdd[:, j] * A[j + 1]) * T[:, j] * inv
+        A[j] = R[:, j] + T[:, j] * T[:, j] * A[j + 1] * inv
+    up, dif, dr = [toa * Ad[0]], [torch.zeros_like(toa)], [toa]
+    for j in range(nlev):
+        inv = 1.0 / (1.0 - R[:, j] * A[j + 1])
+        d = (T[:, j] * dif[-1] + dr[-1] * (T[:, j] * Ad[j + 1] * R[:, j] + Tdd[:, j])) * inv
+        r = dr[-1] * Tdir[:, j]
+        dif.append(d)
+        dr.append(r)
+        up.append(r * Ad[j + 1] + d * A[j + 1])
+    return torch.stack(up, 1), torch.stack(dif, 1), torch.stack(dr, 1)
+
+
+def radiative_transfer(P, main0, aux_n, xd, play, plev, delta_plev, mem_out, T_crm, qn_crm, T_new, qv_new, qn_old,
+                       area_frac, ilev_crm, nh_mem0, ng=16, taps=None):
+    """-> dT_rad (B, 60) scaled by yscale_lev[:, 0], out_sfc_rad (B, 6) scaled by yscale_sca_rad."""
+    B, nlev, _ = main0.shape
+    ncrm = nlev - ilev_crm
+    aux = aux_n * P["xdiv_sca"] + P["xmean_sca"]
+    vmr = qv_new * 1.608079364                                                                # (B,60,1)
+    fact = 1.0 / (1.0 + vmr)
+    m_air = (vmr + 0.04698) * fact
+    col_dry = (delta_plev * 10.0 * 6.02214076e23 * fact) / (m_air * 1000.0 * 100.0 * 9.80665)
+
+    # MCICA: every g-point sees one of the mp_ncol sub-columns
+    sub = subcolumn_of_gpoint(area_frac, ng)                                                  # (B,50,g)
+    T_g = torch.gather(T_crm, 2, sub)
+    qn_g = torch.gather(qn_crm, 2, sub)
+    liq_g = F.hardtanh((T_g - 253.16) * 0.05, 0.0, 1.0)
+    cwp = delta_plev[:, ilev_crm:] / G * qn_g * 1000.0
+    cwp_ice = (1.0 - liq_g) * cwp
+    T_low = T_new[:, ilev_crm:]                                                               # (B,50,1)
+    rei = reitab(T_low)
+    rel = reltab(T_low, aux[:, 13].view(B, 1, 1), aux[:, 12].view(B, 1, 1), aux[:, 15].view(B, 1, 1))
+
+    # LW gas optics
+    xg = torch.cat([T_new, torch.log(play), vmr.sqrt().sqrt(), xd[:, :, 12:13].sqrt().sqrt(),
+                    torch.full_like(T_new, 0.0003887), xd[:, :, 13:15], T_new.new_zeros(B, nlev, 11)], 2)
+    xmin, xmax = P["gas_optics_model_lw.xmin"], P["gas_optics_model_lw.xmax"]
+    xg = torch.relu((xg - xmin) / (xmax - xmin))
+    h = F.softsign(_lin(P, "gas_optics_model_lw.mlp1", xg))
+    h = F.softsign(_lin(P, "gas_optics_model_lw.mlp2", h))
+    h = _lin(P, "gas_optics_model_lw.mlp3", h)
+    nk = h.shape[2] // 2
+    tau_k = col_dry * pow8(P["gas_optics_model_lw.ystd"] * h[:, :, :nk] + P["gas_optics_model_lw.ymean"])
+    pf_k = h[:, :, nk:] ** 2
+    pfrac = torch.softmax(_lin(P, "gas_optics_lw_reduce2", pf_k), 2)                          # (B,60,g)
+    tau_lw = F.softplus(_lin(P, "gas_optics_lw_reduce1", tau_k)) * 0.01
+    ifr = cwp_ice / cwp.clamp(min=1e-8)
+    tau_cld = cwp * 0.090361 * (1.0 - ifr) + cwp * ifr * (1.0 / rei.clamp(13.0, 130.0) + 0.005)
+    tau_lw = tau_lw + torch.cat([tau_cld.new_zeros(B, ilev_crm, ng), tau_cld], 1)
+
+    # LW sources and the no-scattering solver
+    tl, pl, ph = T_new.squeeze(2), play.squeeze(2), plev.squeeze(2)
+    tlev = torch.empty(B, nlev + 1)
+    tlev[:, 0] = tl[:, 0] + (ph[:, 0] - pl[:, 0]) * (tl[:, 1] - tl[:, 0]) / (pl[:, 1] - pl[:, 0])
+    tlev[:, 1:nlev] = (pl[:, :-1] * tl[:, :-1] * (ph[:, 1:nlev] - pl[:, 1:]) + pl[:, 1:] * tl[:, 1:] * (pl[:, :-1] - ph[:, 1:nlev])) \
+        / (ph[:, 1:nlev] * (pl[:, :-1] - pl[:, 1:]))
+    tlev[:, nlev] = tl[:, -1] + (ph[:, nlev] - pl[:, -1]) * (tl[:, -1] - tl[:, -2]) / (pl[:, -1] - pl[:, -2])
+    blev = (tlev ** 4 * SIGMA).unsqueeze(2)                                                   # (B,61,1)
+    src_lev = torch.cat([pfrac * blev[:, :-1], pfrac[:, -1:] * blev[:, -1:]], 1)              # (B,61,g)
+    src_sfc = pfrac[:, -1] * aux[:, 11:12]
+    od = tau_lw * 1.66
+    tr = torch.exp(-od)
+    c = od * 0.2
+    bmean = (src_lev[:, :-1] + src_lev[:, 1:]) * 0.5
+    s_up = (1.0 - tr) * (bmean + c * src_lev[:, :-1]) / (c + 1.0)
+    s_dn = s_up                                                                               # as serialised (see header)
+    dn = [torch.zeros(B, ng)]
+    for j in range(nlev):
+        dn.append(tr[:, j] * dn[-1] + s_dn[:, j])
+    up = [None] * (nlev + 1)
+    up[nlev] = src_sfc
+    for j in range(nlev - 1, -1, -1):
+        up[j] = tr[:, j] * up[j + 1] + s_up[:, j]
+    lw_dn, lw_up = torch.stack(dn, 1).sum(2), torch.stack(up, 1).sum(2)                       # (B,61)
+
+    # SW optical properties from the learned head, then two-stream + adding
+    top0 = T_new.new_zeros(B, ilev_crm, 1)
+    mem60 = torch.cat([T_new.new_zeros(B, ilev_crm, nh_mem0), mem_out[:, :, :nh_mem0]], 1)
+    xr = torch.cat([(torch.log(play) - 0.00515) / 11.59485, (T_new - 160.0) / 180.0, vmr.sqrt().sqrt() / 0.497653,
+                    1.0 - torch.exp(-qn_old * P["lbd_qn"].view(1, -1, 1)), main0[:, :, 12:15],
+                    torch.cat([top0, rel / 13.5], 1), torch.cat([top0, rei / 250.0], 1), mem60], 2)
+    o = _lin(P, "mlp_sw_optprops2", F.softsign(_lin(P, "mlp_sw_optprops1", xr))).view(B, nlev, 3, ng)
+    tau_sw = (pow8(o[:, :, 0]) * (col_dry * 1e-23)).clamp(1e-6, 40.0)
+    ssa, asy = torch.sigmoid(o[:, :, 1]), torch.sigmoid(o[:, :, 2])
+    mu0 = aux[:, 6].clamp(min=1e-6).view(B, 1, 1).expand(B, nlev, ng)
+    R, T, Rdir, Tdd, Tdir = two_stream_sw(mu0, tau_sw, ssa, asy)
+    toa = aux[:, 1:2] * torch.softmax(P["sw_solar_weights"] ** 2, 1)                          # (B,g)
+    n_ir, n_mix = int(round(0.7142857142857143 * ng)), int(round(0.7946428571428571 * ng))
+    band = lambda near, vis: torch.cat([near.expand(B, n_ir), (0.5 * (near + vis)).expand(B, n_mix - n_ir),
+                                        vis.expand(B, ng - n_mix)], 1)
+    alb_dif, alb_dir = band(aux[:, 7:8], aux[:, 9:10]), band(aux[:, 8:9], aux[:, 10:11])
+    sw_up, sw_dif, sw_dir = (torch.relu(f) for f in adding_sw(toa, alb_dif, alb_dir, R, T, Rdir, Tdd, Tdir))
+
+    def split(f):                                                                            # near-IR / visible halves of a surface flux
+        mix = f[:, n_ir:n_mix].sum(1, keepdim=True)
+        return f[:, :n_ir].sum(1, keepdim=True) + 0.5 * mix, f[:, n_mix:].sum(1, keepdim=True) + 0.5 * mix
+    SOLL, SOLS = split(sw_dir[:, -1])
+    SOLLD, SOLSD = split(sw_dif[:, -1])
+    sw_dn = sw_dif.sum(2) + sw_dir.sum(2)
+    sw_net = sw_dn - sw_up.sum(2)
+    sw_dn_sfc = sw_dn[:, -1:]
+    night = (aux[:, 6] < 1e-6).view(B, 1)
+    day = (~night).to(sw_net.dtype)
+    sw_net, sw_dn_sfc, SOLL, SOLS, SOLLD, SOLSD = (v * day for v in (sw_net, sw_dn_sfc, SOLL, SOLS, SOLLD, SOLSD))
+    net = (lw_dn - lw_up) + sw_net
+    dT = -((net[:, 1:] - net[:, :-1]) / delta_plev.squeeze(2)) * 0.009761357302 * P["yscale_lev"][:, 0].view(1, -1)
+    out_sfc_rad = torch.cat([sw_dn_sfc, lw_dn[:, -1:], SOLS, SOLL, SOLSD, SOLLD], 1) * P["yscale_sca_rad"]
+    if taps is not None:
+        taps.update(sub=sub, tau_lw=tau_lw, pfrac=pfrac, lw_dn=lw_dn, lw_up=lw_up, tau_sw=tau_sw, ssa=ssa, asy=asy,
+                    sw_net=sw_net, sw_dn=sw_dn, xr=xr, col_dry=col_dry)
+    return dT, out_sfc_rad
+
+
+def forward(P, inputs_main, inputs_aux, rnn_mem, inputs_denorm, hx2, ilev_crm=10, mp_ncol=4, nh_mem0=15, ng=16, taps=None):
+    """inputs_main (B, 60, 21), inputs_aux (B, 19), rnn_mem (B, 50, 16), inputs_denorm (B, 60, 21)
+    -> out_new (B, 60, 5), out_sfc (B, 8), rnn_mem (B, 50, 16)"""
+    B, nlev, _ = inputs_main.shape
+    hyam, hybm, hyai, hybi = (P[k].reshape(1, -1, 1) for k in ("hyam", "hybm", "hyai", "hybi"))
+    P_old = rnn_mem[:, -1, -1]
+    sp = inputs_aux[:, 0:1].unsqueeze(1) * P["xdiv_sca"][0:1] + P["xmean_sca"][0:1]
+    play = hyam * 100000.0 + sp * hybm
+    plev = sp * hybi + hyai * 100000.0                                                        # (B,61,1)
+    delta_plev = sp * (hybi[:, 1:] - hybi[:, :-1]) + (hyai[:, 1:] - hyai[:, :-1]) * 100000.0
+    main0 = torch.cat([inputs_main, torch.sqrt(play) / 314.0], 2)                             # (B,60,22)
+    xin = torch.cat([main0[:, ilev_crm:, :-4], main0[:, ilev_crm:, -1:]], 2)                  # (B,50,19)
+    x = torch.tanh(_lin(P, "mlp_initial", xin))
+    rnn1_in = torch.flip(torch.cat([x, rnn_mem[:, :, :nh_mem0]], 2), [1])
+    hx = torch.tanh(_lin(P, "mlp_surface1", torch.cat([inputs_aux[:, 0:6], inputs_aux[:, 11:]], 1)))
+    rnn1out, _ = _gru(rnn1_in, hx, P["rnn1.weight_ih_l0"], P["rnn1.weight_hh_l0"], P["rnn1.bias_ih_l0"], P["rnn1.bias_hh_l0"])
+    rnn1out = torch.flip(rnn1out, [1])
+    rnn2out, last_h = _gru(rnn1out, hx2, P["rnn2.weight_ih_l0"], P["rnn2.weight_hh_l0"], P["rnn2.bias_ih_l0"], P["rnn2.bias_hh_l0"])
+    mem_new = _lin(P, "mlp_latent", rnn2out)                                                  # (B,50,15)
+    out = _lin(P, "mlp_output", mem_new)                                                      # (B,50,5)
+    dec = microphysics_decode(P, out, mem_new, rnn2out, last_h, inputs_denorm, delta_plev, play, P_old, ilev_crm, mp_ncol,
+                              copy_dT=False)
+    out_new = dec["out_new"]
+    ys = P["yscale_lev"]
+    T_new = torch.relu(inputs_denorm[:, :, 0:1] + out_new[:, :, 0:1] / ys[:, 0:1] * 1200)
+    qv_new = torch.relu(inputs_denorm[:, :, -1:] + out_new[:, :, 1:2] / ys[:, 1:2] * 1200)
+    qn_old = inputs_denorm[:, :, 2:3] + inputs_denorm[:, :, 3:4]
+    if taps is not None:
+        taps.update(rnn2out=rnn2out, out_mp=out_new.clone(), T_crm=dec["T_crm"], qn_crm=dec["qn_crm"], area_frac=dec["area_frac"])
+    dT_rad, sfc_rad = radiative_transfer(P, main0, inputs_aux, inputs_denorm, play, plev, delta_plev, dec["mem_out"],
+                                         dec["T_crm"], dec["qn_crm"], T_new, qv_new, qn_old, dec["area_frac"],
+                                         ilev_crm, nh_mem0, ng, taps)
+    out_new[:, :, 0] = out_new[:, :, 0] + dT_rad
+    out_sfc = torch.cat([sfc_rad[:, 0:2], dec["precsc"], dec["precc"], sfc_rad[:, 2:]], 1)
+    return out_new, out_sfc, dec["mem_out"]

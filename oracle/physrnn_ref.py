@@ -61,12 +61,25 @@ def forward(P, inputs_main, inputs_aux, rnn_mem, inputs_denorm, hx2, ilev_crm=10
     dT_rad = _lin(P, "mlp_output_rad", rnn2out)                                               # (B,60,1)
     out = _lin(P, "mlp_output", mem_new)                                                      # (B,50,5)
 
-    # ---- microphysics_decode ----
+    dec = microphysics_decode(P, out, mem_new, r2, last_h, inputs_denorm, delta_plev, play, P_old, ilev_crm, mp_ncol)
+    out_new, precc, precsc, mem_out = dec["out_new"], dec["precc"], dec["precsc"], dec["mem_out"]
+    out_new[:, :, 0:1] = out_new[:, :, 0:1] + dT_rad
+    out_sfc = torch.cat([out_sfc_rad[:, 0:2], precsc, precc, out_sfc_rad[:, 2:]], 1)
+    return out_new, out_sfc, mem_out
+
+
+def microphysics_decode(P, out, mem_new, r2, last_h, inputs_denorm, delta_plev, play, P_old, ilev_crm, mp_ncol, copy_dT=True):
+    """rnn/models/models_phys.py:414-748.  copy_dT: the nx = 21 graphs also pass the decoder's raw column-0 output of the
+    levels below ilev_crm + 2 through to out_new; the radiation graphs (oracle/physrnn_rad_ref.py) do not.
+    -> dict with out_new, precc, precsc, mem_out and the updated sub-column state (T_crm, qv_crm, qn_crm, area_frac)."""
+    B, nlev = inputs_denorm.shape[0], inputs_denorm.shape[1]
+    x = out
     ys = P["yscale_lev"][ilev_crm:]                                                           # (50,5)
     out_new = x.new_zeros(B, nlev, 5)
     pres_diff = delta_plev[:, ilev_crm:]                                                      # (B,50,1)
     out_new[:, ilev_crm + 2:, -2:] = out[:, 2:, -2:]
-    out_new[:, ilev_crm + 2:, 0] = out[:, 2:, 0]
+    if copy_dT:
+        out_new[:, ilev_crm + 2:, 0] = out[:, 2:, 0]
     xd = inputs_denorm[:, ilev_crm:]
     qv_gcm, T_gcm, qliq_gcm, qice_gcm = xd[:, :, -1:], xd[:, :, 0:1], xd[:, :, 2:3], xd[:, :, 3:4]
     qn_gcm = qliq_gcm + qice_gcm
@@ -133,6 +146,7 @@ def forward(P, inputs_main, inputs_aux, rnn_mem, inputs_denorm, hx2, ilev_crm=10
     precc = ((sedimentation + released + excess) / 1000).unsqueeze(1)
     snowfrac = F.hardtanh((-inputs_denorm[:, -1, 0:1] + 283.3) / 14.6, 0.0, 1.0)
     precsc = snowfrac * precc
-    out_new[:, :, 0:1] = out_new[:, :, 0:1] + dT_rad
-    out_sfc = torch.cat([out_sfc_rad[:, 0:2], precsc, precc, out_sfc_rad[:, 2:]], 1)
-    return out_new, out_sfc, mem_out
+    ys_ = lambda k: ys[:, k:k + 1]
+    return dict(out_new=out_new, precc=precc, precsc=precsc, mem_out=mem_out, area_frac=area_frac,
+                T_crm=torch.relu(T_crm + dT_crm * 1200 / ys_(0)), qv_crm=torch.relu(qv_crm + dqv_crm * 1200 / ys_(1)),
+                qn_crm=torch.relu(qn_crm + dqn_crm * 1200 / ys_(2)))

@@ -48,8 +48,53 @@ def main(art=ART, name="physrnn_hidden", cases=((8, 11), (37, 12))):
     np.savez_compressed(f"{OUT}/{name}.npz", **d)
 
 
+ART_RAD = DIR + "physRNN-Hidden_lr0.0007.neur128-128_xv4_mp1_num4050_BEST_script_cpu.pt"   # + physical radiation scheme
+
+
+def inputs_rad(P, B, seed):
+    """Inputs of the radiation graphs: the same 21 level columns, 19 surface columns whose radiation entries are drawn in
+    physical units (insolation, cos zenith with night columns, albedos, upwelling LW, ice / land fraction, snow depth)."""
+    xm, _, mem, xd = inputs(P, B, seed)
+    g = torch.Generator().manual_seed(seed + 500)
+    u = lambda *s: torch.rand(*s, generator=g)
+    lev = torch.arange(60) / 59.0
+    xd[:, :, 12] = 1e-8 + 8e-6 * u(B, 60) * (1.0 - lev)                                    # ozone
+    xd[:, :, 13] = 1.6e-6 + 2e-7 * u(B, 60)                                                 # methane
+    xd[:, :, 14] = 3.0e-7 + 3e-8 * u(B, 60)                                                 # nitrous oxide
+    phys = 1.2 * (u(B, 19) - 0.5) * P["xdiv_sca"] + P["xmean_sca"]
+    phys[:, 0] = 98000.0 + 6000.0 * (u(B) - 0.5)                                            # surface pressure
+    phys[:, 6] = 1.3 * u(B) - 0.3                                                           # cos zenith: about a quarter at night
+    phys[:, 1] = 1360.0 * phys[:, 6].clamp(min=0.0)                                         # insolation
+    phys[:, 7:11] = 0.05 + 0.75 * u(B, 4)                                                   # albedos
+    phys[:, 11] = 250.0 + 250.0 * u(B)                                                      # upwelling LW
+    phys[:, 12], phys[:, 13], phys[:, 15] = u(B) * (u(B) > 0.5), u(B), 0.3 * u(B) * (u(B) > 0.5)
+    xs = (phys - P["xmean_sca"]) / P["xdiv_sca"]
+    return xm, xs.contiguous(), mem, xd.contiguous()
+
+
+def main_rad(art=ART_RAD, name="physrnn_rad", cases=((8, 31), (37, 32))):
+    m = torch.jit.load(art, map_location="cpu").eval()
+    P = {k: v.detach().float() for k, v in m.state_dict().items()}
+    d = {"w." + k: v.numpy() for k, v in P.items() if not k.startswith("pres")}
+    for a in ("ilev_crm", "mp_ncol", "nh_mem", "nh_mem0", "nlev_mem", "nh_rnn2", "ng_lw", "ng_sw"):
+        d["attr." + a] = np.array(int(getattr(m, a)), np.int64)
+    for i, (B, seed) in enumerate(cases):
+        xm, xs, mem, xd = inputs_rad(P, B, seed)
+        torch.manual_seed(1000 + seed)
+        with torch.no_grad():
+            out, out_sfc, mem_out = m([xm.clone(), xs.clone(), mem.clone(), xd.clone()])
+        torch.manual_seed(1000 + seed)
+        hx2 = torch.randn(B, 128)
+        d[f"case{i}.cfg"] = np.array([B, seed], np.int64)
+        for k, v in (("hx2", hx2), ("out", out), ("out_sfc", out_sfc), ("mem_out", mem_out)):
+            d[f"case{i}.{k}"] = v.numpy()
+        print(name, i, B, out.abs().max().item(), out_sfc.abs().max().item(), mem_out.abs().max().item(), torch.isfinite(out).all().item())
+    np.savez_compressed(f"{OUT}/{name}.npz", **d)
+
+
 if __name__ == "__main__":
     if not os.path.exists(ART):
         sys.exit("reference not present: golden fixtures can only be regenerated in the build container")
     main()
     main(ART_B, "physrnn_hidden_b", ((8, 21),))
+    main_rad()
