@@ -19,6 +19,7 @@ struct PhysDev {
     int ltop, Lr;           // first level the GRUs see and their sequence length (0 / 60, or ilev / 50)
     int ncol, hdw;          // mp_ncol; width of the head GEMM
     int rad;                // 1: physical radiation scheme (no mlp_output_rad / mlp_surface_output_rad heads)
+    int liq_off;            // column of the mlp_liq_frac_crm head in the head GEMM, or -1: liquid fraction from temperature
     const float *hyam, *hybm, *hyai, *hybi, *yscale_lev, *yscale_sca;
     float xdiv_sca0, xmean_sca0;
     const float *init_wt, *init_b, *s1_wt, *s1_b;   // (nfeat+1, nh), (nx_sfc, nh) transposed
@@ -37,6 +38,9 @@ struct csa_phys {
     // radiation scheme: MLP weights (row-major (out, in), K padded to a multiple of 4) and per-call work arrays
     float *g_w1, *g_b1, *g_w2, *g_b2, *g_w3, *g_b3, *r1_w, *r1_b, *r2_w, *r2_b, *s1_w, *s1_b, *s2_w, *s2_b;
     float *XG, *XR, *RS, *CL, *A1, *A2, *A3, *TP, *S1, *S2;
+    // add_stochastic_layer graphs: rnn3 (MyStochasticGRULayer5 over rnn2's output), its output and the perturbed sequence
+    struct csa_stoch *rnn3 = nullptr;
+    float *H3 = nullptr, *H2p = nullptr;
     std::vector<void *> owned;
 };
 

@@ -22,6 +22,7 @@
 //           surface inputs 0:6 and 11:19, mp_ncol 4, and the physical radiation scheme of phys_rad.hip after the
 //           decoder (num4050)
 #include "phys.h"
+#include "stoch.h"
 __device__ __forceinline__ float ph_softplus(float x) { return x > 20.0f ? x : log1pf(expf(x)); }   // torch.softplus(beta 1, threshold 20)
 template <int N> __device__ __forceinline__ float ph_sum(float v)
 {
@@ -134,7 +135,7 @@ __global__ __launch_bounds__(DT) void phys_decode_kernel(PhysDev d, int B, const
     const float CP = 1004.64f, G = 9.80665f, LV = 2510400.0f, LS = 2844000.0f, OOG = 0.1019716213f;
     const float sp = x_sfc[(size_t)b * d.naux] * d.xdiv_sca0 + d.xmean_sca0;
     const float P_old = mem[((size_t)b * LC + (LC - 1)) * (nm0 + 1) + nm0];
-    const float *last_h = H2 + ((size_t)(d.Lr - 1) * B + b) * nh;
+    const float *last_h = H2 + ((size_t)(d.Lr - 1) * B + b) * nh;      // (H2: whichever sequence ends in the state the release head reads)
 
     // ---- phase A: latent memory -> mlp_output per level; level pressure thickness; surface heads ----
     for (int l = tid; l < LC; l += DT) {
@@ -329,31 +330,37 @@ __global__ __launch_bounds__(DT) void phys_decode_kernel(PhysDev d, int B, const
 #pragma unroll
             for (int k = 0; k < nm0; ++k) xr[9 + k] = L >= ilev ? lat[k] : 0.0f;
         }
-        // cloud optical depth per (CRM level, g-point): every g-point sees one sub-column (physics_rad.py:533)
+        // cloud optical depth per (CRM level, g-point).  use_mcica graphs (mp_ncol 4): every g-point sees one sub-column,
+        // sub-column j owning round-to-largest-remainder(area_j * 16) consecutive g-points (physics_rad.py:533); the
+        // mp_ncol 16 graphs pair g-point g with sub-column g
         for (int e = tid; e < LC * PH_NG; e += DT) {
             const int l = e >> 4, g = e & 15, L = l + ilev;
-            float p[NC], rem[NC], cnt[NC], tot = 0.0f;
+            int sub = g;
+            if constexpr (NC != PH_NG) {
+                float rem[NC], cnt[NC], tot = 0.0f;
 #pragma unroll
-            for (int c = 0; c < NC; ++c) {
-                p[c] = s_area[l * NC + c] * (float)PH_NG;
-                cnt[c] = floorf(p[c]);
-                rem[c] = p[c] - cnt[c];
-                tot += cnt[c];
+                for (int c = 0; c < NC; ++c) {
+                    const float p = s_area[l * NC + c] * (float)PH_NG;
+                    cnt[c] = floorf(p);
+                    rem[c] = p - cnt[c];
+                    tot += cnt[c];
+                }
+                const float deficit = (float)PH_NG - tot;
+                float edge = 0.0f;
+                sub = 0;
+#pragma unroll
+                for (int c = 0; c < NC; ++c) {
+                    int rank = 0;
+#pragma unroll
+                    for (int i = 0; i < NC; ++i) rank += (rem[i] > rem[c] || (rem[i] == rem[c] && i < c)) ? 1 : 0;
+                    edge += cnt[c] + ((float)rank < deficit ? 1.0f : 0.0f);
+                    sub += edge <= (float)g ? 1 : 0;
+                }
+                sub = min(sub, NC - 1);
             }
-            const float deficit = (float)PH_NG - tot;
-            int sub = 0;
-            float edge = 0.0f;
-#pragma unroll
-            for (int c = 0; c < NC; ++c) {
-                int rank = 0;
-#pragma unroll
-                for (int i = 0; i < NC; ++i) rank += (rem[i] > rem[c] || (rem[i] == rem[c] && i < c)) ? 1 : 0;
-                edge += cnt[c] + ((float)rank < deficit ? 1.0f : 0.0f);
-                sub += edge <= (float)g ? 1 : 0;
-            }
-            sub = min(sub, NC - 1);
             const float T_g = s_T[l * NC + sub], qn_g = s_qn[l * NC + sub];
-            const float liq = fminf(fmaxf((T_g - 253.16f) * 0.05f, 0.0f), 1.0f);
+            float liq = fminf(fmaxf((T_g - 253.16f) * 0.05f, 0.0f), 1.0f);
+            if (d.liq_off >= 0) liq = 1.0f / (1.0f + expf(-HD[((size_t)(L - d.ltop) * B + b) * HDW + d.liq_off + sub]));
             const float cwp = s_pd[l] / G * qn_g * 1000.0f, cwp_ice = (1.0f - liq) * cwp;
             const float ifr = cwp_ice / fmaxf(cwp, 1e-8f);
             const float *xd = x_denorm + ((size_t)b * PH_L + L) * nxd;
@@ -374,6 +381,8 @@ struct PhysHostW {           // host pointers of one state_dict, by role
     // radiation scheme
     const float *lbd_qn, *ys_rad, *solar_w, *g_xmin, *g_xmax, *g_ymean, *g_ystd;
     const float *g_w1, *g_b1, *g_w2, *g_b2, *g_w3, *g_b3, *r1_w, *r1_b, *r2_w, *r2_b, *sw1_w, *sw1_b, *sw2_w, *sw2_b;
+    const float *liq_w, *liq_b;              // mlp_liq_frac_crm (mp_ncol, nh), optional
+    const float *s3_ih, *s3_zh, *s3_enc;     // rnn3 = MyStochasticGRULayer5(nh, nh) without bias, optional
 };
 
 // ice effective radius (micron) against temperature, 137 K ... : E3SM's table as listed in rnn/models/physics_rad_e3sm.py:13-59
@@ -409,7 +418,8 @@ static int phys_build(int nx, int nfeat, int naux, int nx_sfc, int sfc_cut, int 
     d.nh = nh; d.ilev = ilev_crm; d.nm0 = nh_mem0; d.Lc = PH_L - ilev_crm;
     d.ltop = rad ? ilev_crm : 0; d.Lr = PH_L - d.ltop;
     d.ncol = mp_ncol; d.rad = rad;
-    d.hdw = rad ? ((PH_NHEAD * mp_ncol + nh_mem0 + 3) / 4) * 4 : PH_NHEAD * mp_ncol + nh_mem0 + 1;
+    d.liq_off = w.liq_w ? PH_NHEAD * mp_ncol + 16 : -1;
+    d.hdw = rad ? ((PH_NHEAD * mp_ncol + nh_mem0 + (w.liq_w ? 1 + mp_ncol : 0) + 3) / 4) * 4 : PH_NHEAD * mp_ncol + nh_mem0 + 1;
     d.hyam = up(w.hyam, 60); d.hybm = up(w.hybm, 60); d.hyai = up(w.hyai, 61); d.hybi = up(w.hybi, 61);
     d.yscale_lev = up(w.ysl, 60 * 5); d.yscale_sca = up(w.yss, 8);
     d.xdiv_sca0 = w.xds[0]; d.xmean_sca0 = w.xms[0];
@@ -449,6 +459,10 @@ static int phys_build(int nx, int nfeat, int naux, int nx_sfc, int sfc_cut, int 
             memcpy(&wh[(size_t)(HDW - 1) * nh], w.rad_w, sizeof(float) * nh);
             bh[HDW - 1] = w.rad_b[0];
         }
+        if (w.liq_w) {
+            memcpy(&wh[(size_t)d.liq_off * nh], w.liq_w, sizeof(float) * mp_ncol * nh);
+            memcpy(&bh[d.liq_off], w.liq_b, sizeof(float) * mp_ncol);
+        }
         h->whead = up(wh.data(), wh.size()); h->bhead = up(bh.data(), bh.size());
     }
     const size_t rows = (size_t)d.Lr * max_batch;
@@ -483,7 +497,11 @@ static int phys_build(int nx, int nfeat, int naux, int nx_sfc, int sfc_cut, int 
         h->A1 = up(nullptr, M * 64); h->A2 = up(nullptr, M * 64); h->A3 = up(nullptr, M * 256); h->TP = up(nullptr, M * 32);
         h->S1 = up(nullptr, M * 32); h->S2 = up(nullptr, M * 48);
     }
-    if (rc != CSA_OK) { for (void *p : h->owned) (void)hipFree(p); delete h; return rc; }
+    if (w.s3_ih && rc == CSA_OK) {
+        rc = csa_stoch_gru5_create(nh, nh, w.s3_ih, w.s3_zh, w.s3_enc, nullptr, nullptr, (int)rows, &h->rnn3);
+        h->H3 = up(nullptr, rows * nh); h->H2p = up(nullptr, rows * nh);
+    }
+    if (rc != CSA_OK) { if (h->rnn3) csa_stoch_destroy(h->rnn3); for (void *p : h->owned) (void)hipFree(p); delete h; return rc; }
     *out = h;
     return CSA_OK;
 }
@@ -508,13 +526,14 @@ extern "C" int csa_phys_create(int nx, int nx_sfc, int nh, int ilev_crm, int mp_
 }
 
 // The radiation graphs (num4050): see include/climsim_amd.h for the pointer order
-extern "C" int csa_phys_rad_create(int nx, int naux, int nh, int ilev_crm, int mp_ncol, int nh_mem0, int ng,
+extern "C" int csa_phys_rad_create(int nx, int naux, int nh, int ilev_crm, int mp_ncol, int nh_mem0, int ng, int flags,
                                    const float *const *w, int max_batch, csa_phys **out)
 {
-    if (!w || !out || max_batch <= 0) { csa_set_error_msg("csa_phys_rad_create: bad argument"); return CSA_ERR_ARG; }
-    if (nh != 128 || mp_ncol != 4 || nh_mem0 != 15 || ilev_crm != 10 || nx != 21 || naux != 19 || ng != PH_NG) {
-        csa_set_error_msg("csa_phys_rad_create: built for the shipped geometry (21 level inputs, 19 surface inputs, GRU 128/128 over 50 levels, "
-                          "mp_ncol 4, 15+1 memory channels, 16 g-points)");
+    if (!w || !out || max_batch <= 0 || (flags & ~7)) { csa_set_error_msg("csa_phys_rad_create: bad argument"); return CSA_ERR_ARG; }
+    const bool mcica = flags & CSA_PHYS_MCICA;
+    if (nh != 128 || mp_ncol != (mcica ? 4 : 16) || nh_mem0 != 15 || ilev_crm != 10 || nx != 21 || naux != 19 || ng != PH_NG) {
+        csa_set_error_msg("csa_phys_rad_create: built for the shipped geometries (21 level inputs, 19 surface inputs, GRU 128/128 over 50 levels, "
+                          "15+1 memory channels, 16 g-points; mp_ncol 4 with MCICA sampling or mp_ncol 16 without)");
         return CSA_ERR_UNSUPPORTED;
     }
     PhysHostW v{};
@@ -527,6 +546,10 @@ extern "C" int csa_phys_rad_create(int nx, int naux, int nh, int ilev_crm, int m
     v.lbd_qn = *p++; v.ys_rad = *p++; v.solar_w = *p++; v.g_xmin = *p++; v.g_xmax = *p++; v.g_ymean = *p++; v.g_ystd = *p++;
     v.g_w1 = *p++; v.g_b1 = *p++; v.g_w2 = *p++; v.g_b2 = *p++; v.g_w3 = *p++; v.g_b3 = *p++;
     v.r1_w = *p++; v.r1_b = *p++; v.r2_w = *p++; v.r2_b = *p++; v.sw1_w = *p++; v.sw1_b = *p++; v.sw2_w = *p++; v.sw2_b = *p++;
+    if (flags & CSA_PHYS_LIQ_FRAC_HEAD) { v.liq_w = *p++; v.liq_b = *p++; }
+    if (flags & CSA_PHYS_STOCHASTIC) { v.s3_ih = *p++; v.s3_zh = *p++; v.s3_enc = *p++; }
+    for (const float *const *q = w; q != p; ++q)
+        if (!*q) { csa_set_error_msg("csa_phys_rad_create: null weight pointer"); return CSA_ERR_ARG; }
     // mlp_initial sees x_main[:, :, 0:nx-3] and the layer pressure; mlp_surface1 sees aux 0:6 and 11:naux
     return phys_build(nx, nx - 3, naux, naux - 5, 6, nh, ilev_crm, mp_ncol, nh_mem0, 1, v, max_batch, out);
 }
@@ -534,20 +557,32 @@ extern "C" int csa_phys_rad_create(int nx, int naux, int nh, int ilev_crm, int m
 extern "C" int csa_phys_destroy(csa_phys *h)
 {
     if (!h) return CSA_ERR_ARG;
+    if (h->rnn3) csa_stoch_destroy(h->rnn3);
     for (void *p : h->owned) (void)hipFree(p);
     delete h;
     return CSA_OK;
 }
 
+__global__ __launch_bounds__(256) void phys_mul_kernel(const f32x4 *__restrict__ a, const f32x4 *__restrict__ b, f32x4 *__restrict__ o, size_t n4)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n4) o[i] = a[i] * b[i];
+}
+
 // x_main (B,60,nx) normalised, x_sfc (B,naux) normalised, rnn_mem (B,50,16), x_denorm (B,60,nxd) raw (T, ., qliq, qice, ..., qv last),
-// hx2 (B,nh): the N(0,1) draw the reference makes for rnn2's initial state.  -> out_lev (B,60,5), out_sfc (B,8), mem_out (B,50,16)
-extern "C" int csa_phys_forward(csa_phys *h, int B, const float *x_main, const float *x_sfc, const float *rnn_mem,
-                                const float *x_denorm, int nxd, const float *hx2, float *out_lev, float *out_sfc, float *mem_out,
-                                void *stream)
+// hx2 (B,nh): the N(0,1) draw the reference makes for rnn2's initial state; add_stochastic_layer graphs also draw hx1 (B,nh), rnn3's
+// initial state, and eps3 (Lr,B,nh), the layer's noise.  -> out_lev (B,60,5), out_sfc (B,8), mem_out (B,50,16)
+extern "C" int csa_phys_forward_noise(csa_phys *h, int B, const float *x_main, const float *x_sfc, const float *rnn_mem,
+                                      const float *x_denorm, int nxd, const float *hx2, const float *hx1, const float *eps3,
+                                      float *out_lev, float *out_sfc, float *mem_out, void *stream)
 {
     if (!h || !x_main || !x_sfc || !rnn_mem || !x_denorm || !hx2 || !out_lev || !out_sfc || !mem_out || B <= 0 || B > h->max_batch || nxd < 5 ||
         (h->d.rad && nxd < 16)) {
         csa_set_error_msg("csa_phys_forward: bad argument");
+        return CSA_ERR_ARG;
+    }
+    if (h->rnn3 && (!hx1 || !eps3)) {
+        csa_set_error_msg("csa_phys_forward: this graph has the stochastic third RNN: pass its N(0,1) draws (csa_phys_forward_noise)");
         return CSA_ERR_ARG;
     }
     hipStream_t s = (hipStream_t)stream;
@@ -564,18 +599,38 @@ extern "C" int csa_phys_forward(csa_phys *h, int B, const float *x_main, const f
     if ((rc = rec(h->whh1p, h->whh1g, h->bhn1, h->hx, h->H1, 1))) return rc;
     if ((rc = launch_proj_gemm(h->H1, h->wih2, h->bias2, h->P, M, 4 * nh, nh, s, 0))) return rc;
     if ((rc = rec(h->whh2p, h->whh2g, h->bhn2, hx2, h->H2, 0))) return rc;
-    if ((rc = launch_proj_gemm(h->H2, h->whead, h->bhead, h->HD, M, d.hdw, nh, s, 0))) return rc;
+    const float *Hhead = h->H2, *Hlast = h->H2;      // the sequence the heads read; the sequence whose last state feeds the release head
+    if (h->rnn3) {                                    // rnn2's output times the stochastic layer's output; last state: the layer's own
+        if ((rc = csa_stoch_gru5_forward(h->rnn3, L, B, h->H2, hx1, eps3, h->H3, stream))) return rc;
+        const size_t n4 = (size_t)M * nh / 4;
+        hipLaunchKernelGGL(phys_mul_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, (const f32x4 *)h->H2, (const f32x4 *)h->H3,
+                           (f32x4 *)h->H2p, n4);
+        CSA_HIP_CHECK(hipGetLastError());
+        Hhead = h->H2p; Hlast = h->H3;
+    }
+    if ((rc = launch_proj_gemm(Hhead, h->whead, h->bhead, h->HD, M, d.hdw, nh, s, 0))) return rc;
     if (d.rad) {
         PhysRadOut ro{x_main, h->XG, h->XR, h->RS, h->CL};
-        hipLaunchKernelGGL((phys_decode_kernel<4, 256, true>), dim3(B), dim3(256), 0, s, d, B, h->HD, h->H2, x_sfc, rnn_mem, x_denorm, nxd,
-                           out_lev, out_sfc, mem_out, ro);
+        if (d.ncol == 4)
+            hipLaunchKernelGGL((phys_decode_kernel<4, 256, true>), dim3(B), dim3(256), 0, s, d, B, h->HD, Hlast, x_sfc, rnn_mem, x_denorm, nxd,
+                               out_lev, out_sfc, mem_out, ro);
+        else
+            hipLaunchKernelGGL((phys_decode_kernel<16, 512, true>), dim3(B), dim3(512), 0, s, d, B, h->HD, Hlast, x_sfc, rnn_mem, x_denorm, nxd,
+                               out_lev, out_sfc, mem_out, ro);
         CSA_HIP_CHECK(hipGetLastError());
         return launch_phys_radiation(h, B, x_sfc, out_lev, out_sfc, s);
     }
-    hipLaunchKernelGGL((phys_decode_kernel<16, 512, false>), dim3(B), dim3(512), 0, s, d, B, h->HD, h->H2, x_sfc, rnn_mem, x_denorm, nxd,
+    hipLaunchKernelGGL((phys_decode_kernel<16, 512, false>), dim3(B), dim3(512), 0, s, d, B, h->HD, Hlast, x_sfc, rnn_mem, x_denorm, nxd,
                        out_lev, out_sfc, mem_out, PhysRadOut{});
     CSA_HIP_CHECK(hipGetLastError());
     return CSA_OK;
+}
+
+extern "C" int csa_phys_forward(csa_phys *h, int B, const float *x_main, const float *x_sfc, const float *rnn_mem,
+                                const float *x_denorm, int nxd, const float *hx2, float *out_lev, float *out_sfc, float *mem_out,
+                                void *stream)
+{
+    return csa_phys_forward_noise(h, B, x_main, x_sfc, rnn_mem, x_denorm, nxd, hx2, nullptr, nullptr, out_lev, out_sfc, mem_out, stream);
 }
 
 // taps for tests: level-major (Lr, B, nh) outputs of rnn1 (level order) and rnn2 of the last call

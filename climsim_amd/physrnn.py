@@ -67,28 +67,34 @@ class physical_RNN_autoreg(torch.nn.Module):
 
     def _init_rad(self, state_dict, ilev_crm, mp_ncol, nh_mem0, max_batch):
         arrs = []
-        for k in _ORDER_RAD:
+        ng = int(state_dict["gas_optics_lw_reduce1.weight"].shape[0])
+        self.stochastic = "rnn3.weight_ih" in state_dict
+        flags = (1 if mp_ncol != ng else 0) | (2 if "mlp_liq_frac_crm.weight" in state_dict else 0) | (4 if self.stochastic else 0)
+        order = (_ORDER_RAD + (["mlp_liq_frac_crm.weight", "mlp_liq_frac_crm.bias"] if flags & 2 else [])
+                 + (["rnn3.weight_ih", "rnn3.weight_zh", "rnn3.weight_encoder"] if flags & 4 else []))
+        for k in order:
             if k not in state_dict:
                 raise RuntimeError(f"physRNN (radiation graph) state_dict lacks {k}")
             v = state_dict[k]
             v = v.detach().cpu().numpy() if isinstance(v, torch.Tensor) else np.asarray(v)
             arrs.append(np.ascontiguousarray(v, np.float32))
-        sd = dict(zip(_ORDER_RAD, arrs))
+        sd = dict(zip(order, arrs))
         self.nh = sd["mlp_initial.weight"].shape[0]
         self.nx = sd["mlp_initial.weight"].shape[1] + 2             # x_main columns: 3 of them bypass mlp_initial, which also sees pressure
         self.nx_sfc = sd["xmean_sca"].shape[0]                      # x_sfc columns (5 of them bypass mlp_surface1)
         self.nlev, self.nlev_mem, self.nh_mem = 60, 60 - ilev_crm, nh_mem0 + 1
-        ng = sd["gas_optics_lw_reduce1.weight"].shape[0]
         FP = ctypes.POINTER(ctypes.c_float)
         warr = (FP * len(arrs))(*[a.ctypes.data_as(FP) for a in arrs])
         h = ctypes.c_void_p()
-        rc = _lib.lib().csa_phys_rad_create(self.nx, self.nx_sfc, self.nh, int(ilev_crm), int(mp_ncol), int(nh_mem0), int(ng), warr,
+        rc = _lib.lib().csa_phys_rad_create(self.nx, self.nx_sfc, self.nh, int(ilev_crm), int(mp_ncol), int(nh_mem0), ng, flags, warr,
                                             int(max_batch), ctypes.byref(h))
         if rc != 0:
             raise RuntimeError(f"csa_phys_rad_create failed ({rc}): {_lib.last_error()}")
         self._h, self.max_batch = h, max_batch
 
-    def forward(self, inp_list, hx2=None):
+    def forward(self, inp_list, hx2=None, hx1=None, eps3=None):
+        """hx2 (B, nh): rnn2's initial state; add_stochastic_layer graphs also take hx1 (B, nh), rnn3's initial state, and eps3
+        (50, B, nh), its noise.  Whatever is not passed is drawn here with torch.randn, as the reference does inside forward."""
         x_main, x_sfc, rnn_mem, x_denorm = inp_list[0], inp_list[1], inp_list[2], inp_list[3]
         B = x_main.shape[0]
         x_main = _check(x_main, (B, self.nlev, self.nx), "inputs_main")
@@ -99,9 +105,15 @@ class physical_RNN_autoreg(torch.nn.Module):
         out = torch.empty(B, self.nlev, 5, device=self.device)
         out_sfc = torch.empty(B, 8, device=self.device)
         mem_out = torch.empty(B, self.nlev_mem, self.nh_mem, device=self.device)
-        rc = _lib.lib().csa_phys_forward(self._h, B, _ptr(x_main), _ptr(x_sfc), _ptr(rnn_mem), _ptr(x_denorm),
-                                         int(x_denorm.shape[-1]), _ptr(hx2), _ptr(out), _ptr(out_sfc), _ptr(mem_out),
-                                         ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream))
+        if getattr(self, "stochastic", False):
+            hx1 = torch.randn(B, self.nh, device=self.device) if hx1 is None else _check(hx1, (B, self.nh), "hx1")
+            eps3 = torch.randn(self.nlev_mem, B, self.nh, device=self.device) if eps3 is None else _check(eps3, (self.nlev_mem, B, self.nh), "eps3")
+            p1, p3 = _ptr(hx1), _ptr(eps3)
+        else:
+            p1 = p3 = None
+        rc = _lib.lib().csa_phys_forward_noise(self._h, B, _ptr(x_main), _ptr(x_sfc), _ptr(rnn_mem), _ptr(x_denorm),
+                                               int(x_denorm.shape[-1]), _ptr(hx2), p1, p3, _ptr(out), _ptr(out_sfc), _ptr(mem_out),
+                                               ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream))
         if rc != 0:
             raise RuntimeError(f"csa_phys_forward failed ({rc}): {_lib.last_error()}")
         return out, out_sfc, mem_out

@@ -127,8 +127,11 @@ def adding_sw(toa, alb_dif, alb_dir, R, T, Rdir, Tdd, Tdir):
 
 
 def radiative_transfer(P, main0, aux_n, xd, play, plev, delta_plev, mem_out, T_crm, qn_crm, T_new, qv_new, qn_old,
-                       area_frac, ilev_crm, nh_mem0, ng=16, taps=None):
-    """-> dT_rad (B, 60) scaled by yscale_lev[:, 0], out_sfc_rad (B, 6) scaled by yscale_sca_rad."""
+                       area_frac, ilev_crm, nh_mem0, ng=16, taps=None, rnn2out=None):
+    """-> dT_rad (B, 60) scaled by yscale_lev[:, 0], out_sfc_rad (B, 6) scaled by yscale_sca_rad.
+    use_mcica graphs (mp_ncol < ng): every g-point samples a sub-column; otherwise g-point g is sub-column g.
+    rnn2out given and `mlp_liq_frac_crm` in P (num83000): the cloud liquid fraction is a learned head instead of the
+    temperature ramp."""
     B, nlev, _ = main0.shape
     ncrm = nlev - ilev_crm
     aux = aux_n * P["xdiv_sca"] + P["xmean_sca"]
@@ -138,10 +141,16 @@ def radiative_transfer(P, main0, aux_n, xd, play, plev, delta_plev, mem_out, T_c
     col_dry = (delta_plev * 10.0 * 6.02214076e23 * fact) / (m_air * 1000.0 * 100.0 * 9.80665)
 
     # MCICA: every g-point sees one of the mp_ncol sub-columns
-    sub = subcolumn_of_gpoint(area_frac, ng)                                                  # (B,50,g)
-    T_g = torch.gather(T_crm, 2, sub)
-    qn_g = torch.gather(qn_crm, 2, sub)
-    liq_g = F.hardtanh((T_g - 253.16) * 0.05, 0.0, 1.0)
+    if area_frac.shape[2] != ng:
+        sub = subcolumn_of_gpoint(area_frac, ng)                                              # (B,50,g)
+        T_g = torch.gather(T_crm, 2, sub)
+        qn_g = torch.gather(qn_crm, 2, sub)
+    else:
+        sub, T_g, qn_g = None, T_crm, qn_crm
+    if "mlp_liq_frac_crm.weight" in P:
+        liq_g = torch.sigmoid(_lin(P, "mlp_liq_frac_crm", rnn2out))
+    else:
+        liq_g = F.hardtanh((T_g - 253.16) * 0.05, 0.0, 1.0)
     cwp = delta_plev[:, ilev_crm:] / G * qn_g * 1000.0
     cwp_ice = (1.0 - liq_g) * cwp
     T_low = T_new[:, ilev_crm:]                                                               # (B,50,1)
@@ -228,9 +237,28 @@ def radiative_transfer(P, main0, aux_n, xd, play, plev, delta_plev, mem_out, T_c
     return dT, out_sfc_rad
 
 
-def forward(P, inputs_main, inputs_aux, rnn_mem, inputs_denorm, hx2, ilev_crm=10, mp_ncol=4, nh_mem0=15, ng=16, taps=None):
+def stochastic_gru(x, h, eps, w_ih, w_zh, w_enc):
+    """MyStochasticGRULayer5 without bias (rnn/models_torch_kernels.py:834-891): x (T, B, nx), h (B, H), eps (T, B, H)."""
+    H, out = h.shape[1], []
+    for t in range(x.shape[0]):
+        d = h @ w_enc
+        z = d[:, :H] + eps[t] * torch.exp(d[:, H:] * 0.5)
+        gx, gz = x[t] @ w_ih, z @ w_zh
+        r = torch.sigmoid(gx[:, :H] + gz[:, :H])
+        u = torch.sigmoid(gx[:, H:2 * H] + gz[:, H:2 * H])
+        n = torch.tanh(gx[:, 2 * H:] + r * gz[:, 2 * H:])
+        h = n + u * (h - n)
+        out.append(h)
+    return torch.stack(out)
+
+
+def forward(P, inputs_main, inputs_aux, rnn_mem, inputs_denorm, hx2, ilev_crm=10, mp_ncol=None, nh_mem0=15, ng=16, taps=None,
+            hx1=None, eps3=None):
     """inputs_main (B, 60, 21), inputs_aux (B, 19), rnn_mem (B, 50, 16), inputs_denorm (B, 60, 21)
-    -> out_new (B, 60, 5), out_sfc (B, 8), rnn_mem (B, 50, 16)"""
+    -> out_new (B, 60, 5), out_sfc (B, 8), rnn_mem (B, 50, 16).
+    add_stochastic_layer graphs (`rnn3.*` in P; num5730, num62104): hx1 (B, nh) and eps3 (50, B, nh) are the two further
+    N(0,1) draws the artefact makes (rnn3's initial state, then the layer's own noise)."""
+    mp_ncol = P["mlp_qv_crm.weight"].shape[0] if mp_ncol is None else mp_ncol
     B, nlev, _ = inputs_main.shape
     hyam, hybm, hyai, hybi = (P[k].reshape(1, -1, 1) for k in ("hyam", "hybm", "hyai", "hybi"))
     P_old = rnn_mem[:, -1, -1]
@@ -246,6 +274,11 @@ def forward(P, inputs_main, inputs_aux, rnn_mem, inputs_denorm, hx2, ilev_crm=10
     rnn1out, _ = _gru(rnn1_in, hx, P["rnn1.weight_ih_l0"], P["rnn1.weight_hh_l0"], P["rnn1.bias_ih_l0"], P["rnn1.bias_hh_l0"])
     rnn1out = torch.flip(rnn1out, [1])
     rnn2out, last_h = _gru(rnn1out, hx2, P["rnn2.weight_ih_l0"], P["rnn2.weight_hh_l0"], P["rnn2.bias_ih_l0"], P["rnn2.bias_hh_l0"])
+    rnn2raw = rnn2out
+    if "rnn3.weight_ih" in P:       # multiplicative perturbation of the hidden sequence; its last state feeds the precipitation head
+        srnn = stochastic_gru(rnn2out.transpose(0, 1), hx1, eps3, P["rnn3.weight_ih"], P["rnn3.weight_zh"], P["rnn3.weight_encoder"])
+        last_h = srnn[-1]
+        rnn2out = rnn2out * srnn.transpose(0, 1)
     mem_new = _lin(P, "mlp_latent", rnn2out)                                                  # (B,50,15)
     out = _lin(P, "mlp_output", mem_new)                                                      # (B,50,5)
     dec = microphysics_decode(P, out, mem_new, rnn2out, last_h, inputs_denorm, delta_plev, play, P_old, ilev_crm, mp_ncol,
@@ -256,10 +289,10 @@ def forward(P, inputs_main, inputs_aux, rnn_mem, inputs_denorm, hx2, ilev_crm=10
     qv_new = torch.relu(inputs_denorm[:, :, -1:] + out_new[:, :, 1:2] / ys[:, 1:2] * 1200)
     qn_old = inputs_denorm[:, :, 2:3] + inputs_denorm[:, :, 3:4]
     if taps is not None:
-        taps.update(rnn2out=rnn2out, out_mp=out_new.clone(), T_crm=dec["T_crm"], qn_crm=dec["qn_crm"], area_frac=dec["area_frac"])
+        taps.update(rnn2out=rnn2raw, out_mp=out_new.clone(), T_crm=dec["T_crm"], qn_crm=dec["qn_crm"], area_frac=dec["area_frac"])
     dT_rad, sfc_rad = radiative_transfer(P, main0, inputs_aux, inputs_denorm, play, plev, delta_plev, dec["mem_out"],
                                          dec["T_crm"], dec["qn_crm"], T_new, qv_new, qn_old, dec["area_frac"],
-                                         ilev_crm, nh_mem0, ng, taps)
+                                         ilev_crm, nh_mem0, ng, taps, rnn2out)
     out_new[:, :, 0] = out_new[:, :, 0] + dT_rad
     out_sfc = torch.cat([sfc_rad[:, 0:2], dec["precsc"], dec["precc"], sfc_rad[:, 2:]], 1)
     return out_new, out_sfc, dec["mem_out"]

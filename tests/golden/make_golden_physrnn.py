@@ -64,6 +64,8 @@ def inputs_rad(P, B, seed):
     phys = 1.2 * (u(B, 19) - 0.5) * P["xdiv_sca"] + P["xmean_sca"]
     phys[:, 0] = 98000.0 + 6000.0 * (u(B) - 0.5)                                            # surface pressure
     phys[:, 6] = 1.3 * u(B) - 0.3                                                           # cos zenith: about a quarter at night
+    phys[0, 6] = -0.2                                                                       # (always one night column ...
+    phys[B - 1, 6] = 0.7                                                                    #  ... and one day column, when B > 1)
     phys[:, 1] = 1360.0 * phys[:, 6].clamp(min=0.0)                                         # insolation
     phys[:, 7:11] = 0.05 + 0.75 * u(B, 4)                                                   # albedos
     phys[:, 11] = 250.0 + 250.0 * u(B)                                                      # upwelling LW
@@ -72,19 +74,29 @@ def inputs_rad(P, B, seed):
     return xm, xs.contiguous(), mem, xd.contiguous()
 
 
+# the other graphs of the radiation family: sub-column = g-point (no MCICA sampling, mp_ncol 16), a learned cloud
+# liquid-fraction head, a stochastic third RNN (MyStochasticGRULayer5) perturbing the hidden sequence
+RAD_FAMILY = {"physrnn_rad_nomcica": "num71535_BEST", "physrnn_rad_liqfrac": "num83000_ep20", "physrnn_rad_stoch_a": "num5730_BEST",
+              "physrnn_rad_stoch_b": "num62104_BEST", "physrnn_rad_stoch_c": "num62104_BEST_ep11"}
+
+
 def main_rad(art=ART_RAD, name="physrnn_rad", cases=((8, 31), (37, 32))):
     m = torch.jit.load(art, map_location="cpu").eval()
     P = {k: v.detach().float() for k, v in m.state_dict().items()}
     d = {"w." + k: v.numpy() for k, v in P.items() if not k.startswith("pres")}
     for a in ("ilev_crm", "mp_ncol", "nh_mem", "nh_mem0", "nlev_mem", "nh_rnn2", "ng_lw", "ng_sw"):
         d["attr." + a] = np.array(int(getattr(m, a)), np.int64)
+    stoch = "rnn3.weight_ih" in P
     for i, (B, seed) in enumerate(cases):
         xm, xs, mem, xd = inputs_rad(P, B, seed)
         torch.manual_seed(1000 + seed)
         with torch.no_grad():
             out, out_sfc, mem_out = m([xm.clone(), xs.clone(), mem.clone(), xd.clone()])
-        torch.manual_seed(1000 + seed)
+        torch.manual_seed(1000 + seed)      # the artefact's draws, in its order: rnn2's state, rnn3's state, rnn3's noise
         hx2 = torch.randn(B, 128)
+        if stoch:
+            d[f"case{i}.hx1"] = torch.randn(B, 128).numpy()
+            d[f"case{i}.eps3"] = torch.randn(50, B, 128).numpy()
         d[f"case{i}.cfg"] = np.array([B, seed], np.int64)
         for k, v in (("hx2", hx2), ("out", out), ("out_sfc", out_sfc), ("mem_out", mem_out)):
             d[f"case{i}.{k}"] = v.numpy()
@@ -92,9 +104,38 @@ def main_rad(art=ART_RAD, name="physrnn_rad", cases=((8, 31), (37, 32))):
     np.savez_compressed(f"{OUT}/{name}.npz", **d)
 
 
+def check_float64():
+    """Formula identity without rounding: every radiation-family artefact converted to float64 and run with float64 default
+    dtype (so that its internal randn / zeros / full are float64 too) against the float64 restatement on the same draws."""
+    sys.path.insert(0, os.path.join(OUT, "..", ".."))
+    from oracle import physrnn_rad_ref as R
+    for name, tag in [("physrnn_rad", "num4050_BEST")] + list(RAD_FAMILY.items()):
+        m = torch.jit.load(ART_RAD.replace("num4050_BEST", tag), map_location="cpu").eval()
+        P = {k: v.detach().double() for k, v in m.state_dict().items()}
+        m = m.double()
+        xm, xs, mem, xd = (t.double() for t in inputs_rad({k: v.float() for k, v in P.items()}, 8, 77))
+        torch.set_default_dtype(torch.float64)
+        try:
+            torch.manual_seed(5)
+            with torch.no_grad():
+                ref = m([xm.clone(), xs.clone(), mem.clone(), xd.clone()])
+            torch.manual_seed(5)
+            hx2 = torch.randn(8, 128)
+            kw = dict(hx1=torch.randn(8, 128), eps3=torch.randn(50, 8, 128)) if "rnn3.weight_ih" in P else {}
+            got = R.forward(P, xm, xs, mem, xd, hx2, **kw)
+        finally:
+            torch.set_default_dtype(torch.float32)
+        print(name, "float64 artefact vs float64 restatement, relative to the block maximum:",
+              ["%.1e" % ((a - b).abs().max() / b.abs().max()).item() for a, b in zip(got, ref)])
+
+
 if __name__ == "__main__":
     if not os.path.exists(ART):
         sys.exit("reference not present: golden fixtures can only be regenerated in the build container")
     main()
     main(ART_B, "physrnn_hidden_b", ((8, 21),))
+    main(ART.replace("_BEST_", "_ep40_"), "physrnn_hidden_ep40", ((8, 22),))
     main_rad()
+    for i, (name, tag) in enumerate(RAD_FAMILY.items()):
+        main_rad(ART_RAD.replace("num4050_BEST", tag), name, ((8, 41 + i),))
+    check_float64()

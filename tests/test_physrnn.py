@@ -30,7 +30,7 @@ def _blocks(out, out_sfc, mem):
     return d
 
 
-FIXTURES = [("physrnn_hidden", 2), ("physrnn_hidden_b", 1)]       # two training runs of the same graph
+FIXTURES = [("physrnn_hidden", 2), ("physrnn_hidden_b", 1), ("physrnn_hidden_ep40", 1)]   # three checkpoints of the same graph
 
 
 @pytest.mark.parametrize("fixture,ncase", FIXTURES)

@@ -1,14 +1,25 @@
-"""physRNN "Hidden" radiation graphs (second slice: `use_physrad`).  Oracle chain:
-  shipped TorchScript artefact ..._num4050_BEST_script_cpu.pt, run in the build container (torch.jit.load, CPU), outputs
-  stored in tests/golden/physrnn_rad.npz
+"""physRNN "Hidden" radiation graphs (second slice: `use_physrad`).  Six shipped artefacts, four graphs:
+  physrnn_rad          num4050_BEST          mp_ncol 4, MCICA sub-column sampling
+  physrnn_rad_nomcica  num71535_BEST         mp_ncol 16, g-point g = sub-column g
+  physrnn_rad_liqfrac  num83000_ep20         + learned cloud liquid-fraction head
+  physrnn_rad_stoch_*  num5730_BEST, num62104_BEST, num62104_BEST_ep11    num4050's graph + stochastic third RNN
+Oracle chain:
+  shipped TorchScript artefact, run in the build container (torch.jit.load, CPU; its internal randn draws reproduced by
+  re-seeding), outputs stored in tests/golden/<fixture>.npz
     -> CPU: the restatement oracle/physrnn_rad_ref.py reproduces those outputs                  (pins the oracle)
     -> GPU: the HIP path (csa_phys_rad_create + csa_phys_forward, through the C-ABI) reproduces them too, and matches the
             float64 restatement at batch sizes the fixture does not hold.
 Tolerance, per output block: max(1e-5 x max|ref|, 3 x noise), noise = the artefact's own float32 rounding measured against
 the float64 restatement.  The radiation scheme raises MLP outputs to the 8th power, multiplies by ~1e22 molecules/cm2 and
 differences net fluxes over thin layers, so the artefact itself sits 3e-5..5e-5 (relative to the block maximum) away from
-exact arithmetic on these inputs; the float64 restatement is separately required to be within 1e-4 of the artefact so that
-"noise" cannot hide a wrong formula."""
+exact arithmetic on these inputs (the stochastic graphs, whose third RNN scales its noise by exp(z/2), up to 2.5e-4); the
+float64 restatement is separately required to be within 3e-3 of the artefact so that "noise" cannot hide a wrong formula
+(the bound is set by cells near the two-stream singularity k * mu0 = 1, physics_rad.py:139, where the direct-beam terms are a
+small difference of large numbers divided by 1 - (k mu0)^2: the reference guards the denominator at 1e-7 and clamps the result,
+but up to there rounding is amplified; seen in these fixtures: 2.3e-3 on one column's SOLL).  Formula identity, free of
+rounding, was checked when the fixtures were generated: the artefacts run in float64 (module.double(), default dtype
+float64) agree with the float64 restatement to 1e-14 on every output of the graphs without such a cell and to 4e-7 otherwise
+(tests/golden/make_golden_physrnn.py::check_float64)."""
 import os
 import numpy as np
 import pytest
@@ -34,26 +45,44 @@ def _blocks(out, out_sfc, mem):
     return d
 
 
-def _ref64(P, xm, xs, mem, xd, hx2, taps=None):
+def _ref64(P, xm, xs, mem, xd, hx2, taps=None, **noise):
     P64 = {k: v.double() for k, v in P.items()}
-    return _blocks(*physrnn_rad_ref.forward(P64, xm.double(), xs.double(), mem.double(), xd.double(), hx2.double(), taps=taps))
+    return _blocks(*physrnn_rad_ref.forward(P64, xm.double(), xs.double(), mem.double(), xd.double(), hx2.double(), taps=taps,
+                                            **{k: v.double() for k, v in noise.items()}))
 
 
-def test_restatement_reproduces_the_artefact():
-    g, P = _load()
-    for i in range(2):
+FIXTURES = [("physrnn_rad", 2), ("physrnn_rad_nomcica", 1), ("physrnn_rad_liqfrac", 1), ("physrnn_rad_stoch_a", 1),
+            ("physrnn_rad_stoch_b", 1), ("physrnn_rad_stoch_c", 1)]
+
+
+def _noise(g, i):
+    return {k: torch.from_numpy(g[f"case{i}.{k}"]) for k in ("hx1", "eps3") if f"case{i}.{k}" in g.files}
+
+
+def _draw_noise(P, B, seed):
+    if "rnn3.weight_ih" not in P:
+        return {}
+    gen = torch.Generator().manual_seed(seed)
+    return {"hx1": torch.randn(B, 128, generator=gen), "eps3": torch.randn(50, B, 128, generator=gen)}
+
+
+@pytest.mark.parametrize("fixture,ncase", FIXTURES)
+def test_restatement_reproduces_the_artefact(fixture, ncase):
+    g, P = _load(fixture)
+    for i in range(ncase):
         B, seed = (int(v) for v in g[f"case{i}.cfg"])
         xm, xs, mem, xd = inputs_rad(P, B, seed)
-        hx2 = torch.from_numpy(g[f"case{i}.hx2"])
-        got = _blocks(*physrnn_rad_ref.forward(P, xm, xs, mem, xd, hx2))
-        r64 = _ref64(P, xm, xs, mem, xd, hx2)
+        hx2, nz = torch.from_numpy(g[f"case{i}.hx2"]), _noise(g, i)
+        got = _blocks(*physrnn_rad_ref.forward(P, xm, xs, mem, xd, hx2, **nz))
+        r64 = _ref64(P, xm, xs, mem, xd, hx2, **nz)
         ref = _blocks(*(torch.from_numpy(g[f"case{i}.{k}"]) for k in ("out", "out_sfc", "mem_out")))
         for k in BLOCKS:
             scale = ref[k].abs().max().item()
             noise = (ref[k].double() - r64[k]).abs().max().item()
             err = (got[k] - ref[k]).abs().max().item()
-            assert noise <= 1e-4 * scale, (i, k, noise, scale)
-            assert err <= max(1e-5 * scale, 3 * noise), (i, k, err, scale, noise)
+            own = (got[k].double() - r64[k]).abs().max().item()        # the float32 restatement's own rounding
+            assert noise <= 3e-3 * scale, (i, k, noise, scale)
+            assert err <= max(1e-5 * scale, 3 * (noise + own)), (i, k, err, scale, noise, own)
         # structure: night columns have no shortwave at the surface; heating reaches the levels above the CRM top;
         # the moisture tendencies do not
         night = (xs[:, 6] * P["xdiv_sca"][6] + P["xmean_sca"][6]) < 1e-6
@@ -61,7 +90,7 @@ def test_restatement_reproduces_the_artefact():
         for c in (0, 4, 5, 6, 7):
             assert torch.all(ref[("out_sfc", c)][night] == 0) and torch.all(ref[("out_sfc", c)][~night] >= 0)
             assert torch.any(ref[("out_sfc", c)][~night] > 0)
-        assert ref[("out", 0)][:, :10].abs().min() > 0 and torch.all(ref[("out", 1)][:, :10] == 0)
+        assert (ref[("out", 0)][:, :10] != 0).float().mean() > 0.9 and torch.all(ref[("out", 1)][:, :10] == 0)
 
 
 def test_subcolumn_sampling_properties():
@@ -85,17 +114,22 @@ def _hip_model(P, max_batch):
     return m
 
 
+def _cuda(d):
+    return {k: v.cuda() for k, v in d.items()}
+
+
 @pytest.mark.gpu
-def test_hip_radiation_graph_matches_the_artefact():
-    g, P = _load()
+@pytest.mark.parametrize("fixture,ncase", FIXTURES)
+def test_hip_radiation_graph_matches_the_artefact(fixture, ncase):
+    g, P = _load(fixture)
     m = _hip_model(P, 64)
-    for i in range(2):
+    for i in range(ncase):
         B, seed = (int(v) for v in g[f"case{i}.cfg"])
         xm, xs, mem, xd = inputs_rad(P, B, seed)
-        hx2 = torch.from_numpy(g[f"case{i}.hx2"])
-        got = _blocks(*(t.cpu() for t in m([xm.cuda(), xs.cuda(), mem.cuda(), xd.cuda()], hx2=hx2.cuda())))
+        hx2, nz = torch.from_numpy(g[f"case{i}.hx2"]), _noise(g, i)
+        got = _blocks(*(t.cpu() for t in m([xm.cuda(), xs.cuda(), mem.cuda(), xd.cuda()], hx2=hx2.cuda(), **_cuda(nz))))
         ref = _blocks(*(torch.from_numpy(g[f"case{i}.{k}"]) for k in ("out", "out_sfc", "mem_out")))
-        r64 = _ref64(P, xm, xs, mem, xd, hx2)
+        r64 = _ref64(P, xm, xs, mem, xd, hx2, **nz)
         for k in BLOCKS:
             scale = ref[k].abs().max().item()
             noise = (ref[k].double() - r64[k]).abs().max().item()
@@ -104,17 +138,20 @@ def test_hip_radiation_graph_matches_the_artefact():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("B", [1, 2, 301, 384])
-def test_hip_radiation_graph_matches_restatement(B):
-    g, P = _load()
+@pytest.mark.parametrize("fixture,B", [("physrnn_rad", 1), ("physrnn_rad", 2), ("physrnn_rad", 301), ("physrnn_rad", 384),
+                                       ("physrnn_rad_nomcica", 301), ("physrnn_rad_liqfrac", 384), ("physrnn_rad_stoch_a", 2),
+                                       ("physrnn_rad_stoch_b", 301), ("physrnn_rad_stoch_c", 384)])
+def test_hip_radiation_graph_matches_restatement(fixture, B):
+    g, P = _load(fixture)
     m = _hip_model(P, 384)
     xm, xs, mem, xd = inputs_rad(P, B, 70 + B)
     hx2 = torch.randn(B, 128, generator=torch.Generator().manual_seed(B))
+    nz = _draw_noise(P, B, 900 + B)
     taps = {}
-    r64 = _ref64(P, xm, xs, mem, xd, hx2, taps)
+    r64 = _ref64(P, xm, xs, mem, xd, hx2, taps, **nz)
     taps32 = {}
-    r32 = _blocks(*physrnn_rad_ref.forward(P, xm, xs, mem, xd, hx2, taps=taps32))
-    got = _blocks(*(t.cpu() for t in m([xm.cuda(), xs.cuda(), mem.cuda(), xd.cuda()], hx2=hx2.cuda())))
+    r32 = _blocks(*physrnn_rad_ref.forward(P, xm, xs, mem, xd, hx2, taps=taps32, **nz))
+    got = _blocks(*(t.cpu() for t in m([xm.cuda(), xs.cuda(), mem.cuda(), xd.cuda()], hx2=hx2.cuda(), **_cuda(nz))))
     # recurrent core first: rnn2 output over the 50 CRM levels against the float64 restatement (|h| <= 1; 50 + 50 dependent steps)
     t2 = m.tap(2, B).cpu().permute(1, 0, 2).double()
     noise = (taps32["rnn2out"].double() - taps["rnn2out"]).abs().max().item()
@@ -148,7 +185,26 @@ def test_hip_radiation_graph_errors_and_rollout_state():
     assert torch.isfinite(out2).all() and torch.isfinite(mem2).all() and mem2.shape == mem.shape
     # a wrong-geometry state_dict is refused, not reinterpreted
     bad = dict(P)
-    bad["mlp_qv_crm.weight"] = torch.zeros(16, 128)
+    bad["mlp_qv_crm.weight"] = torch.zeros(8, 128)
     from climsim_amd.physrnn import physical_RNN_autoreg
     with pytest.raises(RuntimeError):
         physical_RNN_autoreg(bad, max_batch=8)
+
+
+@pytest.mark.gpu
+def test_hip_stochastic_graph_noise_handling():
+    """add_stochastic_layer graph: explicit draws make a call reproducible, absent draws are made per call (as the reference's
+    forward does), a wrong noise shape is refused."""
+    g, P = _load("physrnn_rad_stoch_a")
+    m = _hip_model(P, 16)
+    assert m.stochastic
+    xm, xs, mem, xd = (t.cuda() for t in inputs_rad(P, 8, 5))
+    nz = _cuda(_draw_noise(P, 8, 1))
+    hx2 = torch.randn(8, 128, device="cuda")
+    a = m([xm, xs, mem, xd], hx2=hx2, **nz)
+    b = m([xm, xs, mem, xd], hx2=hx2, **nz)
+    assert all(torch.equal(u, v) for u, v in zip(a, b))
+    c = m([xm, xs, mem, xd], hx2=hx2)
+    assert not torch.equal(a[0], c[0]) and torch.isfinite(c[0]).all()
+    with pytest.raises(RuntimeError):
+        m([xm, xs, mem, xd], hx2=hx2, hx1=nz["hx1"], eps3=nz["eps3"][:49])
