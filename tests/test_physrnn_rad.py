@@ -10,7 +10,8 @@ Oracle chain:
     -> GPU: the HIP path (csa_phys_rad_create + csa_phys_forward, through the C-ABI) reproduces them too, and matches the
             float64 restatement at batch sizes the fixture does not hold.
 Tolerance, per output block: max(1e-5 x max|ref|, 3 x noise), noise = the artefact's own float32 rounding measured against
-the float64 restatement.  The radiation scheme raises MLP outputs to the 8th power, multiplies by ~1e22 molecules/cm2 and
+the float64 restatement (HIP against the float64 restatement; against the artefact itself 4 x noise, by the triangle
+inequality).  Measured: profiles/r2_physrnn_parity.txt -- the HIP error is 0.5-3 x noise in every block of every artefact.  The radiation scheme raises MLP outputs to the 8th power, multiplies by ~1e22 molecules/cm2 and
 differences net fluxes over thin layers, so the artefact itself sits 3e-5..5e-5 (relative to the block maximum) away from
 exact arithmetic on these inputs (the stochastic graphs, whose third RNN scales its noise by exp(z/2), up to 2.5e-4); the
 float64 restatement is separately required to be within 3e-3 of the artefact so that "noise" cannot hide a wrong formula
@@ -133,8 +134,10 @@ def test_hip_radiation_graph_matches_the_artefact(fixture, ncase):
         for k in BLOCKS:
             scale = ref[k].abs().max().item()
             noise = (ref[k].double() - r64[k]).abs().max().item()
-            err = (got[k].double() - ref[k].double()).abs().max().item()
-            assert err <= max(1e-5 * scale, 3 * noise), (i, k, err, scale, noise)
+            # HIP is a third float32 realisation: no further from exact arithmetic than 3x the artefact's own rounding,
+            # hence (triangle inequality) within 4x of the artefact
+            assert (got[k].double() - r64[k]).abs().max().item() <= max(1e-5 * scale, 3 * noise), (i, k, scale, noise)
+            assert (got[k].double() - ref[k].double()).abs().max().item() <= max(1e-5 * scale, 4 * noise), (i, k, scale, noise)
 
 
 @pytest.mark.gpu
