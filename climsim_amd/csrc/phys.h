@@ -20,6 +20,8 @@ struct PhysDev {
     int ncol, hdw;          // mp_ncol; width of the head GEMM
     int rad;                // 1: physical radiation scheme (no mlp_output_rad / mlp_surface_output_rad heads)
     int liq_off;            // column of the mlp_liq_frac_crm head in the head GEMM, or -1: liquid fraction from temperature
+    int physrad;            // the physRNN_physRad-* graphs: clear-sky region 0 and no sub-grid temperature in the decoder, latent heating
+                            // from area-summed rates, vapour mixing ratio q / (1 - q), rnn_mem level-major (50, B, 16) in and out
     const float *hyam, *hybm, *hyai, *hybi, *yscale_lev, *yscale_sca;
     float xdiv_sca0, xmean_sca0;
     const float *init_wt, *init_b, *s1_wt, *s1_b;   // (nfeat+1, nh), (nx_sfc, nh) transposed

@@ -37,6 +37,12 @@ template <int N> __device__ __forceinline__ float ph_max(float v)
     return v;
 }
 
+// row of (column b, CRM level l) in rnn_mem / mem_out: (B, 50, 16), or level-major (50, B, 16) for the physRad graphs
+__device__ __forceinline__ size_t ph_mem_row(const PhysDev &d, int B, int b, int l)
+{
+    return d.physrad ? (size_t)l * B + b : (size_t)b * d.Lc + l;
+}
+
 // one workgroup (128 threads = nh) per grid column: thread j owns hidden unit j of mlp_initial / mlp_surface1
 __global__ __launch_bounds__(128) void phys_prep_kernel(PhysDev d, int B, const float *__restrict__ x_main, const float *__restrict__ x_sfc,
                                                         const float *__restrict__ mem, float *__restrict__ X1, float *__restrict__ hx)
@@ -85,7 +91,7 @@ __global__ __launch_bounds__(128) void phys_prep_kernel(PhysDev d, int B, const 
     // memory channels (15 carried + zero pad to 16), zero above the CRM top
     for (int i = l0 * 16 + j; i < l1 * 16; i += 128) {
         const int l = i >> 4, k = i & 15;
-        const float v = (l >= d.ilev && k < d.nm0) ? mem[((size_t)b * d.Lc + (l - d.ilev)) * (d.nm0 + 1) + k] : 0.0f;
+        const float v = (l >= d.ilev && k < d.nm0) ? mem[ph_mem_row(d, B, b, l - d.ilev) * (d.nm0 + 1) + k] : 0.0f;
         X1[((size_t)(PH_L - 1 - l) * B + b) * K1 + nh + k] = v;
     }
 }
@@ -134,7 +140,7 @@ __global__ __launch_bounds__(DT) void phys_decode_kernel(PhysDev d, int B, const
     const int b = blockIdx.x, tid = threadIdx.x, ilev = d.ilev, hd0 = ilev - d.ltop, HDW = d.hdw;
     const float CP = 1004.64f, G = 9.80665f, LV = 2510400.0f, LS = 2844000.0f, OOG = 0.1019716213f;
     const float sp = x_sfc[(size_t)b * d.naux] * d.xdiv_sca0 + d.xmean_sca0;
-    const float P_old = mem[((size_t)b * LC + (LC - 1)) * (nm0 + 1) + nm0];
+    const float P_old = mem[ph_mem_row(d, B, b, LC - 1) * (nm0 + 1) + nm0];
     const float *last_h = H2 + ((size_t)(d.Lr - 1) * B + b) * nh;      // (H2: whichever sequence ends in the state the release head reads)
 
     // ---- phase A: latent memory -> mlp_output per level; level pressure thickness; surface heads ----
@@ -142,7 +148,7 @@ __global__ __launch_bounds__(DT) void phys_decode_kernel(PhysDev d, int B, const
         const float *hd = HD + ((size_t)(l + hd0) * B + b) * HDW + PH_NHEAD * NC;
         float lat[16];
 #pragma unroll
-        for (int k = 0; k < nm0; ++k) { lat[k] = hd[k]; mem_out[((size_t)b * LC + l) * (nm0 + 1) + k] = lat[k]; }
+        for (int k = 0; k < nm0; ++k) { lat[k] = hd[k]; mem_out[ph_mem_row(d, B, b, l) * (nm0 + 1) + k] = lat[k]; }
 #pragma unroll
         for (int v = 0; v < 5; ++v) {
             float a = d.out_b[v];
@@ -186,6 +192,7 @@ __global__ __launch_bounds__(DT) void phys_decode_kernel(PhysDev d, int B, const
         const float a_raw = hd[H_AREA * NC];
         const float am = ph_max<NC>(a_raw), ae = expf(a_raw - am), area = ae / ph_sum<NC>(ae);
         float qv = ph_softplus(hd[H_QV * NC]), qn = ph_softplus(hd[H_QN * NC]), qi = ph_softplus(hd[H_QICE * NC]);
+        if (d.physrad && c == 0) qn = 0.0f;           // clear-sky region (its condensation head row is zero too: see phys_build)
         const float mqv = ph_sum<NC>(qv * area), mqn = ph_sum<NC>(qn * area), mqi = ph_sum<NC>(qi * area);
         qv *= mqv == 0.0f ? 1.0f : xd[nxd - 1] / mqv;
         qn *= mqn == 0.0f ? 1.0f : (xd[2] + xd[3]) / mqn;
@@ -226,9 +233,12 @@ __global__ __launch_bounds__(DT) void phys_decode_kernel(PhysDev d, int B, const
         const float dqv = (flux_qv_dp - cond) + evap;
         const float dqn = ((flux_qn_dp + cond) - aa) + sed_qn_dp;
         const float *xd = x_denorm + ((size_t)b * PH_L + L) * nxd;
-        const float temp = xd[0] + (ph_sum<NC>(area * flux_t_dp) / ys[0]) * 1200.0f;
+        // physRad graphs: one temperature per level (flux_t_dp is the same in every region) and latent heating from the
+        // area-summed rates; otherwise per sub-column
+        const float temp = xd[0] + ((d.physrad ? flux_t_dp : ph_sum<NC>(area * flux_t_dp)) / ys[0]) * 1200.0f;
         const float liq = fminf(fmaxf((temp - 253.16f) * 0.05f, 0.0f), 1.0f);
-        const float net = ((liq * LV + (1.0f - liq) * LS) * cond - evap * LV) * (1.0f / CP);
+        const float cond_h = d.physrad ? ph_sum<NC>(area * cond) : cond, evap_h = d.physrad ? ph_sum<NC>(area * evap) : evap;
+        const float net = ((liq * LV + (1.0f - liq) * LS) * cond_h - evap_h * LV) * (1.0f / CP);
         const float dT_crm = flux_t_dp + net / ys[1] * ys[0];
         const float sT = ph_sum<NC>(area * dT_crm), sqv = ph_sum<NC>(area * dqv), sqn = ph_sum<NC>(area * dqn);
         const float sprec = ph_sum<NC>(area * (aa - evap));
@@ -288,7 +298,7 @@ __global__ __launch_bounds__(DT) void phys_decode_kernel(PhysDev d, int B, const
         }
     }
     __syncthreads();
-    for (int l = tid; l < LC; l += DT) mem_out[((size_t)b * LC + l) * (nm0 + 1) + nm0] = s_red[0];
+    for (int l = tid; l < LC; l += DT) mem_out[ph_mem_row(d, B, b, l) * (nm0 + 1) + nm0] = s_red[0];
 
     // ---- phase E (RAD): inputs of the radiation scheme -- the artefact's radiative_transfer up to its three MLPs ----
     if constexpr (RAD) {
@@ -299,7 +309,7 @@ __global__ __launch_bounds__(DT) void phys_decode_kernel(PhysDev d, int B, const
             const float *ys = d.yscale_lev + L * 5;
             const float T_new = fmaxf(xd[0] + s_o01[L][0] / ys[0] * 1200.0f, 0.0f);
             const float qv_new = fmaxf(xd[nxd - 1] + s_o01[L][1] / ys[1] * 1200.0f, 0.0f);
-            const float vmr = qv_new * 1.608079364f, fact = 1.0f / (1.0f + vmr), m_air = (vmr + 0.04698f) * fact;
+            const float vmr = (d.physrad ? qv_new / (1.0f - qv_new) : qv_new) * 1.608079364f, fact = 1.0f / (1.0f + vmr), m_air = (vmr + 0.04698f) * fact;
             const float pd = sp * (d.hybi[L + 1] - d.hybi[L]) + (d.hyai[L + 1] - d.hyai[L]) * 100000.0f;
             const float col_dry = (pd * 10.0f * 6.02214076e23f * fact) / (m_air * 1000.0f * 100.0f * 9.80665f);
             const float play = d.hyam[L] * 100000.0f + sp * d.hybm[L], lp = logf(play), v4 = sqrtf(sqrtf(vmr));
@@ -316,7 +326,7 @@ __global__ __launch_bounds__(DT) void phys_decode_kernel(PhysDev d, int B, const
             const float *xm = ro.x_main + ((size_t)b * PH_L + L) * d.nx;
             xr[0] = (lp - 0.00515f) / 11.59485f;
             xr[1] = (T_new - 160.0f) / 180.0f;
-            xr[2] = v4 / 0.497653f;
+            xr[2] = sqrtf(sqrtf(qv_new * 1.608079364f)) / 0.497653f;
             xr[3] = 1.0f - expf(-(xd[2] + xd[3]) * d.lbd_qn[L]);
             xr[4] = xm[12]; xr[5] = xm[13]; xr[6] = xm[14];
             float rel = 0.0f, rei = 0.0f;
@@ -398,7 +408,7 @@ static const float kRetab[PH_NRETAB] = {
     136.457f, 142.446f, 148.608f, 154.956f, 161.503f, 168.262f, 175.248f, 182.473f, 189.952f, 197.699f, 205.728f, 214.055f, 222.694f,
     231.661f, 240.971f, 250.639f};
 
-static int phys_build(int nx, int nfeat, int naux, int nx_sfc, int sfc_cut, int nh, int ilev_crm, int mp_ncol, int nh_mem0, int rad,
+static int phys_build(int nx, int nfeat, int naux, int nx_sfc, int sfc_cut, int nh, int ilev_crm, int mp_ncol, int nh_mem0, int rad, int physrad,
                       const PhysHostW &w, int max_batch, csa_phys **out)
 {
     int ndev = 0;
@@ -417,7 +427,7 @@ static int phys_build(int nx, int nfeat, int naux, int nx_sfc, int sfc_cut, int 
     d.nx = nx; d.nfeat = nfeat; d.naux = naux; d.nx_sfc = nx_sfc; d.sfc_cut = sfc_cut; d.sfc_skip = naux - nx_sfc;
     d.nh = nh; d.ilev = ilev_crm; d.nm0 = nh_mem0; d.Lc = PH_L - ilev_crm;
     d.ltop = rad ? ilev_crm : 0; d.Lr = PH_L - d.ltop;
-    d.ncol = mp_ncol; d.rad = rad;
+    d.ncol = mp_ncol; d.rad = rad; d.physrad = physrad;
     d.liq_off = w.liq_w ? PH_NHEAD * mp_ncol + 16 : -1;
     d.hdw = rad ? ((PH_NHEAD * mp_ncol + nh_mem0 + (w.liq_w ? 1 + mp_ncol : 0) + 3) / 4) * 4 : PH_NHEAD * mp_ncol + nh_mem0 + 1;
     d.hyam = up(w.hyam, 60); d.hybm = up(w.hybm, 60); d.hyai = up(w.hyai, 61); d.hybi = up(w.hybi, 61);
@@ -450,8 +460,17 @@ static int phys_build(int nx, int nfeat, int naux, int nx_sfc, int sfc_cut, int 
         const int HDW = d.hdw;
         std::vector<float> wh((size_t)HDW * nh, 0.0f), bh(HDW, 0.0f);
         for (int k = 0; k < PH_NHEAD; ++k) {
-            memcpy(&wh[(size_t)k * mp_ncol * nh], w.heads[2 * k], sizeof(float) * mp_ncol * nh);
-            memcpy(&bh[k * mp_ncol], w.heads[2 * k + 1], sizeof(float) * mp_ncol);
+            float *wk = &wh[(size_t)k * mp_ncol * nh], *bk = &bh[k * mp_ncol];
+            if (physrad && k == H_T) continue;                            // no sub-grid temperature: the head stays zero
+            if (physrad && (k == H_QN || k == H_COND)) {                  // mp_ncol - 1 cloudy regions; row 0 (clear sky) stays zero
+                memcpy(wk + nh, w.heads[2 * k], sizeof(float) * (mp_ncol - 1) * nh);
+                memcpy(bk + 1, w.heads[2 * k + 1], sizeof(float) * (mp_ncol - 1));
+            } else if (physrad && k == H_EDDY) {                          // one diffusivity per level: the same row for every region
+                for (int c = 0; c < mp_ncol; ++c) { memcpy(wk + (size_t)c * nh, w.heads[2 * k], sizeof(float) * nh); bk[c] = w.heads[2 * k + 1][0]; }
+            } else {
+                memcpy(wk, w.heads[2 * k], sizeof(float) * mp_ncol * nh);
+                memcpy(bk, w.heads[2 * k + 1], sizeof(float) * mp_ncol);
+            }
         }
         memcpy(&wh[(size_t)PH_NHEAD * mp_ncol * nh], w.lat_w, sizeof(float) * nh_mem0 * nh);
         memcpy(&bh[PH_NHEAD * mp_ncol], w.lat_b, sizeof(float) * nh_mem0);
@@ -472,9 +491,9 @@ static int phys_build(int nx, int nfeat, int naux, int nx_sfc, int sfc_cut, int 
         d.xmean_sca = up(w.xms, naux); d.xdiv_sca = up(w.xds, naux); d.lbd_qn = up(w.lbd_qn, 60);
         d.g_xmin = up(w.g_xmin, 18); d.g_xmax = up(w.g_xmax, 18); d.g_ymean = up(w.g_ymean, 128); d.g_ystd = up(w.g_ystd, 128);
         d.ys_rad = up(w.ys_rad, 6); d.retab = up(kRetab, PH_NRETAB);
-        {   // incoming spectral weights: softmax of the squared learned weights (float arithmetic as in the reference)
+        {   // incoming spectral weights: softmax of the squared learned weights (physRad graphs: un-squared), float arithmetic
             float sq[PH_NG], m = -3.0e38f, sum = 0.0f, e[PH_NG];
-            for (int g = 0; g < PH_NG; ++g) { sq[g] = w.solar_w[g] * w.solar_w[g]; m = sq[g] > m ? sq[g] : m; }
+            for (int g = 0; g < PH_NG; ++g) { sq[g] = physrad ? w.solar_w[g] : w.solar_w[g] * w.solar_w[g]; m = sq[g] > m ? sq[g] : m; }
             for (int g = 0; g < PH_NG; ++g) { e[g] = expf(sq[g] - m); sum += e[g]; }
             for (int g = 0; g < PH_NG; ++g) e[g] /= sum;
             d.toa_spec = up(e, PH_NG);
@@ -522,15 +541,19 @@ extern "C" int csa_phys_create(int nx, int nx_sfc, int nh, int ilev_crm, int mp_
     v.lat_w = *p++; v.lat_b = *p++; v.out_w = *p++; v.out_b = *p++; v.sfo_w = *p++; v.sfo_b = *p++; v.rad_w = *p++; v.rad_b = *p++;
     v.rel_w = *p++; v.rel_b = *p++;
     v.heads = p;
-    return phys_build(nx, nx, nx_sfc, nx_sfc, nx_sfc, nh, ilev_crm, mp_ncol, nh_mem0, 0, v, max_batch, out);
+    return phys_build(nx, nx, nx_sfc, nx_sfc, nx_sfc, nh, ilev_crm, mp_ncol, nh_mem0, 0, 0, v, max_batch, out);
 }
 
 // The radiation graphs (num4050): see include/climsim_amd.h for the pointer order
 extern "C" int csa_phys_rad_create(int nx, int naux, int nh, int ilev_crm, int mp_ncol, int nh_mem0, int ng, int flags,
                                    const float *const *w, int max_batch, csa_phys **out)
 {
-    if (!w || !out || max_batch <= 0 || (flags & ~7)) { csa_set_error_msg("csa_phys_rad_create: bad argument"); return CSA_ERR_ARG; }
-    const bool mcica = flags & CSA_PHYS_MCICA;
+    if (!w || !out || max_batch <= 0 || (flags & ~15)) { csa_set_error_msg("csa_phys_rad_create: bad argument"); return CSA_ERR_ARG; }
+    const bool mcica = flags & CSA_PHYS_MCICA, physrad = flags & CSA_PHYS_PHYSRAD;
+    if (physrad && (mcica || !(flags & CSA_PHYS_LIQ_FRAC_HEAD))) {
+        csa_set_error_msg("csa_phys_rad_create: the physRad graphs come without MCICA sampling and with the liquid-fraction head");
+        return CSA_ERR_UNSUPPORTED;
+    }
     if (nh != 128 || mp_ncol != (mcica ? 4 : 16) || nh_mem0 != 15 || ilev_crm != 10 || nx != 21 || naux != 19 || ng != PH_NG) {
         csa_set_error_msg("csa_phys_rad_create: built for the shipped geometries (21 level inputs, 19 surface inputs, GRU 128/128 over 50 levels, "
                           "15+1 memory channels, 16 g-points; mp_ncol 4 with MCICA sampling or mp_ncol 16 without)");
@@ -549,9 +572,12 @@ extern "C" int csa_phys_rad_create(int nx, int naux, int nh, int ilev_crm, int m
     if (flags & CSA_PHYS_LIQ_FRAC_HEAD) { v.liq_w = *p++; v.liq_b = *p++; }
     if (flags & CSA_PHYS_STOCHASTIC) { v.s3_ih = *p++; v.s3_zh = *p++; v.s3_enc = *p++; }
     for (const float *const *q = w; q != p; ++q)
-        if (!*q) { csa_set_error_msg("csa_phys_rad_create: null weight pointer"); return CSA_ERR_ARG; }
+        if (!*q && !(physrad && (q == v.heads + 2 * H_T || q == v.heads + 2 * H_T + 1))) {      // (no mlp_t_crm in the physRad graphs)
+            csa_set_error_msg("csa_phys_rad_create: null weight pointer");
+            return CSA_ERR_ARG;
+        }
     // mlp_initial sees x_main[:, :, 0:nx-3] and the layer pressure; mlp_surface1 sees aux 0:6 and 11:naux
-    return phys_build(nx, nx - 3, naux, naux - 5, 6, nh, ilev_crm, mp_ncol, nh_mem0, 1, v, max_batch, out);
+    return phys_build(nx, nx - 3, naux, naux - 5, 6, nh, ilev_crm, mp_ncol, nh_mem0, 1, physrad ? 1 : 0, v, max_batch, out);
 }
 
 extern "C" int csa_phys_destroy(csa_phys *h)
@@ -572,16 +598,16 @@ __global__ __launch_bounds__(256) void phys_mul_kernel(const f32x4 *__restrict__
 // x_main (B,60,nx) normalised, x_sfc (B,naux) normalised, rnn_mem (B,50,16), x_denorm (B,60,nxd) raw (T, ., qliq, qice, ..., qv last),
 // hx2 (B,nh): the N(0,1) draw the reference makes for rnn2's initial state; add_stochastic_layer graphs also draw hx1 (B,nh), rnn3's
 // initial state, and eps3 (Lr,B,nh), the layer's noise.  -> out_lev (B,60,5), out_sfc (B,8), mem_out (B,50,16)
-extern "C" int csa_phys_forward_noise(csa_phys *h, int B, const float *x_main, const float *x_sfc, const float *rnn_mem,
-                                      const float *x_denorm, int nxd, const float *hx2, const float *hx1, const float *eps3,
-                                      float *out_lev, float *out_sfc, float *mem_out, void *stream)
+static int phys_forward_impl(csa_phys *h, int B, const float *x_main, const float *x_sfc, const float *rnn_mem,
+                             const float *x_denorm, int nxd, const float *hx2, const float *hx1, const float *eps3, const float *srnn,
+                             float *out_lev, float *out_sfc, float *mem_out, void *stream)
 {
     if (!h || !x_main || !x_sfc || !rnn_mem || !x_denorm || !hx2 || !out_lev || !out_sfc || !mem_out || B <= 0 || B > h->max_batch || nxd < 5 ||
         (h->d.rad && nxd < 16)) {
         csa_set_error_msg("csa_phys_forward: bad argument");
         return CSA_ERR_ARG;
     }
-    if (h->rnn3 && (!hx1 || !eps3)) {
+    if (h->rnn3 && !srnn && (!hx1 || !eps3)) {
         csa_set_error_msg("csa_phys_forward: this graph has the stochastic third RNN: pass its N(0,1) draws (csa_phys_forward_noise)");
         return CSA_ERR_ARG;
     }
@@ -601,7 +627,8 @@ extern "C" int csa_phys_forward_noise(csa_phys *h, int B, const float *x_main, c
     if ((rc = rec(h->whh2p, h->whh2g, h->bhn2, hx2, h->H2, 0))) return rc;
     const float *Hhead = h->H2, *Hlast = h->H2;      // the sequence the heads read; the sequence whose last state feeds the release head
     if (h->rnn3) {                                    // rnn2's output times the stochastic layer's output; last state: the layer's own
-        if ((rc = csa_stoch_gru5_forward(h->rnn3, L, B, h->H2, hx1, eps3, h->H3, stream))) return rc;
+        if (srnn) CSA_HIP_CHECK(hipMemcpyAsync(h->H3, srnn, sizeof(float) * (size_t)M * nh, hipMemcpyDeviceToDevice, s));
+        else if ((rc = csa_stoch_gru5_forward(h->rnn3, L, B, h->H2, hx1, eps3, h->H3, stream))) return rc;
         const size_t n4 = (size_t)M * nh / 4;
         hipLaunchKernelGGL(phys_mul_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, (const f32x4 *)h->H2, (const f32x4 *)h->H3,
                            (f32x4 *)h->H2p, n4);
@@ -626,11 +653,36 @@ extern "C" int csa_phys_forward_noise(csa_phys *h, int B, const float *x_main, c
     return CSA_OK;
 }
 
+extern "C" int csa_phys_forward_noise(csa_phys *h, int B, const float *x_main, const float *x_sfc, const float *rnn_mem,
+                                      const float *x_denorm, int nxd, const float *hx2, const float *hx1, const float *eps3,
+                                      float *out_lev, float *out_sfc, float *mem_out, void *stream)
+{
+    return phys_forward_impl(h, B, x_main, x_sfc, rnn_mem, x_denorm, nxd, hx2, hx1, eps3, nullptr, out_lev, out_sfc, mem_out, stream);
+}
+
 extern "C" int csa_phys_forward(csa_phys *h, int B, const float *x_main, const float *x_sfc, const float *rnn_mem,
                                 const float *x_denorm, int nxd, const float *hx2, float *out_lev, float *out_sfc, float *mem_out,
                                 void *stream)
 {
-    return csa_phys_forward_noise(h, B, x_main, x_sfc, rnn_mem, x_denorm, nxd, hx2, nullptr, nullptr, out_lev, out_sfc, mem_out, stream);
+    return phys_forward_impl(h, B, x_main, x_sfc, rnn_mem, x_denorm, nxd, hx2, nullptr, nullptr, nullptr, out_lev, out_sfc, mem_out, stream);
+}
+
+// Test hook (teacher forcing): the forward pass with rnn3's output (Lr, B, nh) supplied instead of computed -- the stages after a
+// chaotic stochastic layer checked on their own (tests/test_physrnn_rad.py).  The layer itself: csa_phys_debug_rnn3.
+extern "C" int csa_phys_debug_forward_srnn(csa_phys *h, int B, const float *x_main, const float *x_sfc, const float *rnn_mem,
+                                           const float *x_denorm, int nxd, const float *hx2, const float *srnn,
+                                           float *out_lev, float *out_sfc, float *mem_out, void *stream)
+{
+    if (!h || !h->rnn3 || !srnn) { csa_set_error_msg("csa_phys_debug_forward_srnn: needs a handle with the stochastic layer and its output"); return CSA_ERR_ARG; }
+    return phys_forward_impl(h, B, x_main, x_sfc, rnn_mem, x_denorm, nxd, hx2, nullptr, nullptr, srnn, out_lev, out_sfc, mem_out, stream);
+}
+
+// Test hook: the handle's own rnn3 on caller-supplied input -- x (T, B, nh), h0 (B, nh), eps (T, B, nh) -> out (T, B, nh); T * B within
+// 50 * max_batch.  With T = 1 and B = all (level, column) pairs this is every step of the layer from the reference's previous state.
+extern "C" int csa_phys_debug_rnn3(csa_phys *h, int T, int B, const float *x, const float *h0, const float *eps, float *out, void *stream)
+{
+    if (!h || !h->rnn3) { csa_set_error_msg("csa_phys_debug_rnn3: this graph has no stochastic layer"); return CSA_ERR_ARG; }
+    return csa_stoch_gru5_forward(h->rnn3, T, B, x, h0, eps, out, stream);
 }
 
 // taps for tests: level-major (Lr, B, nh) outputs of rnn1 (level order) and rnn2 of the last call

@@ -69,10 +69,17 @@ class physical_RNN_autoreg(torch.nn.Module):
         arrs = []
         ng = int(state_dict["gas_optics_lw_reduce1.weight"].shape[0])
         self.stochastic = "rnn3.weight_ih" in state_dict
-        flags = (1 if mp_ncol != ng else 0) | (2 if "mlp_liq_frac_crm.weight" in state_dict else 0) | (4 if self.stochastic else 0)
+        # the physRNN_physRad-* generation: clear-sky region (one row fewer in the two condensate heads), no sub-grid temperature head,
+        # rnn_mem level-major (50, B, 16)
+        self.physrad = "mlp_t_crm.weight" not in state_dict and int(state_dict["mlp_qn_crm.weight"].shape[0]) == mp_ncol - 1
+        flags = ((1 if mp_ncol != ng else 0) | (2 if "mlp_liq_frac_crm.weight" in state_dict else 0) | (4 if self.stochastic else 0)
+                 | (8 if self.physrad else 0))
         order = (_ORDER_RAD + (["mlp_liq_frac_crm.weight", "mlp_liq_frac_crm.bias"] if flags & 2 else [])
                  + (["rnn3.weight_ih", "rnn3.weight_zh", "rnn3.weight_encoder"] if flags & 4 else []))
         for k in order:
+            if self.physrad and k.startswith("mlp_t_crm."):
+                arrs.append(None)
+                continue
             if k not in state_dict:
                 raise RuntimeError(f"physRNN (radiation graph) state_dict lacks {k}")
             v = state_dict[k]
@@ -84,7 +91,7 @@ class physical_RNN_autoreg(torch.nn.Module):
         self.nx_sfc = sd["xmean_sca"].shape[0]                      # x_sfc columns (5 of them bypass mlp_surface1)
         self.nlev, self.nlev_mem, self.nh_mem = 60, 60 - ilev_crm, nh_mem0 + 1
         FP = ctypes.POINTER(ctypes.c_float)
-        warr = (FP * len(arrs))(*[a.ctypes.data_as(FP) for a in arrs])
+        warr = (FP * len(arrs))(*[a.ctypes.data_as(FP) if a is not None else None for a in arrs])
         h = ctypes.c_void_p()
         rc = _lib.lib().csa_phys_rad_create(self.nx, self.nx_sfc, self.nh, int(ilev_crm), int(mp_ncol), int(nh_mem0), ng, flags, warr,
                                             int(max_batch), ctypes.byref(h))
@@ -92,19 +99,28 @@ class physical_RNN_autoreg(torch.nn.Module):
             raise RuntimeError(f"csa_phys_rad_create failed ({rc}): {_lib.last_error()}")
         self._h, self.max_batch = h, max_batch
 
-    def forward(self, inp_list, hx2=None, hx1=None, eps3=None):
+    def forward(self, inp_list, hx2=None, hx1=None, eps3=None, _srnn=None):
         """hx2 (B, nh): rnn2's initial state; add_stochastic_layer graphs also take hx1 (B, nh), rnn3's initial state, and eps3
         (50, B, nh), its noise.  Whatever is not passed is drawn here with torch.randn, as the reference does inside forward."""
         x_main, x_sfc, rnn_mem, x_denorm = inp_list[0], inp_list[1], inp_list[2], inp_list[3]
         B = x_main.shape[0]
         x_main = _check(x_main, (B, self.nlev, self.nx), "inputs_main")
         x_sfc = _check(x_sfc, (B, self.nx_sfc), "inputs_aux")
-        rnn_mem = _check(rnn_mem, (B, self.nlev_mem, self.nh_mem), "rnn_mem")
+        mem_shape = (self.nlev_mem, B, self.nh_mem) if getattr(self, "physrad", False) else (B, self.nlev_mem, self.nh_mem)
+        rnn_mem = _check(rnn_mem, mem_shape, "rnn_mem")
         x_denorm = _check(x_denorm, (B, self.nlev, x_denorm.shape[-1]), "inputs_denorm")
         hx2 = torch.randn(B, self.nh, device=self.device) if hx2 is None else _check(hx2, (B, self.nh), "hx2")
         out = torch.empty(B, self.nlev, 5, device=self.device)
         out_sfc = torch.empty(B, 8, device=self.device)
-        mem_out = torch.empty(B, self.nlev_mem, self.nh_mem, device=self.device)
+        mem_out = torch.empty(*mem_shape, device=self.device)
+        if _srnn is not None:                 # test hook: rnn3's output supplied (teacher forcing), see csa_phys_debug_forward_srnn
+            _srnn = _check(_srnn, (self.nlev_mem, B, self.nh), "srnn")
+            rc = _lib.lib().csa_phys_debug_forward_srnn(self._h, B, _ptr(x_main), _ptr(x_sfc), _ptr(rnn_mem), _ptr(x_denorm),
+                                                        int(x_denorm.shape[-1]), _ptr(hx2), _ptr(_srnn), _ptr(out), _ptr(out_sfc), _ptr(mem_out),
+                                                        ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream))
+            if rc != 0:
+                raise RuntimeError(f"csa_phys_debug_forward_srnn failed ({rc}): {_lib.last_error()}")
+            return out, out_sfc, mem_out
         if getattr(self, "stochastic", False):
             hx1 = torch.randn(B, self.nh, device=self.device) if hx1 is None else _check(hx1, (B, self.nh), "hx1")
             eps3 = torch.randn(self.nlev_mem, B, self.nh, device=self.device) if eps3 is None else _check(eps3, (self.nlev_mem, B, self.nh), "eps3")
@@ -117,6 +133,17 @@ class physical_RNN_autoreg(torch.nn.Module):
         if rc != 0:
             raise RuntimeError(f"csa_phys_forward failed ({rc}): {_lib.last_error()}")
         return out, out_sfc, mem_out
+
+    def debug_rnn3(self, x, h0, eps):
+        """Test hook: this graph's stochastic third RNN alone, x (T, B, nh), h0 (B, nh), eps (T, B, nh) -> (T, B, nh)."""
+        T, B = x.shape[0], x.shape[1]
+        x, h0, eps = _check(x, (T, B, self.nh), "x"), _check(h0, (B, self.nh), "h0"), _check(eps, (T, B, self.nh), "eps")
+        out = torch.empty(T, B, self.nh, device=self.device)
+        rc = _lib.lib().csa_phys_debug_rnn3(self._h, T, B, _ptr(x), _ptr(h0), _ptr(eps), _ptr(out),
+                                            ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream))
+        if rc != 0:
+            raise RuntimeError(f"csa_phys_debug_rnn3 failed ({rc}): {_lib.last_error()}")
+        return out
 
     def tap(self, which, B):
         t = torch.empty(self.nlev_mem if self.use_physrad else 60, B, self.nh, device=self.device)

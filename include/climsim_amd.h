@@ -419,6 +419,12 @@ int csa_phys_tap(csa_phys *h, int which, int B, float *dst, void *stream);
  *        CSA_PHYS_STOCHASTIC     rnn3 = MyStochasticGRULayer5(nh, nh) (rnn/models_torch_kernels.py:834-891) over rnn2's output:
  *                                the heads read rnn2_out * rnn3_out, the precipitation-release head reads rnn3's last state;
  *                                such a handle needs csa_phys_forward_noise.
+ *        CSA_PHYS_PHYSRAD        the physRNN_physRad-* generation of the graph (first geometry: nreg 16, GRU 128/128, e.g.
+ *                                physRNN_physRad-16_nreg16_*_num14751_BEST_script_cpu.pt): region 0 of the mp_ncol = nreg regions is
+ *                                clear sky -- mlp_qn_crm and mlp_evap_cond_vapor_crm are (nreg-1, nh) --, no sub-grid temperature
+ *                                (the mlp_t_crm pair is NULL, mlp_eddy_diff is (1, nh)), latent heating from area-summed rates,
+ *                                vapour mixing ratio q/(1-q), un-squared solar weights, and rnn_mem / mem_out are LEVEL-MAJOR
+ *                                (50, B, 16) as that graph's forward takes and returns them.  Needs LIQ_FRAC_HEAD, excludes MCICA.
  * Same handle type: csa_phys_forward / _tap (50 levels) / _destroy apply; x_sfc is (B, naux = 19), x_denorm needs columns
  * 12..14 = O3, CH4, N2O.
  * w (HOST pointers): the first 24 of csa_phys_create's list (hyam ... mlp_output.b), mlp_precip_release.{w, b}, the 11
@@ -430,12 +436,19 @@ int csa_phys_tap(csa_phys *h, int which, int B, float *dst, void *stream);
  * weight_encoder (nh,2nh)} in the reference's (in, out) layout.
  * csa_phys_forward_noise: csa_phys_forward + hx1 (B,nh), rnn3's initial state, and eps3 (50,B,nh), its noise: the two further
  * N(0,1) draws the reference makes inside forward (both nullable for a handle without rnn3). */
-enum { CSA_PHYS_MCICA = 1, CSA_PHYS_LIQ_FRAC_HEAD = 2, CSA_PHYS_STOCHASTIC = 4 };
+enum { CSA_PHYS_MCICA = 1, CSA_PHYS_LIQ_FRAC_HEAD = 2, CSA_PHYS_STOCHASTIC = 4, CSA_PHYS_PHYSRAD = 8 };
 int csa_phys_rad_create(int nx, int naux, int nh, int ilev_crm, int mp_ncol, int nh_mem0, int ng, int flags,
                         const float *const *w, int max_batch, csa_phys **out);
 int csa_phys_forward_noise(csa_phys *h, int B, const float *x_main, const float *x_sfc, const float *rnn_mem,
                            const float *x_denorm, int nxd, const float *hx2, const float *hx1, const float *eps3,
                            float *out_lev, float *out_sfc, float *mem_out, void *stream);
+/* Test hooks for graphs whose stochastic layer is chaotic on the test inputs (no two float32 implementations agree end to
+ * end): the forward pass with rnn3's output srnn (50,B,nh) supplied (teacher forcing), and the handle's rnn3 alone on
+ * caller-supplied x (T,B,nh), h0 (B,nh), eps (T,B,nh) -> out (T,B,nh), T*B <= 50*max_batch. */
+int csa_phys_debug_forward_srnn(csa_phys *h, int B, const float *x_main, const float *x_sfc, const float *rnn_mem,
+                                const float *x_denorm, int nxd, const float *hx2, const float *srnn,
+                                float *out_lev, float *out_sfc, float *mem_out, void *stream);
+int csa_phys_debug_rnn3(csa_phys *h, int T, int B, const float *x, const float *h0, const float *eps, float *out, void *stream);
 
 /* ---- stochastic recurrent layers ---------------------------------------------------
  * MyStochasticGRULayer5  rnn/models_torch_kernels.py:834-891 (its GPU path = the repo's inline CUDA, :29-252)

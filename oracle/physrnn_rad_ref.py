@@ -127,15 +127,16 @@ def adding_sw(toa, alb_dif, alb_dir, R, T, Rdir, Tdd, Tdir):
 
 
 def radiative_transfer(P, main0, aux_n, xd, play, plev, delta_plev, mem_out, T_crm, qn_crm, T_new, qv_new, qn_old,
-                       area_frac, ilev_crm, nh_mem0, ng=16, taps=None, rnn2out=None):
+                       area_frac, ilev_crm, nh_mem0, ng=16, taps=None, rnn2out=None, physrad=False):
     """-> dT_rad (B, 60) scaled by yscale_lev[:, 0], out_sfc_rad (B, 6) scaled by yscale_sca_rad.
     use_mcica graphs (mp_ncol < ng): every g-point samples a sub-column; otherwise g-point g is sub-column g.
     rnn2out given and `mlp_liq_frac_crm` in P (num83000): the cloud liquid fraction is a learned head instead of the
-    temperature ramp."""
+    temperature ramp.  physrad (the physRNN_physRad-* graphs): water-vapour mixing ratio from specific humidity as q / (1 - q),
+    and the solar spectral weights enter un-squared."""
     B, nlev, _ = main0.shape
     ncrm = nlev - ilev_crm
     aux = aux_n * P["xdiv_sca"] + P["xmean_sca"]
-    vmr = qv_new * 1.608079364                                                                # (B,60,1)
+    vmr = (qv_new / (1.0 - qv_new) if physrad else qv_new) * 1.608079364                      # (B,60,1)
     fact = 1.0 / (1.0 + vmr)
     m_air = (vmr + 0.04698) * fact
     col_dry = (delta_plev * 10.0 * 6.02214076e23 * fact) / (m_air * 1000.0 * 100.0 * 9.80665)
@@ -202,7 +203,7 @@ def radiative_transfer(P, main0, aux_n, xd, play, plev, delta_plev, mem_out, T_c
     # SW optical properties from the learned head, then two-stream + adding
     top0 = T_new.new_zeros(B, ilev_crm, 1)
     mem60 = torch.cat([T_new.new_zeros(B, ilev_crm, nh_mem0), mem_out[:, :, :nh_mem0]], 1)
-    xr = torch.cat([(torch.log(play) - 0.00515) / 11.59485, (T_new - 160.0) / 180.0, vmr.sqrt().sqrt() / 0.497653,
+    xr = torch.cat([(torch.log(play) - 0.00515) / 11.59485, (T_new - 160.0) / 180.0, (qv_new * 1.608079364).sqrt().sqrt() / 0.497653,
                     1.0 - torch.exp(-qn_old * P["lbd_qn"].view(1, -1, 1)), main0[:, :, 12:15],
                     torch.cat([top0, rel / 13.5], 1), torch.cat([top0, rei / 250.0], 1), mem60], 2)
     o = _lin(P, "mlp_sw_optprops2", F.softsign(_lin(P, "mlp_sw_optprops1", xr))).view(B, nlev, 3, ng)
@@ -210,7 +211,7 @@ def radiative_transfer(P, main0, aux_n, xd, play, plev, delta_plev, mem_out, T_c
     ssa, asy = torch.sigmoid(o[:, :, 1]), torch.sigmoid(o[:, :, 2])
     mu0 = aux[:, 6].clamp(min=1e-6).view(B, 1, 1).expand(B, nlev, ng)
     R, T, Rdir, Tdd, Tdir = two_stream_sw(mu0, tau_sw, ssa, asy)
-    toa = aux[:, 1:2] * torch.softmax(P["sw_solar_weights"] ** 2, 1)                          # (B,g)
+    toa = aux[:, 1:2] * torch.softmax(P["sw_solar_weights"] if physrad else P["sw_solar_weights"] ** 2, 1)   # (B,g)
     n_ir, n_mix = int(round(0.7142857142857143 * ng)), int(round(0.7946428571428571 * ng))
     band = lambda near, vis: torch.cat([near.expand(B, n_ir), (0.5 * (near + vis)).expand(B, n_mix - n_ir),
                                         vis.expand(B, ng - n_mix)], 1)
@@ -253,12 +254,14 @@ def stochastic_gru(x, h, eps, w_ih, w_zh, w_enc):
 
 
 def forward(P, inputs_main, inputs_aux, rnn_mem, inputs_denorm, hx2, ilev_crm=10, mp_ncol=None, nh_mem0=15, ng=16, taps=None,
-            hx1=None, eps3=None):
+            hx1=None, eps3=None, srnn=None):
     """inputs_main (B, 60, 21), inputs_aux (B, 19), rnn_mem (B, 50, 16), inputs_denorm (B, 60, 21)
     -> out_new (B, 60, 5), out_sfc (B, 8), rnn_mem (B, 50, 16).
     add_stochastic_layer graphs (`rnn3.*` in P; num5730, num62104): hx1 (B, nh) and eps3 (50, B, nh) are the two further
-    N(0,1) draws the artefact makes (rnn3's initial state, then the layer's own noise)."""
+    N(0,1) draws the artefact makes (rnn3's initial state, then the layer's own noise); srnn (50, B, nh), if given, replaces
+    rnn3's output (teacher forcing: the physRad artefact's rnn3 is chaotic on the synthetic inputs, tests/test_physrnn_rad.py)."""
     mp_ncol = P["mlp_qv_crm.weight"].shape[0] if mp_ncol is None else mp_ncol
+    physrad = P["mlp_qn_crm.weight"].shape[0] == mp_ncol - 1       # `use_clear_sky_region`: the physRNN_physRad-* graphs
     B, nlev, _ = inputs_main.shape
     hyam, hybm, hyai, hybi = (P[k].reshape(1, -1, 1) for k in ("hyam", "hybm", "hyai", "hybi"))
     P_old = rnn_mem[:, -1, -1]
@@ -276,13 +279,16 @@ def forward(P, inputs_main, inputs_aux, rnn_mem, inputs_denorm, hx2, ilev_crm=10
     rnn2out, last_h = _gru(rnn1out, hx2, P["rnn2.weight_ih_l0"], P["rnn2.weight_hh_l0"], P["rnn2.bias_ih_l0"], P["rnn2.bias_hh_l0"])
     rnn2raw = rnn2out
     if "rnn3.weight_ih" in P:       # multiplicative perturbation of the hidden sequence; its last state feeds the precipitation head
-        srnn = stochastic_gru(rnn2out.transpose(0, 1), hx1, eps3, P["rnn3.weight_ih"], P["rnn3.weight_zh"], P["rnn3.weight_encoder"])
+        if srnn is None:
+            srnn = stochastic_gru(rnn2out.transpose(0, 1), hx1, eps3, P["rnn3.weight_ih"], P["rnn3.weight_zh"], P["rnn3.weight_encoder"])
+        if taps is not None:
+            taps["srnn"] = srnn
         last_h = srnn[-1]
         rnn2out = rnn2out * srnn.transpose(0, 1)
     mem_new = _lin(P, "mlp_latent", rnn2out)                                                  # (B,50,15)
     out = _lin(P, "mlp_output", mem_new)                                                      # (B,50,5)
     dec = microphysics_decode(P, out, mem_new, rnn2out, last_h, inputs_denorm, delta_plev, play, P_old, ilev_crm, mp_ncol,
-                              copy_dT=False)
+                              copy_dT=False, clear_sky=physrad)
     out_new = dec["out_new"]
     ys = P["yscale_lev"]
     T_new = torch.relu(inputs_denorm[:, :, 0:1] + out_new[:, :, 0:1] / ys[:, 0:1] * 1200)
@@ -292,7 +298,7 @@ def forward(P, inputs_main, inputs_aux, rnn_mem, inputs_denorm, hx2, ilev_crm=10
         taps.update(rnn2out=rnn2raw, out_mp=out_new.clone(), T_crm=dec["T_crm"], qn_crm=dec["qn_crm"], area_frac=dec["area_frac"])
     dT_rad, sfc_rad = radiative_transfer(P, main0, inputs_aux, inputs_denorm, play, plev, delta_plev, dec["mem_out"],
                                          dec["T_crm"], dec["qn_crm"], T_new, qv_new, qn_old, dec["area_frac"],
-                                         ilev_crm, nh_mem0, ng, taps, rnn2out)
+                                         ilev_crm, nh_mem0, ng, taps, rnn2out, physrad)
     out_new[:, :, 0] = out_new[:, :, 0] + dT_rad
     out_sfc = torch.cat([sfc_rad[:, 0:2], dec["precsc"], dec["precc"], sfc_rad[:, 2:]], 1)
     return out_new, out_sfc, dec["mem_out"]

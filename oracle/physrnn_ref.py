@@ -68,9 +68,14 @@ def forward(P, inputs_main, inputs_aux, rnn_mem, inputs_denorm, hx2, ilev_crm=10
     return out_new, out_sfc, mem_out
 
 
-def microphysics_decode(P, out, mem_new, r2, last_h, inputs_denorm, delta_plev, play, P_old, ilev_crm, mp_ncol, copy_dT=True):
+def microphysics_decode(P, out, mem_new, r2, last_h, inputs_denorm, delta_plev, play, P_old, ilev_crm, mp_ncol, copy_dT=True,
+                        clear_sky=False):
     """rnn/models/models_phys.py:414-748.  copy_dT: the nx = 21 graphs also pass the decoder's raw column-0 output of the
     levels below ilev_crm + 2 through to out_new; the radiation graphs (oracle/physrnn_rad_ref.py) do not.
+    clear_sky (the physRNN_physRad-* graphs, `use_clear_sky_region`, no sub-grid temperature): region 0 holds no condensate
+    (mlp_qn_crm / mlp_evap_cond_vapor_crm have mp_ncol - 1 outputs, a zero is prepended), temperature and eddy heat flux are
+    those of the grid column (mlp_eddy_diff has one output, no mlp_t_crm), and the latent heating is formed from the
+    area-summed condensation / evaporation.
     -> dict with out_new, precc, precsc, mem_out and the updated sub-column state (T_crm, qv_crm, qn_crm, area_frac)."""
     B, nlev = inputs_denorm.shape[0], inputs_denorm.shape[1]
     x = out
@@ -85,21 +90,26 @@ def microphysics_decode(P, out, mem_new, r2, last_h, inputs_denorm, delta_plev, 
     qn_gcm = qliq_gcm + qice_gcm
     qv_crm = F.softplus(_lin(P, "mlp_qv_crm", r2))
     qn_crm = F.softplus(_lin(P, "mlp_qn_crm", r2))
+    if clear_sky:
+        qn_crm = torch.cat([qn_crm.new_zeros(B, nlev - ilev_crm, 1), qn_crm], 2)
     area_frac = torch.softmax(_lin(P, "mlp_subgrid_area_frac", r2), 2)
 
     def rescale(q, gcm):
         mean = (q * area_frac).sum(-1, keepdim=True)
         return q * torch.where(mean == 0, torch.ones_like(mean), gcm / mean)
     qv_crm, qn_crm = rescale(qv_crm, qv_gcm), rescale(qn_crm, qn_gcm)
-    deltaT = _lin(P, "mlp_t_crm", r2)
-    T_crm = T_gcm + (deltaT - (deltaT * area_frac).sum(-1, keepdim=True))
+    if clear_sky:
+        T_crm = T_gcm                                                                         # (B,50,1)
+    else:
+        deltaT = _lin(P, "mlp_t_crm", r2)
+        T_crm = T_gcm + (deltaT - (deltaT * area_frac).sum(-1, keepdim=True))
     flux1 = _lin(P, "mlp_massflux", r2)
     eddy = _lin(P, "mlp_eddy_diff", r2)
     zer = x.new_zeros(B, 1, mp_ncol)
     play_diff = play[:, ilev_crm:] - play[:, ilev_crm - 1:-1]
     fH = (eddy * (CP / G)) * T_crm * play_diff
     fH = torch.cat([fH[:, :-1], -torch.relu(fH[:, -1:])], 1)
-    fH = torch.cat([zer, fH], 1)
+    fH = torch.cat([zer[:, :, :fH.shape[2]], fH], 1)
     flux_t_dp = (fH[:, 1:] - fH[:, :-1]) / pres_diff * (-G / CP)
     f_qv = flux1 * 300000.0 * qv_crm
     f_qn = flux1 * 300000.0 * qn_crm
@@ -115,6 +125,8 @@ def microphysics_decode(P, out, mem_new, r2, last_h, inputs_denorm, delta_plev, 
     flux_qv_dp, flux_qn_dp = div_flux(f_qv), div_flux(f_qn)
     evap_prec = torch.relu(_lin(P, "mlp_evap_prec_crm", r2)) + 1e-6
     cond = _lin(P, "mlp_evap_cond_vapor_crm", r2)
+    if clear_sky:
+        cond = torch.cat([cond.new_zeros(B, nlev - ilev_crm, 1), cond], 2)
     P_vert = torch.softmax(out[:, :, 2], 1) * P_old.unsqueeze(1)                              # (B,50)
     evap_prec = evap_prec * P_vert.unsqueeze(2)
     alpha = torch.relu(_lin(P, "mlp_mp_aa_crm", r2))
@@ -125,9 +137,15 @@ def microphysics_decode(P, out, mem_new, r2, last_h, inputs_denorm, delta_plev, 
     dqn_aa = torch.maximum(dqn_aa, flux_qn_dp + cond + sed_qn_dp - ys2 * (-qn_crm + 0.0006) / 1200)
     dqv_crm = flux_qv_dp - cond + evap_prec
     dqn_crm = flux_qn_dp + cond - dqn_aa + sed_qn_dp
-    temp = T_gcm.squeeze(2) + ((area_frac * flux_t_dp).sum(2) / ys[:, 0]) * 1200
-    liq = F.hardtanh((temp - 253.16) * 0.05, 0.0, 1.0).unsqueeze(2)
-    net_cond = ((liq * LV + (1 - liq) * LS) * cond - evap_prec * LV) * (1 / CP)
+    if clear_sky:
+        temp = T_gcm.squeeze(2) + (flux_t_dp.squeeze(2) / ys[:, 0]) * 1200
+        liq = F.hardtanh((temp - 253.16) * 0.05, 0.0, 1.0).unsqueeze(2)
+        cond_s, evap_s = (area_frac * cond).sum(2, keepdim=True), (area_frac * evap_prec).sum(2, keepdim=True)
+        net_cond = ((liq * LV + (1 - liq) * LS) * cond_s - evap_s * LV) * (1 / CP)
+    else:
+        temp = T_gcm.squeeze(2) + ((area_frac * flux_t_dp).sum(2) / ys[:, 0]) * 1200
+        liq = F.hardtanh((temp - 253.16) * 0.05, 0.0, 1.0).unsqueeze(2)
+        net_cond = ((liq * LV + (1 - liq) * LS) * cond - evap_prec * LV) * (1 / CP)
     dT_crm = flux_t_dp + net_cond / ys1 * ys0
     out_new[:, ilev_crm:, 0] = out_new[:, ilev_crm:, 0] + (area_frac * dT_crm).sum(2)
     out_new[:, ilev_crm:, 1] = (area_frac * dqv_crm).sum(2)

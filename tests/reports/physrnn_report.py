@@ -13,7 +13,8 @@ from climsim_amd.physrnn import physical_RNN_autoreg
 
 FIX = [("physrnn_hidden", "num14564_BEST", 2), ("physrnn_hidden_ep40", "num14564_ep40", 1), ("physrnn_hidden_b", "num49672_BEST", 1),
        ("physrnn_rad", "num4050_BEST", 2), ("physrnn_rad_nomcica", "num71535_BEST", 1), ("physrnn_rad_liqfrac", "num83000_ep20", 1),
-       ("physrnn_rad_stoch_a", "num5730_BEST", 1), ("physrnn_rad_stoch_b", "num62104_BEST", 1), ("physrnn_rad_stoch_c", "num62104_BEST_ep11", 1)]
+       ("physrnn_rad_stoch_a", "num5730_BEST", 1), ("physrnn_rad_stoch_b", "num62104_BEST", 1), ("physrnn_rad_stoch_c", "num62104_BEST_ep11", 1),
+       ("physrad16_a", "physRad-16_nreg16 num14751_BEST", 1)]
 print("fixture | artefact | case B | block: HIP-vs-artefact max|err| / max|ref| ; artefact-vs-float64 restatement (its own rounding) / max|ref|")
 for name, tag, ncase in FIX:
     g = np.load(os.path.join(ROOT, "tests", "golden", name + ".npz"))
@@ -24,8 +25,13 @@ for name, tag, ncase in FIX:
         B, seed = (int(v) for v in g[f"case{i}.cfg"])
         xm, xs, mem, xd = (inputs_rad if rad else inputs)(P, B, seed)
         hx2 = torch.from_numpy(g[f"case{i}.hx2"])
-        nz = {k: torch.from_numpy(g[f"case{i}.{k}"]) for k in ("hx1", "eps3") if f"case{i}.{k}" in g.files}
-        got = [t.cpu().double() for t in m([xm.cuda(), xs.cuda(), mem.cuda(), xd.cuda()], hx2=hx2.cuda(), **{k: v.cuda() for k, v in nz.items()})]
+        nz = {k: torch.from_numpy(g[f"case{i}.{k}"]) for k in ("hx1", "eps3", "srnn") if f"case{i}.{k}" in g.files}
+        hip_kw = {"_srnn": nz["srnn"].cuda()} if "srnn" in nz else {k: v.cuda() for k, v in nz.items()}   # physRad: teacher-forced rnn3
+        lm = getattr(m, "physrad", False)                       # that family takes / returns rnn_mem level-major
+        got = [t.cpu().double() for t in m([xm.cuda(), xs.cuda(), (mem.transpose(0, 1).contiguous() if lm else mem).cuda(), xd.cuda()],
+                                           hx2=hx2.cuda(), **hip_kw)]
+        if lm:
+            got[2] = got[2].transpose(0, 1)
         ref = [torch.from_numpy(g[f"case{i}.{k}"]).double() for k in ("out", "out_sfc", "mem_out")]
         P64 = {k: v.double() for k, v in P.items()}
         fwd = physrnn_rad_ref.forward if rad else physrnn_ref.forward

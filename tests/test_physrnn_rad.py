@@ -3,6 +3,9 @@
   physrnn_rad_nomcica  num71535_BEST         mp_ncol 16, g-point g = sub-column g
   physrnn_rad_liqfrac  num83000_ep20         + learned cloud liquid-fraction head
   physrnn_rad_stoch_*  num5730_BEST, num62104_BEST, num62104_BEST_ep11    num4050's graph + stochastic third RNN
+and the first geometry of the physRNN_physRad-* family (97 of the 114 shipped models):
+  physrad16_a          physRNN_physRad-16_nreg16_*neur128-128_xv4_mp1_num14751_BEST   16 regions, region 0 clear sky, no sub-grid
+                       temperature, liquid-fraction head, stochastic third RNN, q/(1-q) mixing ratio, rnn_mem level-major
 Oracle chain:
   shipped TorchScript artefact, run in the build container (torch.jit.load, CPU; its internal randn draws reproduced by
   re-seeding), outputs stored in tests/golden/<fixture>.npz
@@ -53,11 +56,42 @@ def _ref64(P, xm, xs, mem, xd, hx2, taps=None, **noise):
 
 
 FIXTURES = [("physrnn_rad", 2), ("physrnn_rad_nomcica", 1), ("physrnn_rad_liqfrac", 1), ("physrnn_rad_stoch_a", 1),
-            ("physrnn_rad_stoch_b", 1), ("physrnn_rad_stoch_c", 1)]
+            ("physrnn_rad_stoch_b", 1), ("physrnn_rad_stoch_c", 1), ("physrad16_a", 1)]
 
 
 def _noise(g, i):
-    return {k: torch.from_numpy(g[f"case{i}.{k}"]) for k in ("hx1", "eps3") if f"case{i}.{k}" in g.files}
+    """The artefact's N(0,1) draws; for the physRad fixture also its rnn3 output `srnn` (teacher forcing): that artefact's
+    stochastic layer is chaotic on these synthetic inputs -- a 1e-6 difference in its input grows to 0.1 over the 50 levels
+    (float32 vs float64 of the restatement itself) -- so the end-to-end outputs of two float32 implementations do not agree;
+    the layer is checked step by step (test_*_rnn3_steps) and everything after it with its output supplied."""
+    return {k: torch.from_numpy(g[f"case{i}.{k}"]) for k in ("hx1", "eps3", "srnn") if f"case{i}.{k}" in g.files}
+
+
+def _rnn3_step_inputs(P, r2, hx1, srnn, eps3):
+    """Every step of rnn3 as an independent batch row: input level t, previous state = the reference's output of level t-1."""
+    T, B, H = srnn.shape
+    x = r2.transpose(0, 1).reshape(1, T * B, H)
+    h0 = torch.cat([hx1.unsqueeze(0), srnn[:-1]], 0).reshape(T * B, H)
+    return x, h0, eps3.reshape(1, T * B, H)
+
+
+def test_restatement_rnn3_steps_reproduce_the_artefact():
+    g, P = _load("physrad16_a")
+    B, seed = (int(v) for v in g["case0.cfg"])
+    xm, xs, mem, xd = inputs_rad(P, B, seed)
+    nz, taps = _noise(g, 0), {}
+    physrnn_rad_ref.forward(P, xm, xs, mem, xd, torch.from_numpy(g["case0.hx2"]), taps=taps, **nz)
+    x, h0, eps = _rnn3_step_inputs(P, taps["rnn2out"], nz["hx1"], nz["srnn"], nz["eps3"])
+    got = physrnn_rad_ref.stochastic_gru(x, h0, eps, P["rnn3.weight_ih"], P["rnn3.weight_zh"], P["rnn3.weight_encoder"])
+    err = (got.reshape(nz["srnn"].shape) - nz["srnn"]).abs().max().item()
+    assert err <= 2e-5 * nz["srnn"].abs().max().item(), err
+    # and the reason for the teacher forcing: free-running, float32 and float64 of the same restatement part ways
+    free32 = physrnn_rad_ref.stochastic_gru(taps["rnn2out"].transpose(0, 1), nz["hx1"], nz["eps3"], P["rnn3.weight_ih"], P["rnn3.weight_zh"],
+                                            P["rnn3.weight_encoder"])
+    free64 = physrnn_rad_ref.stochastic_gru(*(t.double() for t in (taps["rnn2out"].transpose(0, 1), nz["hx1"], nz["eps3"], P["rnn3.weight_ih"],
+                                                                  P["rnn3.weight_zh"], P["rnn3.weight_encoder"])))
+    d = (free32.double() - free64).abs().amax((1, 2))
+    assert d[0] < 1e-4 and d[-1] > 100 * d[0]
 
 
 def _draw_noise(P, B, seed):
@@ -119,6 +153,16 @@ def _cuda(d):
     return {k: v.cuda() for k, v in d.items()}
 
 
+def _run(m, xm, xs, mem, xd, **kw):
+    """Fixtures and the restatement keep rnn_mem as (B, 50, 16); the physRad graphs take and return it level-major."""
+    lm = getattr(m, "physrad", False)
+    mem_in = mem.transpose(0, 1).contiguous() if lm else mem
+    if "srnn" in kw:
+        kw = {"hx2": kw["hx2"], "_srnn": kw["srnn"]}
+    out, out_sfc, mem_out = m([xm.cuda(), xs.cuda(), mem_in.cuda(), xd.cuda()], **_cuda(kw))
+    return out.cpu(), out_sfc.cpu(), (mem_out.transpose(0, 1) if lm else mem_out).cpu()
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("fixture,ncase", FIXTURES)
 def test_hip_radiation_graph_matches_the_artefact(fixture, ncase):
@@ -128,7 +172,7 @@ def test_hip_radiation_graph_matches_the_artefact(fixture, ncase):
         B, seed = (int(v) for v in g[f"case{i}.cfg"])
         xm, xs, mem, xd = inputs_rad(P, B, seed)
         hx2, nz = torch.from_numpy(g[f"case{i}.hx2"]), _noise(g, i)
-        got = _blocks(*(t.cpu() for t in m([xm.cuda(), xs.cuda(), mem.cuda(), xd.cuda()], hx2=hx2.cuda(), **_cuda(nz))))
+        got = _blocks(*_run(m, xm, xs, mem, xd, hx2=hx2, **nz))
         ref = _blocks(*(torch.from_numpy(g[f"case{i}.{k}"]) for k in ("out", "out_sfc", "mem_out")))
         r64 = _ref64(P, xm, xs, mem, xd, hx2, **nz)
         for k in BLOCKS:
@@ -143,7 +187,8 @@ def test_hip_radiation_graph_matches_the_artefact(fixture, ncase):
 @pytest.mark.gpu
 @pytest.mark.parametrize("fixture,B", [("physrnn_rad", 1), ("physrnn_rad", 2), ("physrnn_rad", 301), ("physrnn_rad", 384),
                                        ("physrnn_rad_nomcica", 301), ("physrnn_rad_liqfrac", 384), ("physrnn_rad_stoch_a", 2),
-                                       ("physrnn_rad_stoch_b", 301), ("physrnn_rad_stoch_c", 384)])
+                                       ("physrnn_rad_stoch_b", 301), ("physrnn_rad_stoch_c", 384), ("physrad16_a", 2),
+                                       ("physrad16_a", 301), ("physrad16_a", 384)])
 def test_hip_radiation_graph_matches_restatement(fixture, B):
     g, P = _load(fixture)
     m = _hip_model(P, 384)
@@ -152,9 +197,12 @@ def test_hip_radiation_graph_matches_restatement(fixture, B):
     nz = _draw_noise(P, B, 900 + B)
     taps = {}
     r64 = _ref64(P, xm, xs, mem, xd, hx2, taps, **nz)
+    if fixture.startswith("physrad"):            # chaotic rnn3 (see _noise): everything after it with the float64 restatement's output
+        nz = {"srnn": taps["srnn"].float()}
+        r64 = _ref64(P, xm, xs, mem, xd, hx2, taps, **nz)
     taps32 = {}
     r32 = _blocks(*physrnn_rad_ref.forward(P, xm, xs, mem, xd, hx2, taps=taps32, **nz))
-    got = _blocks(*(t.cpu() for t in m([xm.cuda(), xs.cuda(), mem.cuda(), xd.cuda()], hx2=hx2.cuda(), **_cuda(nz))))
+    got = _blocks(*_run(m, xm, xs, mem, xd, hx2=hx2, **nz))
     # recurrent core first: rnn2 output over the 50 CRM levels against the float64 restatement (|h| <= 1; 50 + 50 dependent steps)
     t2 = m.tap(2, B).cpu().permute(1, 0, 2).double()
     noise = (taps32["rnn2out"].double() - taps["rnn2out"]).abs().max().item()
@@ -192,6 +240,23 @@ def test_hip_radiation_graph_errors_and_rollout_state():
     from climsim_amd.physrnn import physical_RNN_autoreg
     with pytest.raises(RuntimeError):
         physical_RNN_autoreg(bad, max_batch=8)
+
+
+@pytest.mark.gpu
+def test_hip_rnn3_steps_reproduce_the_artefact():
+    g, P = _load("physrad16_a")
+    m = _hip_model(P, 16)
+    B, seed = (int(v) for v in g["case0.cfg"])
+    xm, xs, mem, xd = inputs_rad(P, B, seed)
+    nz, taps = _noise(g, 0), {}
+    physrnn_rad_ref.forward(P, xm, xs, mem, xd, torch.from_numpy(g["case0.hx2"]), taps=taps, **nz)
+    x, h0, eps = _rnn3_step_inputs(P, taps["rnn2out"], nz["hx1"], nz["srnn"], nz["eps3"])
+    got = m.debug_rnn3(x.cuda(), h0.cuda(), eps.cuda()).cpu().reshape(nz["srnn"].shape)
+    err = (got - nz["srnn"]).abs().max().item()
+    assert err <= 2e-5 * nz["srnn"].abs().max().item(), err
+    # free-running, the first levels still agree with the artefact (before the divergence has grown)
+    free = m.debug_rnn3(taps["rnn2out"].transpose(0, 1).contiguous().cuda(), nz["hx1"].cuda(), nz["eps3"].cuda()).cpu()
+    assert (free[:5] - nz["srnn"][:5]).abs().max().item() <= 1e-4
 
 
 @pytest.mark.gpu
