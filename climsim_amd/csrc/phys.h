@@ -46,7 +46,7 @@ struct csa_phys {
     std::vector<void *> owned;
 };
 
-#define PH_XG_K 20          // 18 gas-optics inputs, zero-padded
+#define PH_XG_K 24          // 18 gas-optics inputs, zero-padded to a multiple of 8 (two k-quads per MFMA group)
 #define PH_XR_K 24
 
 // phys_rad.hip

@@ -51,6 +51,135 @@ __global__ __launch_bounds__(256) void rad_gas_post_kernel(float *__restrict__ A
     *(f32x4 *)(A3 + row * 256 + c) = v;
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Fused optics: the three MLPs of the scheme for a tile of 32 (level, column) rows per wave, activations never leaving the
+// CU.  Per wave: XG (32 x 24) -> Linear 64 + Softsign -> Linear 64 + Softsign -> Linear 256 in eight 32-column tiles, each tile
+// turned into k-point optical depths N_dry (s x + m)^8 / Planck-fraction logits x^2 in the accumulator registers, passed through
+// LDS and contracted at once with its 32-row slice of the two k-distribution reductions (128 -> 16 each, one 32 x 32
+// accumulator holding both: columns 0-15 optical depth, 16-31 Planck fraction); then XR (32 x 24) -> Linear 32 + Softsign ->
+// Linear 48.  All products on v_mfma_f32_32x32x2_f32 (exact fp32): A operand = activations from LDS (lane = row), B operand =
+// weights straight from global memory / L2 as float4 -- lanes 0-31 take k..k+3 and lanes 32-63 k+4..k+7 of weight row n, so
+// MFMA e of a group contracts the pair (k+e, k+4+e) on both operands.  516 MFMAs per tile; 2 waves (2 tiles) per workgroup.
+// Replaces seven GEMM launches + one elementwise kernel (99 us at 384 columns) -- profiles/r2_physrnn_rad_384_*.
+#define RO_LD 65
+#define RO_LX 25
+struct RadOptics {
+    const float *XG, *XR, *RS;
+    const float *w1, *b1, *w2, *b2, *w3, *b3, *r1w, *r1b, *r2w, *r2b, *s1w, *s1b, *s2w, *s2b, *ystd, *ymean;
+    float *TP, *S2;
+    int M;
+};
+
+template <int K>
+__device__ __forceinline__ f32x16 ro_mma(f32x16 acc, const float *act_row /* LDS: this lane's row + 4*half */,
+                                         const float *__restrict__ w_row /* global: this lane's weight row + 4*half, or null */)
+{
+#pragma unroll
+    for (int g = 0; g < K / 8; ++g) {
+        const f32x4 w = w_row ? *(const f32x4 *)(w_row + 8 * g) : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(act_row[8 * g + e], w[e], acc, 0, 0, 0);
+    }
+    return acc;
+}
+__device__ __forceinline__ f32x16 ro_zero()
+{
+    f32x16 z;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) z[i] = 0.0f;
+    return z;
+}
+__device__ __forceinline__ float ro_softsign(float v) { return v / (1.0f + fabsf(v)); }
+
+__global__ __launch_bounds__(128) void rad_optics_kernel(RadOptics a)
+{
+    __shared__ float sA[2][32 * RO_LD], sB[2][32 * RO_LD], sX[2][32 * RO_LX];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, n = lane & 31, half = lane >> 5;
+    const int row0 = ((int)blockIdx.x * 2 + wave) * 32, M = a.M;
+    float *bA = sA[wave], *bB = sB[wave], *bX = sX[wave];
+    // accumulator register i of this lane belongs to tile row (i & 3) + 8 (i >> 2) + 4 half, tile column n
+    auto drow = [&](int i) { return (i & 3) + 8 * (i >> 2) + 4 * half; };
+
+    for (int i = lane; i < 32 * PH_XG_K; i += 64) {
+        const int rr = i / PH_XG_K, k = i - rr * PH_XG_K;
+        bX[rr * RO_LX + k] = a.XG[(size_t)min(row0 + rr, M - 1) * PH_XG_K + k];
+    }
+    float cd[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) cd[i] = a.RS[(size_t)min(row0 + drow(i), M - 1) * 2];
+    __syncthreads();
+    // gas optics, layer 1: 24 -> 64
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const f32x16 acc = ro_mma<PH_XG_K>(ro_zero(), bX + n * RO_LX + 4 * half, a.w1 + (size_t)(t * 32 + n) * PH_XG_K + 4 * half);
+        const float b = a.b1[t * 32 + n];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) bA[drow(i) * RO_LD + t * 32 + n] = ro_softsign(acc[i] + b);
+    }
+    __syncthreads();
+    // layer 2: 64 -> 64
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const f32x16 acc = ro_mma<64>(ro_zero(), bA + n * RO_LD + 4 * half, a.w2 + (size_t)(t * 32 + n) * 64 + 4 * half);
+        const float b = a.b2[t * 32 + n];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) bB[drow(i) * RO_LD + t * 32 + n] = ro_softsign(acc[i] + b);
+    }
+    __syncthreads();
+    // SW head inputs (bX is free now)
+    for (int i = lane; i < 32 * PH_XR_K; i += 64) {
+        const int rr = i / PH_XR_K, k = i - rr * PH_XR_K;
+        bX[rr * RO_LX + k] = a.XR[(size_t)min(row0 + rr, M - 1) * PH_XR_K + k];
+    }
+    // layer 3 (64 -> 256) tile by tile, each tile reduced 32 -> (16 | 16) at once
+    f32x16 tp = ro_zero();
+    for (int t = 0; t < 8; ++t) {
+        const f32x16 acc = ro_mma<64>(ro_zero(), bB + n * RO_LD + 4 * half, a.w3 + (size_t)(t * 32 + n) * 64 + 4 * half);
+        const int col = t * 32 + n;
+        const float b = a.b3[col];
+        if (t < 4) {
+            const float sd = a.ystd[col], mn = a.ymean[col];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) bA[drow(i) * RO_LD + n] = cd[i] * pr_pow8(sd * (acc[i] + b) + mn);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { const float v = acc[i] + b; bA[drow(i) * RO_LD + n] = v * v; }
+        }
+        __syncthreads();
+        const float *wr = t < 4 ? (n < 16 ? a.r1w + (size_t)n * 128 + t * 32 + 4 * half : nullptr)
+                                : (n >= 16 ? a.r2w + (size_t)(n - 16) * 128 + (t - 4) * 32 + 4 * half : nullptr);
+        tp = ro_mma<32>(tp, bA + n * RO_LD + 4 * half, wr);
+        __syncthreads();
+    }
+    {
+        const float b = n < 16 ? a.r1b[n] : a.r2b[n - 16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int row = row0 + drow(i);
+            if (row < M) a.TP[(size_t)row * 32 + n] = tp[i] + b;
+        }
+    }
+    // SW optical-property head: 24 -> 32 (Softsign) -> 48
+    {
+        const f32x16 acc = ro_mma<PH_XR_K>(ro_zero(), bX + n * RO_LX + 4 * half, a.s1w + (size_t)n * PH_XR_K + 4 * half);
+        const float b = a.s1b[n];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) bA[drow(i) * RO_LD + n] = ro_softsign(acc[i] + b);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const bool ok = t * 32 + n < 48;
+        const f32x16 acc = ro_mma<32>(ro_zero(), bA + n * RO_LD + 4 * half, ok ? a.s2w + (size_t)(t * 32 + n) * 32 + 4 * half : nullptr);
+        const float b = ok ? a.s2b[t * 32 + n] : 0.0f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int row = row0 + drow(i);
+            if (ok && row < M) a.S2[(size_t)row * 48 + t * 32 + n] = acc[i] + b;
+        }
+    }
+}
+
 #define RS_T 256
 __global__ __launch_bounds__(RS_T) void phys_rad_solve_kernel(PhysDev d, int B, const float *__restrict__ x_sfc, const float *__restrict__ TP,
                                                             const float *__restrict__ CL, const float *__restrict__ S2,
@@ -214,6 +343,16 @@ int launch_phys_radiation(csa_phys *h, int B, const float *x_sfc, float *out_lev
     const PhysDev &d = h->d;
     const int M = PH_L * B;
     int rc;
+    static const bool unfused = getenv("CSA_RAD_OPTICS") && !strcmp(getenv("CSA_RAD_OPTICS"), "gemm");   // measurement only: the first version
+    if (!unfused) {
+        RadOptics a{h->XG, h->XR, h->RS, h->g_w1, h->g_b1, h->g_w2, h->g_b2, h->g_w3, h->g_b3, h->r1_w, h->r1_b, h->r2_w, h->r2_b,
+                    h->s1_w, h->s1_b, h->s2_w, h->s2_b, d.g_ystd, d.g_ymean, h->TP, h->S2, M};
+        hipLaunchKernelGGL(rad_optics_kernel, dim3((M + 63) / 64), dim3(128), 0, s, a);
+        CSA_HIP_CHECK(hipGetLastError());
+        hipLaunchKernelGGL(phys_rad_solve_kernel, dim3(B), dim3(RS_T), 0, s, d, B, x_sfc, h->TP, h->CL, h->S2, h->RS, out_lev, out_sfc);
+        CSA_HIP_CHECK(hipGetLastError());
+        return CSA_OK;
+    }
     if ((rc = launch_gemm_act(h->XG, h->g_w1, h->g_b1, h->A1, M, 64, PH_XG_K, 4, 0.0f, 0, s))) return rc;
     if ((rc = launch_gemm_act(h->A1, h->g_w2, h->g_b2, h->A2, M, 64, 64, 4, 0.0f, 0, s))) return rc;
     if ((rc = launch_gemm_act(h->A2, h->g_w3, h->g_b3, h->A3, M, 256, 64, 0, 0.0f, 0, s))) return rc;
