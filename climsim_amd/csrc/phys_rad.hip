@@ -61,8 +61,8 @@ __global__ __launch_bounds__(256) void rad_gas_post_kernel(float *__restrict__ A
 // weights straight from global memory / L2 as float4 -- lanes 0-31 take k..k+3 and lanes 32-63 k+4..k+7 of weight row n, so
 // MFMA e of a group contracts the pair (k+e, k+4+e) on both operands.  516 MFMAs per tile; 2 waves (2 tiles) per workgroup.
 // Replaces seven GEMM launches + one elementwise kernel (99 us at 384 columns) -- profiles/r2_physrnn_rad_384_*.
-#define RO_LD 65
-#define RO_LX 25
+#define RO_LD 68            // multiples of 4 floats: the A operand is read as one ds_read_b128 per MFMA group
+#define RO_LX 28
 struct RadOptics {
     const float *XG, *XR, *RS;
     const float *w1, *b1, *w2, *b2, *w3, *b3, *r1w, *r1b, *r2w, *r2b, *s1w, *s1b, *s2w, *s2b, *ystd, *ymean;
@@ -70,15 +70,22 @@ struct RadOptics {
     int M;
 };
 
-template <int K>
-__device__ __forceinline__ f32x16 ro_mma(f32x16 acc, const float *act_row /* LDS: this lane's row + 4*half */,
-                                         const float *__restrict__ w_row /* global: this lane's weight row + 4*half, or null */)
+// weights of one 32-column tile, K deep: G = K / 8 float4 per lane (lane's weight row, k-quad 4 * half of every group of 8)
+template <int G> struct RoW { f32x4 v[G]; };
+template <int G> __device__ __forceinline__ RoW<G> ro_load(const float *__restrict__ w_row /* or null: zeros */)
+{
+    RoW<G> w;
+#pragma unroll
+    for (int g = 0; g < G; ++g) w.v[g] = w_row ? *(const f32x4 *)(w_row + 8 * g) : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    return w;
+}
+template <int G> __device__ __forceinline__ f32x16 ro_mma(f32x16 acc, const float *act_row /* LDS: lane's row + 4 * half */, const RoW<G> &w)
 {
 #pragma unroll
-    for (int g = 0; g < K / 8; ++g) {
-        const f32x4 w = w_row ? *(const f32x4 *)(w_row + 8 * g) : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    for (int g = 0; g < G; ++g) {
+        const f32x4 x = *(const f32x4 *)(act_row + 8 * g);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(act_row[8 * g + e], w[e], acc, 0, 0, 0);
+        for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(x[e], w.v[g][e], acc, 0, 0, 0);
     }
     return acc;
 }
@@ -91,15 +98,20 @@ __device__ __forceinline__ f32x16 ro_zero()
 }
 __device__ __forceinline__ float ro_softsign(float v) { return v / (1.0f + fabsf(v)); }
 
+// Every tile's weights are requested one tile ahead of their use (they come from L2: ~1 us per dependent round trip, 23 tiles).
 __global__ __launch_bounds__(128) void rad_optics_kernel(RadOptics a)
 {
-    __shared__ float sA[2][32 * RO_LD], sB[2][32 * RO_LD], sX[2][32 * RO_LX];
+    __shared__ __attribute__((aligned(16))) float sA[2][32 * RO_LD];
+    __shared__ __attribute__((aligned(16))) float sB[2][32 * RO_LD];
+    __shared__ __attribute__((aligned(16))) float sX[2][32 * RO_LX];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, n = lane & 31, half = lane >> 5;
     const int row0 = ((int)blockIdx.x * 2 + wave) * 32, M = a.M;
     float *bA = sA[wave], *bB = sB[wave], *bX = sX[wave];
     // accumulator register i of this lane belongs to tile row (i & 3) + 8 (i >> 2) + 4 half, tile column n
     auto drow = [&](int i) { return (i & 3) + 8 * (i >> 2) + 4 * half; };
+    constexpr int G1 = PH_XG_K / 8, GS = PH_XR_K / 8;
 
+    RoW<G1> w1a = ro_load<G1>(a.w1 + (size_t)n * PH_XG_K + 4 * half), w1b = ro_load<G1>(a.w1 + (size_t)(32 + n) * PH_XG_K + 4 * half);
     for (int i = lane; i < 32 * PH_XG_K; i += 64) {
         const int rr = i / PH_XG_K, k = i - rr * PH_XG_K;
         bX[rr * RO_LX + k] = a.XG[(size_t)min(row0 + rr, M - 1) * PH_XG_K + k];
@@ -107,38 +119,51 @@ __global__ __launch_bounds__(128) void rad_optics_kernel(RadOptics a)
     float cd[16];
 #pragma unroll
     for (int i = 0; i < 16; ++i) cd[i] = a.RS[(size_t)min(row0 + drow(i), M - 1) * 2];
+    RoW<8> wn = ro_load<8>(a.w2 + (size_t)n * 64 + 4 * half);                       // layer 2, tile 0
     __syncthreads();
     // gas optics, layer 1: 24 -> 64
+    {
+        f32x16 acc = ro_mma<G1>(ro_zero(), bX + n * RO_LX + 4 * half, w1a);
+        float b = a.b1[n];
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
-        const f32x16 acc = ro_mma<PH_XG_K>(ro_zero(), bX + n * RO_LX + 4 * half, a.w1 + (size_t)(t * 32 + n) * PH_XG_K + 4 * half);
-        const float b = a.b1[t * 32 + n];
+        for (int i = 0; i < 16; ++i) bA[drow(i) * RO_LD + n] = ro_softsign(acc[i] + b);
+        acc = ro_mma<G1>(ro_zero(), bX + n * RO_LX + 4 * half, w1b);
+        b = a.b1[32 + n];
 #pragma unroll
-        for (int i = 0; i < 16; ++i) bA[drow(i) * RO_LD + t * 32 + n] = ro_softsign(acc[i] + b);
+        for (int i = 0; i < 16; ++i) bA[drow(i) * RO_LD + 32 + n] = ro_softsign(acc[i] + b);
     }
-    __syncthreads();
-    // layer 2: 64 -> 64
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-        const f32x16 acc = ro_mma<64>(ro_zero(), bA + n * RO_LD + 4 * half, a.w2 + (size_t)(t * 32 + n) * 64 + 4 * half);
-        const float b = a.b2[t * 32 + n];
-#pragma unroll
-        for (int i = 0; i < 16; ++i) bB[drow(i) * RO_LD + t * 32 + n] = ro_softsign(acc[i] + b);
-    }
+    RoW<8> wm = ro_load<8>(a.w2 + (size_t)(32 + n) * 64 + 4 * half);                // layer 2, tile 1
     __syncthreads();
     // SW head inputs (bX is free now)
     for (int i = lane; i < 32 * PH_XR_K; i += 64) {
         const int rr = i / PH_XR_K, k = i - rr * PH_XR_K;
         bX[rr * RO_LX + k] = a.XR[(size_t)min(row0 + rr, M - 1) * PH_XR_K + k];
     }
+    // layer 2: 64 -> 64
+    {
+        f32x16 acc = ro_mma<8>(ro_zero(), bA + n * RO_LD + 4 * half, wn);
+        wn = ro_load<8>(a.w3 + (size_t)n * 64 + 4 * half);                          // layer 3, tile 0
+        float b = a.b2[n];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) bB[drow(i) * RO_LD + n] = ro_softsign(acc[i] + b);
+        acc = ro_mma<8>(ro_zero(), bA + n * RO_LD + 4 * half, wm);
+        b = a.b2[32 + n];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) bB[drow(i) * RO_LD + 32 + n] = ro_softsign(acc[i] + b);
+    }
+    __syncthreads();
     // layer 3 (64 -> 256) tile by tile, each tile reduced 32 -> (16 | 16) at once
     f32x16 tp = ro_zero();
+#pragma unroll
     for (int t = 0; t < 8; ++t) {
-        const f32x16 acc = ro_mma<64>(ro_zero(), bB + n * RO_LD + 4 * half, a.w3 + (size_t)(t * 32 + n) * 64 + 4 * half);
+        const RoW<8> wc = wn;
+        if (t < 7) wn = ro_load<8>(a.w3 + (size_t)((t + 1) * 32 + n) * 64 + 4 * half);
+        const RoW<4> wr = ro_load<4>(t < 4 ? (n < 16 ? a.r1w + (size_t)n * 128 + t * 32 + 4 * half : nullptr)
+                                           : (n >= 16 ? a.r2w + (size_t)(n - 16) * 128 + (t - 4) * 32 + 4 * half : nullptr));
         const int col = t * 32 + n;
-        const float b = a.b3[col];
+        const float b = a.b3[col], sd = a.ystd[col & 127], mn = a.ymean[col & 127];
+        const f32x16 acc = ro_mma<8>(ro_zero(), bB + n * RO_LD + 4 * half, wc);
         if (t < 4) {
-            const float sd = a.ystd[col], mn = a.ymean[col];
 #pragma unroll
             for (int i = 0; i < 16; ++i) bA[drow(i) * RO_LD + n] = cd[i] * pr_pow8(sd * (acc[i] + b) + mn);
         } else {
@@ -146,11 +171,11 @@ __global__ __launch_bounds__(128) void rad_optics_kernel(RadOptics a)
             for (int i = 0; i < 16; ++i) { const float v = acc[i] + b; bA[drow(i) * RO_LD + n] = v * v; }
         }
         __syncthreads();
-        const float *wr = t < 4 ? (n < 16 ? a.r1w + (size_t)n * 128 + t * 32 + 4 * half : nullptr)
-                                : (n >= 16 ? a.r2w + (size_t)(n - 16) * 128 + (t - 4) * 32 + 4 * half : nullptr);
-        tp = ro_mma<32>(tp, bA + n * RO_LD + 4 * half, wr);
+        tp = ro_mma<4>(tp, bA + n * RO_LD + 4 * half, wr);
         __syncthreads();
     }
+    const RoW<GS> ws1 = ro_load<GS>(a.s1w + (size_t)n * PH_XR_K + 4 * half);
+    const RoW<4> ws2a = ro_load<4>(a.s2w + (size_t)n * 32 + 4 * half), ws2b = ro_load<4>(n < 16 ? a.s2w + (size_t)(32 + n) * 32 + 4 * half : nullptr);
     {
         const float b = n < 16 ? a.r1b[n] : a.r2b[n - 16];
 #pragma unroll
@@ -161,21 +186,26 @@ __global__ __launch_bounds__(128) void rad_optics_kernel(RadOptics a)
     }
     // SW optical-property head: 24 -> 32 (Softsign) -> 48
     {
-        const f32x16 acc = ro_mma<PH_XR_K>(ro_zero(), bX + n * RO_LX + 4 * half, a.s1w + (size_t)n * PH_XR_K + 4 * half);
+        const f32x16 acc = ro_mma<GS>(ro_zero(), bX + n * RO_LX + 4 * half, ws1);
         const float b = a.s1b[n];
 #pragma unroll
         for (int i = 0; i < 16; ++i) bA[drow(i) * RO_LD + n] = ro_softsign(acc[i] + b);
     }
     __syncthreads();
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-        const bool ok = t * 32 + n < 48;
-        const f32x16 acc = ro_mma<32>(ro_zero(), bA + n * RO_LD + 4 * half, ok ? a.s2w + (size_t)(t * 32 + n) * 32 + 4 * half : nullptr);
-        const float b = ok ? a.s2b[t * 32 + n] : 0.0f;
+    {
+        f32x16 acc = ro_mma<4>(ro_zero(), bA + n * RO_LD + 4 * half, ws2a);
+        float b = a.s2b[n];
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             const int row = row0 + drow(i);
-            if (ok && row < M) a.S2[(size_t)row * 48 + t * 32 + n] = acc[i] + b;
+            if (row < M) a.S2[(size_t)row * 48 + n] = acc[i] + b;
+        }
+        acc = ro_mma<4>(ro_zero(), bA + n * RO_LD + 4 * half, ws2b);
+        b = n < 16 ? a.s2b[32 + n] : 0.0f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int row = row0 + drow(i);
+            if (n < 16 && row < M) a.S2[(size_t)row * 48 + 32 + n] = acc[i] + b;
         }
     }
 }
