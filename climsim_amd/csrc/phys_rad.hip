@@ -59,7 +59,7 @@ __global__ __launch_bounds__(256) void rad_gas_post_kernel(float *__restrict__ A
 // accumulator holding both: columns 0-15 optical depth, 16-31 Planck fraction); then XR (32 x 24) -> Linear 32 + Softsign ->
 // Linear 48.  All products on v_mfma_f32_32x32x2_f32 (exact fp32): A operand = activations from LDS (lane = row), B operand =
 // weights straight from global memory / L2 as float4 -- lanes 0-31 take k..k+3 and lanes 32-63 k+4..k+7 of weight row n, so
-// MFMA e of a group contracts the pair (k+e, k+4+e) on both operands.  516 MFMAs per tile; 2 waves (2 tiles) per workgroup.
+// MFMA e of a group contracts the pair (k+e, k+4+e) on both operands.  516 MFMAs per tile; one wave (one tile) per workgroup.
 // Replaces seven GEMM launches + one elementwise kernel (99 us at 384 columns) -- profiles/r2_physrnn_rad_384_*.
 #define RO_LD 68            // multiples of 4 floats: the A operand is read as one ds_read_b128 per MFMA group
 #define RO_LX 28
@@ -72,11 +72,14 @@ struct RadOptics {
 
 // weights of one 32-column tile, K deep: G = K / 8 float4 per lane (lane's weight row, k-quad 4 * half of every group of 8)
 template <int G> struct RoW { f32x4 v[G]; };
-template <int G> __device__ __forceinline__ RoW<G> ro_load(const float *__restrict__ w_row /* or null: zeros */)
+template <int G> __device__ __forceinline__ RoW<G> ro_load(const float *__restrict__ w_row, bool live = true /* false: zeros (w_row still readable) */)
 {
     RoW<G> w;
 #pragma unroll
-    for (int g = 0; g < G; ++g) w.v[g] = w_row ? *(const f32x4 *)(w_row + 8 * g) : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    for (int g = 0; g < G; ++g) {
+        const f32x4 v = *(const f32x4 *)(w_row + 8 * g);        // unconditional load + select: no divergent branch around the load
+        w.v[g] = live ? v : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    }
     return w;
 }
 template <int G> __device__ __forceinline__ f32x16 ro_mma(f32x16 acc, const float *act_row /* LDS: lane's row + 4 * half */, const RoW<G> &w)
@@ -98,15 +101,21 @@ __device__ __forceinline__ f32x16 ro_zero()
 }
 __device__ __forceinline__ float ro_softsign(float v) { return v / (1.0f + fabsf(v)); }
 
-// Every tile's weights are requested one tile ahead of their use (they come from L2: ~1 us per dependent round trip, 23 tiles).
-__global__ __launch_bounds__(128) void rad_optics_kernel(RadOptics a)
+// One wave per workgroup and all LDS traffic wave-private: LDS executes one wave's instructions in order, so a write followed by
+// a read of other lanes' data needs no s_barrier, only a compiler fence (ro_fence).  Every tile's weights are requested one or two
+// tiles ahead of their use (L2 round trips), and in the 256-wide layer the VALU epilogue of tile t ((s x + m)^8 N_dry, LDS
+// transpose) is issued between the MFMAs of tile t + 1 -- an in-order wave would otherwise idle the matrix pipe for a third of
+// the time.
+__device__ __forceinline__ void ro_fence() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); }
+
+__global__ __launch_bounds__(64) void rad_optics_kernel(RadOptics a)
 {
-    __shared__ __attribute__((aligned(16))) float sA[2][32 * RO_LD];
-    __shared__ __attribute__((aligned(16))) float sB[2][32 * RO_LD];
-    __shared__ __attribute__((aligned(16))) float sX[2][32 * RO_LX];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, n = lane & 31, half = lane >> 5;
-    const int row0 = ((int)blockIdx.x * 2 + wave) * 32, M = a.M;
-    float *bA = sA[wave], *bB = sB[wave], *bX = sX[wave];
+    __shared__ __attribute__((aligned(16))) float bA[32 * RO_LD];      // H1, then Y of even tiles, then S1
+    __shared__ __attribute__((aligned(16))) float bB[32 * RO_LD];      // H2
+    __shared__ __attribute__((aligned(16))) float bC[32 * RO_LD];      // Y of odd tiles
+    __shared__ __attribute__((aligned(16))) float bX[32 * RO_LX];      // XG, then XR
+    const int lane = threadIdx.x, n = lane & 31, half = lane >> 5;
+    const int row0 = (int)blockIdx.x * 32, M = a.M;
     // accumulator register i of this lane belongs to tile row (i & 3) + 8 (i >> 2) + 4 half, tile column n
     auto drow = [&](int i) { return (i & 3) + 8 * (i >> 2) + 4 * half; };
     constexpr int G1 = PH_XG_K / 8, GS = PH_XR_K / 8;
@@ -120,7 +129,8 @@ __global__ __launch_bounds__(128) void rad_optics_kernel(RadOptics a)
 #pragma unroll
     for (int i = 0; i < 16; ++i) cd[i] = a.RS[(size_t)min(row0 + drow(i), M - 1) * 2];
     RoW<8> wn = ro_load<8>(a.w2 + (size_t)n * 64 + 4 * half);                       // layer 2, tile 0
-    __syncthreads();
+    RoW<8> wm = ro_load<8>(a.w2 + (size_t)(32 + n) * 64 + 4 * half);                // layer 2, tile 1
+    ro_fence();
     // gas optics, layer 1: 24 -> 64
     {
         f32x16 acc = ro_mma<G1>(ro_zero(), bX + n * RO_LX + 4 * half, w1a);
@@ -132,8 +142,7 @@ __global__ __launch_bounds__(128) void rad_optics_kernel(RadOptics a)
 #pragma unroll
         for (int i = 0; i < 16; ++i) bA[drow(i) * RO_LD + 32 + n] = ro_softsign(acc[i] + b);
     }
-    RoW<8> wm = ro_load<8>(a.w2 + (size_t)(32 + n) * 64 + 4 * half);                // layer 2, tile 1
-    __syncthreads();
+    ro_fence();
     // SW head inputs (bX is free now)
     for (int i = lane; i < 32 * PH_XR_K; i += 64) {
         const int rr = i / PH_XR_K, k = i - rr * PH_XR_K;
@@ -147,35 +156,51 @@ __global__ __launch_bounds__(128) void rad_optics_kernel(RadOptics a)
 #pragma unroll
         for (int i = 0; i < 16; ++i) bB[drow(i) * RO_LD + n] = ro_softsign(acc[i] + b);
         acc = ro_mma<8>(ro_zero(), bA + n * RO_LD + 4 * half, wm);
+        wm = ro_load<8>(a.w3 + (size_t)(32 + n) * 64 + 4 * half);                   // layer 3, tile 1
         b = a.b2[32 + n];
 #pragma unroll
         for (int i = 0; i < 16; ++i) bB[drow(i) * RO_LD + 32 + n] = ro_softsign(acc[i] + b);
     }
-    __syncthreads();
+    ro_fence();
     // layer 3 (64 -> 256) tile by tile, each tile reduced 32 -> (16 | 16) at once
+    const float *hrow = bB + n * RO_LD + 4 * half;
     f32x16 tp = ro_zero();
+    f32x16 accC = ro_mma<8>(ro_zero(), hrow, wn);                                   // tile 0
 #pragma unroll
     for (int t = 0; t < 8; ++t) {
-        const RoW<8> wc = wn;
-        if (t < 7) wn = ro_load<8>(a.w3 + (size_t)((t + 1) * 32 + n) * 64 + 4 * half);
-        const RoW<4> wr = ro_load<4>(t < 4 ? (n < 16 ? a.r1w + (size_t)n * 128 + t * 32 + 4 * half : nullptr)
-                                           : (n >= 16 ? a.r2w + (size_t)(n - 16) * 128 + (t - 4) * 32 + 4 * half : nullptr));
+        // weights in flight: wm = tile t + 1 (arrived or arriving), wn <- tile t + 2; reduction slice of tile t
+        if (t + 2 < 8) wn = ro_load<8>(a.w3 + (size_t)((t + 2) * 32 + n) * 64 + 4 * half);
+        const RoW<4> wr = ro_load<4>((t < 4 ? a.r1w : a.r2w) + (size_t)(n & 15) * 128 + (t & 3) * 32 + 4 * half, t < 4 ? n < 16 : n >= 16);
         const int col = t * 32 + n;
         const float b = a.b3[col], sd = a.ystd[col & 127], mn = a.ymean[col & 127];
-        const f32x16 acc = ro_mma<8>(ro_zero(), bB + n * RO_LD + 4 * half, wc);
-        if (t < 4) {
+        float *Y = (t & 1) ? bC : bA;
+        auto piece = [&](int i) {                    // accumulator register i of tile t -> k-point optical depth / squared logit -> LDS
+            const float v = accC[i] + b;
+            Y[drow(i) * RO_LD + n] = t < 4 ? cd[i] * pr_pow8(sd * v + mn) : v * v;
+        };
+        f32x16 accN = ro_zero();
+        if (t < 7) {
 #pragma unroll
-            for (int i = 0; i < 16; ++i) bA[drow(i) * RO_LD + n] = cd[i] * pr_pow8(sd * (acc[i] + b) + mn);
+            for (int g = 0; g < 8; ++g) {
+                const f32x4 x = *(const f32x4 *)(hrow + 8 * g);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    accN = __builtin_amdgcn_mfma_f32_32x32x2f32(x[e], wm.v[g][e], accN, 0, 0, 0);
+                    if ((e & 1) == 0) piece(2 * g + (e >> 1));
+                    __builtin_amdgcn_sched_barrier(0x3F4);   // memory and scalar instructions may move; MFMA and VALU keep this order
+                }
+            }
         } else {
 #pragma unroll
-            for (int i = 0; i < 16; ++i) { const float v = acc[i] + b; bA[drow(i) * RO_LD + n] = v * v; }
+            for (int i = 0; i < 16; ++i) piece(i);
         }
-        __syncthreads();
-        tp = ro_mma<4>(tp, bA + n * RO_LD + 4 * half, wr);
-        __syncthreads();
+        ro_fence();
+        tp = ro_mma<4>(tp, Y + n * RO_LD + 4 * half, wr);
+        accC = accN;
+        wm = wn;
     }
     const RoW<GS> ws1 = ro_load<GS>(a.s1w + (size_t)n * PH_XR_K + 4 * half);
-    const RoW<4> ws2a = ro_load<4>(a.s2w + (size_t)n * 32 + 4 * half), ws2b = ro_load<4>(n < 16 ? a.s2w + (size_t)(32 + n) * 32 + 4 * half : nullptr);
+    const RoW<4> ws2a = ro_load<4>(a.s2w + (size_t)n * 32 + 4 * half), ws2b = ro_load<4>(a.s2w + (size_t)(32 + (n & 15)) * 32 + 4 * half, n < 16);
     {
         const float b = n < 16 ? a.r1b[n] : a.r2b[n - 16];
 #pragma unroll
@@ -184,14 +209,15 @@ __global__ __launch_bounds__(128) void rad_optics_kernel(RadOptics a)
             if (row < M) a.TP[(size_t)row * 32 + n] = tp[i] + b;
         }
     }
-    // SW optical-property head: 24 -> 32 (Softsign) -> 48
+    // SW optical-property head: 24 -> 32 (Softsign) -> 48   (bA: Y of tile 6 was consumed before tile 7's reduction was issued)
     {
         const f32x16 acc = ro_mma<GS>(ro_zero(), bX + n * RO_LX + 4 * half, ws1);
         const float b = a.s1b[n];
+        ro_fence();
 #pragma unroll
         for (int i = 0; i < 16; ++i) bA[drow(i) * RO_LD + n] = ro_softsign(acc[i] + b);
     }
-    __syncthreads();
+    ro_fence();
     {
         f32x16 acc = ro_mma<4>(ro_zero(), bA + n * RO_LD + 4 * half, ws2a);
         float b = a.s2b[n];
@@ -377,7 +403,7 @@ int launch_phys_radiation(csa_phys *h, int B, const float *x_sfc, float *out_lev
     if (!unfused) {
         RadOptics a{h->XG, h->XR, h->RS, h->g_w1, h->g_b1, h->g_w2, h->g_b2, h->g_w3, h->g_b3, h->r1_w, h->r1_b, h->r2_w, h->r2_b,
                     h->s1_w, h->s1_b, h->s2_w, h->s2_b, d.g_ystd, d.g_ymean, h->TP, h->S2, M};
-        hipLaunchKernelGGL(rad_optics_kernel, dim3((M + 63) / 64), dim3(128), 0, s, a);
+        hipLaunchKernelGGL(rad_optics_kernel, dim3((M + 31) / 32), dim3(64), 0, s, a);
         CSA_HIP_CHECK(hipGetLastError());
         hipLaunchKernelGGL(phys_rad_solve_kernel, dim3(B), dim3(RS_T), 0, s, d, B, x_sfc, h->TP, h->CL, h->S2, h->RS, out_lev, out_sfc);
         CSA_HIP_CHECK(hipGetLastError());
