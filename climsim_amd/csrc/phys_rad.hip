@@ -72,23 +72,23 @@ struct RadOptics {
 
 // weights of one 32-column tile, K deep: G = K / 8 float4 per lane (lane's weight row, k-quad 4 * half of every group of 8)
 template <int G> struct RoW { f32x4 v[G]; };
-template <int G> __device__ __forceinline__ RoW<G> ro_load(const float *__restrict__ w_row, bool live = true /* false: zeros (w_row still readable) */)
+template <int G> __device__ __forceinline__ RoW<G> ro_load(const float *__restrict__ w_row)
 {
     RoW<G> w;
 #pragma unroll
-    for (int g = 0; g < G; ++g) {
-        const f32x4 v = *(const f32x4 *)(w_row + 8 * g);        // unconditional load + select: no divergent branch around the load
-        w.v[g] = live ? v : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-    }
+    for (int g = 0; g < G; ++g) w.v[g] = *(const f32x4 *)(w_row + 8 * g);
     return w;
 }
-template <int G> __device__ __forceinline__ f32x16 ro_mma(f32x16 acc, const float *act_row /* LDS: lane's row + 4 * half */, const RoW<G> &w)
+// live == false: this lane's weight row is all zeros (the select sits here, at the point of use: next to the load it would
+// make the wave wait for the prefetch it has just issued)
+template <int G> __device__ __forceinline__ f32x16 ro_mma(f32x16 acc, const float *act_row /* LDS: lane's row + 4 * half */, const RoW<G> &w,
+                                                         bool live = true)
 {
 #pragma unroll
     for (int g = 0; g < G; ++g) {
         const f32x4 x = *(const f32x4 *)(act_row + 8 * g);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(x[e], w.v[g][e], acc, 0, 0, 0);
+        for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(x[e], live ? w.v[g][e] : 0.0f, acc, 0, 0, 0);
     }
     return acc;
 }
@@ -130,6 +130,11 @@ __global__ __launch_bounds__(64) void rad_optics_kernel(RadOptics a)
     for (int i = 0; i < 16; ++i) cd[i] = a.RS[(size_t)min(row0 + drow(i), M - 1) * 2];
     RoW<8> wn = ro_load<8>(a.w2 + (size_t)n * 64 + 4 * half);                       // layer 2, tile 0
     RoW<8> wm = ro_load<8>(a.w2 + (size_t)(32 + n) * 64 + 4 * half);                // layer 2, tile 1
+    float cb3[8], csd[4], cmn[4];                    // per-column constants of the 256-wide layer, all eight tiles (vmcnt retires in
+#pragma unroll                                       // order: a late scalar load would stall behind the weight prefetches)
+    for (int t = 0; t < 8; ++t) cb3[t] = a.b3[t * 32 + n];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) { csd[t] = a.ystd[t * 32 + n]; cmn[t] = a.ymean[t * 32 + n]; }
     ro_fence();
     // gas optics, layer 1: 24 -> 64
     {
@@ -164,15 +169,19 @@ __global__ __launch_bounds__(64) void rad_optics_kernel(RadOptics a)
     ro_fence();
     // layer 3 (64 -> 256) tile by tile, each tile reduced 32 -> (16 | 16) at once
     const float *hrow = bB + n * RO_LD + 4 * half;
+    auto red_w = [&](int t) {                        // the 32-deep slice of the (16 | 16)-column reduction that tile t feeds
+        return ro_load<4>((t < 4 ? a.r1w : a.r2w) + (size_t)(n & 15) * 128 + (t & 3) * 32 + 4 * half);
+    };
+    RoW<4> wrn = red_w(0);
     f32x16 tp = ro_zero();
     f32x16 accC = ro_mma<8>(ro_zero(), hrow, wn);                                   // tile 0
 #pragma unroll
     for (int t = 0; t < 8; ++t) {
-        // weights in flight: wm = tile t + 1 (arrived or arriving), wn <- tile t + 2; reduction slice of tile t
+        // weights in flight: wm = tile t + 1 (arrived or arriving), wn <- tile t + 2; reduction slice wr of tile t, wrn <- t + 1
+        const RoW<4> wr = wrn;
         if (t + 2 < 8) wn = ro_load<8>(a.w3 + (size_t)((t + 2) * 32 + n) * 64 + 4 * half);
-        const RoW<4> wr = ro_load<4>((t < 4 ? a.r1w : a.r2w) + (size_t)(n & 15) * 128 + (t & 3) * 32 + 4 * half, t < 4 ? n < 16 : n >= 16);
-        const int col = t * 32 + n;
-        const float b = a.b3[col], sd = a.ystd[col & 127], mn = a.ymean[col & 127];
+        if (t + 1 < 8) wrn = red_w(t + 1);
+        const float b = cb3[t], sd = csd[t & 3], mn = cmn[t & 3];
         float *Y = (t & 1) ? bC : bA;
         auto piece = [&](int i) {                    // accumulator register i of tile t -> k-point optical depth / squared logit -> LDS
             const float v = accC[i] + b;
@@ -195,12 +204,12 @@ __global__ __launch_bounds__(64) void rad_optics_kernel(RadOptics a)
             for (int i = 0; i < 16; ++i) piece(i);
         }
         ro_fence();
-        tp = ro_mma<4>(tp, Y + n * RO_LD + 4 * half, wr);
+        tp = ro_mma<4>(tp, Y + n * RO_LD + 4 * half, wr, t < 4 ? n < 16 : n >= 16);
         accC = accN;
         wm = wn;
     }
     const RoW<GS> ws1 = ro_load<GS>(a.s1w + (size_t)n * PH_XR_K + 4 * half);
-    const RoW<4> ws2a = ro_load<4>(a.s2w + (size_t)n * 32 + 4 * half), ws2b = ro_load<4>(a.s2w + (size_t)(32 + (n & 15)) * 32 + 4 * half, n < 16);
+    const RoW<4> ws2a = ro_load<4>(a.s2w + (size_t)n * 32 + 4 * half), ws2b = ro_load<4>(a.s2w + (size_t)(32 + (n & 15)) * 32 + 4 * half);
     {
         const float b = n < 16 ? a.r1b[n] : a.r2b[n - 16];
 #pragma unroll
@@ -226,7 +235,7 @@ __global__ __launch_bounds__(64) void rad_optics_kernel(RadOptics a)
             const int row = row0 + drow(i);
             if (row < M) a.S2[(size_t)row * 48 + n] = acc[i] + b;
         }
-        acc = ro_mma<4>(ro_zero(), bA + n * RO_LD + 4 * half, ws2b);
+        acc = ro_mma<4>(ro_zero(), bA + n * RO_LD + 4 * half, ws2b, n < 16);
         b = n < 16 ? a.s2b[32 + n] : 0.0f;
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
