@@ -79,6 +79,22 @@ template <int G> __device__ __forceinline__ RoW<G> ro_load(const float *__restri
     for (int g = 0; g < G; ++g) w.v[g] = *(const f32x4 *)(w_row + 8 * g);
     return w;
 }
+// A operand held in registers (the same activations feed every 32-column tile of a layer)
+template <int G> __device__ __forceinline__ RoW<G> ro_loada(const float *act_row)
+{
+    RoW<G> x;
+#pragma unroll
+    for (int g = 0; g < G; ++g) x.v[g] = *(const f32x4 *)(act_row + 8 * g);
+    return x;
+}
+template <int G> __device__ __forceinline__ f32x16 ro_mma_r(f32x16 acc, const RoW<G> &x, const RoW<G> &w)
+{
+#pragma unroll
+    for (int g = 0; g < G; ++g)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(x.v[g][e], w.v[g][e], acc, 0, 0, 0);
+    return acc;
+}
 // live == false: this lane's weight row is all zeros (the select sits here, at the point of use: next to the load it would
 // make the wave wait for the prefetch it has just issued)
 template <int G> __device__ __forceinline__ f32x16 ro_mma(f32x16 acc, const float *act_row /* LDS: lane's row + 4 * half */, const RoW<G> &w,
@@ -108,127 +124,54 @@ __device__ __forceinline__ float ro_softsign(float v) { return v / (1.0f + fabsf
 // the time.
 __device__ __forceinline__ void ro_fence() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); }
 
-__global__ __launch_bounds__(64) void rad_optics_kernel(RadOptics a)
+#define RO_WAVES 1          // independent waves per workgroup (1 / 4 measured: 37 / 46 us at 384 columns -- four waves need 119 KB of LDS,
+                            // one workgroup per CU, 180 CUs busy)
+__global__ __launch_bounds__(64 * RO_WAVES) void rad_optics_kernel(RadOptics a)
 {
-    __shared__ __attribute__((aligned(16))) float bA[32 * RO_LD];      // H1, then Y of even tiles, then S1
-    __shared__ __attribute__((aligned(16))) float bB[32 * RO_LD];      // H2
-    __shared__ __attribute__((aligned(16))) float bC[32 * RO_LD];      // Y of odd tiles
-    __shared__ __attribute__((aligned(16))) float bX[32 * RO_LX];      // XG, then XR
-    const int lane = threadIdx.x, n = lane & 31, half = lane >> 5;
-    const int row0 = (int)blockIdx.x * 32, M = a.M;
+    __shared__ __attribute__((aligned(16))) float sA[RO_WAVES][32 * RO_LD];      // H1, then Y of even tiles   (SW: S1)
+    __shared__ __attribute__((aligned(16))) float sB[RO_WAVES][32 * RO_LD];      // H2
+    __shared__ __attribute__((aligned(16))) float sC[RO_WAVES][32 * RO_LD];      // Y of odd tiles
+    __shared__ __attribute__((aligned(16))) float sX[RO_WAVES][32 * RO_LX];      // XG                         (SW: XR)
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, n = lane & 31, half = lane >> 5;
+    const int row0 = ((int)blockIdx.x * RO_WAVES + wave) * 32, M = a.M;
+    if (row0 >= M) return;                           // (no workgroup barrier anywhere below)
+    float *bA = sA[wave], *bB = sB[wave], *bC = sC[wave], *bX = sX[wave];
     // accumulator register i of this lane belongs to tile row (i & 3) + 8 (i >> 2) + 4 half, tile column n
     auto drow = [&](int i) { return (i & 3) + 8 * (i >> 2) + 4 * half; };
     constexpr int G1 = PH_XG_K / 8, GS = PH_XR_K / 8;
-
-    RoW<G1> w1a = ro_load<G1>(a.w1 + (size_t)n * PH_XG_K + 4 * half), w1b = ro_load<G1>(a.w1 + (size_t)(32 + n) * PH_XG_K + 4 * half);
-    for (int i = lane; i < 32 * PH_XG_K; i += 64) {
-        const int rr = i / PH_XG_K, k = i - rr * PH_XG_K;
-        bX[rr * RO_LX + k] = a.XG[(size_t)min(row0 + rr, M - 1) * PH_XG_K + k];
-    }
-    float cd[16];
+    static_assert(PH_XG_K == 24 && PH_XR_K == 24, "tile loader");
+    // an input tile = 32 consecutive rows = 768 consecutive floats: three float4 per lane, all requested before any is used
+    // (a rolled loop of dependent load -> LDS store pairs cost ~1.5 us per trip: 20 us of this kernel's first version)
+    auto load_tile = [&](const float *__restrict__ X) {
+        f32x4 v[3];
+        const size_t tile0 = (size_t)row0 * 24, last4 = (size_t)M * 24 - 4;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) cd[i] = a.RS[(size_t)min(row0 + drow(i), M - 1) * 2];
-    RoW<8> wn = ro_load<8>(a.w2 + (size_t)n * 64 + 4 * half);                       // layer 2, tile 0
-    RoW<8> wm = ro_load<8>(a.w2 + (size_t)(32 + n) * 64 + 4 * half);                // layer 2, tile 1
-    float cb3[8], csd[4], cmn[4];                    // per-column constants of the 256-wide layer, all eight tiles (vmcnt retires in
-#pragma unroll                                       // order: a late scalar load would stall behind the weight prefetches)
-    for (int t = 0; t < 8; ++t) cb3[t] = a.b3[t * 32 + n];
+        for (int j = 0; j < 3; ++j) {
+            const size_t e = tile0 + 4 * (lane + 64 * j);
+            v[j] = *(const f32x4 *)(X + (e < last4 ? e : last4));
+        }
 #pragma unroll
-    for (int t = 0; t < 4; ++t) { csd[t] = a.ystd[t * 32 + n]; cmn[t] = a.ymean[t * 32 + n]; }
-    ro_fence();
-    // gas optics, layer 1: 24 -> 64
-    {
-        f32x16 acc = ro_mma<G1>(ro_zero(), bX + n * RO_LX + 4 * half, w1a);
-        float b = a.b1[n];
-#pragma unroll
-        for (int i = 0; i < 16; ++i) bA[drow(i) * RO_LD + n] = ro_softsign(acc[i] + b);
-        acc = ro_mma<G1>(ro_zero(), bX + n * RO_LX + 4 * half, w1b);
-        b = a.b1[32 + n];
-#pragma unroll
-        for (int i = 0; i < 16; ++i) bA[drow(i) * RO_LD + 32 + n] = ro_softsign(acc[i] + b);
-    }
-    ro_fence();
-    // SW head inputs (bX is free now)
-    for (int i = lane; i < 32 * PH_XR_K; i += 64) {
-        const int rr = i / PH_XR_K, k = i - rr * PH_XR_K;
-        bX[rr * RO_LX + k] = a.XR[(size_t)min(row0 + rr, M - 1) * PH_XR_K + k];
-    }
-    // layer 2: 64 -> 64
-    {
-        f32x16 acc = ro_mma<8>(ro_zero(), bA + n * RO_LD + 4 * half, wn);
-        wn = ro_load<8>(a.w3 + (size_t)n * 64 + 4 * half);                          // layer 3, tile 0
-        float b = a.b2[n];
-#pragma unroll
-        for (int i = 0; i < 16; ++i) bB[drow(i) * RO_LD + n] = ro_softsign(acc[i] + b);
-        acc = ro_mma<8>(ro_zero(), bA + n * RO_LD + 4 * half, wm);
-        wm = ro_load<8>(a.w3 + (size_t)(32 + n) * 64 + 4 * half);                   // layer 3, tile 1
-        b = a.b2[32 + n];
-#pragma unroll
-        for (int i = 0; i < 16; ++i) bB[drow(i) * RO_LD + 32 + n] = ro_softsign(acc[i] + b);
-    }
-    ro_fence();
-    // layer 3 (64 -> 256) tile by tile, each tile reduced 32 -> (16 | 16) at once
-    const float *hrow = bB + n * RO_LD + 4 * half;
-    auto red_w = [&](int t) {                        // the 32-deep slice of the (16 | 16)-column reduction that tile t feeds
-        return ro_load<4>((t < 4 ? a.r1w : a.r2w) + (size_t)(n & 15) * 128 + (t & 3) * 32 + 4 * half);
+        for (int j = 0; j < 3; ++j) {
+            const int e = 4 * (lane + 64 * j), rr = e / 24, k = e - rr * 24;
+            *(f32x4 *)(bX + rr * RO_LX + k) = v[j];
+        }
     };
-    RoW<4> wrn = red_w(0);
-    f32x16 tp = ro_zero();
-    f32x16 accC = ro_mma<8>(ro_zero(), hrow, wn);                                   // tile 0
+
+    if (blockIdx.y == 1) {
+        // ---- SW optical-property head: 24 -> 32 (Softsign) -> 48, its own workgroups (off the gas-optics critical path) ----
+        const RoW<GS> ws1 = ro_load<GS>(a.s1w + (size_t)n * PH_XR_K + 4 * half);
+        const RoW<4> ws2a = ro_load<4>(a.s2w + (size_t)n * 32 + 4 * half), ws2b = ro_load<4>(a.s2w + (size_t)(32 + (n & 15)) * 32 + 4 * half);
+        load_tile(a.XR);
+        ro_fence();
+        {
+            const f32x16 acc = ro_mma<GS>(ro_zero(), bX + n * RO_LX + 4 * half, ws1);
+            const float b = a.s1b[n];
 #pragma unroll
-    for (int t = 0; t < 8; ++t) {
-        // weights in flight: wm = tile t + 1 (arrived or arriving), wn <- tile t + 2; reduction slice wr of tile t, wrn <- t + 1
-        const RoW<4> wr = wrn;
-        if (t + 2 < 8) wn = ro_load<8>(a.w3 + (size_t)((t + 2) * 32 + n) * 64 + 4 * half);
-        if (t + 1 < 8) wrn = red_w(t + 1);
-        const float b = cb3[t], sd = csd[t & 3], mn = cmn[t & 3];
-        float *Y = (t & 1) ? bC : bA;
-        auto piece = [&](int i) {                    // accumulator register i of tile t -> k-point optical depth / squared logit -> LDS
-            const float v = accC[i] + b;
-            Y[drow(i) * RO_LD + n] = t < 4 ? cd[i] * pr_pow8(sd * v + mn) : v * v;
-        };
-        f32x16 accN = ro_zero();
-        if (t < 7) {
-#pragma unroll
-            for (int g = 0; g < 8; ++g) {
-                const f32x4 x = *(const f32x4 *)(hrow + 8 * g);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    accN = __builtin_amdgcn_mfma_f32_32x32x2f32(x[e], wm.v[g][e], accN, 0, 0, 0);
-                    if ((e & 1) == 0) piece(2 * g + (e >> 1));
-                    __builtin_amdgcn_sched_barrier(0x3F4);   // memory and scalar instructions may move; MFMA and VALU keep this order
-                }
-            }
-        } else {
-#pragma unroll
-            for (int i = 0; i < 16; ++i) piece(i);
+            for (int i = 0; i < 16; ++i) bA[drow(i) * RO_LD + n] = ro_softsign(acc[i] + b);
         }
         ro_fence();
-        tp = ro_mma<4>(tp, Y + n * RO_LD + 4 * half, wr, t < 4 ? n < 16 : n >= 16);
-        accC = accN;
-        wm = wn;
-    }
-    const RoW<GS> ws1 = ro_load<GS>(a.s1w + (size_t)n * PH_XR_K + 4 * half);
-    const RoW<4> ws2a = ro_load<4>(a.s2w + (size_t)n * 32 + 4 * half), ws2b = ro_load<4>(a.s2w + (size_t)(32 + (n & 15)) * 32 + 4 * half);
-    {
-        const float b = n < 16 ? a.r1b[n] : a.r2b[n - 16];
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int row = row0 + drow(i);
-            if (row < M) a.TP[(size_t)row * 32 + n] = tp[i] + b;
-        }
-    }
-    // SW optical-property head: 24 -> 32 (Softsign) -> 48   (bA: Y of tile 6 was consumed before tile 7's reduction was issued)
-    {
-        const f32x16 acc = ro_mma<GS>(ro_zero(), bX + n * RO_LX + 4 * half, ws1);
-        const float b = a.s1b[n];
-        ro_fence();
-#pragma unroll
-        for (int i = 0; i < 16; ++i) bA[drow(i) * RO_LD + n] = ro_softsign(acc[i] + b);
-    }
-    ro_fence();
-    {
-        f32x16 acc = ro_mma<4>(ro_zero(), bA + n * RO_LD + 4 * half, ws2a);
+        const RoW<4> x = ro_loada<4>(bA + n * RO_LD + 4 * half);
+        f32x16 acc = ro_mma_r<4>(ro_zero(), x, ws2a);
         float b = a.s2b[n];
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
@@ -242,6 +185,96 @@ __global__ __launch_bounds__(64) void rad_optics_kernel(RadOptics a)
             const int row = row0 + drow(i);
             if (n < 16 && row < M) a.S2[(size_t)row * 48 + 32 + n] = acc[i] + b;
         }
+        return;
+    }
+
+    // ---- LW gas optics ----
+    RoW<G1> w1a = ro_load<G1>(a.w1 + (size_t)n * PH_XG_K + 4 * half), w1b = ro_load<G1>(a.w1 + (size_t)(32 + n) * PH_XG_K + 4 * half);
+    load_tile(a.XG);
+    float cd[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) cd[i] = a.RS[(size_t)min(row0 + drow(i), M - 1) * 2];
+    RoW<8> wn = ro_load<8>(a.w2 + (size_t)n * 64 + 4 * half);                       // layer 2, tile 0
+    RoW<8> wm = ro_load<8>(a.w2 + (size_t)(32 + n) * 64 + 4 * half);                // layer 2, tile 1
+    ro_fence();
+    // layer 1: 24 -> 64
+    {
+        const RoW<G1> x = ro_loada<G1>(bX + n * RO_LX + 4 * half);
+        f32x16 acc = ro_mma_r<G1>(ro_zero(), x, w1a);
+        float b = a.b1[n];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) bA[drow(i) * RO_LD + n] = ro_softsign(acc[i] + b);
+        acc = ro_mma_r<G1>(ro_zero(), x, w1b);
+        b = a.b1[32 + n];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) bA[drow(i) * RO_LD + 32 + n] = ro_softsign(acc[i] + b);
+    }
+    ro_fence();
+    // layer 2: 64 -> 64
+    {
+        const RoW<8> x = ro_loada<8>(bA + n * RO_LD + 4 * half);
+        f32x16 acc = ro_mma_r<8>(ro_zero(), x, wn);
+        wn = ro_load<8>(a.w3 + (size_t)n * 64 + 4 * half);                          // layer 3, tile 0
+        float b = a.b2[n];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) bB[drow(i) * RO_LD + n] = ro_softsign(acc[i] + b);
+        acc = ro_mma_r<8>(ro_zero(), x, wm);
+        wm = ro_load<8>(a.w3 + (size_t)(32 + n) * 64 + 4 * half);                   // layer 3, tile 1
+        b = a.b2[32 + n];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) bB[drow(i) * RO_LD + 32 + n] = ro_softsign(acc[i] + b);
+    }
+    ro_fence();
+    // layer 3 (64 -> 256) tile by tile, each tile reduced 32 -> (16 | 16) at once.  Iteration t: the MFMAs of tile t + 1 with the
+    // VALU epilogue of tile t issued in between, then the reduction of tile t; the weights of tile t + 2 and the reduction slice
+    // and constants of tile t + 1 are in flight meanwhile.  (Fully unrolled 36.6 us, rolled 40.9 us per 384-column launch.)
+    const RoW<8> hx = ro_loada<8>(bB + n * RO_LD + 4 * half);      // H2: the A operand of all eight tiles
+    auto red_w = [&](int t) {                        // the 32-deep slice of the (16 | 16)-column reduction that tile t feeds
+        return ro_load<4>((t < 4 ? a.r1w : a.r2w) + (size_t)(n & 15) * 128 + (t & 3) * 32 + 4 * half);
+    };
+    RoW<4> wrn = red_w(0);
+    float bn = a.b3[n], sdn = a.ystd[n], mnn = a.ymean[n];
+    f32x16 tp = ro_zero();
+    f32x16 accC = ro_mma_r<8>(ro_zero(), hx, wn);                                   // tile 0
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+        const RoW<4> wr = wrn;
+        const float b = bn, sd = sdn, mn = mnn;
+        if (t + 2 < 8) wn = ro_load<8>(a.w3 + (size_t)((t + 2) * 32 + n) * 64 + 4 * half);
+        if (t + 1 < 8) {
+            wrn = red_w(t + 1);
+            bn = a.b3[(t + 1) * 32 + n]; sdn = a.ystd[((t + 1) & 3) * 32 + n]; mnn = a.ymean[((t + 1) & 3) * 32 + n];
+        }
+        float *Y = (t & 1) ? bC : bA;
+        const bool tau = t < 4;                      // optical-depth half of the layer: N_dry (s x + m)^8; else squared logit
+        f32x16 accN = ro_zero(), accM = ro_zero();   // two accumulation chains (even / odd MFMAs)
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                if (t < 7) {
+                    if (e & 1) accM = __builtin_amdgcn_mfma_f32_32x32x2f32(hx.v[g][e], wm.v[g][e], accM, 0, 0, 0);
+                    else accN = __builtin_amdgcn_mfma_f32_32x32x2f32(hx.v[g][e], wm.v[g][e], accN, 0, 0, 0);
+                }
+                if (!(e & 1)) {
+                    const int i = 2 * g + (e >> 1);  // accumulator register i of tile t -> LDS, transposed for the reduction
+                    const float v = accC[i] + b;
+                    Y[drow(i) * RO_LD + n] = tau ? cd[i] * pr_pow8(sd * v + mn) : v * v;
+                }
+                __builtin_amdgcn_sched_barrier(0x3F4);   // memory and scalar instructions may move; MFMA and VALU keep this order
+            }
+        }
+        ro_fence();
+        tp = ro_mma<4>(tp, Y + n * RO_LD + 4 * half, wr, tau ? n < 16 : n >= 16);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) accC[i] = accN[i] + accM[i];
+        wm = wn;
+    }
+    const float b = n < 16 ? a.r1b[n] : a.r2b[n - 16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int row = row0 + drow(i);
+        if (row < M) a.TP[(size_t)row * 32 + n] = tp[i] + b;
     }
 }
 
@@ -412,7 +445,7 @@ int launch_phys_radiation(csa_phys *h, int B, const float *x_sfc, float *out_lev
     if (!unfused) {
         RadOptics a{h->XG, h->XR, h->RS, h->g_w1, h->g_b1, h->g_w2, h->g_b2, h->g_w3, h->g_b3, h->r1_w, h->r1_b, h->r2_w, h->r2_b,
                     h->s1_w, h->s1_b, h->s2_w, h->s2_b, d.g_ystd, d.g_ymean, h->TP, h->S2, M};
-        hipLaunchKernelGGL(rad_optics_kernel, dim3((M + 31) / 32), dim3(64), 0, s, a);
+        hipLaunchKernelGGL(rad_optics_kernel, dim3((M + 32 * RO_WAVES - 1) / (32 * RO_WAVES), 2), dim3(64 * RO_WAVES), 0, s, a);
         CSA_HIP_CHECK(hipGetLastError());
         hipLaunchKernelGGL(phys_rad_solve_kernel, dim3(B), dim3(RS_T), 0, s, d, B, x_sfc, h->TP, h->CL, h->S2, h->RS, out_lev, out_sfc);
         CSA_HIP_CHECK(hipGetLastError());
