@@ -40,7 +40,7 @@ __global__ __launch_bounds__(GB_THREADS) void proj_gemm_kernel(
     //   A + (r-1)*lda (lda = cin), with the first / last third masked to zero on the first / last level
     //   (baseline_models/CNN/training/hpo_train.py:165-177, Conv1D(..., padding="same")).
     // accumulate: C += result (the 1x1 residual projection added onto the block output, :180-184).
-    // act 3: ELU (the pre-output Conv1D(10, 1, activation="elu"), :189-194).  act 4: Softsign (the radiation MLPs, phys_rad.hip).
+    // act 3: ELU (the pre-output Conv1D(10, 1, activation="elu"), :189-194).
     // act: 0 none; 1 LeakyReLU(alpha) on every column; 2 split head: columns < n_lin linear, the rest ReLU
     // (the Keras MLP baseline's Dense(120,linear) || Dense(8,relu) output, step2_retrain.py:118-121)
     // double-buffered LDS: chunk c+1 is written while chunk c is being multiplied -> one barrier
@@ -158,7 +158,6 @@ __global__ __launch_bounds__(GB_THREADS) void proj_gemm_kernel(
                 if (act == 1) v = v > 0.0f ? v : alpha * v;
                 else if (act == 2 && n0 + wn * 64 + j * 32 + (lane & 31) >= n_lin) v = fmaxf(v, 0.0f);
                 else if (act == 3) v = v > 0.0f ? v : expm1f(v);
-                else if (act == 4) v = v / (1.0f + fabsf(v));
                 acc[i][j][r] = v;
             }
 #ifdef GEMM_EXP_NO_STORE   /* diagnostic: keep the accumulators alive, store one value per wave */
@@ -333,7 +332,6 @@ __global__ __launch_bounds__(256) void gemm_small_kernel(
             if (act == 1) v = v > 0.0f ? v : alpha * v;
             else if (act == 2 && col >= n_lin) v = fmaxf(v, 0.0f);
             else if (act == 3) v = v > 0.0f ? v : expm1f(v);
-            else if (act == 4) v = v / (1.0f + fabsf(v));
             if (row < M && col < N) C[(size_t)row * N + col] = v;
         }
     }

@@ -39,7 +39,7 @@ struct csa_phys {
     float *X1, *P, *H1, *H2, *hx, *HD;
     // radiation scheme: MLP weights (row-major (out, in), K padded to a multiple of 4) and per-call work arrays
     float *g_w1, *g_b1, *g_w2, *g_b2, *g_w3, *g_b3, *r1_w, *r1_b, *r2_w, *r2_b, *s1_w, *s1_b, *s2_w, *s2_b;
-    float *XG, *XR, *RS, *CL, *A1, *A2, *A3, *TP, *S1, *S2;
+    float *XG, *XR, *RS, *CL, *TP, *S2;
     // add_stochastic_layer graphs: rnn3 (MyStochasticGRULayer5 over rnn2's output), its output and the perturbed sequence
     struct csa_stoch *rnn3 = nullptr;
     float *H3 = nullptr, *H2p = nullptr;

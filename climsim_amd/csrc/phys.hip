@@ -513,8 +513,7 @@ static int phys_build(int nx, int nfeat, int naux, int nx_sfc, int sfc_cut, int 
         const size_t M = (size_t)PH_L * max_batch;
         h->XG = up(nullptr, M * PH_XG_K); h->XR = up(nullptr, M * PH_XR_K); h->RS = up(nullptr, M * 2);
         h->CL = up(nullptr, (size_t)d.Lc * max_batch * PH_NG);
-        h->A1 = up(nullptr, M * 64); h->A2 = up(nullptr, M * 64); h->A3 = up(nullptr, M * 256); h->TP = up(nullptr, M * 32);
-        h->S1 = up(nullptr, M * 32); h->S2 = up(nullptr, M * 48);
+        h->TP = up(nullptr, M * 32); h->S2 = up(nullptr, M * 48);
     }
     if (w.s3_ih && rc == CSA_OK) {
         rc = csa_stoch_gru5_create(nh, nh, w.s3_ih, w.s3_zh, w.s3_enc, nullptr, nullptr, (int)rows, &h->rnn3);

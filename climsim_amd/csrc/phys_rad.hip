@@ -6,12 +6,12 @@
 // and rnn/layers.py gasopt_mlp (LW gas optics 18 -> 64 -> 64 -> 256, reduced to 16 g-points by two Linear(128, 16)).
 //
 // After phys_decode_kernel<.., RAD> has written the MLP inputs (XG, XR), the per-level scalars (RS: dry-air column, updated
-// temperature) and the MCICA cloud optical depth (CL), one call runs
-//   3 GEMMs (gas optics, Softsign fused) -> rad_gas_post_kernel ((ystd x + ymean)^8 * col_dry | x^2, in place)
-//   -> 2 GEMMs (k-distribution 128 -> 16: optical depth, Planck fraction) -> 2 GEMMs (SW optical-property head)
-//   -> phys_rad_solve_kernel: one workgroup per grid column; two-stream coefficients for its 60 x 16 (level, g-point)
-//      cells in parallel, then the level recurrences (LW no-scattering sweep on wave 0, SW adding method on wave 1, one
-//      lane per g-point), flux sums, heating rate added onto out_lev[:, :, 0], six surface fluxes into out_sfc.
+// temperature) and the cloud optical depth (CL), one call runs two kernels:
+//   rad_optics_kernel     the three MLPs on the matrix pipe, 32 (level, column) rows per wave, activations never leaving the CU
+//                         (gas optics 24 -> 64 -> 64 -> 256 -> k-distribution reduction to 16 + 16; SW head 24 -> 32 -> 48)
+//   phys_rad_solve_kernel one workgroup per grid column; two-stream coefficients for its 60 x 16 (level, g-point) cells in
+//                         parallel, then the level recurrences (LW no-scattering sweep on wave 0, SW adding method on wave 1,
+//                         one lane per g-point), flux sums, heating rate added onto out_lev[:, :, 0], six surface fluxes.
 // The LW downward source equals the upward source, as in the serialised graph.
 #include "phys.h"
 
@@ -31,26 +31,6 @@ __device__ __forceinline__ float pr_pow8(float x) { x *= x; x *= x; return x * x
 __device__ __forceinline__ float pr_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
 __device__ __forceinline__ float pr_softplus(float x) { return x > 20.0f ? x : log1pf(expf(x)); }
 
-// A3 (M, 256) in place: first half -> col_dry * (ystd x + ymean)^8 (k-point optical depths), second half -> x^2
-__global__ __launch_bounds__(256) void rad_gas_post_kernel(float *__restrict__ A3, const float *__restrict__ RS,
-                                                           const float *__restrict__ ystd, const float *__restrict__ ymean, size_t M)
-{
-    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;        // one float4 of a row
-    if (i >= M * 64) return;
-    const size_t row = i >> 6;
-    const int c = (int)(i & 63) * 4;
-    f32x4 v = *(f32x4 *)(A3 + row * 256 + c);
-    if (c < 128) {
-        const float cd = RS[row * 2];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) v[u] = cd * pr_pow8(ystd[c + u] * v[u] + ymean[c + u]);
-    } else {
-#pragma unroll
-        for (int u = 0; u < 4; ++u) v[u] = v[u] * v[u];
-    }
-    *(f32x4 *)(A3 + row * 256 + c) = v;
-}
-
 // ------------------------------------------------------------------------------------------------------------------
 // Fused optics: the three MLPs of the scheme for a tile of 32 (level, column) rows per wave, activations never leaving the
 // CU.  Per wave: XG (32 x 24) -> Linear 64 + Softsign -> Linear 64 + Softsign -> Linear 256 in eight 32-column tiles, each tile
@@ -60,7 +40,7 @@ __global__ __launch_bounds__(256) void rad_gas_post_kernel(float *__restrict__ A
 // Linear 48.  All products on v_mfma_f32_32x32x2_f32 (exact fp32): A operand = activations from LDS (lane = row), B operand =
 // weights straight from global memory / L2 as float4 -- lanes 0-31 take k..k+3 and lanes 32-63 k+4..k+7 of weight row n, so
 // MFMA e of a group contracts the pair (k+e, k+4+e) on both operands.  516 MFMAs per tile; one wave (one tile) per workgroup.
-// Replaces seven GEMM launches + one elementwise kernel (99 us at 384 columns) -- profiles/r2_physrnn_rad_384_*.
+// Replaced seven GEMM launches + one elementwise kernel: 99 -> 27 us at 384 columns (profiles/r2_physrnn_rad_384_*).
 #define RO_LD 68            // multiples of 4 floats: the A operand is read as one ds_read_b128 per MFMA group
 #define RO_LX 28
 struct RadOptics {
@@ -440,26 +420,10 @@ int launch_phys_radiation(csa_phys *h, int B, const float *x_sfc, float *out_lev
 {
     const PhysDev &d = h->d;
     const int M = PH_L * B;
-    int rc;
-    static const bool unfused = getenv("CSA_RAD_OPTICS") && !strcmp(getenv("CSA_RAD_OPTICS"), "gemm");   // measurement only: the first version
-    if (!unfused) {
-        RadOptics a{h->XG, h->XR, h->RS, h->g_w1, h->g_b1, h->g_w2, h->g_b2, h->g_w3, h->g_b3, h->r1_w, h->r1_b, h->r2_w, h->r2_b,
-                    h->s1_w, h->s1_b, h->s2_w, h->s2_b, d.g_ystd, d.g_ymean, h->TP, h->S2, M};
-        hipLaunchKernelGGL(rad_optics_kernel, dim3((M + 32 * RO_WAVES - 1) / (32 * RO_WAVES), 2), dim3(64 * RO_WAVES), 0, s, a);
-        CSA_HIP_CHECK(hipGetLastError());
-        hipLaunchKernelGGL(phys_rad_solve_kernel, dim3(B), dim3(RS_T), 0, s, d, B, x_sfc, h->TP, h->CL, h->S2, h->RS, out_lev, out_sfc);
-        CSA_HIP_CHECK(hipGetLastError());
-        return CSA_OK;
-    }
-    if ((rc = launch_gemm_act(h->XG, h->g_w1, h->g_b1, h->A1, M, 64, PH_XG_K, 4, 0.0f, 0, s))) return rc;
-    if ((rc = launch_gemm_act(h->A1, h->g_w2, h->g_b2, h->A2, M, 64, 64, 4, 0.0f, 0, s))) return rc;
-    if ((rc = launch_gemm_act(h->A2, h->g_w3, h->g_b3, h->A3, M, 256, 64, 0, 0.0f, 0, s))) return rc;
-    hipLaunchKernelGGL(rad_gas_post_kernel, dim3((unsigned)(((size_t)M * 64 + 255) / 256)), dim3(256), 0, s, h->A3, h->RS, d.g_ystd, d.g_ymean, (size_t)M);
+    RadOptics a{h->XG, h->XR, h->RS, h->g_w1, h->g_b1, h->g_w2, h->g_b2, h->g_w3, h->g_b3, h->r1_w, h->r1_b, h->r2_w, h->r2_b,
+                h->s1_w, h->s1_b, h->s2_w, h->s2_b, d.g_ystd, d.g_ymean, h->TP, h->S2, M};
+    hipLaunchKernelGGL(rad_optics_kernel, dim3((M + 32 * RO_WAVES - 1) / (32 * RO_WAVES), 2), dim3(64 * RO_WAVES), 0, s, a);
     CSA_HIP_CHECK(hipGetLastError());
-    if ((rc = launch_gemm_ex(h->A3, h->r1_w, h->r1_b, h->TP, M, 16, 128, 0, 0.0f, 0, 256, 32, 0, 0, 0, s))) return rc;
-    if ((rc = launch_gemm_ex(h->A3 + 128, h->r2_w, h->r2_b, h->TP + 16, M, 16, 128, 0, 0.0f, 0, 256, 32, 0, 0, 0, s))) return rc;
-    if ((rc = launch_gemm_act(h->XR, h->s1_w, h->s1_b, h->S1, M, 32, PH_XR_K, 4, 0.0f, 0, s))) return rc;
-    if ((rc = launch_gemm_act(h->S1, h->s2_w, h->s2_b, h->S2, M, 48, 32, 0, 0.0f, 0, s))) return rc;
     hipLaunchKernelGGL(phys_rad_solve_kernel, dim3(B), dim3(RS_T), 0, s, d, B, x_sfc, h->TP, h->CL, h->S2, h->RS, out_lev, out_sfc);
     CSA_HIP_CHECK(hipGetLastError());
     return CSA_OK;
