@@ -82,7 +82,9 @@ RAD_FAMILY = {"physrnn_rad_nomcica": "num71535_BEST", "physrnn_rad_liqfrac": "nu
 
 # first geometry of the physRNN_physRad-* family (97 of the 114 shipped models): 16 regions of which region 0 is clear sky,
 # no sub-grid temperature, liquid-fraction head, stochastic third RNN, rnn_mem passed level-major (50, B, 16)
-PHYSRAD = {"physrad16_a": "physRNN_physRad-16_nreg16_lr0.0007.neur128-128_xv4_mp1_num14751_BEST_script_cpu.pt"}
+PHYSRAD = {"physrad16_a": "physRNN_physRad-16_nreg16_lr0.0007.neur128-128_xv4_mp1_num14751_BEST_script_cpu.pt",
+           "physrad16_b": "physRNN_physRad-16_nreg16_lr0.0007.neur128-128_xv4_mp1_num55617_BEST_script_cpu.pt",
+           "physrad16_c": "physRNN_physRad-16_nreg16_lr0.0007.neur128-128_xv4_mp1_num55617_ep12_script_cpu.pt"}
 
 
 def staged_srnn(m, xm, xs, mem, seed, out_ref, sfc_ref, xd):

@@ -14,7 +14,8 @@ from climsim_amd.physrnn import physical_RNN_autoreg
 FIX = [("physrnn_hidden", "num14564_BEST", 2), ("physrnn_hidden_ep40", "num14564_ep40", 1), ("physrnn_hidden_b", "num49672_BEST", 1),
        ("physrnn_rad", "num4050_BEST", 2), ("physrnn_rad_nomcica", "num71535_BEST", 1), ("physrnn_rad_liqfrac", "num83000_ep20", 1),
        ("physrnn_rad_stoch_a", "num5730_BEST", 1), ("physrnn_rad_stoch_b", "num62104_BEST", 1), ("physrnn_rad_stoch_c", "num62104_BEST_ep11", 1),
-       ("physrad16_a", "physRad-16_nreg16 num14751_BEST", 1)]
+       ("physrad16_a", "physRad-16_nreg16 num14751_BEST", 1), ("physrad16_b", "physRad-16_nreg16 num55617_BEST", 1),
+       ("physrad16_c", "physRad-16_nreg16 num55617_ep12", 1)]
 print("fixture | artefact | case B | block: HIP-vs-artefact max|err| / max|ref| ; artefact-vs-float64 restatement (its own rounding) / max|ref|")
 for name, tag, ncase in FIX:
     g = np.load(os.path.join(ROOT, "tests", "golden", name + ".npz"))

@@ -4,8 +4,9 @@
   physrnn_rad_liqfrac  num83000_ep20         + learned cloud liquid-fraction head
   physrnn_rad_stoch_*  num5730_BEST, num62104_BEST, num62104_BEST_ep11    num4050's graph + stochastic third RNN
 and the first geometry of the physRNN_physRad-* family (97 of the 114 shipped models):
-  physrad16_a          physRNN_physRad-16_nreg16_*neur128-128_xv4_mp1_num14751_BEST   16 regions, region 0 clear sky, no sub-grid
-                       temperature, liquid-fraction head, stochastic third RNN, q/(1-q) mixing ratio, rnn_mem level-major
+  physrad16_a / b / c  physRNN_physRad-16_nreg16_*neur128-128_xv4_mp1_num14751_BEST, _num55617_BEST, _num55617_ep12: 16 regions,
+                       region 0 clear sky, no sub-grid temperature, liquid-fraction head, stochastic third RNN, q/(1-q) mixing
+                       ratio, rnn_mem level-major
 Oracle chain:
   shipped TorchScript artefact, run in the build container (torch.jit.load, CPU; its internal randn draws reproduced by
   re-seeding), outputs stored in tests/golden/<fixture>.npz
@@ -69,7 +70,7 @@ def _noise_level(*realisations_then_exact):
 
 
 FIXTURES = [("physrnn_rad", 2), ("physrnn_rad_nomcica", 1), ("physrnn_rad_liqfrac", 1), ("physrnn_rad_stoch_a", 1),
-            ("physrnn_rad_stoch_b", 1), ("physrnn_rad_stoch_c", 1), ("physrad16_a", 1)]
+            ("physrnn_rad_stoch_b", 1), ("physrnn_rad_stoch_c", 1), ("physrad16_a", 1), ("physrad16_b", 1), ("physrad16_c", 1)]
 
 
 def _noise(g, i):
@@ -88,8 +89,9 @@ def _rnn3_step_inputs(P, r2, hx1, srnn, eps3):
     return x, h0, eps3.reshape(1, T * B, H)
 
 
-def test_restatement_rnn3_steps_reproduce_the_artefact():
-    g, P = _load("physrad16_a")
+@pytest.mark.parametrize("fixture", ["physrad16_a", "physrad16_b", "physrad16_c"])
+def test_restatement_rnn3_steps_reproduce_the_artefact(fixture):
+    g, P = _load(fixture)
     B, seed = (int(v) for v in g["case0.cfg"])
     xm, xs, mem, xd = inputs_rad(P, B, seed)
     nz, taps = _noise(g, 0), {}
@@ -104,7 +106,7 @@ def test_restatement_rnn3_steps_reproduce_the_artefact():
     free64 = physrnn_rad_ref.stochastic_gru(*(t.double() for t in (taps["rnn2out"].transpose(0, 1), nz["hx1"], nz["eps3"], P["rnn3.weight_ih"],
                                                                   P["rnn3.weight_zh"], P["rnn3.weight_encoder"])))
     d = (free32.double() - free64).abs().amax((1, 2))
-    assert d[0] < 1e-4 and d[-1] > 100 * d[0]
+    assert d[0] < 1e-4 and (fixture != "physrad16_a" or d[-1] > 100 * d[0])
 
 
 def _draw_noise(P, B, seed):
@@ -258,8 +260,9 @@ def test_hip_radiation_graph_errors_and_rollout_state():
 
 
 @pytest.mark.gpu
-def test_hip_rnn3_steps_reproduce_the_artefact():
-    g, P = _load("physrad16_a")
+@pytest.mark.parametrize("fixture", ["physrad16_a", "physrad16_b", "physrad16_c"])
+def test_hip_rnn3_steps_reproduce_the_artefact(fixture):
+    g, P = _load(fixture)
     m = _hip_model(P, 16)
     B, seed = (int(v) for v in g["case0.cfg"])
     xm, xs, mem, xd = inputs_rad(P, B, seed)
