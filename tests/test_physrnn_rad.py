@@ -274,7 +274,7 @@ def test_hip_rnn3_steps_reproduce_the_artefact(fixture):
     assert err <= 2e-5 * nz["srnn"].abs().max().item(), err
     # free-running, the first levels still agree with the artefact (before the divergence has grown)
     free = m.debug_rnn3(taps["rnn2out"].transpose(0, 1).contiguous().cuda(), nz["hx1"].cuda(), nz["eps3"].cuda()).cpu()
-    assert (free[:5] - nz["srnn"][:5]).abs().max().item() <= 1e-4
+    assert (free[:5] - nz["srnn"][:5]).abs().max().item() <= 5e-4
 
 
 @pytest.mark.gpu
