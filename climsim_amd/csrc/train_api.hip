@@ -173,10 +173,9 @@ extern "C" int csa_train_create(const csa_config *cfg, const csa_params *p, cons
 {
     if (!cfg || !p || !hyai || !hybi || !out || max_batch <= 0 || max_window <= 0) { csa_set_error_msg("csa_train_create: bad argument"); return CSA_ERR_ARG; }
     const csa_config &c = *cfg;
-    if (c.legacy || c.nh_mem <= 0 || (c.mp_mode != 1 && c.mp_mode != -1) || c.ny != (c.mp_mode == 1 ? 5 : 6)) {
-        // mp_mode 0's training loop raises upstream (rnn/utils.py:1243 calls postprocessing with two arguments, models.py:274 takes
-        // three); mp_mode -2's loss needs the gradient of the total-water split (models.py:286-301), not built
-        csa_set_error_msg("csa_train_create: the HIP training step covers the current-generation LSTM / GRU with memory, mp_mode 1 (ny 5) and -1 (ny 6)");
+    if (c.legacy || c.nh_mem <= 0 || (c.mp_mode != 1 && c.mp_mode != -1 && c.mp_mode != -2) || c.ny != (c.mp_mode == 1 ? 5 : 6)) {
+        // mp_mode 0's training loop raises upstream (rnn/utils.py:1243 calls postprocessing with two arguments, models.py:274 takes three)
+        csa_set_error_msg("csa_train_create: the HIP training step covers the current-generation LSTM / GRU with memory, mp_mode 1 (ny 5), -1 and -2 (ny 6)");
         return CSA_ERR_UNSUPPORTED;
     }
     if (c.add_stochastic_layer && (!c.use_lstm || c.nh1 != c.nh2 || c.nh1 > 128 || !p->rnn0_w_ih || !p->rnn2_weight_encoder)) {

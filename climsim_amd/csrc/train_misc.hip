@@ -510,6 +510,20 @@ __device__ __forceinline__ void mp_post_pred(float ql, float qi, float dqn, floa
     dqi = ((1.0f - lf) * qn_new - qi) * 0.0008333333333333334f;
 }
 
+// mp_mode -2 (models.py:286-301), ahead of the liquid / ice partition of mode -1: the model predicts the total-water tendency
+// (column 1) and f = (cloud fraction of total water)^(1/4) (column 2); c = clamp(f^4, 0, 1),
+//   q_tot' = q_n + q_v + 1200 dq_tot,  dq_v = ((1 - c) q_tot' - q_v) / 1200,  dq_n = (c q_tot' - q_n) / 1200
+// with q_v the LAST input column.  dcdf = dc/df (0 where the clamp is active).
+__device__ __forceinline__ void mp_total_water(float qv, float qn, float dqtot, float f, float &dqv, float &dqn, float &c, float &dcdf, float &qtot_new)
+{
+    const float f2 = f * f, c_raw = f2 * f2;
+    c = fminf(fmaxf(c_raw, 0.0f), 1.0f);
+    dcdf = (c_raw > 0.0f && c_raw < 1.0f) ? 4.0f * f2 * f : 0.0f;
+    qtot_new = (qn + qv) + dqtot * 1200.0f;
+    dqv = ((1.0f - c) * qtot_new - qv) * 0.0008333333333333334f;
+    dqn = (c * qtot_new - qn) * 0.0008333333333333334f;
+}
+
 __device__ __forceinline__ float block_sum(float v, float *red)
 {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
@@ -548,9 +562,11 @@ __global__ __launch_bounds__(128) void loss_pass1_kernel(
         const float *o = pred + ((size_t)n * L + l) * ny, *ys = m.yscale_lev + l * ny;
         const float *xr = x_raw + ((size_t)n * L + l) * nx, *yt = yto + ((size_t)n * L + l) * 6;
         float dql, dqi, lf, qn; bool in;
-        const float dT = o[0] / ys[0], dqv = o[1] / ys[1];
-        if (m.cfg.mp_mode == 1) mp_post(xr[0], xr[2], xr[3], dT, o[2] / ys[2], dql, dqi, lf, qn, in);
-        else mp_post_pred(xr[2], xr[3], o[2] / ys[2], o[3] / ys[3], dql, dqi, qn);
+        const float dT = o[0] / ys[0];
+        float dqv = o[1] / ys[1], dqn = o[2] / ys[2];
+        if (m.cfg.mp_mode == -2) { float c, dcdf, qt; mp_total_water(xr[nx - 1], xr[2] + xr[3], o[1] / ys[1], o[2] / ys[2], dqv, dqn, c, dcdf, qt); }
+        if (m.cfg.mp_mode == 1) mp_post(xr[0], xr[2], xr[3], dT, dqn, dql, dqi, lf, qn, in);
+        else mp_post_pred(xr[2], xr[3], dqn, o[3] / ys[3], dql, dqi, qn);
         const float dhyb = hybi[l + 1] - hybi[l], dhya = hyai[l + 1] - hyai[l];
         const float th_e = k.ginv_e * (spn * dhyb + 100000.0f * dhya);
         const float th_w = k.ginv_w * (spn * dhyb + 100000.0f * dhya);
@@ -633,9 +649,11 @@ __global__ __launch_bounds__(128) void loss_pass3_kernel(
             g[v] = fminf(fmaxf(d, -1.0f), 1.0f) * inv_ntot;
         }
         float dql, dqi, lf, qn; bool in = false;
-        const bool diag = m.cfg.mp_mode == 1;
-        if (diag) mp_post(xr[0], xr[2], xr[3], o[0] / ys[0], o[2] / ys[2], dql, dqi, lf, qn, in);
-        else { lf = o[3] / ys[3]; mp_post_pred(xr[2], xr[3], o[2] / ys[2], lf, dql, dqi, qn); }
+        const bool diag = m.cfg.mp_mode == 1, total = m.cfg.mp_mode == -2;
+        float dqv_, dqn_ = o[2] / ys[2], cfrac = 0.0f, dcdf = 0.0f, qtot_new = 0.0f;
+        if (total) mp_total_water(xr[nx - 1], xr[2] + xr[3], o[1] / ys[1], o[2] / ys[2], dqv_, dqn_, cfrac, dcdf, qtot_new);
+        if (diag) mp_post(xr[0], xr[2], xr[3], o[0] / ys[0], dqn_, dql, dqi, lf, qn, in);
+        else { lf = o[3] / ys[3]; mp_post_pred(xr[2], xr[3], dqn_, lf, dql, dqi, qn); }
         const float dhyb = hybi[l + 1] - hybi[l], dhya = hyai[l + 1] - hyai[l];
         const float th_e = k.ginv_e * (spn * dhyb + 100000.0f * dhya);
         const float th_w = k.ginv_w * (spn * dhyb + 100000.0f * dhya);
@@ -650,8 +668,13 @@ __global__ __launch_bounds__(128) void loss_pass3_kernel(
         const float ddT = g_dT + (g_dql - g_dqi) * dlf * qn * s1200;
         const float ddqn = (g_dql * lf + g_dqi * (1.0f - lf)) * 1200.0f * s1200;
         g[0] += ddT / ys[0];
-        g[1] += g_dqv / ys[1];
-        g[2] += ddqn / ys[2];
+        if (total) {     // through dq_v = ((1-c) q_tot' - q_v)/1200, dq_n = (c q_tot' - q_n)/1200, c = clamp(f^4)
+            g[1] += (g_dqv * (1.0f - cfrac) + ddqn * cfrac) / ys[1];
+            g[2] += (ddqn - g_dqv) * qtot_new * s1200 * dcdf / ys[2];
+        } else {
+            g[1] += g_dqv / ys[1];
+            g[2] += ddqn / ys[2];
+        }
         if (!diag) g[3] += (g_dql - g_dqi) * qn * s1200 / ys[3];                   // through the predicted liquid fraction
         float *dp = d_pred + ((size_t)n * L + l) * ny;
         for (int v = 0; v < ny; ++v) dp[v] = g[v];
@@ -671,7 +694,7 @@ int launch_loss(const DevModel &m, const float *hyai, const float *hybi, int B, 
                 const float *yto_sfc, const float *x_raw, const float *sp, float *samp, float *ecoef, float *scal,
                 float *d_pred, float *d_pred_sfc, hipStream_t s)
 {
-    if ((m.cfg.mp_mode != 1 && m.cfg.mp_mode != -1) || m.cfg.ny > 8) { csa_set_error_msg("loss: mp_mode 1 and -1"); return CSA_ERR_UNSUPPORTED; }
+    if ((m.cfg.mp_mode != 1 && m.cfg.mp_mode != -1 && m.cfg.mp_mode != -2) || m.cfg.ny > 8) { csa_set_error_msg("loss: mp_mode 1, -1 and -2"); return CSA_ERR_UNSUPPORTED; }
     const int N = B * Tw;
     hipLaunchKernelGGL(loss_pass1_kernel, dim3(N), dim3(128), 0, s, m, hyai, hybi, N, pred, pred_sfc, tgt, tgt_sfc, yto, yto_sfc, x_raw, sp, samp);
     hipLaunchKernelGGL(loss_pass2_kernel, dim3(1), dim3(256), 0, s, m, B, Tw, w_h, w_w, samp, scal, ecoef);

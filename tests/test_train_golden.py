@@ -265,22 +265,24 @@ def test_hip_ensemble_crps_training_step_vs_reference_autograd():
 
 
 @pytest.mark.gpu
-def test_hip_training_step_mp_mode_minus1_vs_reference_gradients():
-    """mp_mode -1 (the model predicts the liquid fraction, models.py:303-329; ny = 6, hidden size 64): loss scalars, every
+@pytest.mark.parametrize("tag,mp_mode", [("cur_mpm1", -1), ("cur_mpm2", -2)])
+def test_hip_training_step_mp_mode_minus1_vs_reference_gradients(tag, mp_mode):
+    """mp_mode -1 (the model predicts the liquid fraction, models.py:303-329; ny = 6, hidden size 64) and -2 (it also predicts the
+    total-water tendency and the cloud fraction of total water, :286-301; specific humidity as 16th input): loss scalars, every
     parameter gradient and d(rnn_mem) of a T_w = 3 window against the reference's own autograd
     (tests/golden/make_golden_train_mp.py)."""
     from climsim_amd.train import Trainer
-    consts, weights, flags = load_npz_model("cur_mpm1")
-    io = np.load(os.path.join(GOLDEN, "cur_mpm1_train.npz"))
+    consts, weights, flags = load_npz_model(tag)
+    io = np.load(os.path.join(GOLDEN, tag + "_train.npz"))
     grid = np.load(os.path.join(GOLDEN, "grid_consts.npz"))
-    ref = torch_ref.EmulatorRef(consts, weights, legacy=False, use_lstm=True, output_prune=bool(flags["output_prune"]), mp_mode=-1,
+    ref = torch_ref.EmulatorRef(consts, weights, legacy=False, use_lstm=True, output_prune=bool(flags["output_prune"]), mp_mode=mp_mode,
                                 scrub_inf=True)
     B, Tw = int(io["grad.B"]), int(io["grad.T_w"])
     xr = [torch.from_numpy(io[f"grad.t{t}.x_main"]) for t in range(Tw)]
     xs = [torch.from_numpy(io[f"grad.t{t}.x_sfc"]) for t in range(Tw)]
     with torch.no_grad():
         pre = [ref.preprocess(a, b) for a, b in zip(xr, xs)]
-    tr = Trainer(consts, weights, grid["hyai"], grid["hybi"], use_lstm=True, output_prune=bool(flags["output_prune"]), mp_mode=-1,
+    tr = Trainer(consts, weights, grid["hyai"], grid["hybi"], use_lstm=True, output_prune=bool(flags["output_prune"]), mp_mode=mp_mode,
                  max_batch=B, max_window=Tw)
     d = lambda t: torch.as_tensor(t).contiguous().cuda()
     cut = lambda a: [d(a[t * B:(t + 1) * B]) for t in range(Tw)]
