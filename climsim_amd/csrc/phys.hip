@@ -136,7 +136,8 @@ __global__ __launch_bounds__(DT) void phys_decode_kernel(PhysDev d, int B, const
     __shared__ float s_T[LC * NC];                    // sub-column temperature (RAD: overwritten with its updated value)
     __shared__ float s_o01[PH_L][2];                  // RAD: the decoder's dT, dqv of every level (zero above the CRM top)
     __shared__ float s_scal[16];
-    constexpr int nh = 128, nm0 = 15;                 // enforced by csa_phys_create: compile-time trip counts (see phys_prep_kernel)
+    constexpr int nm0 = 15;                           // enforced by csa_phys_create: compile-time trip counts (see phys_prep_kernel)
+    const int nh = d.nh;
     const int b = blockIdx.x, tid = threadIdx.x, ilev = d.ilev, hd0 = ilev - d.ltop, HDW = d.hdw;
     const float CP = 1004.64f, G = 9.80665f, LV = 2510400.0f, LS = 2844000.0f, OOG = 0.1019716213f;
     const float sp = x_sfc[(size_t)b * d.naux] * d.xdiv_sca0 + d.xmean_sca0;
@@ -164,7 +165,6 @@ __global__ __launch_bounds__(DT) void phys_decode_kernel(PhysDev d, int B, const
         if (!RAD || o == 6) {
             const float *w = o < 6 ? d.sfo_w + o * nh : d.rel_w;
             float a = 0.0f;
-#pragma unroll
             for (int k = 0; k < nh / 8; ++k) a = fmaf(last_h[part + 8 * k], w[part + 8 * k], a);
             a += __shfl_xor(a, 4); a += __shfl_xor(a, 2); a += __shfl_xor(a, 1);
             if (part == 0) s_scal[o] = a + (o < 6 ? d.sfo_b[o] : d.rel_b[0]);
@@ -553,9 +553,9 @@ extern "C" int csa_phys_rad_create(int nx, int naux, int nh, int ilev_crm, int m
         csa_set_error_msg("csa_phys_rad_create: the physRad graphs come without MCICA sampling and with the liquid-fraction head");
         return CSA_ERR_UNSUPPORTED;
     }
-    if (nh != 128 || mp_ncol != (mcica ? 4 : 16) || nh_mem0 != 15 || ilev_crm != 10 || nx != 21 || naux != 19 || ng != PH_NG) {
-        csa_set_error_msg("csa_phys_rad_create: built for the shipped geometries (21 level inputs, 19 surface inputs, GRU 128/128 over 50 levels, "
-                          "15+1 memory channels, 16 g-points; mp_ncol 4 with MCICA sampling or mp_ncol 16 without)");
+    if ((nh != 128 && nh != 96) || mp_ncol != (mcica ? 4 : 16) || nh_mem0 != 15 || ilev_crm != 10 || nx != 21 || naux != 19 || ng != PH_NG) {
+        csa_set_error_msg("csa_phys_rad_create: built for the shipped geometries (21 level inputs, 19 surface inputs, GRU 128/128 or 96/96 over 50 "
+                          "levels, 15+1 memory channels, 16 g-points; mp_ncol 4 with MCICA sampling or mp_ncol 16 without)");
         return CSA_ERR_UNSUPPORTED;
     }
     PhysHostW v{};

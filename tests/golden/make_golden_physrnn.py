@@ -84,7 +84,8 @@ RAD_FAMILY = {"physrnn_rad_nomcica": "num71535_BEST", "physrnn_rad_liqfrac": "nu
 # no sub-grid temperature, liquid-fraction head, stochastic third RNN, rnn_mem passed level-major (50, B, 16)
 PHYSRAD = {"physrad16_a": "physRNN_physRad-16_nreg16_lr0.0007.neur128-128_xv4_mp1_num14751_BEST_script_cpu.pt",
            "physrad16_b": "physRNN_physRad-16_nreg16_lr0.0007.neur128-128_xv4_mp1_num55617_BEST_script_cpu.pt",
-           "physrad16_c": "physRNN_physRad-16_nreg16_lr0.0007.neur128-128_xv4_mp1_num55617_ep12_script_cpu.pt"}
+           "physrad16_c": "physRNN_physRad-16_nreg16_lr0.0007.neur128-128_xv4_mp1_num55617_ep12_script_cpu.pt",
+           "physrad16_nh96": "physRNN_physRad-16_nreg16_lr0.0007.neur96-96_xv4_mp1_num20600_BEST_script_cpu.pt"}   # GRU 96/96, no rnn3
 
 
 def staged_srnn(m, xm, xs, mem, seed, out_ref, sfc_ref, xd):
@@ -141,10 +142,11 @@ def main_rad(art=ART_RAD, name="physrnn_rad", cases=((8, 31), (37, 32)), mem_lev
             else:
                 out, out_sfc, mem_out = m([xm.clone(), xs.clone(), mem.clone(), xd.clone()])
         torch.manual_seed(1000 + seed)      # the artefact's draws, in its order: rnn2's state, rnn3's state, rnn3's noise
-        hx2 = torch.randn(B, 128)
+        nh = P["rnn2.weight_hh_l0"].shape[1]
+        hx2 = torch.randn(B, nh)
         if stoch:
-            d[f"case{i}.hx1"] = torch.randn(B, 128).numpy()
-            d[f"case{i}.eps3"] = torch.randn(50, B, 128).numpy()
+            d[f"case{i}.hx1"] = torch.randn(B, nh).numpy()
+            d[f"case{i}.eps3"] = torch.randn(50, B, nh).numpy()
         if stoch and mem_level_major:
             # This family's rnn3 is chaotic on these inputs (a 1e-6 difference in its input grows to 0.1 over the 50 levels), so no
             # two float32 implementations agree end to end.  Store the artefact's own rnn3 output for teacher-forced checks: the same
@@ -176,8 +178,9 @@ def check_float64():
             if lm:
                 ref[2] = ref[2].transpose(0, 1)
             torch.manual_seed(5)
-            hx2 = torch.randn(8, 128)
-            kw = dict(hx1=torch.randn(8, 128), eps3=torch.randn(50, 8, 128)) if "rnn3.weight_ih" in P else {}
+            nh = P["rnn2.weight_hh_l0"].shape[1]
+            hx2 = torch.randn(8, nh)
+            kw = dict(hx1=torch.randn(8, nh), eps3=torch.randn(50, 8, nh)) if "rnn3.weight_ih" in P else {}
             got = R.forward(P, xm, xs, mem, xd, hx2, **kw)
         finally:
             torch.set_default_dtype(torch.float32)

@@ -4,6 +4,7 @@
   physrnn_rad_liqfrac  num83000_ep20         + learned cloud liquid-fraction head
   physrnn_rad_stoch_*  num5730_BEST, num62104_BEST, num62104_BEST_ep11    num4050's graph + stochastic third RNN
 and the first geometry of the physRNN_physRad-* family (97 of the 114 shipped models):
+  physrad16_nh96       physRNN_physRad-16_nreg16_*neur96-96_xv4_mp1_num20600_BEST: the same graph with GRU 96/96 and no third RNN
   physrad16_a / b / c  physRNN_physRad-16_nreg16_*neur128-128_xv4_mp1_num14751_BEST, _num55617_BEST, _num55617_ep12: 16 regions,
                        region 0 clear sky, no sub-grid temperature, liquid-fraction head, stochastic third RNN, q/(1-q) mixing
                        ratio, rnn_mem level-major
@@ -70,7 +71,8 @@ def _noise_level(*realisations_then_exact):
 
 
 FIXTURES = [("physrnn_rad", 2), ("physrnn_rad_nomcica", 1), ("physrnn_rad_liqfrac", 1), ("physrnn_rad_stoch_a", 1),
-            ("physrnn_rad_stoch_b", 1), ("physrnn_rad_stoch_c", 1), ("physrad16_a", 1), ("physrad16_b", 1), ("physrad16_c", 1)]
+            ("physrnn_rad_stoch_b", 1), ("physrnn_rad_stoch_c", 1), ("physrad16_a", 1), ("physrad16_b", 1), ("physrad16_c", 1),
+            ("physrad16_nh96", 1)]
 
 
 def _noise(g, i):
@@ -113,7 +115,8 @@ def _draw_noise(P, B, seed):
     if "rnn3.weight_ih" not in P:
         return {}
     gen = torch.Generator().manual_seed(seed)
-    return {"hx1": torch.randn(B, 128, generator=gen), "eps3": torch.randn(50, B, 128, generator=gen)}
+    nh = P["rnn2.weight_hh_l0"].shape[1]
+    return {"hx1": torch.randn(B, nh, generator=gen), "eps3": torch.randn(50, B, nh, generator=gen)}
 
 
 @pytest.mark.parametrize("fixture,ncase", FIXTURES)
@@ -205,12 +208,12 @@ def test_hip_radiation_graph_matches_the_artefact(fixture, ncase):
 @pytest.mark.parametrize("fixture,B", [("physrnn_rad", 1), ("physrnn_rad", 2), ("physrnn_rad", 301), ("physrnn_rad", 384),
                                        ("physrnn_rad_nomcica", 301), ("physrnn_rad_liqfrac", 384), ("physrnn_rad_stoch_a", 2),
                                        ("physrnn_rad_stoch_b", 301), ("physrnn_rad_stoch_c", 384), ("physrad16_a", 2),
-                                       ("physrad16_a", 301), ("physrad16_a", 384)])
+                                       ("physrad16_a", 301), ("physrad16_a", 384), ("physrad16_nh96", 384)])
 def test_hip_radiation_graph_matches_restatement(fixture, B):
     g, P = _load(fixture)
     m = _hip_model(P, 384)
     xm, xs, mem, xd = inputs_rad(P, B, 70 + B)
-    hx2 = torch.randn(B, 128, generator=torch.Generator().manual_seed(B))
+    hx2 = torch.randn(B, P["rnn2.weight_hh_l0"].shape[1], generator=torch.Generator().manual_seed(B))
     nz = _draw_noise(P, B, 900 + B)
     taps = {}
     r64 = _ref64(P, xm, xs, mem, xd, hx2, taps, **nz)
