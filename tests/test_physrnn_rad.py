@@ -217,7 +217,7 @@ def test_hip_radiation_graph_matches_restatement(fixture, B):
     nz = _draw_noise(P, B, 900 + B)
     taps = {}
     r64 = _ref64(P, xm, xs, mem, xd, hx2, taps, **nz)
-    if fixture.startswith("physrad"):            # chaotic rnn3 (see _noise): everything after it with the float64 restatement's output
+    if fixture.startswith("physrad") and "rnn3.weight_ih" in P:            # chaotic rnn3 (see _noise): everything after it with the float64 restatement's output
         nz = {"srnn": taps["srnn"].float()}
         r64 = _ref64(P, xm, xs, mem, xd, hx2, taps, **nz)
     taps32 = {}
