@@ -13,7 +13,6 @@
 // HBM-bound elementwise kernel: reads 3.6 KB + 76 B (+3.8 KB memory) per column, writes the
 // rnn1 input rows X1 (L,B,nh1+nh_mem) in SEQUENCE order (t = 0 is the surface level).
 #include "common.h"
-#include <cstring>
 
 #define PREP_THREADS 128
 #define PREP_MAX_NXP 32   // nx+1 upper bound held in registers
@@ -184,167 +183,11 @@ __global__ __launch_bounds__(PREP_THREADS) void prep_kernel(
     }
 }
 
-// ------------------------------------------------------------------------------------------------------------------
-// Row-streaming form (round 2): one workgroup per (level, block of PREP_CB consecutive columns) instead of per (column, level
-// slice).  X1 is level-major, so the PREP_CB rows a workgroup produces are ONE contiguous run of PREP_CB * (nh1 + nh_mem) floats
-// (9.2 KB for 16 columns) instead of 15 separate 576-byte rows 221 KB apart, and a thread's mlp_initial weights are fetched
-// once per 16 outputs.  The small, strided reads are the inputs (60 B per column and level).  Same arithmetic, same summation
-// order as prep_kernel.  The surface / TOA initial states are formed by the level-0 workgroups (dispatched first).
-#define PREP_CB 16
-template <int NXP>
-__global__ __launch_bounds__(PREP_THREADS) void prep_rows_kernel(
-    DevModel m, int B, int normalised,
-    const float *__restrict__ x_main, const float *__restrict__ x_sfc,
-    const float *__restrict__ mem_in, float *__restrict__ X1, float *__restrict__ hc0,
-    float *__restrict__ X16out, float *__restrict__ xs_out)
-{
-    __shared__ __attribute__((aligned(16))) float xl[PREP_CB * NXP];     // (column, input), zero padded beyond nx + 1
-    __shared__ float xs[PREP_CB * 32];                                    // normalised surface inputs (level-0 workgroups)
-    const int L = m.cfg.nlev, nx = m.cfg.nx, nxp = nx + 1, nxs = m.cfg.nx_sfc;
-    const int nh1 = m.cfg.nh1, nh2 = m.cfg.nh2, nm = m.cfg.nh_mem, nin1 = nh1 + nm;
-    const int nhm = nh1 > nh2 ? nh1 : nh2;
-    const int l = blockIdx.y, b0 = blockIdx.x * PREP_CB, nc = min(PREP_CB, B - b0), tid = threadIdx.x;
-    const int t = m.cfg.add_stochastic_layer ? l : L - 1 - l;            // sequence position of this level (rnn0 runs downward)
-    float w0[NXP];
-    float bj0 = 0.0f;
-    if (tid < nh1) {
-#pragma unroll
-        for (int v = 0; v < NXP; ++v) w0[v] = v < nxp ? m.init_wt[v * nh1 + tid] : 0.0f;
-        bj0 = m.init_b[tid];
-    }
-    auto sfc_norm = [&](int b, int v) {
-        float x = x_sfc[(size_t)b * nxs + v];
-        if (!normalised) {
-            if (m.cfg.snowhice_fix && x >= 1e10f) x = -1.0f;
-            x = (x - m.xmean_sca[v]) / m.xdiv_sca[v];
-        }
-        return x;
-    };
-    if (l == 0)
-        for (int idx = tid; idx < nc * nxs; idx += PREP_THREADS) { const int c = idx / nxs, v = idx - c * nxs; xs[c * 32 + v] = sfc_norm(b0 + c, v); }
-    // ---- level inputs of the block's columns --------------------------------------------------
-    for (int idx = tid; idx < PREP_CB * NXP; idx += PREP_THREADS) {
-        const int c = idx / NXP, v = idx - c * NXP, b = b0 + c, gi = l * nx + v;
-        float x = 0.0f;
-        if (c < nc && v < nx) {
-            const int qmode = normalised ? 0 : m.cfg.q_input_mode, nxr = nx - (qmode == 1);
-            const float *xrow = x_main + ((size_t)b * L + l) * nxr;
-            x = v < nxr ? xrow[v] : 0.0f;
-            if ((qmode == 1 && v == nxr) || (qmode == 2 && v == 1)) {
-                const float pres = m.hyam[l] * 100000.0f + x_sfc[(size_t)b * nxs] * m.hybm[l];   // RAW surface pressure
-                x = prep_rh_to_q(xrow[1], xrow[0], pres);
-            }
-            if (!normalised) {
-                if (m.cfg.v5_input) {      // rnn/utils.py:186-198
-                    if (v == 2) {
-                        x = xrow[2] + xrow[3];
-                        if (m.cfg.qinput_prune && l < 15) x = 0.0f;
-                        x = 1.0f - expf(-x * m.lbd_qn[l]);
-                    }
-                    if (v == 3) x = fminf(fmaxf((xrow[0] - 253.16f) * 0.05f, 0.0f), 1.0f);
-                } else {
-                    if (v == 2) x = 1.0f - expf(-x * m.lbd_qc[l]);
-                    if (v == 3) x = 1.0f - expf(-x * m.lbd_qi[l]);
-                }
-                x = (x - m.xmean_lev[gi]) / m.xdiv_lev[gi];
-                if (!m.cfg.v5_input && m.cfg.qinput_prune && v == 2 && l < 15) x = 0.0f;
-                if (m.cfg.rh_prune && v == 1 && !isnan(x)) x = fminf(fmaxf(x, 0.0f), 1.2f);
-                if (isnan(x)) x = 0.0f;
-                if (m.cfg.scrub_inf && isinf(x)) x = 0.0f;
-            }
-        } else if (c < nc && v == nx) {    // pressure feature, from the normalised surface pressure as the reference forms it
-            const float sp = sfc_norm(b, 0) * m.xdiv_sca[0] + m.xmean_sca[0];
-            x = sqrtf(m.hyam[l] * 100000.0f + sp * m.hybm[l]) / 314.0f;
-        }
-        xl[idx] = x;
-    }
-    __syncthreads();
-    if (X16out) {   // training: keep what the backward of mlp_initial / the surface MLPs needs
-        for (int idx = tid; idx < nc * nxp; idx += PREP_THREADS) {
-            const int c = idx / nxp, v = idx - c * nxp;
-            X16out[((size_t)(b0 + c) * L + l) * nxp + v] = xl[c * NXP + v];
-        }
-        if (l == 0)
-            for (int idx = tid; idx < nc * nxs; idx += PREP_THREADS) { const int c = idx / nxs, v = idx - c * nxs; xs_out[(size_t)(b0 + c) * nxs + v] = xs[c * 32 + v]; }
-    }
-
-    // ---- initial states (level-0 workgroups) ---------------------------------------------------
-    if (l == 0) {
-        for (int j = tid; j < nh1; j += PREP_THREADS) {
-            float a[PREP_CB], c2[PREP_CB];
-#pragma unroll
-            for (int c = 0; c < PREP_CB; ++c) { a[c] = m.s1_b[j]; c2[c] = m.cfg.use_lstm ? m.s2_b[j] : 0.0f; }
-            for (int v = 0; v < nxs; ++v) {
-                const float w1 = m.s1_wt[v * nh1 + j], w2 = m.cfg.use_lstm ? m.s2_wt[v * nh1 + j] : 0.0f;
-#pragma unroll
-                for (int c = 0; c < PREP_CB; ++c) { const float x = xs[c * 32 + v]; a[c] += w1 * x; c2[c] += w2 * x; }
-            }
-#pragma unroll
-            for (int c = 0; c < PREP_CB; ++c)
-                if (c < nc) {
-                    hc0[((size_t)0 * B + b0 + c) * nhm + j] = tanhf(a[c]);
-                    if (m.cfg.use_lstm) hc0[((size_t)1 * B + b0 + c) * nhm + j] = m.cfg.legacy ? tanhf(c2[c]) : c2[c];
-                }
-        }
-        if (!m.cfg.legacy)
-            for (int j = tid; j < nh2; j += PREP_THREADS)
-                for (int c = 0; c < nc; ++c) {
-                    const float t0 = xs[c * 32 + 1], t1 = xs[c * 32 + 6];
-                    hc0[((size_t)2 * B + b0 + c) * nhm + j] = m.toa1_b[j] + m.toa1_wt[j] * t0 + m.toa1_wt[nh2 + j] * t1;
-                    if (m.cfg.use_lstm)
-                        hc0[((size_t)3 * B + b0 + c) * nhm + j] = m.toa2_b[j] + m.toa2_wt[j] * t0 + m.toa2_wt[nh2 + j] * t1;
-                }
-    }
-
-    // ---- mlp_initial + tanh: PREP_CB consecutive X1 rows ----------------------------------------
-    float *row0 = X1 + ((size_t)t * B + b0) * nin1;
-    for (int j = tid; j < nh1; j += PREP_THREADS) {
-        float w[NXP];
-        float bj = bj0;
-#pragma unroll
-        for (int v = 0; v < NXP; ++v) w[v] = w0[v];
-        if (j != tid) {
-#pragma unroll
-            for (int v = 0; v < NXP; ++v) w[v] = v < nxp ? m.init_wt[v * nh1 + j] : 0.0f;
-            bj = m.init_b[j];
-        }
-#pragma unroll 4
-        for (int c = 0; c < PREP_CB; ++c) {
-            const f32x4 *xr = (const f32x4 *)(xl + c * NXP);
-            float a0 = bj, a1 = 0.0f;
-#pragma unroll
-            for (int q = 0; q < NXP / 4; ++q) {
-                const f32x4 xv = xr[q];
-                a0 += w[4 * q] * xv.x; a1 += w[4 * q + 1] * xv.y;
-                a0 += w[4 * q + 2] * xv.z; a1 += w[4 * q + 3] * xv.w;
-            }
-            if (c < nc) row0[(size_t)c * nin1 + j] = prep_tanh(a0 + a1);
-        }
-    }
-    // ---- memory concat -------------------------------------------------------------------------
-    for (int idx = tid; idx < nc * nm; idx += PREP_THREADS) {
-        const int c = idx / nm, k = idx - c * nm, b = b0 + c;
-        const float v = m.cfg.legacy ? mem_in[((size_t)b * L + t) * nm + k]
-                                     : mem_in[((size_t)l * (m.mem_B > 0 ? m.mem_B : B) + m.mem_off + b) * nm + k];
-        row0[(size_t)c * nin1 + nh1 + k] = v;
-    }
-}
-
 static int launch_prep_impl(const DevModel &m, int B, int normalised, const float *x_main, const float *x_sfc,
                             const float *mem_in, float *X1, float *hc0, float *X16, float *xs_n, hipStream_t s)
 {
-    const int nxp = m.cfg.nx + 1, NXP = nxp <= 16 ? 16 : 32;
-    static const bool by_column = getenv("CSA_PREP") && !strcmp(getenv("CSA_PREP"), "columns");   // measurement only: the round-1 form
-    if (!by_column && m.cfg.nx_sfc <= 32) {
-        const dim3 grid((B + PREP_CB - 1) / PREP_CB, m.cfg.nlev), block(PREP_THREADS);
-        if (NXP == 16)
-            hipLaunchKernelGGL(prep_rows_kernel<16>, grid, block, 0, s, m, B, normalised, x_main, x_sfc, mem_in, X1, hc0, X16, xs_n);
-        else
-            hipLaunchKernelGGL(prep_rows_kernel<32>, grid, block, 0, s, m, B, normalised, x_main, x_sfc, mem_in, X1, hc0, X16, xs_n);
-        CSA_HIP_CHECK(hipGetLastError());
-        return CSA_OK;
-    }
     const int lper = (m.cfg.nlev + PREP_LSPLIT - 1) / PREP_LSPLIT;
+    const int nxp = m.cfg.nx + 1, NXP = nxp <= 16 ? 16 : 32;
     const size_t shm = sizeof(float) * ((size_t)lper * NXP + m.cfg.nx_sfc + 4);
     const dim3 grid(B, PREP_LSPLIT), block(PREP_THREADS);
     if (NXP == 16)
