@@ -36,10 +36,9 @@ struct csa_emulator {
     double acc_ms[6] = {};
     long n_prof = 0;
     bool pending = false;
-    // column parts on up to three streams (run_forward_halves): side streams + fork / join events
-    hipStream_t side = nullptr, side2 = nullptr;
-    hipEvent_t ov_ev[3] = {};
-    int max_parts = 0;           // CSA_MAX_PARTS (experiments): 0 = automatic
+    // column halves on two streams (run_forward_halves): side stream + fork / join events
+    hipStream_t side = nullptr;
+    hipEvent_t ov_ev[2] = {};
     int rec1_max_batch = 256;    // largest batch that uses the one-column-per-workgroup recurrent kernel (csa_set_rec1_max_batch)
     int halves = 2;              // two column halves on two streams (run_forward_halves): 0 off, 1 on, 2 auto (B >= 640)
 };
@@ -251,10 +250,8 @@ extern "C" int csa_create(const csa_config *cfg, const csa_params *hp, int max_b
             rc = csa_stoch_lstm4_create(cfg->nh1, cfg->nh2, hp->rnn2_weight_encoder, (int)(L * Bm), &h->stoch);
         if (rc == CSA_OK) {
             if (hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking) != hipSuccess) rc = CSA_ERR_HIP;
-            if (rc == CSA_OK && hipStreamCreateWithFlags(&h->side2, hipStreamNonBlocking) != hipSuccess) rc = CSA_ERR_HIP;
-            for (int i = 0; i < 3 && rc == CSA_OK; ++i)
+            for (int i = 0; i < 2 && rc == CSA_OK; ++i)
                 if (hipEventCreateWithFlags(&h->ov_ev[i], hipEventDisableTiming) != hipSuccess) rc = CSA_ERR_HIP;
-            if (const char *e = getenv("CSA_MAX_PARTS")) h->max_parts = atoi(e);
         }
     }
     if (rc != CSA_OK) {
@@ -274,9 +271,8 @@ extern "C" int csa_destroy(csa_emulator *h)
     free_all(h);
     if (h->stoch) (void)csa_stoch_destroy(h->stoch);
     for (int i = 0; i < 7; ++i) if (h->ev[i]) (void)hipEventDestroy(h->ev[i]);
-    for (int i = 0; i < 3; ++i) if (h->ov_ev[i]) (void)hipEventDestroy(h->ov_ev[i]);
+    for (int i = 0; i < 2; ++i) if (h->ov_ev[i]) (void)hipEventDestroy(h->ov_ev[i]);
     if (h->side) (void)hipStreamDestroy(h->side);
-    if (h->side2) (void)hipStreamDestroy(h->side2);
     delete h;
     return CSA_OK;
 }
@@ -434,47 +430,34 @@ static int run_chain(csa_emulator *h, int B, int normalised, int mode, const flo
     return launch_head(dm, B, mode, H2, x_main, x_sfc, y0, y1, y2, s);
 }
 
-// Column parts on separate streams: the batch is cut into independent column ranges, each runs its six launches on one of up to
-// three streams (caller's + two internal), so that one part's projection GEMM fills the issue gaps and idle CUs of another part's
-// recurrence.  Two halves up to 2,048 columns; beyond that parts of at most 1,024 columns dealt round-robin to three streams: the
-// four-column recurrence runs 256 workgroups = 1,024 columns per round, and a launch of 1,350 columns (338 workgroups) costs 171 us
-// against 102 us for 1,024 -- 2,700 columns as 3 x 900 keeps every recurrence launch within one round.
 static int run_forward_halves(csa_emulator *h, int B, int normalised, int mode, const float *x_main, const float *x_sfc,
                               const float *mem_in, const float *hx2, const float *cx2, float *y0, float *y1, float *y2,
                               hipStream_t s)
 {
     const csa_config &c = h->dm.cfg;
-    const int L = c.nlev;
+    const int L = c.nlev, B0 = ((B / 2) + 1) & ~1, B1 = B - B0;
     const size_t nhm = c.nh1 > c.nh2 ? c.nh1 : c.nh2, nin1 = c.nh1 + c.nh_mem;
     const int nxr = normalised ? c.nx : c.nx - (c.q_input_mode == 1);
     const int W = 6 * L + c.ny_sfc + L * c.nh_mem;
-    int nparts = B <= 2048 ? 2 : (B + 1023) / 1024;
-    if (h->max_parts > 0 && nparts > h->max_parts) nparts = h->max_parts;
-    const int psize = (((B + nparts - 1) / nparts) + 3) & ~3;          // multiple of 4 (columns per workgroup of the recurrence)
-    nparts = (B + psize - 1) / psize;
-    const int nstream = nparts < 3 ? nparts : 3;
-    hipStream_t S[3] = {s, h->side, h->side2};
+    hipStream_t T = h->side;
     int rc;
     CSA_HIP_CHECK(hipEventRecord(h->ov_ev[0], s));
-    for (int k = 1; k < nstream; ++k) CSA_HIP_CHECK(hipStreamWaitEvent(S[k], h->ov_ev[0], 0));
+    CSA_HIP_CHECK(hipStreamWaitEvent(T, h->ov_ev[0], 0));
     // level-major memory tensors (current generation) are addressed through (mem_B, mem_off); batch-first ones by pointer
     const bool lm = !c.legacy && c.nh_mem > 0;
-    for (int k = 0; k < nparts; ++k) {
-        const size_t o = (size_t)k * psize;                           // first column of the part: batch-first offsets of every caller
-        const int Bk = (int)((size_t)B - o < (size_t)psize ? B - o : psize);   // tensor, the matching range of every scratch buffer
-        float *y0k = y0 + (mode == HEAD_PACKED ? o * W : o * L * (mode == HEAD_RAW || c.mp_mode == 0 ? c.ny : 6));
-        rc = run_chain(h, Bk, normalised, mode, x_main + o * L * nxr, x_sfc + o * c.nx_sfc,
-                       mem_in ? (lm ? mem_in : mem_in + o * L * c.nh_mem) : nullptr,
-                       hx2 ? hx2 + o * c.nh2 : nullptr, cx2 ? cx2 + o * c.nh2 : nullptr, y0k, y1 ? y1 + o * c.ny_sfc : nullptr,
-                       y2 ? (lm ? y2 : y2 + o * L * c.nh_mem) : nullptr, h->X1 + (size_t)L * o * nin1, h->P + (size_t)L * o * 4 * nhm,
-                       h->H1 + (size_t)L * o * c.nh1, h->H2 + (size_t)L * o * c.nh2, h->hc0 + 4 * o * nhm, lm ? B : 0, lm ? (int)o : 0,
-                       S[k % nstream], B);
-        if (rc) return rc;
-    }
-    for (int k = 1; k < nstream; ++k) {
-        CSA_HIP_CHECK(hipEventRecord(h->ov_ev[k], S[k]));
-        CSA_HIP_CHECK(hipStreamWaitEvent(s, h->ov_ev[k], 0));
-    }
+    if ((rc = run_chain(h, B0, normalised, mode, x_main, x_sfc, mem_in, hx2, cx2, y0, y1, y2, h->X1, h->P, h->H1, h->H2, h->hc0,
+                        lm ? B : 0, 0, s, B))) return rc;
+    // second half: batch-first offsets of every caller tensor, the upper part of every scratch buffer
+    const size_t o = B0;
+    float *y0b = y0 + (mode == HEAD_PACKED ? o * W : o * L * (mode == HEAD_RAW || c.mp_mode == 0 ? c.ny : 6));
+    rc = run_chain(h, B1, normalised, mode, x_main + o * L * nxr, x_sfc + o * c.nx_sfc,
+                   mem_in ? (lm ? mem_in : mem_in + o * L * c.nh_mem) : nullptr,
+                   hx2 ? hx2 + o * c.nh2 : nullptr, cx2 ? cx2 + o * c.nh2 : nullptr, y0b, y1 ? y1 + o * c.ny_sfc : nullptr,
+                   y2 ? (lm ? y2 : y2 + o * L * c.nh_mem) : nullptr, h->X1 + (size_t)L * o * nin1, h->P + (size_t)L * o * 4 * nhm,
+                   h->H1 + (size_t)L * o * c.nh1, h->H2 + (size_t)L * o * c.nh2, h->hc0 + 4 * o * nhm, lm ? B : 0, lm ? B0 : 0, T, B);
+    if (rc) return rc;
+    CSA_HIP_CHECK(hipEventRecord(h->ov_ev[1], T));
+    CSA_HIP_CHECK(hipStreamWaitEvent(s, h->ov_ev[1], 0));
     return CSA_OK;
 }
 
