@@ -297,3 +297,31 @@ def test_hip_stochastic_graph_noise_handling():
     assert not torch.equal(a[0], c[0]) and torch.isfinite(c[0]).all()
     with pytest.raises(RuntimeError):
         m([xm, xs, mem, xd], hx2=hx2, hx1=nz["hx1"], eps3=nz["eps3"][:49])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fixture", ["physrnn_rad", "physrad16_b"])
+def test_hip_radiation_graph_properties_at_shard_size(fixture):
+    """2,700 columns (the per-GPU shard of the high-resolution grid): deterministic, finite, and a column's result does not
+    depend on which other columns share the call (rows of a 640-column call = the same rows of the 2,700-column call, bit for
+    bit: same kernel classes -- two-column GRU recurrence, 128 / 64-row GEMM tiles with identical k order)."""
+    g, P = _load(fixture)
+    m = _hip_model(P, 2700)
+    B = 2700
+    xm, xs, mem, xd = inputs_rad(P, B, 4242)
+    nh = P["rnn2.weight_hh_l0"].shape[1]
+    gen = torch.Generator().manual_seed(7)
+    kw = {"hx2": torch.randn(B, nh, generator=gen)}
+    if "rnn3.weight_ih" in P:
+        kw.update(hx1=torch.randn(B, nh, generator=gen), eps3=torch.randn(50, B, nh, generator=gen))
+    a = _run(m, xm, xs, mem, xd, **kw)
+    b = _run(m, xm, xs, mem, xd, **kw)
+    assert all(torch.equal(u, v) for u, v in zip(a, b)) and all(torch.isfinite(u).all() for u in a)
+    n = 640
+    sub = {k: (v[:, :n] if k == "eps3" else v[:n]).contiguous() for k, v in kw.items()}
+    c = _run(m, xm[:n].contiguous(), xs[:n].contiguous(), mem[:n].contiguous(), xd[:n].contiguous(), **sub)
+    for u, v in zip(a, c):
+        assert torch.equal(u[:n], v)
+    # night columns: no shortwave reaches the surface; precipitation is never negative
+    night = (xs[:, 6] * P["xdiv_sca"][6] + P["xmean_sca"][6]) < 1e-6
+    assert night.any() and torch.all(a[1][night][:, [0, 4, 5, 6, 7]] == 0) and torch.all(a[1][:, 3] >= 0)
