@@ -684,6 +684,45 @@ extern "C" int csa_phys_debug_rnn3(csa_phys *h, int T, int B, const float *x, co
     return csa_stoch_gru5_forward(h->rnn3, T, B, x, h0, eps, out, stream);
 }
 
+// physical_RNN_autoreg.postprocessing (the artefacts' exported method; rnn/models/models.py:273-339 with mp_mode 1): tendencies
+// de-normalised, the cloud-water tendency split into liquid and ice by the temperature ramp at the UPDATED temperature.
+// out (B,60,5) [dT, dqv, dqn, du, dv] normalised -> out6 (B,60,6) [dT, dqv, dqliq, dqice, du, dv] physical; out_sfc / yscale_sca.
+__global__ __launch_bounds__(256) void phys_post_kernel(PhysDev d, int B, const float *__restrict__ out, const float *__restrict__ out_sfc,
+                                                        const float *__restrict__ x_denorm, int nxd, float *__restrict__ out6,
+                                                        float *__restrict__ out_sfc_d)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < B * PH_L) {
+        const int L = i % PH_L;
+        const float *o = out + (size_t)i * 5, *ys = d.yscale_lev + L * 5, *xd = x_denorm + (size_t)i * nxd;
+        float v[5];
+#pragma unroll
+        for (int k = 0; k < 5; ++k) v[k] = o[k] / ys[k];
+        const float T_new = xd[0] + v[0] * 1200.0f;
+        const float lf = fminf(fmaxf((T_new - 253.16f) * 0.05f, 0.0f), 1.0f);
+        const float qn_new = (xd[2] + xd[3]) + v[2] * 1200.0f;
+        float *r = out6 + (size_t)i * 6;
+        r[0] = v[0]; r[1] = v[1];
+        r[2] = (lf * qn_new - xd[2]) * 0.0008333333333333334f;
+        r[3] = ((1.0f - lf) * qn_new - xd[3]) * 0.0008333333333333334f;
+        r[4] = v[3]; r[5] = v[4];
+    }
+    if (i < B * 8) out_sfc_d[i] = out_sfc[i] / d.yscale_sca[i & 7];
+}
+
+extern "C" int csa_phys_postprocess(csa_phys *h, int B, const float *out, const float *out_sfc, const float *x_denorm, int nxd,
+                                    float *out6, float *out_sfc_denorm, void *stream)
+{
+    if (!h || !out || !out_sfc || !x_denorm || !out6 || !out_sfc_denorm || B <= 0 || nxd < 4) {
+        csa_set_error_msg("csa_phys_postprocess: bad argument");
+        return CSA_ERR_ARG;
+    }
+    hipLaunchKernelGGL(phys_post_kernel, dim3((B * PH_L + 255) / 256), dim3(256), 0, (hipStream_t)stream, h->d, B, out, out_sfc, x_denorm, nxd,
+                       out6, out_sfc_denorm);
+    CSA_HIP_CHECK(hipGetLastError());
+    return CSA_OK;
+}
+
 // taps for tests: level-major (Lr, B, nh) outputs of rnn1 (level order) and rnn2 of the last call
 extern "C" int csa_phys_tap(csa_phys *h, int which, int B, float *dst, void *stream)
 {

@@ -134,6 +134,19 @@ class physical_RNN_autoreg(torch.nn.Module):
             raise RuntimeError(f"csa_phys_forward failed ({rc}): {_lib.last_error()}")
         return out, out_sfc, mem_out
 
+    def postprocessing(self, out, out_sfc, x_denorm):
+        """The module's exported method (rnn/models/models.py:273-339): (out (B,60,5), out_sfc (B,8)) normalised ->
+        (out (B,60,6) physical with the cloud-water tendency split into liquid / ice, out_sfc / yscale_sca)."""
+        B = out.shape[0]
+        out, out_sfc = _check(out, (B, self.nlev, 5), "out"), _check(out_sfc, (B, 8), "out_sfc")
+        x_denorm = _check(x_denorm, (B, self.nlev, x_denorm.shape[-1]), "x_denorm")
+        out6, sfc = torch.empty(B, self.nlev, 6, device=self.device), torch.empty(B, 8, device=self.device)
+        rc = _lib.lib().csa_phys_postprocess(self._h, B, _ptr(out), _ptr(out_sfc), _ptr(x_denorm), int(x_denorm.shape[-1]), _ptr(out6), _ptr(sfc),
+                                             ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream))
+        if rc != 0:
+            raise RuntimeError(f"csa_phys_postprocess failed ({rc}): {_lib.last_error()}")
+        return out6, sfc
+
     def debug_rnn3(self, x, h0, eps):
         """Test hook: this graph's stochastic third RNN alone, x (T, B, nh), h0 (B, nh), eps (T, B, nh) -> (T, B, nh)."""
         T, B = x.shape[0], x.shape[1]

@@ -407,6 +407,11 @@ int csa_phys_forward(csa_phys *h, int B, const float *x_main, const float *x_sfc
                      const float *x_denorm, int nxd, const float *hx2, float *out_lev, float *out_sfc, float *mem_out,
                      void *stream);
 int csa_phys_tap(csa_phys *h, int which, int B, float *dst, void *stream);
+/* The module's exported `postprocessing(out, out_sfc, x_denorm)` (rnn/models/models.py:273-339, mp_mode 1): out (B,60,5)
+ * normalised -> out6 (B,60,6) physical [dT, dqv, dqliq, dqice, du, dv] (cloud-water tendency split by the temperature ramp
+ * at the updated temperature), out_sfc (B,8) / yscale_sca -> out_sfc_denorm. */
+int csa_phys_postprocess(csa_phys *h, int B, const float *out, const float *out_sfc, const float *x_denorm, int nxd,
+                         float *out6, float *out_sfc_denorm, void *stream);
 
 /* The radiation graphs of the same model family (`use_physrad`: physRNN-Hidden_*_num4050 / num71535 / num83000 / num5730 /
  * num62104): 21 level inputs of which the first 18 and the layer pressure feed mlp_initial, both GRUs over the 50 CRM

@@ -44,6 +44,9 @@ def main(art=ART, name="physrnn_hidden", cases=((8, 11), (37, 12))):
         d[f"case{i}.cfg"] = np.array([B, seed], np.int64)
         for k, v in (("hx2", hx2), ("out", out), ("out_sfc", out_sfc), ("mem_out", mem_out)):
             d[f"case{i}.{k}"] = v.numpy()
+        with torch.no_grad():               # the module's exported postprocessing on its own outputs
+            p6, psfc = m.postprocessing(out.clone(), out_sfc.clone(), xd.clone())
+        d[f"case{i}.post_lev"], d[f"case{i}.post_sfc"] = p6.numpy(), psfc.numpy()
         print(i, B, out.abs().max().item(), out_sfc.abs().max().item(), mem_out.abs().max().item(), torch.isfinite(out).all().item())
     np.savez_compressed(f"{OUT}/{name}.npz", **d)
 
@@ -147,6 +150,10 @@ def main_rad(art=ART_RAD, name="physrnn_rad", cases=((8, 31), (37, 32)), mem_lev
         if stoch:
             d[f"case{i}.hx1"] = torch.randn(B, nh).numpy()
             d[f"case{i}.eps3"] = torch.randn(50, B, nh).numpy()
+        if not mem_level_major:
+            with torch.no_grad():           # the module's exported postprocessing on its own outputs
+                p6, psfc = m.postprocessing(out.clone(), out_sfc.clone(), xd.clone())
+            d[f"case{i}.post_lev"], d[f"case{i}.post_sfc"] = p6.numpy(), psfc.numpy()
         if stoch and mem_level_major:
             # This family's rnn3 is chaotic on these inputs (a 1e-6 difference in its input grows to 0.1 over the 50 levels), so no
             # two float32 implementations agree end to end.  Store the artefact's own rnn3 output for teacher-forced checks: the same

@@ -121,3 +121,26 @@ def test_hip_physrnn_errors_and_rollout_state():
     assert all(torch.equal(a, b) for a, b in zip(keep, (xm, xs, mem, xd)))
     out2, _, mem2 = m([xm, xs, mem1, xd])
     assert torch.isfinite(out2).all() and torch.isfinite(mem2).all() and mem2.shape == mem.shape
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fixture,gen", [("physrnn_hidden", "inputs"), ("physrnn_rad", "inputs_rad")])
+def test_hip_physrnn_postprocessing_matches_the_artefact(fixture, gen):
+    """The module's exported `postprocessing(out, out_sfc, x_denorm)` (models.py:273-339) applied to the artefact's own outputs."""
+    import make_golden_physrnn as G
+    g, P = _load(fixture)
+    m = _hip_model(P, 64)
+    for i in range(2):
+        B, seed = (int(v) for v in g[f"case{i}.cfg"])
+        xd = getattr(G, gen)(P, B, seed)[3]
+        out, out_sfc = torch.from_numpy(g[f"case{i}.out"]), torch.from_numpy(g[f"case{i}.out_sfc"])
+        p6, psfc = m.postprocessing(out.cuda(), out_sfc.cuda(), xd.cuda())
+        r6, rsfc = torch.from_numpy(g[f"case{i}.post_lev"]), torch.from_numpy(g[f"case{i}.post_sfc"])
+        for c in range(6):
+            scale = r6[..., c].abs().max().item()
+            # columns 2, 3: (lf * (qn + 1200 dqn) - q) / 1200 -- a difference of two numbers that agree to ~1e-3: 1e-5 of the
+            # LARGER of the tendency and q / 1200
+            if c in (2, 3):
+                scale = max(scale, xd[..., c].abs().max().item() / 1200.0)
+            assert (p6[..., c].cpu() - r6[..., c]).abs().max().item() <= 1e-5 * scale, c
+        assert (psfc.cpu() - rsfc).abs().max().item() <= 1e-6 * rsfc.abs().max().item()
