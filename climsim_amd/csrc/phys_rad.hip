@@ -342,12 +342,14 @@ __global__ __launch_bounds__(RS_T) void phys_rad_solve_kernel(PhysDev d, int B, 
         const int g = tid;
         float f = 0.0f;
         s_ldn[g] = 0.0f;
+#pragma unroll 4                                      // (the LDS operands of the next levels are fetched ahead of the dependent chain)
         for (int j = 0; j < L; ++j) {
             f = s_tr[j * NG + g] * f + s_su[j * NG + g];
             s_ldn[(j + 1) * NG + g] = f;
         }
         f = s_pf[(L - 1) * NG + g] * s_aux[11];       // surface emission (emissivity 1)
         s_lup[L * NG + g] = f;
+#pragma unroll 4
         for (int j = L - 1; j >= 0; --j) {
             f = s_tr[j * NG + g] * f + s_su[j * NG + g];
             s_lup[j * NG + g] = f;
@@ -359,6 +361,7 @@ __global__ __launch_bounds__(RS_T) void phys_rad_solve_kernel(PhysDev d, int B, 
         float A = g < n_ir ? s_aux[7] : g < n_mix ? (s_aux[7] + s_aux[9]) * 0.5f : s_aux[9];
         float Ad = g < n_ir ? s_aux[8] : g < n_mix ? (s_aux[8] + s_aux[10]) * 0.5f : s_aux[10];
         s_A[L * NG + g] = A; s_Ad[L * NG + g] = Ad;
+#pragma unroll 4
         for (int j = L - 1; j >= 0; --j) {
             const int e = j * NG + g;
             const float inv = 1.0f / (1.0f - A * s_R[e]);
@@ -368,6 +371,7 @@ __global__ __launch_bounds__(RS_T) void phys_rad_solve_kernel(PhysDev d, int B, 
         }
         float dif = 0.0f, dr = toa;
         s_sup[g] = fmaxf(toa * Ad, 0.0f); s_sdf[g] = 0.0f; s_sdr[g] = fmaxf(toa, 0.0f);
+#pragma unroll 4
         for (int j = 0; j < L; ++j) {
             const int e = j * NG + g;
             const float Ab = s_A[e + NG], Adb = s_Ad[e + NG];
@@ -381,7 +385,7 @@ __global__ __launch_bounds__(RS_T) void phys_rad_solve_kernel(PhysDev d, int B, 
     }
     __syncthreads();
     // ---- spectral sums, net flux per interface, surface diagnostics ----
-    const float day = s_aux[6] < 1e-6f ? 0.0f : 1.0f;
+    const bool day = !(s_aux[6] < 1e-6f);           // night columns: shortwave terms are SET to zero (assignment upstream, so no 0 * inf)
     if (tid <= L) {
         const int j = tid;
         float ldn = 0.0f, lup = 0.0f, up = 0.0f, df = 0.0f, dr = 0.0f;
@@ -391,7 +395,7 @@ __global__ __launch_bounds__(RS_T) void phys_rad_solve_kernel(PhysDev d, int B, 
             up += s_sup[j * NG + g]; df += s_sdf[j * NG + g]; dr += s_sdr[j * NG + g];
         }
         const float sw_dn = df + dr;
-        s_net[j] = (ldn - lup) + day * (sw_dn - up);
+        s_net[j] = (ldn - lup) + (day ? sw_dn - up : 0.0f);
         if (j == L) {
             float dir_ir = 0.0f, dir_mix = 0.0f, dir_vis = 0.0f, dif_ir = 0.0f, dif_mix = 0.0f, dif_vis = 0.0f;
             for (int g = 0; g < NG; ++g) {
@@ -399,12 +403,12 @@ __global__ __launch_bounds__(RS_T) void phys_rad_solve_kernel(PhysDev d, int B, 
                 if (g < 11) { dir_ir += a; dif_ir += c; } else if (g < 13) { dir_mix += a; dif_mix += c; } else { dir_vis += a; dif_vis += c; }
             }
             float *os = out_sfc + (size_t)b * 8;
-            os[0] = day * sw_dn * d.ys_rad[0];
+            os[0] = (day ? sw_dn : 0.0f) * d.ys_rad[0];
             os[1] = ldn * d.ys_rad[1];
-            os[4] = day * (dir_vis + 0.5f * dir_mix) * d.ys_rad[2];      // SOLS
-            os[5] = day * (dir_ir + 0.5f * dir_mix) * d.ys_rad[3];       // SOLL
-            os[6] = day * (dif_vis + 0.5f * dif_mix) * d.ys_rad[4];      // SOLSD
-            os[7] = day * (dif_ir + 0.5f * dif_mix) * d.ys_rad[5];       // SOLLD
+            os[4] = (day ? dir_vis + 0.5f * dir_mix : 0.0f) * d.ys_rad[2];      // SOLS
+            os[5] = (day ? dir_ir + 0.5f * dir_mix : 0.0f) * d.ys_rad[3];       // SOLL
+            os[6] = (day ? dif_vis + 0.5f * dif_mix : 0.0f) * d.ys_rad[4];      // SOLSD
+            os[7] = (day ? dif_ir + 0.5f * dif_mix : 0.0f) * d.ys_rad[5];       // SOLLD
         }
     }
     __syncthreads();
