@@ -2,6 +2,7 @@
 max-over-ranks timing, the one flat gradient all-reduce) -- and, through the oracle, that
 sharded evaluation reproduces the unsharded result bit for bit (columns are independent)."""
 import os
+import re
 import socket
 
 import numpy as np
@@ -149,5 +150,8 @@ def test_bench_spawns_its_own_ranks_before_touching_the_gpu():
     if torch.cuda.is_available() and torch.cuda.device_count() >= 2:
         assert r.returncode == 0 and '"n_gpus": 2' in r.stdout
     else:
+        # each rank stops at its own device check; the elastic agent may tear the other one down before it has printed, so
+        # either rank's message -- under a 2-rank launch (WORLD_SIZE 2 is what makes bench.py reach that check) -- is the proof
         assert r.returncode != 0
-        assert "LOCAL_RANK 1 but only" in r.stderr or '"n_gpus": 2' in r.stdout, r.stderr[-2000:]
+        assert re.search(r"LOCAL_RANK [01] but only", r.stderr) or '"n_gpus": 2' in r.stdout, r.stderr[-2000:]
+        assert "nproc" in r.stderr or "local_rank" in r.stderr or "torch.distributed" in r.stderr or "elastic" in r.stderr, r.stderr[-2000:]
