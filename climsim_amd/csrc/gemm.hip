@@ -236,75 +236,9 @@ int launch_gemm_ex(const float *A, const float *W, const float *bias, float *C, 
     return launch_gemm_epi(A, W, bias, C, M, N, K, act, alpha, n_lin, lda, ldc, conv_L, conv_cin, e, s);
 }
 
-// The narrow remainder of an output whose width is not a multiple of 128: columns [n_base, N), at most 32, as a 128 x 32 tile per
-// workgroup (4 waves along M, one accumulator each; operands straight from LDS as in the main kernel).  The input gradient of
-// rnn1 is (rows) x (nh + 16): with 128-wide tiles only, its 16 memory columns cost a second full tile.  Plain GEMM + bias only.
-__global__ __launch_bounds__(GB_THREADS) void proj_gemm_narrow_kernel(
-    const float *__restrict__ A, const float *__restrict__ W, const float *__restrict__ bias, float *__restrict__ C,
-    int M, int N, int K, int n_base, int lda, int ldc)
-{
-    __shared__ float As[2][GB_M * GB_LD];
-    __shared__ float Ws[2][32 * GB_LD];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int m0 = blockIdx.x * GB_M;
-    const int lr = tid >> 2, kq = (tid & 3) * 4;
-    f32x4 ra[2], rw;
-    auto gload = [&](int k0) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int row = m0 + lr + 64 * i, k = k0 + kq;
-            ra[i] = (row < M && k < K) ? *(const f32x4 *)(A + (size_t)row * lda + k) : f32x4{0, 0, 0, 0};
-        }
-        const int col = n_base + lr, k = k0 + kq;
-        rw = (lr < 32 && col < N && k < K) ? *(const f32x4 *)(W + (size_t)col * K + k) : f32x4{0, 0, 0, 0};
-    };
-    auto sstore = [&](int buf) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            float *pa = As[buf] + (lr + 64 * i) * GB_LD + kq;
-            pa[0] = ra[i].x; pa[1] = ra[i].y; pa[2] = ra[i].z; pa[3] = ra[i].w;
-        }
-        if (lr < 32) { float *pw = Ws[buf] + lr * GB_LD + kq; pw[0] = rw.x; pw[1] = rw.y; pw[2] = rw.z; pw[3] = rw.w; }
-    };
-    f32x16 acc;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-    const int arow = (wave * 32 + (lane & 31)) * GB_LD + (lane >> 5), wrow = (lane & 31) * GB_LD + (lane >> 5);
-    gload(0);
-    sstore(0);
-    __syncthreads();
-    const int nchunk = (K + GB_K - 1) / GB_K;
-    for (int c = 0; c < nchunk; ++c) {
-        const int cur = c & 1;
-        if (c + 1 < nchunk) gload((c + 1) * GB_K);
-        const float *as = As[cur], *ws = Ws[cur];
-#pragma unroll
-        for (int kk = 0; kk < GB_K / 2; ++kk) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(as[arow + kk * 2], ws[wrow + kk * 2], acc, 0, 0, 0);
-        if (c + 1 < nchunk) sstore(cur ^ 1);
-        __syncthreads();
-    }
-    const int col = n_base + (lane & 31);
-    const float bv = (bias && col < N) ? bias[col] : 0.0f;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int row = m0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        if (row < M && col < N) C[(size_t)row * ldc + col] = acc[r] + bv;
-    }
-}
-
 int launch_gemm_epi(const float *A, const float *W, const float *bias, float *C, int M, int N, int K, int act, float alpha,
                     int n_lin, int lda, int ldc, int conv_L, int conv_cin, const GemmEpi &epi, hipStream_t s)
 {
-    // a remainder of at most 32 columns beyond a multiple of 128 goes to the narrow-tile kernel (plain GEMMs only; same k order per
-    // element in both kernels, so the values do not depend on the routing)
-    if (act == 0 && conv_L == 0 && !epi.addsrc && !epi.mask && !epi.gate && N > GB_N && N % GB_N > 0 && N % GB_N <= 32 && K % 4 == 0 && lda % 4 == 0) {
-        const int Nc = N - N % GB_N;
-        const int rc = launch_gemm_epi(A, W, bias, C, M, Nc, K, act, alpha, n_lin, lda, ldc, conv_L, conv_cin, epi, s);
-        if (rc) return rc;
-        hipLaunchKernelGGL(proj_gemm_narrow_kernel, dim3((M + GB_M - 1) / GB_M), dim3(GB_THREADS), 0, s, A, W, bias, C, M, N, K, Nc, lda, ldc);
-        CSA_HIP_CHECK(hipGetLastError());
-        return CSA_OK;
-    }
     if ((lda % 4) || (conv_L > 0 && (conv_cin % 4 || K != 3 * conv_cin))) {
         csa_set_error_msg("gemm_ex: lda and cin must be multiples of 4, K = 3*cin in conv mode");
         return CSA_ERR_UNSUPPORTED;

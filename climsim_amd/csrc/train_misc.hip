@@ -18,9 +18,8 @@
 #define TN_MK 16
 __global__ __launch_bounds__(256) void gemm_tn_partial_kernel(
     TnSegs segs, int lda, int ldb, float *__restrict__ Cpart,
-    int M, int N1, int N2, int N2c, int rows_per_split, int splits_per_seg, int conv_L, int conv_cin)
+    int M, int N1, int N2, int rows_per_split, int splits_per_seg, int conv_L, int conv_cin)
 {
-    // N2c <= N2: the columns [0, N2c) of the result are computed here (the rest by gemm_tn_narrow_kernel); N2 stays the row stride.
     // segs: up to TN_MAX_SEGS (A, B) pairs of M rows each, contracted into ONE result (the T_w time steps of a TBPTT
     // window share their weight gradient): split z works on segment z / splits_per_seg.
     const float *__restrict__ A = segs.A[blockIdx.z / splits_per_seg];
@@ -61,8 +60,8 @@ __global__ __launch_bounds__(256) void gemm_tn_partial_kernel(
                     okb = !((l == 0 && c2 < conv_cin) || (l == conv_L - 1 && c2 >= 2 * conv_cin));
                 }
                 if (okb) {
-                    if (n20 + sc + 3 < N2c) vb[h] = *(const f32x4 *)pb;
-                    else for (int e = 0; e < 4; ++e) if (n20 + sc + e < N2c) vb[h][e] = pb[e];
+                    if (n20 + sc + 3 < N2) vb[h] = *(const f32x4 *)pb;
+                    else for (int e = 0; e < 4; ++e) if (n20 + sc + e < N2) vb[h][e] = pb[e];
                 }
             }
         }
@@ -105,72 +104,8 @@ __global__ __launch_bounds__(256) void gemm_tn_partial_kernel(
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int c1 = n10 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                if (c1 < N1 && c2 < N2c) C[(size_t)c1 * N2 + c2] = acc[i][j][r];
+                if (c1 < N1 && c2 < N2) C[(size_t)c1 * N2 + c2] = acc[i][j][r];
             }
-    }
-}
-
-// The narrow remainder of a result whose width is not a multiple of 128: columns [n2_base, N2), at most 32 of them, as a
-// 128 x 32 tile per workgroup (4 waves along N1, one MFMA accumulator each).  rnn1's input-weight gradient is (4 nh) x (nh + 16):
-// with 128-wide tiles only, the 16 memory columns cost a second full tile -- 44 % of that GEMM's matrix work for 11 % of its result.
-__global__ __launch_bounds__(256) void gemm_tn_narrow_kernel(
-    TnSegs segs, int lda, int ldb, float *__restrict__ Cpart,
-    int M, int N1, int N2, int n2_base, int rows_per_split, int splits_per_seg)
-{
-    const float *__restrict__ A = segs.A[blockIdx.z / splits_per_seg];
-    const float *__restrict__ Bm = segs.B[blockIdx.z / splits_per_seg];
-    __shared__ float As[2][TN_MK][TN_T];
-    __shared__ float Bs[2][TN_MK][32];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int n10 = blockIdx.x * TN_T, split = blockIdx.z;
-    const int m_begin = (split % splits_per_seg) * rows_per_split, m_end = min(M, m_begin + rows_per_split);
-    f32x16 acc;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-    const int sr = tid >> 5, sc = (tid & 31) * 4;          // A: 16 rows x 128 floats, two float4 per thread
-    const int br = tid >> 4, bc = (tid & 15) * 2;          // B: 16 rows x 32 floats, one float2 per thread
-    f32x4 va[2];
-    float vb[2];
-    auto gload = [&](int m0) {
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int m = m0 + sr + 8 * h;
-            va[h] = f32x4{0, 0, 0, 0};
-            if (m < m_end) {
-                const float *pa = A + (size_t)m * lda + n10 + sc;
-                if (n10 + sc + 3 < N1) va[h] = *(const f32x4 *)pa;
-                else for (int e = 0; e < 4; ++e) if (n10 + sc + e < N1) va[h][e] = pa[e];
-            }
-        }
-        const int m = m0 + br;
-#pragma unroll
-        for (int e = 0; e < 2; ++e) vb[e] = (m < m_end && n2_base + bc + e < N2) ? Bm[(size_t)m * ldb + n2_base + bc + e] : 0.0f;
-    };
-    auto sstore = [&](int buf) {
-#pragma unroll
-        for (int h = 0; h < 2; ++h) *(f32x4 *)&As[buf][sr + 8 * h][sc] = va[h];
-        Bs[buf][br][bc] = vb[0]; Bs[buf][br][bc + 1] = vb[1];
-    };
-    if (m_begin < m_end) { gload(m_begin); sstore(0); }
-    __syncthreads();
-    int cur = 0;
-    for (int m0 = m_begin; m0 < m_end; m0 += TN_MK, cur ^= 1) {
-        const bool more = m0 + TN_MK < m_end;
-        if (more) gload(m0 + TN_MK);
-#pragma unroll
-        for (int kk = 0; kk < TN_MK / 2; ++kk) {
-            const int kr = kk * 2 + (lane >> 5);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(As[cur][kr][wave * 32 + (lane & 31)], Bs[cur][kr][lane & 31], acc, 0, 0, 0);
-        }
-        if (more) sstore(cur ^ 1);
-        __syncthreads();
-    }
-    float *C = Cpart + (size_t)split * N1 * N2;
-    const int c2 = n2_base + (lane & 31);
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int c1 = n10 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        if (c1 < N1 && c2 < N2) C[(size_t)c1 * N2 + c2] = acc[r];
     }
 }
 
@@ -198,16 +133,8 @@ int launch_gemm_tn_segs(const TnSegs &segs, int lda, int ldb, float *Cpart, int 
     const int sps = nsplit / segs.n;
     int rps = (M + sps - 1) / sps;
     rps = (rps + TN_MK - 1) / TN_MK * TN_MK;
-    // a remainder of at most 32 columns beyond a multiple of 128 goes to the narrow-tile kernel (same k order per element:
-    // every result element is one chain over its split's rows in both kernels, so the values do not depend on the routing)
-    const int rem = N2 % TN_T;
-    const bool narrow = conv_L == 0 && N2 > TN_T && rem > 0 && rem <= 32;
-    const int N2c = narrow ? N2 - rem : N2;
-    dim3 grid((N1 + TN_T - 1) / TN_T, (N2c + TN_T - 1) / TN_T, nsplit);
-    hipLaunchKernelGGL(gemm_tn_partial_kernel, grid, dim3(256), 0, s, segs, lda, ldb, Cpart, M, N1, N2, N2c, rps, sps, conv_L, conv_cin);
-    if (narrow)
-        hipLaunchKernelGGL(gemm_tn_narrow_kernel, dim3((N1 + TN_T - 1) / TN_T, 1, nsplit), dim3(256), 0, s, segs, lda, ldb, Cpart, M, N1, N2, N2c,
-                           rps, sps);
+    dim3 grid((N1 + TN_T - 1) / TN_T, (N2 + TN_T - 1) / TN_T, nsplit);
+    hipLaunchKernelGGL(gemm_tn_partial_kernel, grid, dim3(256), 0, s, segs, lda, ldb, Cpart, M, N1, N2, rps, sps, conv_L, conv_cin);
     CSA_HIP_CHECK(hipGetLastError());
     return CSA_OK;
 }
