@@ -29,7 +29,8 @@ struct PhysDev {
     const float *sfo_w, *sfo_b;                     // mlp_surface_output_rad (6, nh)            (rad == 0)
     const float *rel_w, *rel_b;                     // mlp_precip_release (1, nh)
     // radiation scheme (rad == 1)
-    const float *xmean_sca, *xdiv_sca, *lbd_qn, *g_xmin, *g_xmax, *g_ymean, *g_ystd, *ys_rad, *toa_spec, *retab;
+    const float *xmean_sca, *xdiv_sca, *lbd_qn, *g_xmin, *g_range, *g_ymean, *g_ystd, *ys_rad, *toa_spec, *retab;
+    int lw_dn;              // 1: the LW downward sweep gets its own source (later exports); 0: the upward one, as first serialised
 };
 
 struct csa_phys {

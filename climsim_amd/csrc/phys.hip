@@ -321,7 +321,7 @@ __global__ __launch_bounds__(DT) void phys_decode_kernel(PhysDev d, int B, const
             float *xg = ro.XG + row * PH_XG_K;
 #pragma unroll
             for (int k = 0; k < PH_XG_K; ++k)
-                xg[k] = k < 18 ? fmaxf((f[k] - d.g_xmin[k]) / (d.g_xmax[k] - d.g_xmin[k]), 0.0f) : 0.0f;
+                xg[k] = k < 18 ? fmaxf((f[k] - d.g_xmin[k]) / d.g_range[k], 0.0f) : 0.0f;
             float *xr = ro.XR + row * PH_XR_K;
             const float *xm = ro.x_main + ((size_t)b * PH_L + L) * d.nx;
             xr[0] = (lp - 0.00515f) / 11.59485f;
@@ -389,7 +389,7 @@ struct PhysHostW {           // host pointers of one state_dict, by role
     const float *lat_w, *lat_b, *out_w, *out_b, *sfo_w, *sfo_b, *rad_w, *rad_b, *rel_w, *rel_b;
     const float *const *heads;    // 11 x (weight (mp_ncol, nh), bias) in head-GEMM column order
     // radiation scheme
-    const float *lbd_qn, *ys_rad, *solar_w, *g_xmin, *g_xmax, *g_ymean, *g_ystd;
+    const float *lbd_qn, *ys_rad, *solar_w, *g_xmin, *g_xmax /* or the range itself, see lw_dn */, *g_ymean, *g_ystd;
     const float *g_w1, *g_b1, *g_w2, *g_b2, *g_w3, *g_b3, *r1_w, *r1_b, *r2_w, *r2_b, *sw1_w, *sw1_b, *sw2_w, *sw2_b;
     const float *liq_w, *liq_b;              // mlp_liq_frac_crm (mp_ncol, nh), optional
     const float *s3_ih, *s3_zh, *s3_enc;     // rnn3 = MyStochasticGRULayer5(nh, nh) without bias, optional
@@ -409,7 +409,7 @@ static const float kRetab[PH_NRETAB] = {
     231.661f, 240.971f, 250.639f};
 
 static int phys_build(int nx, int nfeat, int naux, int nx_sfc, int sfc_cut, int nh, int ilev_crm, int mp_ncol, int nh_mem0, int rad, int physrad,
-                      const PhysHostW &w, int max_batch, csa_phys **out)
+                      int lw_dn, const PhysHostW &w, int max_batch, csa_phys **out)
 {
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) { csa_set_error_msg("csa_phys_create: no HIP device"); return CSA_ERR_HIP; }
@@ -489,7 +489,13 @@ static int phys_build(int nx, int nfeat, int naux, int nx_sfc, int sfc_cut, int 
     h->H2 = up(nullptr, rows * nh); h->hx = up(nullptr, (size_t)max_batch * nh); h->HD = up(nullptr, rows * d.hdw);
     if (rad) {
         d.xmean_sca = up(w.xms, naux); d.xdiv_sca = up(w.xds, naux); d.lbd_qn = up(w.lbd_qn, 60);
-        d.g_xmin = up(w.g_xmin, 18); d.g_xmax = up(w.g_xmax, 18); d.g_ymean = up(w.g_ymean, 128); d.g_ystd = up(w.g_ystd, 128);
+        {   // normalisation range of the gas-optics inputs: xmax - xmin (float, as the reference subtracts) or the stored `xdiv`
+            float rg[18];
+            for (int k = 0; k < 18; ++k) rg[k] = lw_dn ? w.g_xmax[k] : w.g_xmax[k] - w.g_xmin[k];
+            d.g_range = up(rg, 18);
+        }
+        d.lw_dn = lw_dn;
+        d.g_xmin = up(w.g_xmin, 18); d.g_ymean = up(w.g_ymean, 128); d.g_ystd = up(w.g_ystd, 128);
         d.ys_rad = up(w.ys_rad, 6); d.retab = up(kRetab, PH_NRETAB);
         {   // incoming spectral weights: softmax of the squared learned weights (physRad graphs: un-squared), float arithmetic
             float sq[PH_NG], m = -3.0e38f, sum = 0.0f, e[PH_NG];
@@ -540,21 +546,22 @@ extern "C" int csa_phys_create(int nx, int nx_sfc, int nh, int ilev_crm, int mp_
     v.lat_w = *p++; v.lat_b = *p++; v.out_w = *p++; v.out_b = *p++; v.sfo_w = *p++; v.sfo_b = *p++; v.rad_w = *p++; v.rad_b = *p++;
     v.rel_w = *p++; v.rel_b = *p++;
     v.heads = p;
-    return phys_build(nx, nx, nx_sfc, nx_sfc, nx_sfc, nh, ilev_crm, mp_ncol, nh_mem0, 0, 0, v, max_batch, out);
+    return phys_build(nx, nx, nx_sfc, nx_sfc, nx_sfc, nh, ilev_crm, mp_ncol, nh_mem0, 0, 0, 0, v, max_batch, out);
 }
 
 // The radiation graphs (num4050): see include/climsim_amd.h for the pointer order
 extern "C" int csa_phys_rad_create(int nx, int naux, int nh, int ilev_crm, int mp_ncol, int nh_mem0, int ng, int flags,
                                    const float *const *w, int max_batch, csa_phys **out)
 {
-    if (!w || !out || max_batch <= 0 || (flags & ~15)) { csa_set_error_msg("csa_phys_rad_create: bad argument"); return CSA_ERR_ARG; }
+    if (!w || !out || max_batch <= 0 || (flags & ~31)) { csa_set_error_msg("csa_phys_rad_create: bad argument"); return CSA_ERR_ARG; }
     const bool mcica = flags & CSA_PHYS_MCICA, physrad = flags & CSA_PHYS_PHYSRAD;
     if (physrad && (mcica || !(flags & CSA_PHYS_LIQ_FRAC_HEAD))) {
         csa_set_error_msg("csa_phys_rad_create: the physRad graphs come without MCICA sampling and with the liquid-fraction head");
         return CSA_ERR_UNSUPPORTED;
     }
-    if ((nh != 128 && nh != 96) || mp_ncol != (mcica ? 4 : 16) || nh_mem0 != 15 || ilev_crm != 10 || nx != 21 || naux != 19 || ng != PH_NG) {
-        csa_set_error_msg("csa_phys_rad_create: built for the shipped geometries (21 level inputs, 19 surface inputs, GRU 128/128 or 96/96 over 50 "
+    if ((nh != 128 && nh != 112 && nh != 96) || mp_ncol != (mcica ? 4 : 16) || nh_mem0 != 15 || ilev_crm != 10 || (nx != 21 && nx != 16) || naux != 19 ||
+        ng != PH_NG) {
+        csa_set_error_msg("csa_phys_rad_create: built for the shipped geometries (21 or 16 level inputs, 19 surface inputs, GRU 128 / 112 / 96 over 50 "
                           "levels, 15+1 memory channels, 16 g-points; mp_ncol 4 with MCICA sampling or mp_ncol 16 without)");
         return CSA_ERR_UNSUPPORTED;
     }
@@ -576,7 +583,7 @@ extern "C" int csa_phys_rad_create(int nx, int naux, int nh, int ilev_crm, int m
             return CSA_ERR_ARG;
         }
     // mlp_initial sees x_main[:, :, 0:nx-3] and the layer pressure; mlp_surface1 sees aux 0:6 and 11:naux
-    return phys_build(nx, nx - 3, naux, naux - 5, 6, nh, ilev_crm, mp_ncol, nh_mem0, 1, physrad ? 1 : 0, v, max_batch, out);
+    return phys_build(nx, nx - 3, naux, naux - 5, 6, nh, ilev_crm, mp_ncol, nh_mem0, 1, physrad ? 1 : 0, (flags & CSA_PHYS_LATER_EXPORT) ? 1 : 0, v, max_batch, out);
 }
 
 extern "C" int csa_phys_destroy(csa_phys *h)

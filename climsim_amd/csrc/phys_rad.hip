@@ -264,7 +264,7 @@ __global__ __launch_bounds__(RS_T) void phys_rad_solve_kernel(PhysDev d, int B, 
                                                             const float *__restrict__ RS, float *__restrict__ out_lev, float *__restrict__ out_sfc)
 {
     constexpr int L = PH_L, NG = PH_NG, NC = L * NG, NI = (L + 1) * NG;
-    __shared__ float s_tr[NC], s_su[NC], s_pf[NC];                               // LW: transmittance, source, Planck fraction
+    __shared__ float s_tr[NC], s_su[NC], s_sd[NC], s_pf[NC];                     // LW: transmittance, up / down source, Planck fraction
     __shared__ float s_R[NC], s_T[NC], s_Rd[NC], s_Td[NC], s_Tdir[NC];           // SW layer properties
     __shared__ float s_A[NI], s_Ad[NI];                                          // SW: albedo of everything below an interface
     __shared__ float s_ldn[NI], s_lup[NI], s_sup[NI], s_sdf[NI], s_sdr[NI];      // per g-point fluxes at the interfaces
@@ -333,8 +333,10 @@ __global__ __launch_bounds__(RS_T) void phys_rad_solve_kernel(PhysDev d, int B, 
         const int lv = e >> 4;
         const float top = s_pf[e] * s_bl[lv];
         const float bot = lv < L - 1 ? s_pf[e + NG] * s_bl[lv + 1] : s_pf[e] * s_bl[L];
-        const float c = s_su[e] * 0.2f;
-        s_su[e] = (1.0f - s_tr[e]) * ((top + bot) * 0.5f + c * top) / (c + 1.0f);
+        const float c = s_su[e] * 0.2f, up = (1.0f - s_tr[e]) * ((top + bot) * 0.5f + c * top) / (c + 1.0f);
+        s_su[e] = up;
+        // the first exports hand the UPWARD source to the downward sweep as well (an aliased view in the serialised graph)
+        s_sd[e] = d.lw_dn ? (1.0f - s_tr[e]) * ((top + bot) * 0.5f + c * bot) / (c + 1.0f) : up;
     }
     __syncthreads();
     // ---- level recurrences, one lane per g-point: LW on wave 0, SW on wave 1 ----
@@ -344,7 +346,7 @@ __global__ __launch_bounds__(RS_T) void phys_rad_solve_kernel(PhysDev d, int B, 
         s_ldn[g] = 0.0f;
 #pragma unroll 4                                      // (the LDS operands of the next levels are fetched ahead of the dependent chain)
         for (int j = 0; j < L; ++j) {
-            f = s_tr[j * NG + g] * f + s_su[j * NG + g];
+            f = s_tr[j * NG + g] * f + s_sd[j * NG + g];
             s_ldn[(j + 1) * NG + g] = f;
         }
         f = s_pf[(L - 1) * NG + g] * s_aux[11];       // surface emission (emissivity 1)

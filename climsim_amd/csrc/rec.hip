@@ -889,6 +889,7 @@ int launch_rec1_gru(int nh, const float *whh_packed, const float *bhn, const flo
     switch (nh) {
     case 64:  hipLaunchKernelGGL((gru_rec1_kernel<64>), grid, block, 0, s, (const f32x4 *)whh_packed, bhn, P, h0, Hout, B, L, reverse_out); break;
     case 96:  hipLaunchKernelGGL((gru_rec1_kernel<96>), grid, block, 0, s, (const f32x4 *)whh_packed, bhn, P, h0, Hout, B, L, reverse_out); break;
+    case 112: hipLaunchKernelGGL((gru_rec1_kernel<112>), grid, block, 0, s, (const f32x4 *)whh_packed, bhn, P, h0, Hout, B, L, reverse_out); break;
     case 128: hipLaunchKernelGGL((gru_rec1_kernel<128>), grid, block, 0, s, (const f32x4 *)whh_packed, bhn, P, h0, Hout, B, L, reverse_out); break;
     case 144: hipLaunchKernelGGL((gru_rec1_kernel<144>), grid, block, 0, s, (const f32x4 *)whh_packed, bhn, P, h0, Hout, B, L, reverse_out); break;
     default:
@@ -970,6 +971,7 @@ int launch_rec2_gru(int nh, const float *whh_g2, const float *bhn, const float *
     switch (nh) {
     case 64:  hipLaunchKernelGGL((gru_rec2_kernel<64>), grid, block, 0, s, (const f32x4 *)whh_g2, bhn, P, h0, Hout, B, L, reverse_out); break;
     case 96:  hipLaunchKernelGGL((gru_rec2_kernel<96>), grid, block, 0, s, (const f32x4 *)whh_g2, bhn, P, h0, Hout, B, L, reverse_out); break;
+    case 112: hipLaunchKernelGGL((gru_rec2_kernel<112>), grid, block, 0, s, (const f32x4 *)whh_g2, bhn, P, h0, Hout, B, L, reverse_out); break;
     case 128: hipLaunchKernelGGL((gru_rec2_kernel<128>), grid, block, 0, s, (const f32x4 *)whh_g2, bhn, P, h0, Hout, B, L, reverse_out); break;
     case 144: hipLaunchKernelGGL((gru_rec2_kernel<144>), grid, block, 0, s, (const f32x4 *)whh_g2, bhn, P, h0, Hout, B, L, reverse_out); break;
     default:

@@ -161,8 +161,8 @@ def radiative_transfer(P, main0, aux_n, xd, play, plev, delta_plev, mem_out, T_c
     # LW gas optics
     xg = torch.cat([T_new, torch.log(play), vmr.sqrt().sqrt(), xd[:, :, 12:13].sqrt().sqrt(),
                     torch.full_like(T_new, 0.0003887), xd[:, :, 13:15], T_new.new_zeros(B, nlev, 11)], 2)
-    xmin, xmax = P["gas_optics_model_lw.xmin"], P["gas_optics_model_lw.xmax"]
-    xg = torch.relu((xg - xmin) / (xmax - xmin))
+    xmin = P["gas_optics_model_lw.xmin"]            # (the later exports store the range xmax - xmin as a buffer `xdiv`)
+    xg = torch.relu((xg - xmin) / (P["gas_optics_model_lw.xdiv"] if "gas_optics_model_lw.xdiv" in P else P["gas_optics_model_lw.xmax"] - xmin))
     h = F.softsign(_lin(P, "gas_optics_model_lw.mlp1", xg))
     h = F.softsign(_lin(P, "gas_optics_model_lw.mlp2", h))
     h = _lin(P, "gas_optics_model_lw.mlp3", h)
@@ -190,7 +190,9 @@ def radiative_transfer(P, main0, aux_n, xd, play, plev, delta_plev, mem_out, T_c
     c = od * 0.2
     bmean = (src_lev[:, :-1] + src_lev[:, 1:]) * 0.5
     s_up = (1.0 - tr) * (bmean + c * src_lev[:, :-1]) / (c + 1.0)
-    s_dn = s_up                                                                               # as serialised (see header)
+    # as serialised (see header): the downward source is the upward one -- except in the later exports (recognised by their
+    # `xdiv` buffer), whose radiative_transfer passes the proper downward source
+    s_dn = (1.0 - tr) * (bmean + c * src_lev[:, 1:]) / (c + 1.0) if "gas_optics_model_lw.xdiv" in P else s_up
     dn = [torch.zeros(B, ng)]
     for j in range(nlev):
         dn.append(tr[:, j] * dn[-1] + s_dn[:, j])

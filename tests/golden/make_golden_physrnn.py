@@ -57,6 +57,12 @@ ART_RAD = DIR + "physRNN-Hidden_lr0.0007.neur128-128_xv4_mp1_num4050_BEST_script
 def inputs_rad(P, B, seed):
     """Inputs of the radiation graphs: the same 21 level columns, 19 surface columns whose radiation entries are drawn in
     physical units (insolation, cos zenith with night columns, albedos, upwelling LW, ice / land fraction, snow depth)."""
+    keep = None
+    if P["xmean_lev"].shape[1] == 16:   # the 16-input graphs: the 21-input layout without columns 15..19 (gases stay at 12..14, q_v last)
+        keep = list(range(15)) + [20]
+        xm21, xd21 = torch.zeros(60, 21), torch.ones(60, 21)
+        xm21[:, keep], xd21[:, keep] = P["xmean_lev"], P["xdiv_lev"]
+        P = dict(P, xmean_lev=xm21, xdiv_lev=xd21)
     xm, _, mem, xd = inputs(P, B, seed)
     g = torch.Generator().manual_seed(seed + 500)
     u = lambda *s: torch.rand(*s, generator=g)
@@ -74,7 +80,9 @@ def inputs_rad(P, B, seed):
     phys[:, 11] = 250.0 + 250.0 * u(B)                                                      # upwelling LW
     phys[:, 12], phys[:, 13], phys[:, 15] = u(B) * (u(B) > 0.5), u(B), 0.3 * u(B) * (u(B) > 0.5)
     xs = (phys - P["xmean_sca"]) / P["xdiv_sca"]
-    return xm, xs.contiguous(), mem, xd.contiguous()
+    if keep is not None:
+        xm, xd = xm[:, :, keep], xd[:, :, keep]
+    return xm.contiguous(), xs.contiguous(), mem, xd.contiguous()
 
 
 # the other graphs of the radiation family: sub-column = g-point (no MCICA sampling, mp_ncol 16), a learned cloud
@@ -88,7 +96,10 @@ RAD_FAMILY = {"physrnn_rad_nomcica": "num71535_BEST", "physrnn_rad_liqfrac": "nu
 PHYSRAD = {"physrad16_a": "physRNN_physRad-16_nreg16_lr0.0007.neur128-128_xv4_mp1_num14751_BEST_script_cpu.pt",
            "physrad16_b": "physRNN_physRad-16_nreg16_lr0.0007.neur128-128_xv4_mp1_num55617_BEST_script_cpu.pt",
            "physrad16_c": "physRNN_physRad-16_nreg16_lr0.0007.neur128-128_xv4_mp1_num55617_ep12_script_cpu.pt",
-           "physrad16_nh96": "physRNN_physRad-16_nreg16_lr0.0007.neur96-96_xv4_mp1_num20600_BEST_script_cpu.pt"}   # GRU 96/96, no rnn3
+           "physrad16_nh96": "physRNN_physRad-16_nreg16_lr0.0007.neur96-96_xv4_mp1_num20600_BEST_script_cpu.pt",   # GRU 96/96, no rnn3
+           # GRU 112/112, 16 level inputs, a later revision of the serialised scheme (LW downward source of its own, `xdiv` buffer)
+           "physrad16_nh112_a": "physRNN_physRad-16_nreg16_lr0.0007.neur112-112_xv4_mp1_num34341_BEST_script_cpu.pt",
+           "physrad16_nh112_b": "physRNN_physRad-16_nreg16_lr0.0007.neur112-112_xv4_mp1_num37201_BEST_script_cpu.pt"}
 
 
 def staged_srnn(m, xm, xs, mem, seed, out_ref, sfc_ref, xd):
