@@ -345,14 +345,23 @@ __global__ __launch_bounds__(DT) void phys_decode_kernel(PhysDev d, int B, const
         // mp_ncol 16 graphs pair g-point g with sub-column g
         for (int e = tid; e < LC * PH_NG; e += DT) {
             const int l = e >> 4, g = e & 15, L = l + ilev;
-            int sub = g;
+            int sub = g, c0 = 0;
             if constexpr (NC != PH_NG) {
+                // physRad graphs with MCICA (nreg 4): the g-points sample the CLOUDY regions 1.. only, fractions renormalised
+                c0 = d.physrad ? 1 : 0;
+                float psum = 1.0f;
+                if (d.physrad) {
+                    psum = 0.0f;
+#pragma unroll
+                    for (int c = 1; c < NC; ++c) psum += s_area[l * NC + c];
+                }
                 float rem[NC], cnt[NC], tot = 0.0f;
 #pragma unroll
                 for (int c = 0; c < NC; ++c) {
-                    const float p = s_area[l * NC + c] * (float)PH_NG;
-                    cnt[c] = floorf(p);
-                    rem[c] = p - cnt[c];
+                    const float a = s_area[l * NC + c];
+                    const float p = (d.physrad ? a / psum : a) * (float)PH_NG;
+                    cnt[c] = c < c0 ? 0.0f : floorf(p);
+                    rem[c] = c < c0 ? -1.0f : p - cnt[c];               // (a skipped region never ranks)
                     tot += cnt[c];
                 }
                 const float deficit = (float)PH_NG - tot;
@@ -363,12 +372,15 @@ __global__ __launch_bounds__(DT) void phys_decode_kernel(PhysDev d, int B, const
                     int rank = 0;
 #pragma unroll
                     for (int i = 0; i < NC; ++i) rank += (rem[i] > rem[c] || (rem[i] == rem[c] && i < c)) ? 1 : 0;
-                    edge += cnt[c] + ((float)rank < deficit ? 1.0f : 0.0f);
-                    sub += edge <= (float)g ? 1 : 0;
+                    if (c >= c0) {
+                        edge += cnt[c] + ((float)rank < deficit ? 1.0f : 0.0f);
+                        sub += edge <= (float)g ? 1 : 0;
+                    }
                 }
-                sub = min(sub, NC - 1);
+                sub = min(sub, NC - 1 - c0);
             }
-            const float T_g = s_T[l * NC + sub], qn_g = s_qn[l * NC + sub];
+            const float T_g = s_T[l * NC + c0 + sub], qn_g = s_qn[l * NC + c0 + sub];   // (the liquid-fraction head below is read at `sub`,
+                                                                                      //  un-shifted, as the serialised graph gathers it)
             float liq = fminf(fmaxf((T_g - 253.16f) * 0.05f, 0.0f), 1.0f);
             if (d.liq_off >= 0) liq = 1.0f / (1.0f + expf(-HD[((size_t)(L - d.ltop) * B + b) * HDW + d.liq_off + sub]));
             const float cwp = s_pd[l] / G * qn_g * 1000.0f, cwp_ice = (1.0f - liq) * cwp;
@@ -555,8 +567,8 @@ extern "C" int csa_phys_rad_create(int nx, int naux, int nh, int ilev_crm, int m
 {
     if (!w || !out || max_batch <= 0 || (flags & ~31)) { csa_set_error_msg("csa_phys_rad_create: bad argument"); return CSA_ERR_ARG; }
     const bool mcica = flags & CSA_PHYS_MCICA, physrad = flags & CSA_PHYS_PHYSRAD;
-    if (physrad && (mcica || !(flags & CSA_PHYS_LIQ_FRAC_HEAD))) {
-        csa_set_error_msg("csa_phys_rad_create: the physRad graphs come without MCICA sampling and with the liquid-fraction head");
+    if (physrad && !(flags & CSA_PHYS_LIQ_FRAC_HEAD)) {
+        csa_set_error_msg("csa_phys_rad_create: the physRad graphs come with the liquid-fraction head");
         return CSA_ERR_UNSUPPORTED;
     }
     if ((nh != 128 && nh != 112 && nh != 96) || mp_ncol != (mcica ? 4 : 16) || nh_mem0 != 15 || ilev_crm != 10 || (nx != 21 && nx != 16) || naux != 19 ||

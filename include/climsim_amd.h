@@ -429,7 +429,8 @@ int csa_phys_postprocess(csa_phys *h, int B, const float *out, const float *out_
  *                                clear sky -- mlp_qn_crm and mlp_evap_cond_vapor_crm are (nreg-1, nh) --, no sub-grid temperature
  *                                (the mlp_t_crm pair is NULL, mlp_eddy_diff is (1, nh)), latent heating from area-summed rates,
  *                                vapour mixing ratio q/(1-q), un-squared solar weights, and rnn_mem / mem_out are LEVEL-MAJOR
- *                                (50, B, 16) as that graph's forward takes and returns them.  Needs LIQ_FRAC_HEAD, excludes MCICA.
+ *                                (50, B, 16) as that graph's forward takes and returns them.  Needs LIQ_FRAC_HEAD; with MCICA (nreg 4) the g-points
+ *                                sample the cloudy regions 1.. only (fractions renormalised).
  *        CSA_PHYS_LATER_EXPORT   a later revision of the serialised scheme (e.g. physRNN_physRad-16_nreg16_*neur112-112*_num34341):
  *                                the LW downward sweep gets its own layer source (the first exports feed it the upward one), and the
  *                                `xmax` slot of the pointer list carries the gas-optics input range (buffer `xdiv`) itself.

@@ -142,16 +142,20 @@ def radiative_transfer(P, main0, aux_n, xd, play, plev, delta_plev, mem_out, T_c
     col_dry = (delta_plev * 10.0 * 6.02214076e23 * fact) / (m_air * 1000.0 * 100.0 * 9.80665)
 
     # MCICA: every g-point sees one of the mp_ncol sub-columns
-    if area_frac.shape[2] != ng:
+    liq_head = torch.sigmoid(_lin(P, "mlp_liq_frac_crm", rnn2out)) if "mlp_liq_frac_crm.weight" in P else None
+    if area_frac.shape[2] != ng and physrad:
+        # nreg 4 physRad graphs: the g-points sample the CLOUDY regions 1.. only (fractions renormalised); the serialised graph
+        # gathers the liquid fraction with the same indices un-shifted, i.e. from regions 0..nreg-2 -- kept
+        pc = area_frac[:, :, 1:]
+        sub = subcolumn_of_gpoint(pc / pc.sum(-1, keepdim=True), ng)
+        T_g, qn_g, liq_head = None, torch.gather(qn_crm[:, :, 1:], 2, sub), torch.gather(liq_head, 2, sub)
+    elif area_frac.shape[2] != ng:
         sub = subcolumn_of_gpoint(area_frac, ng)                                              # (B,50,g)
         T_g = torch.gather(T_crm, 2, sub)
         qn_g = torch.gather(qn_crm, 2, sub)
     else:
         sub, T_g, qn_g = None, T_crm, qn_crm
-    if "mlp_liq_frac_crm.weight" in P:
-        liq_g = torch.sigmoid(_lin(P, "mlp_liq_frac_crm", rnn2out))
-    else:
-        liq_g = F.hardtanh((T_g - 253.16) * 0.05, 0.0, 1.0)
+    liq_g = liq_head if liq_head is not None else F.hardtanh((T_g - 253.16) * 0.05, 0.0, 1.0)
     cwp = delta_plev[:, ilev_crm:] / G * qn_g * 1000.0
     cwp_ice = (1.0 - liq_g) * cwp
     T_low = T_new[:, ilev_crm:]                                                               # (B,50,1)
