@@ -299,7 +299,7 @@ def aux_workload(a, rank, world, dist):
         def step():
             m(x)
         flop_col, what = 2.0 * sum(dims[i] * dims[i + 1] for i in range(len(dims) - 1)), "Keras MLP baseline forward"
-    elif a.workload == "physrnn_384":
+    elif a.workload.startswith("physrnn_") and not a.workload.startswith("physrnn_rad_"):
         import numpy as np
         sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests", "golden"))
         from make_golden_physrnn import inputs as phys_inputs
@@ -315,7 +315,7 @@ def aux_workload(a, rank, world, dist):
             o, osfc, state["mem"] = m([xs_[0], xs_[1], state["mem"], xs_[3]], hx2=hx2)
         flop_col = 60 * (2.0 * 22 * 128 + 2.0 * 384 * (143 + 128) + 2.0 * 384 * 256 + 2.0 * 192 * 128) + 50 * 16 * 150.0
         what = "physRNN-Hidden (BiGRU 128/128 + microphysics decoder), weights of the shipped artefact"
-    elif a.workload == "physrnn_rad_384":
+    elif a.workload.startswith("physrnn_rad_"):
         import numpy as np
         sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests", "golden"))
         from make_golden_physrnn import inputs_rad
@@ -393,7 +393,7 @@ def aux_workload(a, rank, world, dist):
             flush=True)
 
 
-AUX = ["cur_lstm144_384", "cur_lstm128_384", "cur_gru128_384", "mlp_384", "online_mlp_384", "physrnn_384", "physrnn_rad_384", "cnn_384", "cnn_train_384",
+AUX = ["cur_lstm144_384", "cur_lstm128_384", "cur_gru128_384", "mlp_384", "online_mlp_384", "physrnn_384", "physrnn_rad_384", "physrnn_2700", "physrnn_rad_2700", "cnn_384", "cnn_train_384",
        "cnn_train_512", "cnn_train_2700"]
 
 
