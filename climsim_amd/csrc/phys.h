@@ -30,6 +30,7 @@ struct PhysDev {
     const float *rel_w, *rel_b;                     // mlp_precip_release (1, nh)
     // radiation scheme (rad == 1)
     const float *xmean_sca, *xdiv_sca, *lbd_qn, *g_xmin, *g_range, *g_ymean, *g_ystd, *ys_rad, *toa_spec, *retab;
+    const float *cld_w, *cld_b;   // cloud_optics_lw (16, 19), (16): learned cloud LW optical depth per unit path (num88955), or null
     int lw_dn;              // 1: the LW downward sweep gets its own source (later exports); 0: the upward one, as first serialised
 };
 

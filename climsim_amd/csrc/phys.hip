@@ -389,7 +389,22 @@ __global__ __launch_bounds__(DT) void phys_decode_kernel(PhysDev d, int B, const
             const float *ys = d.yscale_lev + L * 5;
             const float T_new = fmaxf(xd[0] + s_o01[L][0] / ys[0] * 1200.0f, 0.0f);
             const float rei = fminf(fmaxf(ph_reitab(d.retab, T_new), 13.0f), 130.0f);
-            ro.CL[((size_t)l * B + b) * PH_NG + g] = cwp * 0.090361f * (1.0f - ifr) + cwp * ifr * (1.0f / rei + 0.005f);
+            float tau_cld = cwp * 0.090361f * (1.0f - ifr) + cwp * ifr * (1.0f / rei + 0.005f);
+            if (d.cld_w) {          // learned optics: ReLU(Linear([(T_crm - 160) / 180, r_ice / 125, r_liq / 13.5, new memory (15 + stored water)]))
+                const float *aux = x_sfc + (size_t)b * d.naux, *wr = d.cld_w + g * 19;
+                const float rel = ph_reltab(T_new, aux[13] * d.xdiv_sca[13] + d.xmean_sca[13], aux[12] * d.xdiv_sca[12] + d.xmean_sca[12],
+                                            aux[15] * d.xdiv_sca[15] + d.xmean_sca[15]);
+                const float *lat = HD + ((size_t)(L - d.ltop) * B + b) * HDW + PH_NHEAD * NC;
+                float a = d.cld_b[g];
+                a = fmaf(wr[0], (s_T[l * NC] - 160.0f) / 180.0f, a);
+                a = fmaf(wr[1], ph_reitab(d.retab, T_new) / 125.0f, a);
+                a = fmaf(wr[2], rel / 13.5f, a);
+#pragma unroll
+                for (int k = 0; k < nm0; ++k) a = fmaf(wr[3 + k], lat[k], a);
+                a = fmaf(wr[3 + nm0], s_red[0], a);
+                tau_cld = cwp * fmaxf(a, 0.0f);
+            }
+            ro.CL[((size_t)l * B + b) * PH_NG + g] = tau_cld;
         }
     }
 }
@@ -405,6 +420,7 @@ struct PhysHostW {           // host pointers of one state_dict, by role
     const float *g_w1, *g_b1, *g_w2, *g_b2, *g_w3, *g_b3, *r1_w, *r1_b, *r2_w, *r2_b, *sw1_w, *sw1_b, *sw2_w, *sw2_b;
     const float *liq_w, *liq_b;              // mlp_liq_frac_crm (mp_ncol, nh), optional
     const float *s3_ih, *s3_zh, *s3_enc;     // rnn3 = MyStochasticGRULayer5(nh, nh) without bias, optional
+    const float *cld_w, *cld_b;              // cloud_optics_lw (16, 19), optional
 };
 
 // ice effective radius (micron) against temperature, 137 K ... : E3SM's table as listed in rnn/models/physics_rad_e3sm.py:13-59
@@ -507,6 +523,8 @@ static int phys_build(int nx, int nfeat, int naux, int nx_sfc, int sfc_cut, int 
             d.g_range = up(rg, 18);
         }
         d.lw_dn = lw_dn;
+        d.cld_w = w.cld_w ? up(w.cld_w, PH_NG * 19) : nullptr;
+        d.cld_b = w.cld_w ? up(w.cld_b, PH_NG) : nullptr;
         d.g_xmin = up(w.g_xmin, 18); d.g_ymean = up(w.g_ymean, 128); d.g_ystd = up(w.g_ystd, 128);
         d.ys_rad = up(w.ys_rad, 6); d.retab = up(kRetab, PH_NRETAB);
         {   // incoming spectral weights: softmax of the squared learned weights (physRad graphs: un-squared), float arithmetic
@@ -565,10 +583,14 @@ extern "C" int csa_phys_create(int nx, int nx_sfc, int nh, int ilev_crm, int mp_
 extern "C" int csa_phys_rad_create(int nx, int naux, int nh, int ilev_crm, int mp_ncol, int nh_mem0, int ng, int flags,
                                    const float *const *w, int max_batch, csa_phys **out)
 {
-    if (!w || !out || max_batch <= 0 || (flags & ~31)) { csa_set_error_msg("csa_phys_rad_create: bad argument"); return CSA_ERR_ARG; }
+    if (!w || !out || max_batch <= 0 || (flags & ~63)) { csa_set_error_msg("csa_phys_rad_create: bad argument"); return CSA_ERR_ARG; }
     const bool mcica = flags & CSA_PHYS_MCICA, physrad = flags & CSA_PHYS_PHYSRAD;
-    if (physrad && !(flags & CSA_PHYS_LIQ_FRAC_HEAD)) {
-        csa_set_error_msg("csa_phys_rad_create: the physRad graphs come with the liquid-fraction head");
+    if (physrad && !(flags & (CSA_PHYS_LIQ_FRAC_HEAD | CSA_PHYS_CLOUD_OPTICS_LW))) {
+        csa_set_error_msg("csa_phys_rad_create: the physRad graphs come with the liquid-fraction head or the learned cloud optics");
+        return CSA_ERR_UNSUPPORTED;
+    }
+    if ((flags & CSA_PHYS_CLOUD_OPTICS_LW) && (!physrad || mcica)) {
+        csa_set_error_msg("csa_phys_rad_create: the learned cloud optics belong to the 16-region physRad graphs");
         return CSA_ERR_UNSUPPORTED;
     }
     if ((nh != 128 && nh != 112 && nh != 96) || mp_ncol != (mcica ? 4 : 16) || nh_mem0 != 15 || ilev_crm != 10 || (nx != 21 && nx != 16) || naux != 19 ||
@@ -589,6 +611,7 @@ extern "C" int csa_phys_rad_create(int nx, int naux, int nh, int ilev_crm, int m
     v.r1_w = *p++; v.r1_b = *p++; v.r2_w = *p++; v.r2_b = *p++; v.sw1_w = *p++; v.sw1_b = *p++; v.sw2_w = *p++; v.sw2_b = *p++;
     if (flags & CSA_PHYS_LIQ_FRAC_HEAD) { v.liq_w = *p++; v.liq_b = *p++; }
     if (flags & CSA_PHYS_STOCHASTIC) { v.s3_ih = *p++; v.s3_zh = *p++; v.s3_enc = *p++; }
+    if (flags & CSA_PHYS_CLOUD_OPTICS_LW) { v.cld_w = *p++; v.cld_b = *p++; }
     for (const float *const *q = w; q != p; ++q)
         if (!*q && !(physrad && (q == v.heads + 2 * H_T || q == v.heads + 2 * H_T + 1))) {      // (no mlp_t_crm in the physRad graphs)
             csa_set_error_msg("csa_phys_rad_create: null weight pointer");

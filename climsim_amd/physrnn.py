@@ -73,9 +73,11 @@ class physical_RNN_autoreg(torch.nn.Module):
         # rnn_mem level-major (50, B, 16)
         self.physrad = "mlp_t_crm.weight" not in state_dict and int(state_dict["mlp_qn_crm.weight"].shape[0]) == mp_ncol - 1
         flags = ((1 if mp_ncol != ng else 0) | (2 if "mlp_liq_frac_crm.weight" in state_dict else 0) | (4 if self.stochastic else 0)
-                 | (8 if self.physrad else 0) | (16 if "gas_optics_model_lw.xdiv" in state_dict else 0))
+                 | (8 if self.physrad else 0) | (16 if "gas_optics_model_lw.xdiv" in state_dict else 0)
+                 | (32 if "cloud_optics_lw.weight" in state_dict else 0))
         order = (_ORDER_RAD + (["mlp_liq_frac_crm.weight", "mlp_liq_frac_crm.bias"] if flags & 2 else [])
-                 + (["rnn3.weight_ih", "rnn3.weight_zh", "rnn3.weight_encoder"] if flags & 4 else []))
+                 + (["rnn3.weight_ih", "rnn3.weight_zh", "rnn3.weight_encoder"] if flags & 4 else [])
+                 + (["cloud_optics_lw.weight", "cloud_optics_lw.bias"] if flags & 32 else []))
         for k in order:
             if flags & 16 and k == "gas_optics_model_lw.xmax":       # later exports: the range itself travels in this slot
                 k = "gas_optics_model_lw.xdiv"

@@ -434,6 +434,8 @@ int csa_phys_postprocess(csa_phys *h, int B, const float *out, const float *out_
  *        CSA_PHYS_LATER_EXPORT   a later revision of the serialised scheme (e.g. physRNN_physRad-16_nreg16_*neur112-112*_num34341):
  *                                the LW downward sweep gets its own layer source (the first exports feed it the upward one), and the
  *                                `xmax` slot of the pointer list carries the gas-optics input range (buffer `xdiv`) itself.
+ *        CSA_PHYS_CLOUD_OPTICS_LW cloud LW optical depth per unit path = ReLU(cloud_optics_lw([(T-160)/180, r_ice/125, r_liq/13.5,
+ *                                new memory])) instead of the liquid / ice rule (num88955); two more pointers {w (16,19), b} at the end.
  * nx = 21 or 16 level inputs (the last three before q_v and the pressure feature bypass mlp_initial), GRU 128 / 112 / 96.
  * Same handle type: csa_phys_forward / _tap (50 levels) / _destroy apply; x_sfc is (B, naux = 19), x_denorm needs columns
  * 12..14 = O3, CH4, N2O.
@@ -446,7 +448,8 @@ int csa_phys_postprocess(csa_phys *h, int B, const float *out, const float *out_
  * weight_encoder (nh,2nh)} in the reference's (in, out) layout.
  * csa_phys_forward_noise: csa_phys_forward + hx1 (B,nh), rnn3's initial state, and eps3 (50,B,nh), its noise: the two further
  * N(0,1) draws the reference makes inside forward (both nullable for a handle without rnn3). */
-enum { CSA_PHYS_MCICA = 1, CSA_PHYS_LIQ_FRAC_HEAD = 2, CSA_PHYS_STOCHASTIC = 4, CSA_PHYS_PHYSRAD = 8, CSA_PHYS_LATER_EXPORT = 16 };
+enum { CSA_PHYS_MCICA = 1, CSA_PHYS_LIQ_FRAC_HEAD = 2, CSA_PHYS_STOCHASTIC = 4, CSA_PHYS_PHYSRAD = 8, CSA_PHYS_LATER_EXPORT = 16,
+       CSA_PHYS_CLOUD_OPTICS_LW = 32 };
 int csa_phys_rad_create(int nx, int naux, int nh, int ilev_crm, int mp_ncol, int nh_mem0, int ng, int flags,
                         const float *const *w, int max_batch, csa_phys **out);
 int csa_phys_forward_noise(csa_phys *h, int B, const float *x_main, const float *x_sfc, const float *rnn_mem,

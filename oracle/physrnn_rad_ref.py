@@ -155,7 +155,7 @@ def radiative_transfer(P, main0, aux_n, xd, play, plev, delta_plev, mem_out, T_c
         qn_g = torch.gather(qn_crm, 2, sub)
     else:
         sub, T_g, qn_g = None, T_crm, qn_crm
-    liq_g = liq_head if liq_head is not None else F.hardtanh((T_g - 253.16) * 0.05, 0.0, 1.0)
+    liq_g = liq_head if liq_head is not None else F.hardtanh((T_g - 253.16) * 0.05, 0.0, 1.0)   # (unused with cloud_optics_lw)
     cwp = delta_plev[:, ilev_crm:] / G * qn_g * 1000.0
     cwp_ice = (1.0 - liq_g) * cwp
     T_low = T_new[:, ilev_crm:]                                                               # (B,50,1)
@@ -175,8 +175,12 @@ def radiative_transfer(P, main0, aux_n, xd, play, plev, delta_plev, mem_out, T_c
     pf_k = h[:, :, nk:] ** 2
     pfrac = torch.softmax(_lin(P, "gas_optics_lw_reduce2", pf_k), 2)                          # (B,60,g)
     tau_lw = F.softplus(_lin(P, "gas_optics_lw_reduce1", tau_k)) * 0.01
-    ifr = cwp_ice / cwp.clamp(min=1e-8)
-    tau_cld = cwp * 0.090361 * (1.0 - ifr) + cwp * ifr * (1.0 / rei.clamp(13.0, 130.0) + 0.005)
+    if "cloud_optics_lw.weight" in P:   # num88955: cloud LW optical depth per unit path from a learned Linear(19, 16) + ReLU
+        x_cld = torch.cat([(T_crm - 160.0) / 180.0, rei / 125.0, rel / 13.5, mem_out], 2)
+        tau_cld = cwp * torch.relu(_lin(P, "cloud_optics_lw", x_cld))
+    else:
+        ifr = cwp_ice / cwp.clamp(min=1e-8)
+        tau_cld = cwp * 0.090361 * (1.0 - ifr) + cwp * ifr * (1.0 / rei.clamp(13.0, 130.0) + 0.005)
     tau_lw = tau_lw + torch.cat([tau_cld.new_zeros(B, ilev_crm, ng), tau_cld], 1)
 
     # LW sources and the no-scattering solver

@@ -101,6 +101,7 @@ PHYSRAD = {"physrad16_a": "physRNN_physRad-16_nreg16_lr0.0007.neur128-128_xv4_mp
            "physrad16_nh112_a": "physRNN_physRad-16_nreg16_lr0.0007.neur112-112_xv4_mp1_num34341_BEST_script_cpu.pt",
            "physrad16_nh112_b": "physRNN_physRad-16_nreg16_lr0.0007.neur112-112_xv4_mp1_num37201_BEST_script_cpu.pt",
            # four regions (one clear, three cloudy), the 16 g-points sample the cloudy ones; GRU 112/112, 21 and 16 level inputs
+           "physrad16_nh112_cld": "physRNN_physRad-16_nreg16_lr0.0007.neur112-112_xv4_mp1_num88955_BEST_script_cpu.pt",   # learned cloud LW optics
            "physrad4_a": "physRNN_physRad-16_nreg4_lr0.0007.neur112-112_xv4_mp1_num35741_BEST_script_cpu.pt",
            "physrad4_b": "physRNN_physRad-16_nreg4_lr0.0007.neur112-112_xv4_mp1_num95220_BEST_script_cpu.pt"}
 

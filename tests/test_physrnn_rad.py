@@ -5,6 +5,8 @@
   physrnn_rad_stoch_*  num5730_BEST, num62104_BEST, num62104_BEST_ep11    num4050's graph + stochastic third RNN
 and the first geometry of the physRNN_physRad-* family (97 of the 114 shipped models):
   physrad16_nh96       physRNN_physRad-16_nreg16_*neur96-96_xv4_mp1_num20600_BEST: the same graph with GRU 96/96 and no third RNN
+  physrad16_nh112_cld  physRNN_physRad-16_nreg16_*neur112-112_xv4_mp1_num88955_BEST: as nh112_a/b, cloud LW optical depth from a learned
+                       Linear(19, 16) + ReLU instead of the liquid / ice rule
   physrad4_a/b         physRNN_physRad-16_nreg4_*neur112-112_xv4_mp1_num35741_BEST (21 inputs), _num95220_BEST (16 inputs): four regions, the
                        g-points sample the three cloudy ones (MCICA), otherwise as the nh112 graphs
   physrad16_nh112_a/b  physRNN_physRad-16_nreg16_*neur112-112_xv4_mp1_num34341_BEST, _num37201_BEST: GRU 112/112, 16 level inputs, no
@@ -77,7 +79,7 @@ def _noise_level(*realisations_then_exact):
 FIXTURES = [("physrnn_rad", 2), ("physrnn_rad_nomcica", 1), ("physrnn_rad_liqfrac", 1), ("physrnn_rad_stoch_a", 1),
             ("physrnn_rad_stoch_b", 1), ("physrnn_rad_stoch_c", 1), ("physrad16_a", 1), ("physrad16_b", 1), ("physrad16_c", 1),
             ("physrad16_nh96", 1), ("physrad16_nh112_a", 1), ("physrad16_nh112_b", 1),
-            ("physrad4_a", 1), ("physrad4_b", 1)]
+            ("physrad4_a", 1), ("physrad4_b", 1), ("physrad16_nh112_cld", 1)]
 
 
 def _noise(g, i):
@@ -214,7 +216,8 @@ def test_hip_radiation_graph_matches_the_artefact(fixture, ncase):
                                        ("physrnn_rad_nomcica", 301), ("physrnn_rad_liqfrac", 384), ("physrnn_rad_stoch_a", 2),
                                        ("physrnn_rad_stoch_b", 301), ("physrnn_rad_stoch_c", 384), ("physrad16_a", 2),
                                        ("physrad16_a", 301), ("physrad16_a", 384), ("physrad16_nh96", 384),
-                                       ("physrad16_nh112_a", 301), ("physrad16_nh112_b", 384), ("physrad4_a", 384), ("physrad4_b", 301)])
+                                       ("physrad16_nh112_a", 301), ("physrad16_nh112_b", 384), ("physrad4_a", 384), ("physrad4_b", 301),
+                                       ("physrad16_nh112_cld", 384)])
 def test_hip_radiation_graph_matches_restatement(fixture, B):
     g, P = _load(fixture)
     m = _hip_model(P, 384)
