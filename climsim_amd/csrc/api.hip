@@ -373,6 +373,10 @@ static int launch_rec_auto(const csa_emulator *h, int layer, const float *P, con
     const float *wg = layer == 1 ? d.whh1g : d.whh2g;
     if (!d.cfg.use_lstm && wg)
         return launch_rec2_gru(nh, wg, layer == 1 ? d.bhn1 : d.bhn2, P, h0, Hout, B, L, reverse_out, s);
+    if (!d.cfg.use_lstm) {     // (the first-generation kernel reads GRU projections padded to four per unit: training only)
+        csa_set_error_msg("forward: no inference GRU kernel for this hidden size");
+        return CSA_ERR_UNSUPPORTED;
+    }
     return launch_rec(d.cfg.use_lstm, nh, layer == 1 ? d.whh1p : d.whh2p, layer == 1 ? d.bhn1 : d.bhn2, P, h0, c0, Hout, B, L,
                       reverse_out, s);
 }
@@ -397,9 +401,9 @@ static int run_forward_stoch(csa_emulator *h, int B, int normalised, int mode, c
     const int L = c.nlev, nh = c.nh1;
     int rc;
     if ((rc = launch_prep(h->dm, B, normalised, x_main, x_sfc, mem_in, nullptr, nullptr, h->X1, h->hc0, s))) return rc;
-    if ((rc = launch_proj_gemm(h->X1, h->dm.wih1, h->dm.bias1, h->P, L * B, 4 * nh, nh + c.nh_mem, s))) return rc;
+    if ((rc = launch_proj_gemm(h->X1, h->dm.wih1, h->dm.bias1, h->P, L * B, gate_stride(c.use_lstm) * nh, nh + c.nh_mem, s))) return rc;
     if ((rc = launch_rec_auto(h, 1, h->P, hx0, cx0, h->H1, B, L, /*reverse_out=*/1, s))) return rc;
-    if ((rc = launch_proj_gemm(h->H1, h->dm.wih2, h->dm.bias2, h->P, L * B, 4 * nh, nh, s))) return rc;
+    if ((rc = launch_proj_gemm(h->H1, h->dm.wih2, h->dm.bias2, h->P, L * B, gate_stride(c.use_lstm) * nh, nh, s))) return rc;
     if ((rc = launch_rec_auto(h, 2, h->P, h->hc0, h->hc0 + (size_t)B * nh, h->H2, B, L, /*reverse_out=*/1, s))) return rc;
     if ((rc = csa_stoch_lstm4_forward(h->stoch, L, B, h->H2, h->hc0 + (size_t)2 * B * nh, h->hc0 + (size_t)3 * B * nh, eps,
                                       h->H1, nullptr, nullptr, s))) return rc;
@@ -423,9 +427,9 @@ static int run_chain(csa_emulator *h, int B, int normalised, int mode, const flo
     if ((rc = launch_prep(dm, B, normalised, x_main, x_sfc, mem_in, hx2, cx2, X1, hc0, s))) return rc;
     const float *h2 = c.legacy ? hx2 : hc0 + (size_t)2 * B * nhm;
     const float *c2 = c.legacy ? cx2 : hc0 + (size_t)3 * B * nhm;
-    if ((rc = launch_proj_gemm(X1, h->dm.wih1, h->dm.bias1, P, L * B, 4 * c.nh1, c.nh1 + c.nh_mem, s, L * Bclass))) return rc;
+    if ((rc = launch_proj_gemm(X1, h->dm.wih1, h->dm.bias1, P, L * B, gate_stride(c.use_lstm) * c.nh1, c.nh1 + c.nh_mem, s, L * Bclass))) return rc;
     if ((rc = launch_rec_auto(h, 1, P, hc0, hc0 + (size_t)B * nhm, H1, B, L, 1, s, Bclass))) return rc;
-    if ((rc = launch_proj_gemm(H1, h->dm.wih2, h->dm.bias2, P, L * B, 4 * c.nh2, c.nh1, s, L * Bclass))) return rc;
+    if ((rc = launch_proj_gemm(H1, h->dm.wih2, h->dm.bias2, P, L * B, gate_stride(c.use_lstm) * c.nh2, c.nh1, s, L * Bclass))) return rc;
     if ((rc = launch_rec_auto(h, 2, P, h2, c2, H2, B, L, 0, s, Bclass))) return rc;
     return launch_head(dm, B, mode, H2, x_main, x_sfc, y0, y1, y2, s);
 }
@@ -494,12 +498,12 @@ static int run_forward(csa_emulator *h, int B, int normalised, int mode,
     const float *c2 = c.legacy ? cx2 : h->hc0 + (size_t)3 * B * nhm;
     PROF_MARK(1);
     // rnn1: upward over the flipped sequence; hidden sequence stored back in level order
-    if ((rc = launch_proj_gemm(h->X1, h->dm.wih1, h->dm.bias1, h->P, L * B, 4 * c.nh1, c.nh1 + c.nh_mem, s))) return rc;
+    if ((rc = launch_proj_gemm(h->X1, h->dm.wih1, h->dm.bias1, h->P, L * B, gate_stride(c.use_lstm) * c.nh1, c.nh1 + c.nh_mem, s))) return rc;
     PROF_MARK(2);
     if ((rc = launch_rec_auto(h, 1, h->P, h->hc0, h->hc0 + (size_t)B * nhm, h->H1, B, L, /*reverse_out=*/1, s))) return rc;
     PROF_MARK(3);
     // rnn2: downward in level order
-    if ((rc = launch_proj_gemm(h->H1, h->dm.wih2, h->dm.bias2, h->P, L * B, 4 * c.nh2, c.nh1, s))) return rc;
+    if ((rc = launch_proj_gemm(h->H1, h->dm.wih2, h->dm.bias2, h->P, L * B, gate_stride(c.use_lstm) * c.nh2, c.nh1, s))) return rc;
     PROF_MARK(4);
     if ((rc = launch_rec_auto(h, 2, h->P, h2, c2, h->H2, B, L, /*reverse_out=*/0, s))) return rc;
     PROF_MARK(5);
@@ -604,8 +608,8 @@ extern "C" int csa_debug_stage(csa_emulator *h, int stage, int B, const float *i
     case 0:
         if (!in1 || !out1) { csa_set_error_msg("csa_debug_stage(prep): null tensor"); return CSA_ERR_ARG; }
         return launch_prep(h->dm, B, 0, in0, in1, in2, in3, in4, out0, out1, s);
-    case 1: return launch_proj_gemm(in0, h->dm.wih1, h->dm.bias1, out0, L * B, 4 * c.nh1, c.nh1 + c.nh_mem, s);
-    case 3: return launch_proj_gemm(in0, h->dm.wih2, h->dm.bias2, out0, L * B, 4 * c.nh2, c.nh1, s);
+    case 1: return launch_proj_gemm(in0, h->dm.wih1, h->dm.bias1, out0, L * B, gate_stride(c.use_lstm) * c.nh1, c.nh1 + c.nh_mem, s);
+    case 3: return launch_proj_gemm(in0, h->dm.wih2, h->dm.bias2, out0, L * B, gate_stride(c.use_lstm) * c.nh2, c.nh1, s);
     case 2:
     case 4:
         if (!in1 || (c.use_lstm && !in2)) { csa_set_error_msg("csa_debug_stage(rec): null state"); return CSA_ERR_ARG; }

@@ -468,7 +468,7 @@ static int phys_build(int nx, int nfeat, int naux, int nx_sfc, int sfc_cut, int 
     d.out_w = up(w.out_w, 5 * nh_mem0); d.out_b = up(w.out_b, 5);
     if (!rad) { d.sfo_w = up(w.sfo_w, 6 * nh); d.sfo_b = up(w.sfo_b, 6); }
     d.rel_w = up(w.rel_w, nh); d.rel_b = up(w.rel_b, 1);
-    // GRU layers: W_ih rows to unit-major [r, z, n, 0]; rnn1's K = nh + 15 padded to nh + 16 with a zero column
+    // GRU layers: W_ih rows to unit-major [r, z, n]; rnn1's K = nh + 15 padded to nh + 16 with a zero column
     {
         const int Kin = nh + nh_mem0, K1 = nh + 16;
         std::vector<float> wpad((size_t)3 * nh * K1, 0.0f), wp, bp, bhn;
@@ -664,9 +664,9 @@ static int phys_forward_impl(csa_phys *h, int B, const float *x_main, const floa
         return B <= 256 ? launch_rec1_gru(nh, whh, bhn, h->P, h0, Hout, B, L, reverse, s)
                         : launch_rec2_gru(nh, whg, bhn, h->P, h0, Hout, B, L, reverse, s);
     };
-    if ((rc = launch_proj_gemm(h->X1, h->wih1, h->bias1, h->P, M, 4 * nh, nh + 16, s, 0))) return rc;
+    if ((rc = launch_proj_gemm(h->X1, h->wih1, h->bias1, h->P, M, 3 * nh, nh + 16, s, 0))) return rc;
     if ((rc = rec(h->whh1p, h->whh1g, h->bhn1, h->hx, h->H1, 1))) return rc;
-    if ((rc = launch_proj_gemm(h->H1, h->wih2, h->bias2, h->P, M, 4 * nh, nh, s, 0))) return rc;
+    if ((rc = launch_proj_gemm(h->H1, h->wih2, h->bias2, h->P, M, 3 * nh, nh, s, 0))) return rc;
     if ((rc = rec(h->whh2p, h->whh2g, h->bhn2, hx2, h->H2, 0))) return rc;
     const float *Hhead = h->H2, *Hlast = h->H2;      // the sequence the heads read; the sequence whose last state feeds the release head
     if (h->rnn3) {                                    // rnn2's output times the stochastic layer's output; last state: the layer's own

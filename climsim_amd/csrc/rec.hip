@@ -645,7 +645,7 @@ __global__ __launch_bounds__(NH * 4, (NH / 16 + 3) / 4) void lstm_rec4m_kernel(
 //   r[s] = acc[s].x + xor1(acc[s].y);  v0 = r[0] + xor2(r[2]);  v1 = r[1] + xor2(r[1])
 // every lane has W_hn h (v1) and the (r,z)-gate sum of ITS group (v0): p<2 the reset gate, p>=2 the update gate.
 // 8 DPP adds per step (the all-reduce of rec_kernel<NH,3> needs 12 plus a select), 96 packed FMAs as before.
-// P rows are [r, z, n, 0] per unit: lane group g reads the 8-byte pair at offset g -> (r,z) or (z,n); the p>=2 lanes own
+// P rows are [r, z, n] per unit: lane group g reads the 8-byte pair at offset g -> (r,z) or (z,n); the p>=2 lanes own
 // h_t: they receive r over one DPP move, form n = tanh(x_n + r (W_hn h + b_hn)) and h = (1-z) n + z h.
 template <int NH>
 __global__ __launch_bounds__(NH * 4, (NH / 16 + 3) / 4) void gru_rec2_kernel(
@@ -680,8 +680,8 @@ __global__ __launch_bounds__(NH * 4, (NH / 16 + 3) / 4) void gru_rec2_kernel(
     const int slotS = CPY + 2 * u + (1 - col) + 4 * (u / KC);
     if (owner) { hbuf[0][slotN] = h; hbuf[0][slotS] = h; }
 
-    const float *Pb = P + (size_t)b * (4 * NH) + u * 4 + grp;
-    const size_t Pstep = (size_t)B * (4 * NH);
+    const float *Pb = P + (size_t)b * (3 * NH) + u * 3 + grp;      // rows are [r, z, n] per unit, unpadded: 4-byte-aligned pairs
+    const size_t Pstep = (size_t)B * (3 * NH);
     const int rdoff = col * CPY + p * CH;
     f32x2 preA = f32x2{Pb[0], Pb[1]}, preB = preA;
     __syncthreads();
@@ -816,7 +816,7 @@ __global__ __launch_bounds__(NH * 4, (NH / 16 + 3) / 4) void lstm_rec1_kernel(
 
 // GRU, one column per workgroup (small batches): lane (u, p) holds the three gate rows of unit u for its k-quarter as
 // k-pairs (48 v_pk_fma_f32 per step), the quad all-reduces the three sums (6 DPP adds) and every lane of the quad
-// evaluates the cell redundantly.  P rows are [r, z, n, pad] per unit (pack.h), b_hn is kept apart as in rec_kernel.
+// evaluates the cell redundantly.  P rows are [r, z, n] per unit (pack.h), b_hn is kept apart as in rec_kernel.
 template <int NH>
 __global__ __launch_bounds__(NH * 4, (NH / 16 + 3) / 4) void gru_rec1_kernel(
     const f32x4 *__restrict__ Wp4, const float *__restrict__ bhn, const float *__restrict__ P,
@@ -842,16 +842,16 @@ __global__ __launch_bounds__(NH * 4, (NH / 16 + 3) / 4) void gru_rec1_kernel(
     const int hslot = u + 4 * (u / KC);
     if (p == 0) hbuf[0][hslot] = h;
     asm volatile("" : "+v"(h));
-    const float *Pb = P + (size_t)b * (4 * NH) + u * 4;
-    const size_t Pstep = (size_t)B * (4 * NH);
-    f32x4 preA = *(const f32x4 *)Pb, preB = preA;
+    const float *Pb = P + (size_t)b * (3 * NH) + u * 3;           // rows are [r, z, n] per unit, unpadded
+    const size_t Pstep = (size_t)B * (3 * NH);
+    f32x3 preA = {Pb[0], Pb[1], Pb[2]}, preB = preA;
     __syncthreads();
 #define GRU1_STEP(T, CUR, NXT)                                                                     \
     {                                                                                              \
         const int t_ = (T);                                                                        \
         {   /* unconditional prefetch + unconditional wait: see lstm_rec2_kernel */                 \
             const float *pn = Pb + (size_t)(t_ + 1 < L ? t_ + 1 : L - 1) * Pstep;                  \
-            asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(NXT) : "v"(pn) : "memory");     \
+            asm volatile("global_load_dwordx3 %0, %1, off" : "=&v"(NXT) : "v"(pn) : "memory");     \
         }                                                                                          \
         const f32x4 *hp = (const f32x4 *)&hbuf[t_ & 1][p * CH];                                    \
         f32x2 acc[3] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};                                       \
