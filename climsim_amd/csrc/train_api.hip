@@ -294,7 +294,7 @@ extern "C" int csa_train_create(const csa_config *cfg, const csa_params *p, cons
         for (int k = 0; k < K; ++k) for (int n = 0; n < 4 * nh; ++n) t[(size_t)k * 4 * nh + n] = o_wih + rowmap[n] * K + k;
         wihT = (float *)add_gather(h, t, nullptr, rc);
     };
-    // GRU (pack.h: n' = u*4 + [r, z, n, pad]): explicit index maps; -1 = padding (gathers read 0, scatters skip).
+    // GRU (training keeps four per unit, n' = u*4 + [r, z, n, pad]; inference packs three, pack.h): explicit index maps; -1 = padding (gathers read 0, scatters skip).
     // The saved-gate buffer after BPTT holds [dr~, dz~, dn~, g_hn] per unit (train_rec.hip): W_ih / b_ih gradients take
     // columns 0,1,2, W_hh / b_hh gradients take columns 0,1 and 3 (as gate row n).
     struct GruMaps { std::vector<int> wih, whh, ba, bb; } gm1, gm2;
