@@ -291,6 +291,7 @@ __global__ __launch_bounds__(RS_T) void phys_rad_solve_kernel(PhysDev d, int B, 
     }
     const float mu0 = fmaxf(s_aux[6], 1e-6f);
     // ---- per (level, g-point) cell: LW optical depth + Planck fraction, SW two-stream coefficients ----
+#pragma unroll                                       // (four trips: the global loads of all of them are issued before the first is used)
     for (int e0 = 0; e0 < NC; e0 += RS_T) {
         const int e = e0 + tid, lv = min(e >> 4, L - 1), g = e & 15;
         const bool ok = e < NC;
