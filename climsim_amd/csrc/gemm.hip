@@ -249,9 +249,10 @@ int launch_gemm_epi(const float *A, const float *W, const float *bias, float *C,
     }
     int tiles_m = (M + GB_M - 1) / GB_M;
     const int tiles_n = (N + GB_N - 1) / GB_N;
-    // narrow outputs (N <= 256) whose 128-row tiling gives the 256 CUs fewer than two workgroups each: 64-row tiles
+    // narrow outputs (N <= 384) whose 128-row tiling gives the 256 CUs fewer than two or three workgroups each: 64-row tiles
     static const int m64 = getenv("CSA_GEMM_M64") ? atoi(getenv("CSA_GEMM_M64")) : 1;
-    const bool half_m = m64 && tiles_n <= 2 && tiles_m * tiles_n < 512 && M > 64;
+    // (three N-tiles: the unpadded GRU projection, N = 3 nh = 384 -- 183.8 -> 179.7 us per cur_gru128 call with 64-row tiles)
+    const bool half_m = m64 && ((tiles_n <= 2 && tiles_m * tiles_n < 512) || (tiles_n == 3 && tiles_m * tiles_n < 768)) && M > 64;
     if (half_m) tiles_m = (M + 63) / 64;
 #ifdef GEMM_EXP_EXTRA_LDS
     static const int extra_lds = getenv("CSA_GEMM_EXTRA_LDS") ? atoi(getenv("CSA_GEMM_EXTRA_LDS")) : 0;   // diagnostic: caps occupancy
