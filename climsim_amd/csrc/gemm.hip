@@ -252,6 +252,7 @@ int launch_gemm_epi(const float *A, const float *W, const float *bias, float *C,
     // narrow outputs (N <= 384) whose 128-row tiling gives the 256 CUs fewer than two or three workgroups each: 64-row tiles
     static const int m64 = getenv("CSA_GEMM_M64") ? atoi(getenv("CSA_GEMM_M64")) : 1;
     // (three N-tiles: the unpadded GRU projection, N = 3 nh = 384 -- 183.8 -> 179.7 us per cur_gru128 call with 64-row tiles)
+    // (four N-tiles, the LSTM projection at 23,040 rows: 64-row tiles measured 0.2044 against 0.2037 ms per step -- not taken)
     const bool half_m = m64 && ((tiles_n <= 2 && tiles_m * tiles_n < 512) || (tiles_n == 3 && tiles_m * tiles_n < 768)) && M > 64;
     if (half_m) tiles_m = (M + 63) / 64;
 #ifdef GEMM_EXP_EXTRA_LDS
