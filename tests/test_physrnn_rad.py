@@ -334,3 +334,39 @@ def test_hip_radiation_graph_properties_at_shard_size(fixture):
     # night columns: no shortwave reaches the surface; precipitation is never negative
     night = (xs[:, 6] * P["xdiv_sca"][6] + P["xmean_sca"][6]) < 1e-6
     assert night.any() and torch.all(a[1][night][:, [0, 4, 5, 6, 7]] == 0) and torch.all(a[1][:, 3] >= 0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fixture", ["physrnn_rad", "physrad16_b"])
+def test_hip_radiation_graph_call_can_be_captured_by_the_caller(fixture):
+    """A call allocates no device memory of its own and only launches on the caller's stream (the stochastic layer's side of it
+    included), so a host can capture it into a hipGraph -- torch.cuda.CUDAGraph over the ctypes call -- and replay it over
+    persistent buffers: replays are bit-identical to eager calls and see new buffer contents."""
+    g, P = _load(fixture)
+    m = _hip_model(P, 64)
+    B = 48
+    xm, xs, mem, xd = inputs_rad(P, B, 9)
+    if getattr(m, "physrad", False):
+        mem = mem.transpose(0, 1).contiguous()
+    nh = P["rnn2.weight_hh_l0"].shape[1]
+    gen = torch.Generator().manual_seed(3)
+    kw = {"hx2": torch.randn(B, nh, generator=gen).cuda()}
+    if "rnn3.weight_ih" in P:
+        kw.update(hx1=torch.randn(B, nh, generator=gen).cuda(), eps3=torch.randn(50, B, nh, generator=gen).cuda())
+    args = [xm.cuda(), xs.cuda(), mem.cuda(), xd.cuda()]
+    ref = [t.clone() for t in m(args, **kw)]
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        out = m(args, **kw)
+    for _ in range(2):
+        graph.replay()
+        torch.cuda.synchronize()
+        assert all(torch.equal(a, b) for a, b in zip(out, ref))
+    args[2].mul_(0.5)                                # same pointers, new memory contents: the replay must see them
+    graph.replay()
+    torch.cuda.synchronize()
+    new = [t.clone() for t in out]
+    eager = m(args, **kw)
+    assert all(torch.equal(a, b) for a, b in zip(new, eager)) and not torch.equal(new[0], ref[0])
+    del graph
