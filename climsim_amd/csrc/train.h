@@ -17,7 +17,9 @@ int launch_gemm_tn_partial(const float *A, int lda, const float *Bm, int ldb, fl
 #define TN_MAX_SEGS 8
 struct TnSegs { const float *A[TN_MAX_SEGS]; const float *B[TN_MAX_SEGS]; int n; };
 int launch_gemm_tn_segs(const TnSegs &segs, int lda, int ldb, float *Cpart, int M, int N1, int N2,
-                        int nsplit, int conv_L, int conv_cin, hipStream_t s);
+                        int nsplit, int conv_L, int conv_cin, hipStream_t s, float *Csum = nullptr);
+int launch_gemm_tn_partial_cs(const float *A, int lda, const float *Bm, int ldb, float *Cpart, float *Csum, int M, int N1, int N2,
+                              int nsplit, hipStream_t s);
 int launch_gemm_tn_conv(const float *A, int lda, const float *Bm, int ldb, float *Cpart, int M, int N1, int N2,
                         int nsplit, int conv_L, int conv_cin, hipStream_t s);
 int launch_colsum_partial(const float *A, float *part, int M, int N, int nsplit, hipStream_t s);

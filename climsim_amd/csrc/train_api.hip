@@ -50,6 +50,7 @@ struct csa_trainer {
     std::vector<Slot> slots;
     // work buffers
     float *dH2, *dH1, *dX1, *dhc1, *dhc2, *part, *samp, *ecoef, *sp;
+    float *part_b = nullptr;         // partial bias gradients (column sums of dP), a side output of the W_ih GEMM
     float *rtmp = nullptr;           // first-stage sums of the per-column partial reductions
     size_t part_floats;
     int nsplit;
@@ -447,6 +448,7 @@ extern "C" int csa_train_create(const csa_config *cfg, const csa_params *p, cons
     const size_t pcol = Bm * (size_t)std::max(head_bwd_partial_floats(c), prep_bwd_partial_floats(c));
     h->part_floats = pf > pcol ? pf : pcol;
     h->part = dalloc<float>(h, h->part_floats, rc);
+    h->part_b = dalloc<float>(h, (size_t)h->nsplit * 4 * std::max(c.nh1, c.nh2), rc);
     h->rtmp = dalloc<float>(h, (size_t)32 * std::max(head_bwd_partial_floats(c), prep_bwd_partial_floats(c)), rc);
     h->samp = dalloc<float>(h, (size_t)max_window * Bm * 9, rc);
     h->ecoef = dalloc<float>(h, Bm, rc);
@@ -635,13 +637,12 @@ extern "C" int csa_train_backward(csa_trainer *h, int slot, int B, const float *
     { StageTimer tm(h, 3, s);
     if ((rc = launch_proj_gemm(S.GP2, h->wih2T, nullptr, h->dH1, M, nh1, 4 * nh2, s))) return rc; }
     if (!h->defer) {
-        if ((rc = launch_gemm_tn_partial(S.GP2, 4 * nh2, S.H1lev, nh1, h->part, M, 4 * nh2, nh1, ns, s))) return rc;
+        if ((rc = launch_gemm_tn_partial_cs(S.GP2, 4 * nh2, S.H1lev, nh1, h->part, h->part_b, M, 4 * nh2, nh1, ns, s))) return rc;
         if ((rc = launch_reduce_partials(h->part, ns, 4 * nh2 * nh1, h->map_wih2, nullptr, grads, s))) return rc;
+        if ((rc = launch_reduce_partials(h->part_b, ns, 4 * nh2, h->map_b2a, h->map_b2b, grads, s))) return rc;
         if ((rc = launch_gemm_tn_partial(S.GP2, 4 * nh2, S.H2, nh2, h->part, M, 4 * nh2, nh2, ns, s))) return rc;
         if ((rc = launch_reduce_partials(h->part, ns, 4 * nh2 * nh2, h->map_whh2, nullptr, grads, s))) return rc;
     }
-    if ((rc = launch_colsum_partial(S.GP2, h->part, M, 4 * nh2, ns, s))) return rc;
-    if ((rc = launch_reduce_partials(h->part, ns, 4 * nh2, h->map_b2a, h->map_b2b, grads, s))) return rc;
     // rnn1 (upward): dH1 is in level order, the recurrence runs in sequence order
     { StageTimer tm(h, 1, s);
     if (c.use_lstm) {
@@ -652,8 +653,9 @@ extern "C" int csa_train_backward(csa_trainer *h, int slot, int B, const float *
     { StageTimer tm(h, 3, s);
     if ((rc = launch_proj_gemm(S.GP1, h->wih1T, nullptr, h->dX1, M, nin1, 4 * nh1, s))) return rc; }
     if (!h->defer) {
-        if ((rc = launch_gemm_tn_partial(S.GP1, 4 * nh1, S.X1, nin1, h->part, M, 4 * nh1, nin1, ns, s))) return rc;
+        if ((rc = launch_gemm_tn_partial_cs(S.GP1, 4 * nh1, S.X1, nin1, h->part, h->part_b, M, 4 * nh1, nin1, ns, s))) return rc;
         if ((rc = launch_reduce_partials(h->part, ns, 4 * nh1 * nin1, h->map_wih1, nullptr, grads, s))) return rc;
+        if ((rc = launch_reduce_partials(h->part_b, ns, 4 * nh1, h->map_b1a, h->map_b1b, grads, s))) return rc;
         if ((rc = launch_gemm_tn_partial(S.GP1, 4 * nh1, S.H1seq, nh1, h->part, M, 4 * nh1, nh1, ns, s))) return rc;
         if ((rc = launch_reduce_partials(h->part, ns, 4 * nh1 * nh1, h->map_whh1, nullptr, grads, s))) return rc;
     } else {
@@ -662,8 +664,6 @@ extern "C" int csa_train_backward(csa_trainer *h, int slot, int B, const float *
         h->pending.push_back(slot);
         h->pending_B = B;
     }
-    if ((rc = launch_colsum_partial(S.GP1, h->part, M, 4 * nh1, ns, s))) return rc;
-    if ((rc = launch_reduce_partials(h->part, ns, 4 * nh1, h->map_b1a, h->map_b1b, grads, s))) return rc;
     // mlp_initial / surface / TOA MLPs, gradient w.r.t. the incoming memory
     if ((rc = launch_prep_bwd(h->dm, B, h->dX1, S.X1, S.X16, S.xs, S.hc0, h->dhc1, h->dhc2, d_mem_in, h->part, s))) return rc;
     return launch_reduce_partials_2stage(h->part, B, prep_bwd_partial_floats(c), h->map_prep, nullptr, grads, h->rtmp, 32, s);
@@ -690,17 +690,19 @@ extern "C" int csa_train_flush_wgrad(csa_trainer *h, float *grads, void *stream)
     const int ns = (h->nsplit / nseg) * nseg;      // same number of partials as one per-step call, shared by the segments
     int rc;
     StageTimer tm(h, 4, s);
-    auto run = [&](float *Slot::*a, float *Slot::*b, int N1, int N2, const int *map) {
+    // ba / bb: the bias gradient (column sums of dP over all pending steps) comes out of the W_ih GEMM of each RNN
+    auto run = [&](float *Slot::*a, float *Slot::*b, int N1, int N2, const int *map, const int *ba, const int *bb) {
         TnSegs g{};
         g.n = nseg;
         for (int i = 0; i < nseg; ++i) { g.A[i] = h->slots[h->pending[i]].*a; g.B[i] = h->slots[h->pending[i]].*b; }
-        if ((rc = launch_gemm_tn_segs(g, N1, N2, h->part, M, N1, N2, ns, 0, 0, s))) return rc;
-        return launch_reduce_partials(h->part, ns, N1 * N2, map, nullptr, grads, s);
+        if ((rc = launch_gemm_tn_segs(g, N1, N2, h->part, M, N1, N2, ns, 0, 0, s, ba ? h->part_b : nullptr))) return rc;
+        if ((rc = launch_reduce_partials(h->part, ns, N1 * N2, map, nullptr, grads, s))) return rc;
+        return ba ? launch_reduce_partials(h->part_b, ns, N1, ba, bb, grads, s) : CSA_OK;
     };
-    if ((rc = run(&Slot::GP2, &Slot::H1lev, 4 * nh2, nh1, h->map_wih2))) return rc;
-    if ((rc = run(&Slot::GP2, &Slot::H2, 4 * nh2, nh2, h->map_whh2))) return rc;
-    if ((rc = run(&Slot::GP1, &Slot::X1, 4 * nh1, nin1, h->map_wih1))) return rc;
-    if ((rc = run(&Slot::GP1, &Slot::H1seq, 4 * nh1, nh1, h->map_whh1))) return rc;
+    if ((rc = run(&Slot::GP2, &Slot::H1lev, 4 * nh2, nh1, h->map_wih2, h->map_b2a, h->map_b2b))) return rc;
+    if ((rc = run(&Slot::GP2, &Slot::H2, 4 * nh2, nh2, h->map_whh2, nullptr, nullptr))) return rc;
+    if ((rc = run(&Slot::GP1, &Slot::X1, 4 * nh1, nin1, h->map_wih1, h->map_b1a, h->map_b1b))) return rc;
+    if ((rc = run(&Slot::GP1, &Slot::H1seq, 4 * nh1, nh1, h->map_whh1, nullptr, nullptr))) return rc;
     h->pending.clear();
     return CSA_OK;
 }

@@ -17,9 +17,11 @@
 #define TN_T 128
 #define TN_MK 16
 __global__ __launch_bounds__(256) void gemm_tn_partial_kernel(
-    TnSegs segs, int lda, int ldb, float *__restrict__ Cpart,
+    TnSegs segs, int lda, int ldb, float *__restrict__ Cpart, float *__restrict__ Csum,
     int M, int N1, int N2, int rows_per_split, int splits_per_seg, int conv_L, int conv_cin)
 {
+    // Csum (optional): partial column sums of A, Csum[split][n1] (the bias gradient rides on the rows this kernel
+    // stages anyway; only the blockIdx.y == 0 workgroups keep them).
     // segs: up to TN_MAX_SEGS (A, B) pairs of M rows each, contracted into ONE result (the T_w time steps of a TBPTT
     // window share their weight gradient): split z works on segment z / splits_per_seg.
     const float *__restrict__ A = segs.A[blockIdx.z / splits_per_seg];
@@ -42,7 +44,8 @@ __global__ __launch_bounds__(256) void gemm_tn_partial_kernel(
     // staging: 16 rows x 128 floats per operand = 512 float4, two per thread.  The global loads of chunk c+1 are
     // issued before the MFMAs of chunk c (register prefetch), so their latency hides behind 2048 MFMA cycles.
     const int sr = tid >> 5, sc = (tid & 31) * 4;
-    f32x4 va[2], vb[2];
+    f32x4 va[2], vb[2], cs = {0, 0, 0, 0};
+    const bool do_cs = Csum != nullptr && blockIdx.y == 0;
     auto gload = [&](int m0) {
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
@@ -72,6 +75,7 @@ __global__ __launch_bounds__(256) void gemm_tn_partial_kernel(
             *(f32x4 *)&As[buf][sr + 8 * h][sc] = va[h];
             *(f32x4 *)&Bs[buf][sr + 8 * h][sc] = vb[h];
         }
+        if (do_cs) cs += va[0] + va[1];      // here, not in gload: the loads are still in flight behind the MFMAs there
     };
     if (m_begin < m_end) {
         gload(m_begin);
@@ -107,12 +111,31 @@ __global__ __launch_bounds__(256) void gemm_tn_partial_kernel(
                 if (c1 < N1 && c2 < N2) C[(size_t)c1 * N2 + c2] = acc[i][j][r];
             }
     }
+    if (do_cs) {      // block-uniform; the loop's last barrier has released As
+        *(f32x4 *)&As[0][sr][sc] = cs;
+        __syncthreads();
+        if (tid < TN_T && n10 + tid < N1) {
+            float t = 0.0f;
+#pragma unroll
+            for (int r = 0; r < 8; ++r) t += As[0][r][tid];
+            Csum[(size_t)split * N1 + n10 + tid] = t;
+        }
+    }
 }
 
 int launch_gemm_tn_partial(const float *A, int lda, const float *Bm, int ldb, float *Cpart, int M, int N1, int N2,
                            int nsplit, hipStream_t s)
 {
     return launch_gemm_tn_conv(A, lda, Bm, ldb, Cpart, M, N1, N2, nsplit, 0, 0, s);
+}
+
+// the same, plus the partial column sums of A into Csum[nsplit][N1]
+int launch_gemm_tn_partial_cs(const float *A, int lda, const float *Bm, int ldb, float *Cpart, float *Csum, int M, int N1, int N2,
+                              int nsplit, hipStream_t s)
+{
+    TnSegs g{};
+    g.A[0] = A; g.B[0] = Bm; g.n = 1;
+    return launch_gemm_tn_segs(g, lda, ldb, Cpart, M, N1, N2, nsplit, 0, 0, s, Csum);
 }
 
 int launch_gemm_tn_conv(const float *A, int lda, const float *Bm, int ldb, float *Cpart, int M, int N1, int N2,
@@ -125,7 +148,7 @@ int launch_gemm_tn_conv(const float *A, int lda, const float *Bm, int ldb, float
 
 // nsplit = TOTAL number of partials (a multiple of segs.n); every segment has M rows
 int launch_gemm_tn_segs(const TnSegs &segs, int lda, int ldb, float *Cpart, int M, int N1, int N2,
-                        int nsplit, int conv_L, int conv_cin, hipStream_t s)
+                        int nsplit, int conv_L, int conv_cin, hipStream_t s, float *Csum)
 {
     if (segs.n <= 0 || segs.n > TN_MAX_SEGS || nsplit % segs.n) { csa_set_error_msg("gemm_tn: bad segment count"); return CSA_ERR_ARG; }
     if (conv_L > 0 && (conv_cin % 4 || N2 != 3 * conv_cin)) { csa_set_error_msg("gemm_tn(conv): cin multiple of 4 and N2 = 3*cin required"); return CSA_ERR_UNSUPPORTED; }
@@ -134,7 +157,7 @@ int launch_gemm_tn_segs(const TnSegs &segs, int lda, int ldb, float *Cpart, int 
     int rps = (M + sps - 1) / sps;
     rps = (rps + TN_MK - 1) / TN_MK * TN_MK;
     dim3 grid((N1 + TN_T - 1) / TN_T, (N2 + TN_T - 1) / TN_T, nsplit);
-    hipLaunchKernelGGL(gemm_tn_partial_kernel, grid, dim3(256), 0, s, segs, lda, ldb, Cpart, M, N1, N2, rps, sps, conv_L, conv_cin);
+    hipLaunchKernelGGL(gemm_tn_partial_kernel, grid, dim3(256), 0, s, segs, lda, ldb, Cpart, Csum, M, N1, N2, rps, sps, conv_L, conv_cin);
     CSA_HIP_CHECK(hipGetLastError());
     return CSA_OK;
 }
