@@ -126,8 +126,38 @@ def adding_sw(toa, alb_dif, alb_dir, R, T, Rdir, Tdd, Tdir):
     return torch.stack(up, 1), torch.stack(dif, 1), torch.stack(dr, 1)
 
 
+def band_table(rows, ng, lims=(37, 71, 80)):
+    """physics_rad_e3sm.py:146-156 / :278-288: the four Slingo / Ebert-Curry bands spread over ng g-points in RRTMGP's order
+    (band 4 first): rows is a list of 4-vectors -> (len(rows), ng).  lims: last RRTMGP g-point (of 112) of bands 4, 3, 2 -- as
+    serialised in num94634 (37, 71, 80); the current source has (29, 71, 80)."""
+    b4, b3, b2 = (int(round(l / 112 * ng)) for l in lims)
+    idx = [3] * b4 + [2] * (b3 - b4) + [1] * (b2 - b3) + [0] * (ng - b2)
+    return torch.tensor(rows)[:, idx]
+
+
+SLINGO = [[2.817e-02, 2.682e-02, 2.264e-02, 1.281e-02], [1.305, 1.346, 1.454, 1.641], [-5.62e-08, -6.94e-06, 4.64e-04, 0.201],
+          [1.63e-07, 2.35e-05, 1.24e-03, 7.56e-03], [0.829, 0.794, 0.754, 0.826], [2.482e-03, 4.226e-03, 6.560e-03, 4.353e-03]]
+EBERT_CURRY = [[3.448e-03] * 4, [2.431] * 4, [1.00e-05, 1.10e-04, 1.861e-02, 0.46658], [0.0, 1.405e-05, 8.328e-04, 2.05e-05],
+               [0.7661, 0.7730, 0.794, 0.9595], [5.851e-04, 5.665e-04, 7.267e-04, 1.076e-04]]
+
+
+def cloud_optics_sw(re, rows, lo, hi, ng):
+    """physics_rad_e3sm.py:98 slingo_liq_cloud_optics_sw / :265 ec_ice_optics_sw: re (B, n, 1) effective radius ->
+    extinction per unit water path, single-scattering albedo, asymmetry, each (B, n, ng)."""
+    y = band_table(rows, ng).to(re.dtype)
+    r = re.clamp(lo, hi)
+    return y[0] + y[1] / r, (1.0 - y[2] - r * y[3]).clamp(max=0.999999), y[4] + r * y[5]
+
+
+def gas_optics_sw(P, name, x, col_dry):
+    """rnn/layers.py gasopt_mlp as serialised in num94634: two Softsign layers, tau = col_dry * (ystd * y + ymean)^8."""
+    h = F.softsign(_lin(P, name + ".mlp1", x))
+    h = F.softsign(_lin(P, name + ".mlp2", h))
+    return col_dry * pow8(P[name + ".ystd"] * _lin(P, name + ".mlp3", h) + P[name + ".ymean"])
+
+
 def radiative_transfer(P, main0, aux_n, xd, play, plev, delta_plev, mem_out, T_crm, qn_crm, T_new, qv_new, qn_old,
-                       area_frac, ilev_crm, nh_mem0, ng=16, taps=None, rnn2out=None, physrad=False):
+                       area_frac, ilev_crm, nh_mem0, ng=16, taps=None, rnn2out=None, physrad=False, qv_crm=None):
     """-> dT_rad (B, 60) scaled by yscale_lev[:, 0], out_sfc_rad (B, 6) scaled by yscale_sca_rad.
     use_mcica graphs (mp_ncol < ng): every g-point samples a sub-column; otherwise g-point g is sub-column g.
     rnn2out given and `mlp_liq_frac_crm` in P (num83000): the cloud liquid fraction is a learned head instead of the
@@ -200,7 +230,8 @@ def radiative_transfer(P, main0, aux_n, xd, play, plev, delta_plev, mem_out, T_c
     s_up = (1.0 - tr) * (bmean + c * src_lev[:, :-1]) / (c + 1.0)
     # as serialised (see header): the downward source is the upward one -- except in the later exports (recognised by their
     # `xdiv` buffer), whose radiative_transfer passes the proper downward source
-    s_dn = (1.0 - tr) * (bmean + c * src_lev[:, 1:]) / (c + 1.0) if "gas_optics_model_lw.xdiv" in P else s_up
+    e3sm_sw = "gas_optics_model_sw1.mlp1.weight" in P          # (that generation views `source_up` twice again)
+    s_dn = (1.0 - tr) * (bmean + c * src_lev[:, 1:]) / (c + 1.0) if "gas_optics_model_lw.xdiv" in P and not e3sm_sw else s_up
     dn = [torch.zeros(B, ng)]
     for j in range(nlev):
         dn.append(tr[:, j] * dn[-1] + s_dn[:, j])
@@ -210,15 +241,50 @@ def radiative_transfer(P, main0, aux_n, xd, play, plev, delta_plev, mem_out, T_c
         up[j] = tr[:, j] * up[j + 1] + s_up[:, j]
     lw_dn, lw_up = torch.stack(dn, 1).sum(2), torch.stack(up, 1).sum(2)                       # (B,61)
 
-    # SW optical properties from the learned head, then two-stream + adding
     top0 = T_new.new_zeros(B, ilev_crm, 1)
-    mem60 = torch.cat([T_new.new_zeros(B, ilev_crm, nh_mem0), mem_out[:, :, :nh_mem0]], 1)
-    xr = torch.cat([(torch.log(play) - 0.00515) / 11.59485, (T_new - 160.0) / 180.0, (qv_new * 1.608079364).sqrt().sqrt() / 0.497653,
-                    1.0 - torch.exp(-qn_old * P["lbd_qn"].view(1, -1, 1)), main0[:, :, 12:15],
-                    torch.cat([top0, rel / 13.5], 1), torch.cat([top0, rei / 250.0], 1), mem60], 2)
-    o = _lin(P, "mlp_sw_optprops2", F.softsign(_lin(P, "mlp_sw_optprops1", xr))).view(B, nlev, 3, ng)
-    tau_sw = (pow8(o[:, :, 0]) * (col_dry * 1e-23)).clamp(1e-6, 40.0)
-    ssa, asy = torch.sigmoid(o[:, :, 1]), torch.sigmoid(o[:, :, 2])
+    if e3sm_sw:
+        # SW optical properties of the physics_rad_e3sm generation (num94634 and the frozen `*_wrapped` exports): two gas-optics
+        # MLPs (absorption, Rayleigh scattering) evaluated for the humidity of the two largest regions of every level and
+        # averaged, reduced 112 -> ng; Slingo liquid / Ebert-Curry ice cloud optics per region (region g = g-point g)
+        qc = qv_crm.clamp(max=0.05)
+        vmr_c = qc / (1.0 - qc) * 1.608079364
+        v12 = torch.gather(vmr_c, 2, torch.topk(area_frac, 2, dim=2).indices)                 # (B,50,2)
+        v_top = vmr.sqrt().sqrt()[:, :ilev_crm]         # as serialised: the levels above the CRM carry the FOURTH ROOT here
+        tau_k = sca_k = 0.0
+        for j in range(2):
+            v = torch.cat([v_top, v12[:, :, j:j + 1]], 1)
+            f = 1.0 / (v + 1.0)
+            col = (delta_plev * 6.02214076e24 * f) / ((v + 0.04698) * f * 980665)
+            x = torch.cat([T_new, torch.log(play), v.sqrt().sqrt(), xd[:, :, 12:13].sqrt().sqrt(), torch.full_like(T_new, 0.0003887),
+                           xd[:, :, 14:15], xd[:, :, 13:14]], 2)
+            x = (x - P["gas_optics_model_sw1.xmin"]) / P["gas_optics_model_sw1.xdiv"]         # (both models: the first one's range)
+            tau_k = tau_k + 0.5 * gas_optics_sw(P, "gas_optics_model_sw1", x, col)
+            sca_k = sca_k + 0.5 * gas_optics_sw(P, "gas_optics_model_sw2", x, col)
+        tau_abs = F.softplus(_lin(P, "gas_optics_sw_reduce1", tau_k)) * 0.01 + 1e-9
+        tau_sca = F.softplus(_lin(P, "gas_optics_sw_reduce2", sca_k)) * 0.01
+        kl, wl, gl = cloud_optics_sw(rel, SLINGO, 4.2, 16.0, ng)
+        ki, wi, gi = cloud_optics_sw(rei, EBERT_CURRY, 13.0, 130.0, ng)
+        cwp_liq = liq_g * cwp
+        pad = lambda t: torch.cat([t.new_zeros(B, ilev_crm, ng), t], 1)
+        c_tau = pad(cwp_ice * ki + cwp_liq * kl)
+        c_sca = cwp_liq * (kl * wl) + cwp_ice * (ki * wi)
+        c_asy = pad((cwp_liq * (kl * wl * gl) + cwp_ice * (ki * wi * gi)) / (c_sca + 1e-7))
+        c_sca = pad(c_sca)
+        tau_sw = tau_abs + tau_sca + c_tau
+        sca = tau_sca + c_sca
+        asy = c_asy * c_sca / sca
+        ssa = sca / tau_sw
+        xr = None
+    else:
+        # SW optical properties from the learned head
+        mem60 = torch.cat([T_new.new_zeros(B, ilev_crm, nh_mem0), mem_out[:, :, :nh_mem0]], 1)
+        xr = torch.cat([(torch.log(play) - 0.00515) / 11.59485, (T_new - 160.0) / 180.0, (qv_new * 1.608079364).sqrt().sqrt() / 0.497653,
+                        1.0 - torch.exp(-qn_old * P["lbd_qn"].view(1, -1, 1)), main0[:, :, 12:15],
+                        torch.cat([top0, rel / 13.5], 1), torch.cat([top0, rei / 250.0], 1), mem60], 2)
+        o = _lin(P, "mlp_sw_optprops2", F.softsign(_lin(P, "mlp_sw_optprops1", xr))).view(B, nlev, 3, ng)
+        tau_sw = (pow8(o[:, :, 0]) * (col_dry * 1e-23)).clamp(1e-6, 40.0)
+        ssa, asy = torch.sigmoid(o[:, :, 1]), torch.sigmoid(o[:, :, 2])
+    # two-stream + adding
     mu0 = aux[:, 6].clamp(min=1e-6).view(B, 1, 1).expand(B, nlev, ng)
     R, T, Rdir, Tdd, Tdir = two_stream_sw(mu0, tau_sw, ssa, asy)
     toa = aux[:, 1:2] * torch.softmax(P["sw_solar_weights"] if physrad else P["sw_solar_weights"] ** 2, 1)   # (B,g)
@@ -308,7 +374,7 @@ def forward(P, inputs_main, inputs_aux, rnn_mem, inputs_denorm, hx2, ilev_crm=10
         taps.update(rnn2out=rnn2raw, out_mp=out_new.clone(), T_crm=dec["T_crm"], qn_crm=dec["qn_crm"], area_frac=dec["area_frac"])
     dT_rad, sfc_rad = radiative_transfer(P, main0, inputs_aux, inputs_denorm, play, plev, delta_plev, dec["mem_out"],
                                          dec["T_crm"], dec["qn_crm"], T_new, qv_new, qn_old, dec["area_frac"],
-                                         ilev_crm, nh_mem0, ng, taps, rnn2out, physrad)
+                                         ilev_crm, nh_mem0, ng, taps, rnn2out, physrad, dec["qv_crm"])
     out_new[:, :, 0] = out_new[:, :, 0] + dT_rad
     out_sfc = torch.cat([sfc_rad[:, 0:2], dec["precsc"], dec["precc"], sfc_rad[:, 2:]], 1)
     return out_new, out_sfc, dec["mem_out"]
