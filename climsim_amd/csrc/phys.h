@@ -32,7 +32,29 @@ struct PhysDev {
     const float *xmean_sca, *xdiv_sca, *lbd_qn, *g_xmin, *g_range, *g_ymean, *g_ystd, *ys_rad, *toa_spec, *retab;
     const float *cld_w, *cld_b;   // cloud_optics_lw (16, 19), (16): learned cloud LW optical depth per unit path (num88955), or null
     int lw_dn;              // 1: the LW downward sweep gets its own source (later exports); 0: the upward one, as first serialised
+    // physics_rad_e3sm generation (num94634): SW optical properties from two gas-optics MLPs + Slingo / Ebert-Curry cloud optics
+    const float *swg;       // the packed block of include/climsim_amd.h (CSA_PHYS_SW_GAS), or null: SW head MLP
 };
+
+// layout of the CSA_PHYS_SW_GAS block (floats): input range, two gas-optics models, the two 112 -> 16 reductions (transposed),
+// cloud-optics coefficients per g-point
+#define SWG_NK 112
+#define SWG_XMIN 0
+#define SWG_XDIV 8
+#define SWG_MODEL0 16
+#define SWG_W1 0                               // (32, 8): 7 inputs, zero-padded
+#define SWG_B1 (SWG_W1 + 32 * 8)
+#define SWG_W2 (SWG_B1 + 32)                   // (32, 32)
+#define SWG_B2 (SWG_W2 + 32 * 32)
+#define SWG_W3 (SWG_B2 + 32)                   // (112, 32)
+#define SWG_B3 (SWG_W3 + SWG_NK * 32)
+#define SWG_YSTD (SWG_B3 + SWG_NK)
+#define SWG_YMEAN (SWG_YSTD + SWG_NK)
+#define SWG_MODEL_FLOATS (SWG_YMEAN + SWG_NK)
+#define SWG_RED (SWG_MODEL0 + 2 * SWG_MODEL_FLOATS)   // reduce1^T (112, 16), bias (16), reduce2^T (112, 16), bias (16)
+#define SWG_RED_FLOATS (SWG_NK * 16 + 16)
+#define SWG_CLD (SWG_RED + 2 * SWG_RED_FLOATS)        // (12, 16): Slingo A..F then Ebert-Curry a..f, per g-point
+#define SWG_FLOATS (SWG_CLD + 12 * 16)
 
 struct csa_phys {
     PhysDev d;
@@ -42,6 +64,7 @@ struct csa_phys {
     // radiation scheme: MLP weights (row-major (out, in), K padded to a multiple of 4) and per-call work arrays
     float *g_w1, *g_b1, *g_w2, *g_b2, *g_w3, *g_b3, *r1_w, *r1_b, *r2_w, *r2_b, *s1_w, *s1_b, *s2_w, *s2_b;
     float *XG, *XR, *RS, *CL, *TP, *S2;
+    float *CS = nullptr;    // SW_GAS: cloud SW extinction, scattering, asymmetry per (CRM level, column, g-point): (Lc * B, 48)
     // add_stochastic_layer graphs: rnn3 (MyStochasticGRULayer5 over rnn2's output), its output and the perturbed sequence
     struct csa_stoch *rnn3 = nullptr;
     float *H3 = nullptr, *H2p = nullptr;

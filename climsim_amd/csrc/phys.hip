@@ -117,7 +117,7 @@ __device__ __forceinline__ float ph_reltab(float t, float landfrac, float icefra
 // Radiation work arrays written by the decoder when RAD (consumed by phys_rad.hip); rows are (level, column), level-major
 struct PhysRadOut {
     const float *x_main;
-    float *XG, *XR, *RS, *CL;
+    float *XG, *XR, *RS, *CL, *CS;
 };
 
 // decoder workgroup: DT threads over the LC * NC (level, sub-column) cells -- 800 cells in two passes of 512 for
@@ -246,6 +246,7 @@ __global__ __launch_bounds__(DT) void phys_decode_kernel(PhysDev d, int B, const
         if (RAD && ok) {                              // sub-column state after the step, as the radiation scheme sees it
             s_T[e] = fmaxf(s_T[e] + dT_crm * 1200.0f / ys[0], 0.0f);
             s_qn[e] = fmaxf(qn + dqn * 1200.0f / ys[2], 0.0f);
+            s_qv[e] = fmaxf(qv + dqv * 1200.0f / ys[1], 0.0f);
         }
         if (ok && c == 0) {
             float *o = out_lev + ((size_t)b * PH_L + L) * 5;
@@ -323,6 +324,32 @@ __global__ __launch_bounds__(DT) void phys_decode_kernel(PhysDev d, int B, const
             for (int k = 0; k < PH_XG_K; ++k)
                 xg[k] = k < 18 ? fmaxf((f[k] - d.g_xmin[k]) / d.g_range[k], 0.0f) : 0.0f;
             float *xr = ro.XR + row * PH_XR_K;
+            if (d.swg) {
+                // physics_rad_e3sm generation: inputs of the SW gas-optics MLPs for the humidity of the two largest regions of the
+                // level (above the CRM: the grid-mean value -- its FOURTH ROOT, as the serialised graph concatenates it)
+                float v[2] = {v4, v4};
+                if (L >= ilev) {
+                    const float *ar = s_area + (L - ilev) * NC;
+                    int i0 = 0, i1 = -1;
+#pragma unroll
+                    for (int c = 1; c < NC; ++c) if (ar[c] > ar[i0]) i0 = c;
+#pragma unroll
+                    for (int c = 0; c < NC; ++c) if (c != i0 && (i1 < 0 || ar[c] > ar[i1])) i1 = c;
+                    const float q0 = fminf(s_qv[(L - ilev) * NC + i0], 0.05f), q1 = fminf(s_qv[(L - ilev) * NC + i1], 0.05f);
+                    v[0] = q0 / (1.0f - q0) * 1.608079364f; v[1] = q1 / (1.0f - q1) * 1.608079364f;
+                }
+                const float *xmin = d.swg + SWG_XMIN, *xdiv = d.swg + SWG_XDIV;
+                xr[0] = (T_new - xmin[0]) / xdiv[0]; xr[1] = (lp - xmin[1]) / xdiv[1];
+                xr[3] = (sqrtf(sqrtf(xd[12])) - xmin[3]) / xdiv[3]; xr[4] = (0.0003887f - xmin[4]) / xdiv[4];
+                xr[5] = (xd[14] - xmin[5]) / xdiv[5]; xr[6] = (xd[13] - xmin[6]) / xdiv[6];
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const float fj = 1.0f / (v[j] + 1.0f);
+                    xr[j ? 7 : 2] = (sqrtf(sqrtf(v[j])) - xmin[2]) / xdiv[2];
+                    xr[8 + j] = ((pd * 6.02214076e24f) * fj) / (((v[j] + 0.04698f) * fj) * 980665.0f);
+                }
+                continue;
+            }
             const float *xm = ro.x_main + ((size_t)b * PH_L + L) * d.nx;
             xr[0] = (lp - 0.00515f) / 11.59485f;
             xr[1] = (T_new - 160.0f) / 180.0f;
@@ -405,6 +432,19 @@ __global__ __launch_bounds__(DT) void phys_decode_kernel(PhysDev d, int B, const
                 tau_cld = cwp * fmaxf(a, 0.0f);
             }
             ro.CL[((size_t)l * B + b) * PH_NG + g] = tau_cld;
+            if (d.swg) {            // Slingo liquid / Ebert-Curry ice SW optics of region g (physics_rad_e3sm.py:98, :265)
+                const float *aux = x_sfc + (size_t)b * d.naux, *t = d.swg + SWG_CLD + g;
+                const float rl = fminf(fmaxf(ph_reltab(T_new, aux[13] * d.xdiv_sca[13] + d.xmean_sca[13], aux[12] * d.xdiv_sca[12] + d.xmean_sca[12],
+                                                       aux[15] * d.xdiv_sca[15] + d.xmean_sca[15]), 4.2f), 16.0f);
+                const float kl = t[0] + t[16] / rl, wl = fminf((1.0f - t[32]) - rl * t[48], 0.999999f), gl = t[64] + rl * t[80];
+                const float ki = t[96] + t[112] / rei, wi = fminf((1.0f - t[128]) - rei * t[144], 0.999999f), gi = t[160] + rei * t[176];
+                const float cwp_liq = liq * cwp, sl = kl * wl, si = ki * wi;
+                const float c_sca = cwp_liq * sl + cwp_ice * si;
+                float *cs = ro.CS + ((size_t)l * B + b) * 48 + g;
+                cs[0] = cwp_ice * ki + cwp_liq * kl;
+                cs[16] = c_sca;
+                cs[32] = (cwp_liq * (sl * gl) + cwp_ice * (si * gi)) / (c_sca + 1e-7f);
+            }
         }
     }
 }
@@ -421,6 +461,7 @@ struct PhysHostW {           // host pointers of one state_dict, by role
     const float *liq_w, *liq_b;              // mlp_liq_frac_crm (mp_ncol, nh), optional
     const float *s3_ih, *s3_zh, *s3_enc;     // rnn3 = MyStochasticGRULayer5(nh, nh) without bias, optional
     const float *cld_w, *cld_b;              // cloud_optics_lw (16, 19), optional
+    const float *swg;                        // CSA_PHYS_SW_GAS block (SWG_FLOATS), optional
 };
 
 // ice effective radius (micron) against temperature, 137 K ... : E3SM's table as listed in rnn/models/physics_rad_e3sm.py:13-59
@@ -522,7 +563,7 @@ static int phys_build(int nx, int nfeat, int naux, int nx_sfc, int sfc_cut, int 
             for (int k = 0; k < 18; ++k) rg[k] = lw_dn ? w.g_xmax[k] : w.g_xmax[k] - w.g_xmin[k];
             d.g_range = up(rg, 18);
         }
-        d.lw_dn = lw_dn;
+        d.lw_dn = lw_dn && !w.swg;   // (the SW gas-optics generation carries `xdiv` too, but views the upward source twice again)
         d.cld_w = w.cld_w ? up(w.cld_w, PH_NG * 19) : nullptr;
         d.cld_b = w.cld_w ? up(w.cld_b, PH_NG) : nullptr;
         d.g_xmin = up(w.g_xmin, 18); d.g_ymean = up(w.g_ymean, 128); d.g_ystd = up(w.g_ystd, 128);
@@ -544,8 +585,13 @@ static int phys_build(int nx, int nfeat, int naux, int nx_sfc, int sfc_cut, int 
         h->g_w3 = up(w.g_w3, 256 * 64); h->g_b3 = up(w.g_b3, 256);
         h->r1_w = up(w.r1_w, 16 * 128); h->r1_b = up(w.r1_b, 16);
         h->r2_w = up(w.r2_w, 16 * 128); h->r2_b = up(w.r2_b, 16);
-        h->s1_w = up(w.sw1_w, 32 * PH_XR_K); h->s1_b = up(w.sw1_b, 32);
-        h->s2_w = up(w.sw2_w, 48 * 32); h->s2_b = up(w.sw2_b, 48);
+        if (w.swg) {
+            d.swg = up(w.swg, SWG_FLOATS);
+            h->CS = up(nullptr, (size_t)d.Lc * max_batch * 48);
+        } else {
+            h->s1_w = up(w.sw1_w, 32 * PH_XR_K); h->s1_b = up(w.sw1_b, 32);
+            h->s2_w = up(w.sw2_w, 48 * 32); h->s2_b = up(w.sw2_b, 48);
+        }
         const size_t M = (size_t)PH_L * max_batch;
         h->XG = up(nullptr, M * PH_XG_K); h->XR = up(nullptr, M * PH_XR_K); h->RS = up(nullptr, M * 2);
         h->CL = up(nullptr, (size_t)d.Lc * max_batch * PH_NG);
@@ -583,7 +629,7 @@ extern "C" int csa_phys_create(int nx, int nx_sfc, int nh, int ilev_crm, int mp_
 extern "C" int csa_phys_rad_create(int nx, int naux, int nh, int ilev_crm, int mp_ncol, int nh_mem0, int ng, int flags,
                                    const float *const *w, int max_batch, csa_phys **out)
 {
-    if (!w || !out || max_batch <= 0 || (flags & ~63)) { csa_set_error_msg("csa_phys_rad_create: bad argument"); return CSA_ERR_ARG; }
+    if (!w || !out || max_batch <= 0 || (flags & ~127)) { csa_set_error_msg("csa_phys_rad_create: bad argument"); return CSA_ERR_ARG; }
     const bool mcica = flags & CSA_PHYS_MCICA, physrad = flags & CSA_PHYS_PHYSRAD;
     if (physrad && !(flags & (CSA_PHYS_LIQ_FRAC_HEAD | CSA_PHYS_CLOUD_OPTICS_LW))) {
         csa_set_error_msg("csa_phys_rad_create: the physRad graphs come with the liquid-fraction head or the learned cloud optics");
@@ -608,12 +654,23 @@ extern "C" int csa_phys_rad_create(int nx, int naux, int nh, int ilev_crm, int m
     v.heads = p; p += 2 * PH_NHEAD;
     v.lbd_qn = *p++; v.ys_rad = *p++; v.solar_w = *p++; v.g_xmin = *p++; v.g_xmax = *p++; v.g_ymean = *p++; v.g_ystd = *p++;
     v.g_w1 = *p++; v.g_b1 = *p++; v.g_w2 = *p++; v.g_b2 = *p++; v.g_w3 = *p++; v.g_b3 = *p++;
-    v.r1_w = *p++; v.r1_b = *p++; v.r2_w = *p++; v.r2_b = *p++; v.sw1_w = *p++; v.sw1_b = *p++; v.sw2_w = *p++; v.sw2_b = *p++;
+    v.r1_w = *p++; v.r1_b = *p++; v.r2_w = *p++; v.r2_b = *p++;
+    const float *const *const sw_head = p;           // the four SW-head slots: unused (may be null) with the SW gas-optics models
+    v.sw1_w = *p++; v.sw1_b = *p++; v.sw2_w = *p++; v.sw2_b = *p++;
     if (flags & CSA_PHYS_LIQ_FRAC_HEAD) { v.liq_w = *p++; v.liq_b = *p++; }
     if (flags & CSA_PHYS_STOCHASTIC) { v.s3_ih = *p++; v.s3_zh = *p++; v.s3_enc = *p++; }
     if (flags & CSA_PHYS_CLOUD_OPTICS_LW) { v.cld_w = *p++; v.cld_b = *p++; }
+    const float *const *swh = nullptr;
+    if (flags & CSA_PHYS_SW_GAS) {
+        if (!physrad || mcica || !(flags & CSA_PHYS_LIQ_FRAC_HEAD) || (flags & CSA_PHYS_CLOUD_OPTICS_LW)) {
+            csa_set_error_msg("csa_phys_rad_create: the SW gas-optics models belong to the 16-region physRad graphs with the liquid-fraction head");
+            return CSA_ERR_UNSUPPORTED;
+        }
+        v.swg = *p++;
+        swh = sw_head;
+    }
     for (const float *const *q = w; q != p; ++q)
-        if (!*q && !(physrad && (q == v.heads + 2 * H_T || q == v.heads + 2 * H_T + 1))) {      // (no mlp_t_crm in the physRad graphs)
+        if (!*q && !(physrad && (q == v.heads + 2 * H_T || q == v.heads + 2 * H_T + 1)) && !(swh && q >= swh && q < swh + 4)) {      // (no mlp_t_crm in the physRad graphs)
             csa_set_error_msg("csa_phys_rad_create: null weight pointer");
             return CSA_ERR_ARG;
         }
@@ -680,7 +737,7 @@ static int phys_forward_impl(csa_phys *h, int B, const float *x_main, const floa
     }
     if ((rc = launch_proj_gemm(Hhead, h->whead, h->bhead, h->HD, M, d.hdw, nh, s, 0))) return rc;
     if (d.rad) {
-        PhysRadOut ro{x_main, h->XG, h->XR, h->RS, h->CL};
+        PhysRadOut ro{x_main, h->XG, h->XR, h->RS, h->CL, h->CS};
         if (d.ncol == 4)
             hipLaunchKernelGGL((phys_decode_kernel<4, 256, true>), dim3(B), dim3(256), 0, s, d, B, h->HD, Hlast, x_sfc, rnn_mem, x_denorm, nxd,
                                out_lev, out_sfc, mem_out, ro);

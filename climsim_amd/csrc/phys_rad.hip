@@ -258,6 +258,102 @@ __global__ __launch_bounds__(64 * RO_WAVES) void rad_optics_kernel(RadOptics a)
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// physics_rad_e3sm generation: SW optical properties of every (level, column) row.  Two lanes per row, one per humidity
+// variant (the two largest regions); each lane runs both gas-optics MLPs 7 -> 32 -> 32 -> 112 on its variant, the pair
+// averages tau = col_dry * (ystd * y + ymean)^8 through one cross-lane add, and each lane reduces 112 -> 8 of the 16
+// g-points (absorption and Rayleigh).  Weights (SWG_FLOATS, 56 KB) sit in LDS and are read as wave-wide broadcasts.
+// fp32 VALU: 2 * 2 * (7*32 + 32*32 + 32*112) + 2 * 112 * 16 = 23.3 kFMA per row.
+// S2 row: [tau_sw (16) | ssa (16) | asymmetry (16)] -- final values (the solver applies no activation for this generation).
+#define SG_T 128
+__global__ __launch_bounds__(SG_T) void rad_sw_gas_kernel(const float *__restrict__ XR, const float *__restrict__ swg, const float *__restrict__ CS,
+                                                          float *__restrict__ S2, int M, int B, int ilev)
+{
+    __shared__ __attribute__((aligned(16))) float sw[SWG_FLOATS];
+    for (int i = threadIdx.x; i < SWG_FLOATS / 4; i += SG_T) ((f32x4 *)sw)[i] = ((const f32x4 *)swg)[i];
+    __syncthreads();
+    const int var = threadIdx.x & 1;
+    const int row_raw = blockIdx.x * (SG_T / 2) + (threadIdx.x >> 1);
+    const bool ok = row_raw < M;
+    const int row = ok ? row_raw : M - 1;
+    const float *xr = XR + (size_t)row * PH_XR_K;
+    float x[8];
+    {
+        const f32x4 a = *(const f32x4 *)xr, c = *(const f32x4 *)(xr + 4);
+        x[0] = a.x; x[1] = a.y; x[2] = var ? c.w : a.z; x[3] = a.w; x[4] = c.x; x[5] = c.y; x[6] = c.z; x[7] = 0.0f;
+    }
+    const float col = xr[8 + var];
+    float h2[2][32];
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+        const float *W = sw + SWG_MODEL0 + m * SWG_MODEL_FLOATS;
+        float h1[32];
+#pragma unroll
+        for (int j = 0; j < 32; ++j) {
+            const f32x4 w0 = *(const f32x4 *)(W + SWG_W1 + j * 8), w1 = *(const f32x4 *)(W + SWG_W1 + j * 8 + 4);
+            float a = W[SWG_B1 + j];
+            a = fmaf(w0.x, x[0], a); a = fmaf(w0.y, x[1], a); a = fmaf(w0.z, x[2], a); a = fmaf(w0.w, x[3], a);
+            a = fmaf(w1.x, x[4], a); a = fmaf(w1.y, x[5], a); a = fmaf(w1.z, x[6], a);
+            h1[j] = a / (1.0f + fabsf(a));
+        }
+#pragma unroll
+        for (int j = 0; j < 32; ++j) {
+            const f32x4 *wr = (const f32x4 *)(W + SWG_W2 + j * 32);
+            float a0 = W[SWG_B2 + j], a1 = 0.0f;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const f32x4 w = wr[q];
+                a0 = fmaf(w.x, h1[4 * q], a0); a1 = fmaf(w.y, h1[4 * q + 1], a1);
+                a0 = fmaf(w.z, h1[4 * q + 2], a0); a1 = fmaf(w.w, h1[4 * q + 3], a1);
+            }
+            const float a = a0 + a1;
+            h2[m][j] = a / (1.0f + fabsf(a));
+        }
+    }
+    float acc[2][8];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int g = 0; g < 8; ++g) acc[m][g] = 0.0f;
+    for (int k = 0; k < SWG_NK; ++k) {
+        float t[2];
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            const float *W = sw + SWG_MODEL0 + m * SWG_MODEL_FLOATS;
+            const f32x4 *wr = (const f32x4 *)(W + SWG_W3 + k * 32);
+            float a0 = W[SWG_B3 + k], a1 = 0.0f;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const f32x4 w = wr[q];
+                a0 = fmaf(w.x, h2[m][4 * q], a0); a1 = fmaf(w.y, h2[m][4 * q + 1], a1);
+                a0 = fmaf(w.z, h2[m][4 * q + 2], a0); a1 = fmaf(w.w, h2[m][4 * q + 3], a1);
+            }
+            const float y = fmaf(W[SWG_YSTD + k], a0 + a1, W[SWG_YMEAN + k]);
+            const float tv = col * pr_pow8(y);
+            t[m] = (tv + __shfl_xor(tv, 1)) * 0.5f;
+            const f32x4 *rr = (const f32x4 *)(sw + SWG_RED + m * SWG_RED_FLOATS + k * 16 + var * 8);
+            const f32x4 r0 = rr[0], r1 = rr[1];
+            acc[m][0] = fmaf(r0.x, t[m], acc[m][0]); acc[m][1] = fmaf(r0.y, t[m], acc[m][1]);
+            acc[m][2] = fmaf(r0.z, t[m], acc[m][2]); acc[m][3] = fmaf(r0.w, t[m], acc[m][3]);
+            acc[m][4] = fmaf(r1.x, t[m], acc[m][4]); acc[m][5] = fmaf(r1.y, t[m], acc[m][5]);
+            acc[m][6] = fmaf(r1.z, t[m], acc[m][6]); acc[m][7] = fmaf(r1.w, t[m], acc[m][7]);
+        }
+    }
+    // gas + cloud -> layer optical depth, single-scattering albedo, asymmetry (region g is g-point g)
+    const int L = row / B, b = row - L * B;
+    const float *cs = L >= ilev ? CS + ((size_t)(L - ilev) * B + b) * 48 : nullptr;
+    float *o = S2 + (size_t)row * 48 + var * 8;
+#pragma unroll
+    for (int g8 = 0; g8 < 8; ++g8) {
+        const int g = var * 8 + g8;
+        const float t_abs = pr_softplus(acc[0][g8] + sw[SWG_RED + SWG_NK * 16 + g]) * 0.01f + 1e-9f;
+        const float t_sca = pr_softplus(acc[1][g8] + sw[SWG_RED + SWG_RED_FLOATS + SWG_NK * 16 + g]) * 0.01f;
+        const float c_tau = cs ? cs[g] : 0.0f, c_sca = cs ? cs[16 + g] : 0.0f, c_asy = cs ? cs[32 + g] : 0.0f;
+        const float tau = (t_abs + t_sca) + c_tau, sca = t_sca + c_sca;
+        if (ok) { o[g8] = tau; o[16 + g8] = sca / tau; o[32 + g8] = (c_asy * c_sca) / sca; }
+    }
+}
+
 #define RS_T 256
 __global__ __launch_bounds__(RS_T) void phys_rad_solve_kernel(PhysDev d, int B, const float *__restrict__ x_sfc, const float *__restrict__ TP,
                                                             const float *__restrict__ CL, const float *__restrict__ S2,
@@ -301,8 +397,9 @@ __global__ __launch_bounds__(RS_T) void phys_rad_solve_kernel(PhysDev d, int B, 
         const float tau = pr_softplus(tp[g]) * 0.01f + (lv >= ilev ? CL[((size_t)(lv - ilev) * B + b) * NG + g] : 0.0f);
         const float od_lw = tau * 1.66f;
         const float *o = S2 + row * 48;
-        const float od = fminf(fmaxf(pr_pow8(o[g]) * (s_cd[lv] * 1e-23f), 1e-6f), 40.0f);
-        const float ssa = pr_sigmoid(o[16 + g]), asy = pr_sigmoid(o[32 + g]);
+        // SW head: logits; SW gas-optics generation (d.swg): the final values
+        const float od = d.swg ? o[g] : fminf(fmaxf(pr_pow8(o[g]) * (s_cd[lv] * 1e-23f), 1e-6f), 40.0f);
+        const float ssa = d.swg ? o[16 + g] : pr_sigmoid(o[16 + g]), asy = d.swg ? o[32 + g] : pr_sigmoid(o[32 + g]);
         // two-stream coefficients (physics_rad.py:139)
         const float t_dir = expf(-od / mu0);
         const float g1 = (8.0f - ssa * (5.0f + 3.0f * asy)) * 0.25f, g2 = 3.0f * (ssa * (1.0f - asy)) * 0.25f;
@@ -429,8 +526,13 @@ int launch_phys_radiation(csa_phys *h, int B, const float *x_sfc, float *out_lev
     const int M = PH_L * B;
     RadOptics a{h->XG, h->XR, h->RS, h->g_w1, h->g_b1, h->g_w2, h->g_b2, h->g_w3, h->g_b3, h->r1_w, h->r1_b, h->r2_w, h->r2_b,
                 h->s1_w, h->s1_b, h->s2_w, h->s2_b, d.g_ystd, d.g_ymean, h->TP, h->S2, M};
-    hipLaunchKernelGGL(rad_optics_kernel, dim3((M + 32 * RO_WAVES - 1) / (32 * RO_WAVES), 2), dim3(64 * RO_WAVES), 0, s, a);
+    // grid y: 0 = LW gas optics, 1 = SW head (absent in the SW gas-optics generation, which has its own kernel)
+    hipLaunchKernelGGL(rad_optics_kernel, dim3((M + 32 * RO_WAVES - 1) / (32 * RO_WAVES), d.swg ? 1 : 2), dim3(64 * RO_WAVES), 0, s, a);
     CSA_HIP_CHECK(hipGetLastError());
+    if (d.swg) {
+        hipLaunchKernelGGL(rad_sw_gas_kernel, dim3((M + SG_T / 2 - 1) / (SG_T / 2)), dim3(SG_T), 0, s, h->XR, d.swg, h->CS, h->S2, M, B, d.ilev);
+        CSA_HIP_CHECK(hipGetLastError());
+    }
     hipLaunchKernelGGL(phys_rad_solve_kernel, dim3(B), dim3(RS_T), 0, s, d, B, x_sfc, h->TP, h->CL, h->S2, h->RS, out_lev, out_sfc);
     CSA_HIP_CHECK(hipGetLastError());
     return CSA_OK;

@@ -31,6 +31,38 @@ _ORDER_RAD = ([k for k in _ORDER if not k.startswith(("mlp_surface_output_rad", 
                  for n in ("weight", "bias")])
 
 
+# Slingo (1989) liquid and Ebert-Curry ice SW cloud-optics coefficients in their four bands (rnn/models/physics_rad_e3sm.py:108-113,
+# :267-272), and the last RRTMGP g-point (of 112) of bands 4, 3, 2 as the shipped exports serialise the band -> g-point spread
+_SLINGO = [[2.817e-02, 2.682e-02, 2.264e-02, 1.281e-02], [1.305, 1.346, 1.454, 1.641], [-5.62e-08, -6.94e-06, 4.64e-04, 0.201],
+           [1.63e-07, 2.35e-05, 1.24e-03, 7.56e-03], [0.829, 0.794, 0.754, 0.826], [2.482e-03, 4.226e-03, 6.560e-03, 4.353e-03]]
+_EBERT_CURRY = [[3.448e-03] * 4, [2.431] * 4, [1.00e-05, 1.10e-04, 1.861e-02, 0.46658], [0.0, 1.405e-05, 8.328e-04, 2.05e-05],
+                [0.7661, 0.7730, 0.794, 0.9595], [5.851e-04, 5.665e-04, 7.267e-04, 1.076e-04]]
+_SW_BAND_LIMITS = (37, 71, 80)
+
+
+def _sw_gas_block(state_dict, ng, band_limits=_SW_BAND_LIMITS):
+    """The CSA_PHYS_SW_GAS weight block of include/climsim_amd.h (layout: csrc/phys.h SWG_*)."""
+    f = lambda k: np.asarray(state_dict[k].detach().cpu() if isinstance(state_dict[k], torch.Tensor) else state_dict[k], np.float32)
+    if ng != 16:
+        raise RuntimeError("physRNN SW gas optics: built for 16 g-points")
+    pad8 = lambda v: np.concatenate([v, np.ones(8 - v.shape[0], np.float32)])
+    parts = [pad8(f("gas_optics_model_sw1.xmin")) * np.r_[np.ones(7), 0].astype(np.float32), pad8(f("gas_optics_model_sw1.xdiv"))]
+    for m in ("gas_optics_model_sw1", "gas_optics_model_sw2"):
+        w1 = f(m + ".mlp1.weight")
+        if w1.shape != (32, 7) or f(m + ".mlp2.weight").shape != (32, 32) or f(m + ".mlp3.weight").shape != (112, 32):
+            raise RuntimeError("physRNN SW gas optics: built for the shipped 7 -> 32 -> 32 -> 112 models")
+        parts += [np.concatenate([w1, np.zeros((32, 1), np.float32)], 1).ravel(), f(m + ".mlp1.bias"), f(m + ".mlp2.weight").ravel(),
+                  f(m + ".mlp2.bias"), f(m + ".mlp3.weight").ravel(), f(m + ".mlp3.bias"), f(m + ".ystd"), f(m + ".ymean")]
+    for r in ("gas_optics_sw_reduce1", "gas_optics_sw_reduce2"):
+        parts += [np.ascontiguousarray(f(r + ".weight").T).ravel(), f(r + ".bias")]
+    b4, b3, b2 = (int(round(l / 112 * ng)) for l in band_limits)
+    idx = [3] * b4 + [2] * (b3 - b4) + [1] * (b2 - b3) + [0] * (ng - b2)
+    parts.append(np.asarray(_SLINGO + _EBERT_CURRY, np.float32)[:, idx].ravel())
+    blk = np.ascontiguousarray(np.concatenate([np.asarray(p, np.float32).ravel() for p in parts]), np.float32)
+    assert blk.size == 14352, blk.size
+    return blk
+
+
 class physical_RNN_autoreg(torch.nn.Module):
     def __init__(self, state_dict, *, ilev_crm=10, mp_ncol=None, nh_mem0=15, max_batch=4096):
         super().__init__()
@@ -74,14 +106,15 @@ class physical_RNN_autoreg(torch.nn.Module):
         self.physrad = "mlp_t_crm.weight" not in state_dict and int(state_dict["mlp_qn_crm.weight"].shape[0]) == mp_ncol - 1
         flags = ((1 if mp_ncol != ng else 0) | (2 if "mlp_liq_frac_crm.weight" in state_dict else 0) | (4 if self.stochastic else 0)
                  | (8 if self.physrad else 0) | (16 if "gas_optics_model_lw.xdiv" in state_dict else 0)
-                 | (32 if "cloud_optics_lw.weight" in state_dict else 0))
+                 | (32 if "cloud_optics_lw.weight" in state_dict else 0)
+                 | (64 if "gas_optics_model_sw1.mlp1.weight" in state_dict else 0))
         order = (_ORDER_RAD + (["mlp_liq_frac_crm.weight", "mlp_liq_frac_crm.bias"] if flags & 2 else [])
                  + (["rnn3.weight_ih", "rnn3.weight_zh", "rnn3.weight_encoder"] if flags & 4 else [])
                  + (["cloud_optics_lw.weight", "cloud_optics_lw.bias"] if flags & 32 else []))
         for k in order:
             if flags & 16 and k == "gas_optics_model_lw.xmax":       # later exports: the range itself travels in this slot
                 k = "gas_optics_model_lw.xdiv"
-            if self.physrad and k.startswith("mlp_t_crm."):
+            if (self.physrad and k.startswith("mlp_t_crm.")) or (flags & 64 and k.startswith("mlp_sw_optprops")):
                 arrs.append(None)
                 continue
             if k not in state_dict:
@@ -89,6 +122,8 @@ class physical_RNN_autoreg(torch.nn.Module):
             v = state_dict[k]
             v = v.detach().cpu().numpy() if isinstance(v, torch.Tensor) else np.asarray(v)
             arrs.append(np.ascontiguousarray(v, np.float32))
+        if flags & 64:
+            arrs.append(_sw_gas_block(state_dict, ng))
         sd = dict(zip(order, arrs))
         self.nh = sd["mlp_initial.weight"].shape[0]
         self.nx = sd["mlp_initial.weight"].shape[1] + 2             # x_main columns: 3 of them bypass mlp_initial, which also sees pressure

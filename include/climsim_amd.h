@@ -436,6 +436,17 @@ int csa_phys_postprocess(csa_phys *h, int B, const float *out, const float *out_
  *                                `xmax` slot of the pointer list carries the gas-optics input range (buffer `xdiv`) itself.
  *        CSA_PHYS_CLOUD_OPTICS_LW cloud LW optical depth per unit path = ReLU(cloud_optics_lw([(T-160)/180, r_ice/125, r_liq/13.5,
  *                                new memory])) instead of the liquid / ice rule (num88955); two more pointers {w (16,19), b} at the end.
+ *        CSA_PHYS_SW_GAS         the physics_rad_e3sm generation (physRNN_physRad-16_nreg16_*neur128-128*_num94634; the geometry of
+ *                                the frozen *_wrapped exports): no SW head MLP (its four pointer slots may be NULL) -- SW optical
+ *                                depth from two gas-optics MLPs 7 -> 32 -> 32 -> 112 (absorption, Rayleigh), evaluated for the
+ *                                humidity of the two largest regions of each level and averaged, reduced 112 -> 16; Slingo liquid
+ *                                / Ebert-Curry ice cloud optics per region; the LW downward sweep reads the upward source (set
+ *                                LATER_EXPORT for the `xdiv` slot only -- this flag wins for the source).  One more pointer at the
+ *                                end: a block of 14352 floats = gas_optics_model_sw1.{xmin (7, padded to 8), xdiv (8)}, then for
+ *                                sw1 and sw2 {mlp1.w (32,8 zero-padded), b (32), mlp2.w (32,32), b, mlp3.w (112,32), b, ystd (112),
+ *                                ymean (112)}, gas_optics_sw_reduce1 {w TRANSPOSED (112,16), b (16)}, _reduce2 likewise, then the
+ *                                cloud coefficients (12,16): Slingo A..F and Ebert-Curry a..f spread over the 16 g-points
+ *                                (climsim_amd/physrnn.py builds it; oracle/physrnn_rad_ref.py band_table has the band limits).
  * nx = 21 or 16 level inputs (the last three before q_v and the pressure feature bypass mlp_initial), GRU 128 / 112 / 96.
  * Same handle type: csa_phys_forward / _tap (50 levels) / _destroy apply; x_sfc is (B, naux = 19), x_denorm needs columns
  * 12..14 = O3, CH4, N2O.
@@ -449,7 +460,7 @@ int csa_phys_postprocess(csa_phys *h, int B, const float *out, const float *out_
  * csa_phys_forward_noise: csa_phys_forward + hx1 (B,nh), rnn3's initial state, and eps3 (50,B,nh), its noise: the two further
  * N(0,1) draws the reference makes inside forward (both nullable for a handle without rnn3). */
 enum { CSA_PHYS_MCICA = 1, CSA_PHYS_LIQ_FRAC_HEAD = 2, CSA_PHYS_STOCHASTIC = 4, CSA_PHYS_PHYSRAD = 8, CSA_PHYS_LATER_EXPORT = 16,
-       CSA_PHYS_CLOUD_OPTICS_LW = 32 };
+       CSA_PHYS_CLOUD_OPTICS_LW = 32, CSA_PHYS_SW_GAS = 64 };
 int csa_phys_rad_create(int nx, int naux, int nh, int ilev_crm, int mp_ncol, int nh_mem0, int ng, int flags,
                         const float *const *w, int max_batch, csa_phys **out);
 int csa_phys_forward_noise(csa_phys *h, int B, const float *x_main, const float *x_sfc, const float *rnn_mem,
