@@ -34,6 +34,7 @@ struct PhysDev {
     int lw_dn;              // 1: the LW downward sweep gets its own source (later exports); 0: the upward one, as first serialised
     // physics_rad_e3sm generation (num94634): SW optical properties from two gas-optics MLPs + Slingo / Ebert-Curry cloud optics
     const float *swg;       // the packed block of include/climsim_amd.h (CSA_PHYS_SW_GAS), or null: SW head MLP
+    const float *cld_sw_w, *cld_sw_b;   // learned SW cloud optics (48, 19), (48): cloud_optics_sw2 o cloud_optics_sw composed (num88741), or null
 };
 
 // layout of the CSA_PHYS_SW_GAS block (floats): input range, two gas-optics models, the two 112 -> 16 reductions (transposed),

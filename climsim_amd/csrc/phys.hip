@@ -432,7 +432,28 @@ __global__ __launch_bounds__(DT) void phys_decode_kernel(PhysDev d, int B, const
                 tau_cld = cwp * fmaxf(a, 0.0f);
             }
             ro.CL[((size_t)l * B + b) * PH_NG + g] = tau_cld;
-            if (d.swg) {            // Slingo liquid / Ebert-Curry ice SW optics of region g (physics_rad_e3sm.py:98, :265)
+            if (d.swg && d.cld_sw_w) {   // learned SW cloud optics on the LW scheme's inputs: extinction per unit path, albedo, asymmetry of g-point g
+                const float *aux = x_sfc + (size_t)b * d.naux;
+                const float rel = ph_reltab(T_new, aux[13] * d.xdiv_sca[13] + d.xmean_sca[13], aux[12] * d.xdiv_sca[12] + d.xmean_sca[12],
+                                            aux[15] * d.xdiv_sca[15] + d.xmean_sca[15]);
+                const float *lat = HD + ((size_t)(L - d.ltop) * B + b) * HDW + PH_NHEAD * NC;
+                const float x0 = (s_T[l * NC] - 160.0f) / 180.0f, x1 = ph_reitab(d.retab, T_new) / 125.0f, x2 = rel / 13.5f;
+                float o3[3];
+#pragma unroll
+                for (int q = 0; q < 3; ++q) {
+                    const float *wr = d.cld_sw_w + (q * PH_NG + g) * 19;
+                    float a = d.cld_sw_b[q * PH_NG + g];
+                    a = fmaf(wr[0], x0, a); a = fmaf(wr[1], x1, a); a = fmaf(wr[2], x2, a);
+#pragma unroll
+                    for (int k = 0; k < nm0; ++k) a = fmaf(wr[3 + k], lat[k], a);
+                    o3[q] = fmaf(wr[3 + nm0], s_red[0], a);
+                }
+                const float c_tau = cwp * fmaxf(o3[0], 0.0f);
+                float *cs = ro.CS + ((size_t)l * B + b) * 48 + g;
+                cs[0] = c_tau;
+                cs[16] = c_tau / (1.0f + expf(-o3[1]));
+                cs[32] = 1.0f / (1.0f + expf(-o3[2]));
+            } else if (d.swg) {     // Slingo liquid / Ebert-Curry ice SW optics of region g (physics_rad_e3sm.py:98, :265)
                 const float *aux = x_sfc + (size_t)b * d.naux, *t = d.swg + SWG_CLD + g;
                 const float rl = fminf(fmaxf(ph_reltab(T_new, aux[13] * d.xdiv_sca[13] + d.xmean_sca[13], aux[12] * d.xdiv_sca[12] + d.xmean_sca[12],
                                                        aux[15] * d.xdiv_sca[15] + d.xmean_sca[15]), 4.2f), 16.0f);
@@ -462,6 +483,7 @@ struct PhysHostW {           // host pointers of one state_dict, by role
     const float *s3_ih, *s3_zh, *s3_enc;     // rnn3 = MyStochasticGRULayer5(nh, nh) without bias, optional
     const float *cld_w, *cld_b;              // cloud_optics_lw (16, 19), optional
     const float *swg;                        // CSA_PHYS_SW_GAS block (SWG_FLOATS), optional
+    const float *cld_sw_w, *cld_sw_b;        // composed learned SW cloud optics (48, 19), (48), optional
 };
 
 // ice effective radius (micron) against temperature, 137 K ... : E3SM's table as listed in rnn/models/physics_rad_e3sm.py:13-59
@@ -563,7 +585,8 @@ static int phys_build(int nx, int nfeat, int naux, int nx_sfc, int sfc_cut, int 
             for (int k = 0; k < 18; ++k) rg[k] = lw_dn ? w.g_xmax[k] : w.g_xmax[k] - w.g_xmin[k];
             d.g_range = up(rg, 18);
         }
-        d.lw_dn = lw_dn && !w.swg;   // (the SW gas-optics generation carries `xdiv` too, but views the upward source twice again)
+        // (num94634, the SW gas-optics graph with the Slingo / Ebert-Curry cloud optics, carries `xdiv` too but views the upward source twice again)
+        d.lw_dn = lw_dn && !(w.swg && !w.cld_sw_w);
         d.cld_w = w.cld_w ? up(w.cld_w, PH_NG * 19) : nullptr;
         d.cld_b = w.cld_w ? up(w.cld_b, PH_NG) : nullptr;
         d.g_xmin = up(w.g_xmin, 18); d.g_ymean = up(w.g_ymean, 128); d.g_ystd = up(w.g_ystd, 128);
@@ -588,6 +611,7 @@ static int phys_build(int nx, int nfeat, int naux, int nx_sfc, int sfc_cut, int 
         if (w.swg) {
             d.swg = up(w.swg, SWG_FLOATS);
             h->CS = up(nullptr, (size_t)d.Lc * max_batch * 48);
+            if (w.cld_sw_w) { d.cld_sw_w = up(w.cld_sw_w, 48 * 19); d.cld_sw_b = up(w.cld_sw_b, 48); }
         } else {
             h->s1_w = up(w.sw1_w, 32 * PH_XR_K); h->s1_b = up(w.sw1_b, 32);
             h->s2_w = up(w.sw2_w, 48 * 32); h->s2_b = up(w.sw2_b, 48);
@@ -629,7 +653,7 @@ extern "C" int csa_phys_create(int nx, int nx_sfc, int nh, int ilev_crm, int mp_
 extern "C" int csa_phys_rad_create(int nx, int naux, int nh, int ilev_crm, int mp_ncol, int nh_mem0, int ng, int flags,
                                    const float *const *w, int max_batch, csa_phys **out)
 {
-    if (!w || !out || max_batch <= 0 || (flags & ~127)) { csa_set_error_msg("csa_phys_rad_create: bad argument"); return CSA_ERR_ARG; }
+    if (!w || !out || max_batch <= 0 || (flags & ~255)) { csa_set_error_msg("csa_phys_rad_create: bad argument"); return CSA_ERR_ARG; }
     const bool mcica = flags & CSA_PHYS_MCICA, physrad = flags & CSA_PHYS_PHYSRAD;
     if (physrad && !(flags & (CSA_PHYS_LIQ_FRAC_HEAD | CSA_PHYS_CLOUD_OPTICS_LW))) {
         csa_set_error_msg("csa_phys_rad_create: the physRad graphs come with the liquid-fraction head or the learned cloud optics");
@@ -662,12 +686,19 @@ extern "C" int csa_phys_rad_create(int nx, int naux, int nh, int ilev_crm, int m
     if (flags & CSA_PHYS_CLOUD_OPTICS_LW) { v.cld_w = *p++; v.cld_b = *p++; }
     const float *const *swh = nullptr;
     if (flags & CSA_PHYS_SW_GAS) {
-        if (!physrad || mcica || !(flags & CSA_PHYS_LIQ_FRAC_HEAD) || (flags & CSA_PHYS_CLOUD_OPTICS_LW)) {
-            csa_set_error_msg("csa_phys_rad_create: the SW gas-optics models belong to the 16-region physRad graphs with the liquid-fraction head");
+        const bool learned = (flags & CSA_PHYS_CLOUD_OPTICS_LW) && (flags & CSA_PHYS_CLOUD_OPTICS_SW);
+        const bool tabled = (flags & CSA_PHYS_LIQ_FRAC_HEAD) && !(flags & (CSA_PHYS_CLOUD_OPTICS_LW | CSA_PHYS_CLOUD_OPTICS_SW));
+        if (!physrad || mcica || !(learned || tabled)) {
+            csa_set_error_msg("csa_phys_rad_create: the SW gas-optics models belong to the 16-region physRad graphs, with the liquid-fraction head "
+                              "(Slingo / Ebert-Curry cloud optics) or with both learned cloud-optics layers");
             return CSA_ERR_UNSUPPORTED;
         }
         v.swg = *p++;
         swh = sw_head;
+        if (flags & CSA_PHYS_CLOUD_OPTICS_SW) { v.cld_sw_w = *p++; v.cld_sw_b = *p++; }
+    } else if (flags & CSA_PHYS_CLOUD_OPTICS_SW) {
+        csa_set_error_msg("csa_phys_rad_create: the learned SW cloud optics come with the SW gas-optics models");
+        return CSA_ERR_UNSUPPORTED;
     }
     for (const float *const *q = w; q != p; ++q)
         if (!*q && !(physrad && (q == v.heads + 2 * H_T || q == v.heads + 2 * H_T + 1)) && !(swh && q >= swh && q < swh + 4)) {      // (no mlp_t_crm in the physRad graphs)

@@ -107,7 +107,8 @@ class physical_RNN_autoreg(torch.nn.Module):
         flags = ((1 if mp_ncol != ng else 0) | (2 if "mlp_liq_frac_crm.weight" in state_dict else 0) | (4 if self.stochastic else 0)
                  | (8 if self.physrad else 0) | (16 if "gas_optics_model_lw.xdiv" in state_dict else 0)
                  | (32 if "cloud_optics_lw.weight" in state_dict else 0)
-                 | (64 if "gas_optics_model_sw1.mlp1.weight" in state_dict else 0))
+                 | (64 if "gas_optics_model_sw1.mlp1.weight" in state_dict else 0)
+                 | (128 if "cloud_optics_sw.weight" in state_dict else 0))
         order = (_ORDER_RAD + (["mlp_liq_frac_crm.weight", "mlp_liq_frac_crm.bias"] if flags & 2 else [])
                  + (["rnn3.weight_ih", "rnn3.weight_zh", "rnn3.weight_encoder"] if flags & 4 else [])
                  + (["cloud_optics_lw.weight", "cloud_optics_lw.bias"] if flags & 32 else []))
@@ -124,6 +125,10 @@ class physical_RNN_autoreg(torch.nn.Module):
             arrs.append(np.ascontiguousarray(v, np.float32))
         if flags & 64:
             arrs.append(_sw_gas_block(state_dict, ng))
+        if flags & 128:         # two Linear layers without an activation between them: composed here (float64, rounded once)
+            f64 = lambda k: np.asarray(state_dict[k].detach().cpu() if isinstance(state_dict[k], torch.Tensor) else state_dict[k], np.float64)
+            w1, b1, w2, b2 = (f64("cloud_optics_sw" + k) for k in (".weight", ".bias", "2.weight", "2.bias"))
+            arrs += [np.ascontiguousarray(w2 @ w1, np.float32), np.ascontiguousarray(w2 @ b1 + b2, np.float32)]
         sd = dict(zip(order, arrs))
         self.nh = sd["mlp_initial.weight"].shape[0]
         self.nx = sd["mlp_initial.weight"].shape[1] + 2             # x_main columns: 3 of them bypass mlp_initial, which also sees pressure

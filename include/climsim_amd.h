@@ -447,6 +447,11 @@ int csa_phys_postprocess(csa_phys *h, int B, const float *out, const float *out_
  *                                ymean (112)}, gas_optics_sw_reduce1 {w TRANSPOSED (112,16), b (16)}, _reduce2 likewise, then the
  *                                cloud coefficients (12,16): Slingo A..F and Ebert-Curry a..f spread over the 16 g-points
  *                                (climsim_amd/physrnn.py builds it; oracle/physrnn_rad_ref.py band_table has the band limits).
+ *        CSA_PHYS_CLOUD_OPTICS_SW with SW_GAS and CLOUD_OPTICS_LW (num88741): SW cloud optics learned as well -- [extinction per unit
+ *                                path (ReLU) | single-scattering albedo (sigmoid) | asymmetry (sigmoid)] x 16 g-points =
+ *                                cloud_optics_sw2(cloud_optics_sw(x)) on the LW layer's 19 inputs; the two Linear layers have no
+ *                                activation between them and travel COMPOSED: two more pointers {w (48,19) = W2 W1, b (48) =
+ *                                W2 b1 + b2} after the SW_GAS block.  This graph keeps LATER_EXPORT's own LW downward source.
  * nx = 21 or 16 level inputs (the last three before q_v and the pressure feature bypass mlp_initial), GRU 128 / 112 / 96.
  * Same handle type: csa_phys_forward / _tap (50 levels) / _destroy apply; x_sfc is (B, naux = 19), x_denorm needs columns
  * 12..14 = O3, CH4, N2O.
@@ -460,7 +465,7 @@ int csa_phys_postprocess(csa_phys *h, int B, const float *out, const float *out_
  * csa_phys_forward_noise: csa_phys_forward + hx1 (B,nh), rnn3's initial state, and eps3 (50,B,nh), its noise: the two further
  * N(0,1) draws the reference makes inside forward (both nullable for a handle without rnn3). */
 enum { CSA_PHYS_MCICA = 1, CSA_PHYS_LIQ_FRAC_HEAD = 2, CSA_PHYS_STOCHASTIC = 4, CSA_PHYS_PHYSRAD = 8, CSA_PHYS_LATER_EXPORT = 16,
-       CSA_PHYS_CLOUD_OPTICS_LW = 32, CSA_PHYS_SW_GAS = 64 };
+       CSA_PHYS_CLOUD_OPTICS_LW = 32, CSA_PHYS_SW_GAS = 64, CSA_PHYS_CLOUD_OPTICS_SW = 128 };
 int csa_phys_rad_create(int nx, int naux, int nh, int ilev_crm, int mp_ncol, int nh_mem0, int ng, int flags,
                         const float *const *w, int max_batch, csa_phys **out);
 int csa_phys_forward_noise(csa_phys *h, int B, const float *x_main, const float *x_sfc, const float *rnn_mem,

@@ -230,8 +230,10 @@ def radiative_transfer(P, main0, aux_n, xd, play, plev, delta_plev, mem_out, T_c
     s_up = (1.0 - tr) * (bmean + c * src_lev[:, :-1]) / (c + 1.0)
     # as serialised (see header): the downward source is the upward one -- except in the later exports (recognised by their
     # `xdiv` buffer), whose radiative_transfer passes the proper downward source
-    e3sm_sw = "gas_optics_model_sw1.mlp1.weight" in P          # (that generation views `source_up` twice again)
-    s_dn = (1.0 - tr) * (bmean + c * src_lev[:, 1:]) / (c + 1.0) if "gas_optics_model_lw.xdiv" in P and not e3sm_sw else s_up
+    e3sm_sw = "gas_optics_model_sw1.mlp1.weight" in P
+    # (num94634, the single-function radiative_transfer of that generation, views `source_up` twice again; num88741 does not)
+    own_dn = "gas_optics_model_lw.xdiv" in P and not (e3sm_sw and "cloud_optics_sw.weight" not in P)
+    s_dn = (1.0 - tr) * (bmean + c * src_lev[:, 1:]) / (c + 1.0) if own_dn else s_up
     dn = [torch.zeros(B, ng)]
     for j in range(nlev):
         dn.append(tr[:, j] * dn[-1] + s_dn[:, j])
@@ -262,14 +264,20 @@ def radiative_transfer(P, main0, aux_n, xd, play, plev, delta_plev, mem_out, T_c
             sca_k = sca_k + 0.5 * gas_optics_sw(P, "gas_optics_model_sw2", x, col)
         tau_abs = F.softplus(_lin(P, "gas_optics_sw_reduce1", tau_k)) * 0.01 + 1e-9
         tau_sca = F.softplus(_lin(P, "gas_optics_sw_reduce2", sca_k)) * 0.01
-        kl, wl, gl = cloud_optics_sw(rel, SLINGO, 4.2, 16.0, ng)
-        ki, wi, gi = cloud_optics_sw(rei, EBERT_CURRY, 13.0, 130.0, ng)
-        cwp_liq = liq_g * cwp
         pad = lambda t: torch.cat([t.new_zeros(B, ilev_crm, ng), t], 1)
-        c_tau = pad(cwp_ice * ki + cwp_liq * kl)
-        c_sca = cwp_liq * (kl * wl) + cwp_ice * (ki * wi)
-        c_asy = pad((cwp_liq * (kl * wl * gl) + cwp_ice * (ki * wi * gi)) / (c_sca + 1e-7))
-        c_sca = pad(c_sca)
+        if "cloud_optics_sw.weight" in P:   # num88741: learned SW cloud optics, two Linear layers (19 -> 32 -> 3 * ng) on the LW scheme's inputs
+            o = _lin(P, "cloud_optics_sw2", _lin(P, "cloud_optics_sw", x_cld)).view(B, ncrm, 3, ng)
+            c_tau = cwp * torch.relu(o[:, :, 0])
+            c_sca = pad(torch.sigmoid(o[:, :, 1]) * c_tau)
+            c_tau, c_asy = pad(c_tau), pad(torch.sigmoid(o[:, :, 2]))
+        else:
+            kl, wl, gl = cloud_optics_sw(rel, SLINGO, 4.2, 16.0, ng)
+            ki, wi, gi = cloud_optics_sw(rei, EBERT_CURRY, 13.0, 130.0, ng)
+            cwp_liq = liq_g * cwp
+            c_tau = pad(cwp_ice * ki + cwp_liq * kl)
+            c_sca = cwp_liq * (kl * wl) + cwp_ice * (ki * wi)
+            c_asy = pad((cwp_liq * (kl * wl * gl) + cwp_ice * (ki * wi * gi)) / (c_sca + 1e-7))
+            c_sca = pad(c_sca)
         tau_sw = tau_abs + tau_sca + c_tau
         sca = tau_sca + c_sca
         asy = c_asy * c_sca / sca

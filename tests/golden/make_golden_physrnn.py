@@ -106,7 +106,9 @@ PHYSRAD = {"physrad16_a": "physRNN_physRad-16_nreg16_lr0.0007.neur128-128_xv4_mp
            "physrad4_b": "physRNN_physRad-16_nreg4_lr0.0007.neur112-112_xv4_mp1_num95220_BEST_script_cpu.pt",
            # the physics_rad_e3sm generation: SW gas-optics MLPs on the two largest regions' humidity, Slingo / Ebert-Curry cloud
            # optics, learned liquid fraction; GRU 128/128 (the geometry of the frozen `*_wrapped` exports)
-           "physrad16_e3sm": "physRNN_physRad-16_nreg16_lr0.0007.neur128-128_xv4_mp1_num94634_BEST_script_cpu.pt"}
+           "physrad16_e3sm": "physRNN_physRad-16_nreg16_lr0.0007.neur128-128_xv4_mp1_num94634_BEST_script_cpu.pt",
+           # num88955's graph (learned cloud LW optics, GRU 112/112) with the SW gas-optics models and learned SW cloud optics
+           "physrad16_e3sm_cld": "physRNN_physRad-16_nreg16_lr0.0007.neur112-112_xv4_mp1_num88741_BEST_script_cpu.pt"}
 
 
 def staged_srnn(m, xm, xs, mem, seed, out_ref, sfc_ref, xd):

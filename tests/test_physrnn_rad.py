@@ -79,7 +79,7 @@ def _noise_level(*realisations_then_exact):
 FIXTURES = [("physrnn_rad", 2), ("physrnn_rad_nomcica", 1), ("physrnn_rad_liqfrac", 1), ("physrnn_rad_stoch_a", 1),
             ("physrnn_rad_stoch_b", 1), ("physrnn_rad_stoch_c", 1), ("physrad16_a", 1), ("physrad16_b", 1), ("physrad16_c", 1),
             ("physrad16_nh96", 1), ("physrad16_nh112_a", 1), ("physrad16_nh112_b", 1),
-            ("physrad4_a", 1), ("physrad4_b", 1), ("physrad16_nh112_cld", 1), ("physrad16_e3sm", 1)]
+            ("physrad4_a", 1), ("physrad4_b", 1), ("physrad16_nh112_cld", 1), ("physrad16_e3sm", 1), ("physrad16_e3sm_cld", 1)]
 
 
 def _noise(g, i):
