@@ -299,6 +299,27 @@ def aux_workload(a, rank, world, dist):
         def step():
             m(x)
         flop_col, what = 2.0 * sum(dims[i] * dims[i + 1] for i in range(len(dims) - 1)), "Keras MLP baseline forward"
+    elif a.workload.startswith("physrnn_e3sm_"):
+        # the generation of the radiation scheme the frozen *_wrapped exports deploy (physics_rad_e3sm): weights of num94634
+        import numpy as np
+        sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests", "golden"))
+        from make_golden_physrnn import inputs_rad
+        from climsim_amd.physrnn import physical_RNN_autoreg
+        gz = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests", "golden", "physrad16_e3sm.npz"))
+        Pw = {k[2:]: torch.from_numpy(gz[k]) for k in gz.files if k.startswith("w.")}
+        m = physical_RNN_autoreg(Pw, max_batch=B)
+        xs_ = [t.cuda() for t in inputs_rad(Pw, B, 300 + rank)]
+        hx2 = torch.randn(B, 128, generator=g).cuda()
+        state = {"mem": xs_[2].transpose(0, 1).contiguous()}       # this generation takes and returns the memory level-major (50, B, 16)
+
+        def step():
+            o, osfc, state["mem"] = m([xs_[0], xs_[1], state["mem"], xs_[3]], hx2=hx2)
+        # 50-level BiGRU + 11 x 16-wide head GEMM + 16-region decoder; radiation on 60 levels: LW gas optics 18-64-64-256 and
+        # 2 x (128 -> 16); SW gas optics 2 models x 2 humidity variants x (7-32-32-112) and 2 x (112 -> 16); ~250 flop per
+        # (level, g-point) cell of the cloud optics / two-stream / adding / LW sweeps
+        flop_col = (50 * (2.0 * 20 * 128 + 2.0 * 384 * (143 + 128) + 2.0 * 384 * 256 + 2.0 * 212 * 128) + 50 * 16 * 150.0
+                    + 60 * 2.0 * (18 * 64 + 64 * 64 + 64 * 256 + 2 * 128 * 16 + 4 * (7 * 32 + 32 * 32 + 32 * 112) + 2 * 112 * 16) + 60 * 16 * 250.0)
+        what = "physRNN_physRad-16 nreg16, physics_rad_e3sm generation (BiGRU 128/128 over 50 levels + decoder + LW/SW gas-optics MLPs + solver), weights of num94634"
     elif a.workload.startswith("physrnn_") and not a.workload.startswith("physrnn_rad_"):
         import numpy as np
         sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests", "golden"))
@@ -393,7 +414,7 @@ def aux_workload(a, rank, world, dist):
             flush=True)
 
 
-AUX = ["cur_lstm144_384", "cur_lstm128_384", "cur_gru128_384", "mlp_384", "online_mlp_384", "physrnn_384", "physrnn_rad_384", "physrnn_2700", "physrnn_rad_2700", "cnn_384", "cnn_train_384",
+AUX = ["cur_lstm144_384", "cur_lstm128_384", "cur_gru128_384", "mlp_384", "online_mlp_384", "physrnn_384", "physrnn_rad_384", "physrnn_2700", "physrnn_rad_2700", "physrnn_e3sm_384", "physrnn_e3sm_2700", "cnn_384", "cnn_train_384",
        "cnn_train_512", "cnn_train_2700"]
 
 

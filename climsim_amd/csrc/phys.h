@@ -37,23 +37,28 @@ struct PhysDev {
     const float *cld_sw_w, *cld_sw_b;   // learned SW cloud optics (48, 19), (48): cloud_optics_sw2 o cloud_optics_sw composed (num88741), or null
 };
 
-// layout of the CSA_PHYS_SW_GAS block (floats): input range, two gas-optics models, the two 112 -> 16 reductions (transposed),
-// cloud-optics coefficients per g-point
+// layout of the CSA_PHYS_SW_GAS block (floats): input range, two gas-optics models, the two 112 -> 16 reductions, cloud-optics
+// coefficients per g-point.  The 112-wide axis is zero-padded to 128 (four 32-column MFMA tiles; a padded k-point has
+// ystd = ymean = 0, i.e. optical depth 0, and zero reduction weights).
 #define SWG_NK 112
+#define SWG_NKP 128
+#define SWG_LD1 12                             // row strides (floats) of the weight matrices: K + 4, so that the 32 lanes reading
+#define SWG_LDK 36                             // weight rows n = 0..31 as float4 (MFMA B operand) spread over all LDS banks
+#define SWG_LDR 132
 #define SWG_XMIN 0
 #define SWG_XDIV 8
 #define SWG_MODEL0 16
-#define SWG_W1 0                               // (32, 8): 7 inputs, zero-padded
-#define SWG_B1 (SWG_W1 + 32 * 8)
-#define SWG_W2 (SWG_B1 + 32)                   // (32, 32)
-#define SWG_B2 (SWG_W2 + 32 * 32)
-#define SWG_W3 (SWG_B2 + 32)                   // (112, 32)
-#define SWG_B3 (SWG_W3 + SWG_NK * 32)
-#define SWG_YSTD (SWG_B3 + SWG_NK)
-#define SWG_YMEAN (SWG_YSTD + SWG_NK)
-#define SWG_MODEL_FLOATS (SWG_YMEAN + SWG_NK)
-#define SWG_RED (SWG_MODEL0 + 2 * SWG_MODEL_FLOATS)   // reduce1^T (112, 16), bias (16), reduce2^T (112, 16), bias (16)
-#define SWG_RED_FLOATS (SWG_NK * 16 + 16)
+#define SWG_W1 0                               // (32, 8 of 12): 7 inputs, zero-padded
+#define SWG_B1 (SWG_W1 + 32 * SWG_LD1)
+#define SWG_W2 (SWG_B1 + 32)                   // (32, 32 of 36)
+#define SWG_B2 (SWG_W2 + 32 * SWG_LDK)
+#define SWG_W3 (SWG_B2 + 32)                   // (128, 32 of 36)
+#define SWG_B3 (SWG_W3 + SWG_NKP * SWG_LDK)
+#define SWG_YSTD (SWG_B3 + SWG_NKP)
+#define SWG_YMEAN (SWG_YSTD + SWG_NKP)
+#define SWG_MODEL_FLOATS (SWG_YMEAN + SWG_NKP)
+#define SWG_RED (SWG_MODEL0 + 2 * SWG_MODEL_FLOATS)   // reduce1 (16, 128 of 132), bias (16), reduce2 likewise
+#define SWG_RED_FLOATS (16 * SWG_LDR + 16)
 #define SWG_CLD (SWG_RED + 2 * SWG_RED_FLOATS)        // (12, 16): Slingo A..F then Ebert-Curry a..f, per g-point
 #define SWG_FLOATS (SWG_CLD + 12 * 16)
 

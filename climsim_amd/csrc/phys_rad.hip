@@ -259,98 +259,134 @@ __global__ __launch_bounds__(64 * RO_WAVES) void rad_optics_kernel(RadOptics a)
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// physics_rad_e3sm generation: SW optical properties of every (level, column) row.  Two lanes per row, one per humidity
-// variant (the two largest regions); each lane runs both gas-optics MLPs 7 -> 32 -> 32 -> 112 on its variant, the pair
-// averages tau = col_dry * (ystd * y + ymean)^8 through one cross-lane add, and each lane reduces 112 -> 8 of the 16
-// g-points (absorption and Rayleigh).  Weights (SWG_FLOATS, 56 KB) sit in LDS and are read as wave-wide broadcasts.
-// fp32 VALU: 2 * 2 * (7*32 + 32*32 + 32*112) + 2 * 112 * 16 = 23.3 kFMA per row.
+// physics_rad_e3sm generation: SW optical properties of every (level, column) row, on the matrix pipe like rad_optics_kernel.
+// A wave owns a tile of 32 rows; for each humidity variant (the two largest regions) and each gas-optics model (absorption,
+// Rayleigh) it runs 8 -> 32 -> 32 -> 128 (112 used) tile by tile, turns every 32-column tile into k-point optical depths
+// col_dry (ystd y + ymean)^8 in the accumulator registers, passes it through LDS and contracts it at once with its slice of
+// the model's 112 -> 16 reduction -- one 32 x 32 accumulator for everything: columns 0-15 absorption, 16-31 Rayleigh, both
+// variants summed (the average of the two is taken after the linear reduction).  592 v_mfma_f32_32x32x2_f32 per tile.
+// The weights (SWG_FLOATS, 69 KB, rows padded by 4 floats against bank conflicts of the B-operand reads) sit in LDS, shared by
+// the four waves of a workgroup; everything else is wave-private.
 // S2 row: [tau_sw (16) | ssa (16) | asymmetry (16)] -- final values (the solver applies no activation for this generation).
-#define SG_T 128
-__global__ __launch_bounds__(SG_T) void rad_sw_gas_kernel(const float *__restrict__ XR, const float *__restrict__ swg, const float *__restrict__ CS,
-                                                          float *__restrict__ S2, int M, int B, int ilev)
+// First version (fp32 VALU, two lanes per row): 66.8 us per 384-column call; this one: see profiles/r2_physrnn_e3sm_*.
+#define SG_WAVES 4
+#define SG_LD 36            // 32-wide activations: row stride 32 + 4 floats (b128 operand reads, as RO_LD)
+__global__ __launch_bounds__(64 * SG_WAVES) void rad_sw_gas_kernel(const float *__restrict__ XR, const float *__restrict__ swg, const float *__restrict__ CS,
+                                                                   float *__restrict__ S2, int M, int B, int ilev)
 {
     __shared__ __attribute__((aligned(16))) float sw[SWG_FLOATS];
-    for (int i = threadIdx.x; i < SWG_FLOATS / 4; i += SG_T) ((f32x4 *)sw)[i] = ((const f32x4 *)swg)[i];
-    __syncthreads();
-    const int var = threadIdx.x & 1;
-    const int row_raw = blockIdx.x * (SG_T / 2) + (threadIdx.x >> 1);
-    const bool ok = row_raw < M;
-    const int row = ok ? row_raw : M - 1;
-    const float *xr = XR + (size_t)row * PH_XR_K;
-    float x[8];
-    {
-        const f32x4 a = *(const f32x4 *)xr, c = *(const f32x4 *)(xr + 4);
-        x[0] = a.x; x[1] = a.y; x[2] = var ? c.w : a.z; x[3] = a.w; x[4] = c.x; x[5] = c.y; x[6] = c.z; x[7] = 0.0f;
+    __shared__ __attribute__((aligned(16))) float sA[SG_WAVES][2][32 * SG_LD];   // per variant: H1, then the k-point tile Y
+    __shared__ __attribute__((aligned(16))) float sB[SG_WAVES][2][32 * SG_LD];   // per variant: H2; [0] at the end: the reduced tile
+    __shared__ __attribute__((aligned(16))) float sX[SG_WAVES][32 * RO_LX];      // XR rows: [x (7), x2' | col_dry (2) | ... | variant-2 input (8) at 16]
+    {   // weights -> LDS: all sixteen loads of a thread in flight before the first store (a rolled load -> store loop pays one
+        // L2 round trip per trip)
+        constexpr int N4 = SWG_FLOATS / 4, T = 64 * SG_WAVES, J = (N4 + T - 1) / T;
+        f32x4 v[J];
+#pragma unroll
+        for (int j = 0; j < J; ++j) v[j] = ((const f32x4 *)swg)[min((int)threadIdx.x + T * j, N4 - 1)];
+#pragma unroll
+        for (int j = 0; j < J; ++j) if ((int)threadIdx.x + T * j < N4) ((f32x4 *)sw)[threadIdx.x + T * j] = v[j];
     }
-    const float col = xr[8 + var];
-    float h2[2][32];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, n = lane & 31, half = lane >> 5;
+    const int row0 = ((int)blockIdx.x * SG_WAVES + wave) * 32;
+    float *bX = sX[wave];
+    auto drow = [&](int i) { return (i & 3) + 8 * (i >> 2) + 4 * half; };
+    static_assert(PH_XR_K == 24, "tile loader");
+    if (row0 < M) {
+        f32x4 v[3];
+        const size_t tile0 = (size_t)row0 * 24, last4 = (size_t)M * 24 - 4;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const size_t e = tile0 + 4 * (lane + 64 * j);
+            v[j] = *(const f32x4 *)(XR + (e < last4 ? e : last4));
+        }
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int e = 4 * (lane + 64 * j), rr = e / 24, k = e - rr * 24;
+            *(f32x4 *)(bX + rr * RO_LX + k) = v[j];
+        }
+    }
+    __syncthreads();
+    if (row0 >= M) return;                           // (no workgroup barrier below)
+    if (lane < 32) {                                  // second variant: the same inputs with its own humidity feature
+        float *r = bX + lane * RO_LX;
+        const f32x4 a = *(const f32x4 *)r, c = *(const f32x4 *)(r + 4);
+        *(f32x4 *)(r + 16) = f32x4{a.x, a.y, c.w, a.w};
+        *(f32x4 *)(r + 20) = f32x4{c.x, c.y, c.z, 0.0f};
+    }
+    ro_fence();
+    // the two variants are independent until the reduction: their stages are written side by side so that the VALU epilogue
+    // of one overlaps the MFMAs of the other
+    float *bA0 = sA[wave][0], *bA1 = sA[wave][1], *bB0 = sB[wave][0], *bB1 = sB[wave][1];
+    float cd0[16], cd1[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { cd0[i] = bX[drow(i) * RO_LX + 8]; cd1[i] = bX[drow(i) * RO_LX + 9]; }
+    const RoW<1> xa = ro_loada<1>(bX + n * RO_LX + 4 * half), xb = ro_loada<1>(bX + n * RO_LX + 16 + 4 * half);
+    f32x16 tp0 = ro_zero(), tp1 = ro_zero();
 #pragma unroll
     for (int m = 0; m < 2; ++m) {
         const float *W = sw + SWG_MODEL0 + m * SWG_MODEL_FLOATS;
-        float h1[32];
+        {   // layer 1: 8 -> 32 (the weight of input column 7 is zero: variant 0 leaves the other variant's feature there)
+            const RoW<1> w = ro_load<1>(W + SWG_W1 + n * SWG_LD1 + 4 * half);
+            const f32x16 a0 = ro_mma_r<1>(ro_zero(), xa, w), a1 = ro_mma_r<1>(ro_zero(), xb, w);
+            const float b = W[SWG_B1 + n];
 #pragma unroll
-        for (int j = 0; j < 32; ++j) {
-            const f32x4 w0 = *(const f32x4 *)(W + SWG_W1 + j * 8), w1 = *(const f32x4 *)(W + SWG_W1 + j * 8 + 4);
-            float a = W[SWG_B1 + j];
-            a = fmaf(w0.x, x[0], a); a = fmaf(w0.y, x[1], a); a = fmaf(w0.z, x[2], a); a = fmaf(w0.w, x[3], a);
-            a = fmaf(w1.x, x[4], a); a = fmaf(w1.y, x[5], a); a = fmaf(w1.z, x[6], a);
-            h1[j] = a / (1.0f + fabsf(a));
+            for (int i = 0; i < 16; ++i) { bA0[drow(i) * SG_LD + n] = ro_softsign(a0[i] + b); bA1[drow(i) * SG_LD + n] = ro_softsign(a1[i] + b); }
         }
+        ro_fence();
+        {   // layer 2: 32 -> 32
+            const RoW<4> x0 = ro_loada<4>(bA0 + n * SG_LD + 4 * half), x1 = ro_loada<4>(bA1 + n * SG_LD + 4 * half);
+            const RoW<4> w = ro_load<4>(W + SWG_W2 + n * SWG_LDK + 4 * half);
+            const f32x16 a0 = ro_mma_r<4>(ro_zero(), x0, w), a1 = ro_mma_r<4>(ro_zero(), x1, w);
+            const float b = W[SWG_B2 + n];
 #pragma unroll
-        for (int j = 0; j < 32; ++j) {
-            const f32x4 *wr = (const f32x4 *)(W + SWG_W2 + j * 32);
-            float a0 = W[SWG_B2 + j], a1 = 0.0f;
-#pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const f32x4 w = wr[q];
-                a0 = fmaf(w.x, h1[4 * q], a0); a1 = fmaf(w.y, h1[4 * q + 1], a1);
-                a0 = fmaf(w.z, h1[4 * q + 2], a0); a1 = fmaf(w.w, h1[4 * q + 3], a1);
-            }
-            const float a = a0 + a1;
-            h2[m][j] = a / (1.0f + fabsf(a));
+            for (int i = 0; i < 16; ++i) { bB0[drow(i) * SG_LD + n] = ro_softsign(a0[i] + b); bB1[drow(i) * SG_LD + n] = ro_softsign(a1[i] + b); }
         }
+        ro_fence();
+        const RoW<4> h0 = ro_loada<4>(bB0 + n * SG_LD + 4 * half), h1 = ro_loada<4>(bB1 + n * SG_LD + 4 * half);
+        const float *R = sw + SWG_RED + m * SWG_RED_FLOATS;
+        const bool live = m == 0 ? n < 16 : n >= 16;
+#pragma unroll
+        for (int t = 0; t < SWG_NKP / 32; ++t) {      // layer 3 tile t, reduced at once
+            const RoW<4> w = ro_load<4>(W + SWG_W3 + (t * 32 + n) * SWG_LDK + 4 * half);
+            const RoW<4> wr = ro_load<4>(R + (n & 15) * SWG_LDR + t * 32 + 4 * half);
+            const float b = W[SWG_B3 + t * 32 + n], sd = W[SWG_YSTD + t * 32 + n], mn = W[SWG_YMEAN + t * 32 + n];
+            const f32x16 a0 = ro_mma_r<4>(ro_zero(), h0, w);
+            const f32x16 a1 = ro_mma_r<4>(ro_zero(), h1, w);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) bA0[drow(i) * SG_LD + n] = cd0[i] * pr_pow8(sd * (a0[i] + b) + mn);
+            ro_fence();
+            tp0 = ro_mma<4>(tp0, bA0 + n * SG_LD + 4 * half, wr, live);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) bA1[drow(i) * SG_LD + n] = cd1[i] * pr_pow8(sd * (a1[i] + b) + mn);
+            ro_fence();
+            tp1 = ro_mma<4>(tp1, bA1 + n * SG_LD + 4 * half, wr, live);
+        }
+        ro_fence();
     }
-    float acc[2][8];
+    float *bB = bB0;
+    {   // mean of the two variants + bias; through LDS so that one lane sees absorption and Rayleigh of a (row, g-point)
+        const float b = sw[SWG_RED + (n >> 4) * SWG_RED_FLOATS + 16 * SWG_LDR + (n & 15)];
 #pragma unroll
-    for (int m = 0; m < 2; ++m)
-#pragma unroll
-        for (int g = 0; g < 8; ++g) acc[m][g] = 0.0f;
-    for (int k = 0; k < SWG_NK; ++k) {
-        float t[2];
-#pragma unroll
-        for (int m = 0; m < 2; ++m) {
-            const float *W = sw + SWG_MODEL0 + m * SWG_MODEL_FLOATS;
-            const f32x4 *wr = (const f32x4 *)(W + SWG_W3 + k * 32);
-            float a0 = W[SWG_B3 + k], a1 = 0.0f;
-#pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const f32x4 w = wr[q];
-                a0 = fmaf(w.x, h2[m][4 * q], a0); a1 = fmaf(w.y, h2[m][4 * q + 1], a1);
-                a0 = fmaf(w.z, h2[m][4 * q + 2], a0); a1 = fmaf(w.w, h2[m][4 * q + 3], a1);
-            }
-            const float y = fmaf(W[SWG_YSTD + k], a0 + a1, W[SWG_YMEAN + k]);
-            const float tv = col * pr_pow8(y);
-            t[m] = (tv + __shfl_xor(tv, 1)) * 0.5f;
-            const f32x4 *rr = (const f32x4 *)(sw + SWG_RED + m * SWG_RED_FLOATS + k * 16 + var * 8);
-            const f32x4 r0 = rr[0], r1 = rr[1];
-            acc[m][0] = fmaf(r0.x, t[m], acc[m][0]); acc[m][1] = fmaf(r0.y, t[m], acc[m][1]);
-            acc[m][2] = fmaf(r0.z, t[m], acc[m][2]); acc[m][3] = fmaf(r0.w, t[m], acc[m][3]);
-            acc[m][4] = fmaf(r1.x, t[m], acc[m][4]); acc[m][5] = fmaf(r1.y, t[m], acc[m][5]);
-            acc[m][6] = fmaf(r1.z, t[m], acc[m][6]); acc[m][7] = fmaf(r1.w, t[m], acc[m][7]);
-        }
+        for (int i = 0; i < 16; ++i) bB[drow(i) * SG_LD + n] = (tp0[i] + tp1[i]) * 0.5f + b;
     }
+    ro_fence();
     // gas + cloud -> layer optical depth, single-scattering albedo, asymmetry (region g is g-point g)
-    const int L = row / B, b = row - L * B;
-    const float *cs = L >= ilev ? CS + ((size_t)(L - ilev) * B + b) * 48 : nullptr;
-    float *o = S2 + (size_t)row * 48 + var * 8;
+    const int g = lane & 15;
 #pragma unroll
-    for (int g8 = 0; g8 < 8; ++g8) {
-        const int g = var * 8 + g8;
-        const float t_abs = pr_softplus(acc[0][g8] + sw[SWG_RED + SWG_NK * 16 + g]) * 0.01f + 1e-9f;
-        const float t_sca = pr_softplus(acc[1][g8] + sw[SWG_RED + SWG_RED_FLOATS + SWG_NK * 16 + g]) * 0.01f;
-        const float c_tau = cs ? cs[g] : 0.0f, c_sca = cs ? cs[16 + g] : 0.0f, c_asy = cs ? cs[32 + g] : 0.0f;
+    for (int j = 0; j < 8; ++j) {
+        const int r = (lane >> 4) + 4 * j, row = row0 + r;
+        if (row >= M) continue;
+        const float t_abs = pr_softplus(bB[r * SG_LD + g]) * 0.01f + 1e-9f, t_sca = pr_softplus(bB[r * SG_LD + 16 + g]) * 0.01f;
+        const int L = row / B, b = row - L * B;
+        float c_tau = 0.0f, c_sca = 0.0f, c_asy = 0.0f;
+        if (L >= ilev) {
+            const float *cs = CS + ((size_t)(L - ilev) * B + b) * 48;
+            c_tau = cs[g]; c_sca = cs[16 + g]; c_asy = cs[32 + g];
+        }
         const float tau = (t_abs + t_sca) + c_tau, sca = t_sca + c_sca;
-        if (ok) { o[g8] = tau; o[16 + g8] = sca / tau; o[32 + g8] = (c_asy * c_sca) / sca; }
+        float *o = S2 + (size_t)row * 48;
+        o[g] = tau; o[16 + g] = sca / tau; o[32 + g] = (c_asy * c_sca) / sca;
     }
 }
 
@@ -530,7 +566,7 @@ int launch_phys_radiation(csa_phys *h, int B, const float *x_sfc, float *out_lev
     hipLaunchKernelGGL(rad_optics_kernel, dim3((M + 32 * RO_WAVES - 1) / (32 * RO_WAVES), d.swg ? 1 : 2), dim3(64 * RO_WAVES), 0, s, a);
     CSA_HIP_CHECK(hipGetLastError());
     if (d.swg) {
-        hipLaunchKernelGGL(rad_sw_gas_kernel, dim3((M + SG_T / 2 - 1) / (SG_T / 2)), dim3(SG_T), 0, s, h->XR, d.swg, h->CS, h->S2, M, B, d.ilev);
+        hipLaunchKernelGGL(rad_sw_gas_kernel, dim3((M + 32 * SG_WAVES - 1) / (32 * SG_WAVES)), dim3(64 * SG_WAVES), 0, s, h->XR, d.swg, h->CS, h->S2, M, B, d.ilev);
         CSA_HIP_CHECK(hipGetLastError());
     }
     hipLaunchKernelGGL(phys_rad_solve_kernel, dim3(B), dim3(RS_T), 0, s, d, B, x_sfc, h->TP, h->CL, h->S2, h->RS, out_lev, out_sfc);

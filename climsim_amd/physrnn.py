@@ -47,19 +47,21 @@ def _sw_gas_block(state_dict, ng, band_limits=_SW_BAND_LIMITS):
         raise RuntimeError("physRNN SW gas optics: built for 16 g-points")
     pad8 = lambda v: np.concatenate([v, np.ones(8 - v.shape[0], np.float32)])
     parts = [pad8(f("gas_optics_model_sw1.xmin")) * np.r_[np.ones(7), 0].astype(np.float32), pad8(f("gas_optics_model_sw1.xdiv"))]
+    padk = lambda a: np.concatenate([a, np.zeros((128 - a.shape[0],) + a.shape[1:], np.float32)])      # the 112-wide axis -> 128
+    padc = lambda a, ld: np.concatenate([a, np.zeros((a.shape[0], ld - a.shape[1]), np.float32)], 1).ravel()   # row stride K + 4 (LDS banks)
     for m in ("gas_optics_model_sw1", "gas_optics_model_sw2"):
         w1 = f(m + ".mlp1.weight")
         if w1.shape != (32, 7) or f(m + ".mlp2.weight").shape != (32, 32) or f(m + ".mlp3.weight").shape != (112, 32):
             raise RuntimeError("physRNN SW gas optics: built for the shipped 7 -> 32 -> 32 -> 112 models")
-        parts += [np.concatenate([w1, np.zeros((32, 1), np.float32)], 1).ravel(), f(m + ".mlp1.bias"), f(m + ".mlp2.weight").ravel(),
-                  f(m + ".mlp2.bias"), f(m + ".mlp3.weight").ravel(), f(m + ".mlp3.bias"), f(m + ".ystd"), f(m + ".ymean")]
+        parts += [padc(w1, 12), f(m + ".mlp1.bias"), padc(f(m + ".mlp2.weight"), 36), f(m + ".mlp2.bias"),
+                  padc(padk(f(m + ".mlp3.weight")), 36), padk(f(m + ".mlp3.bias")), padk(f(m + ".ystd")), padk(f(m + ".ymean"))]
     for r in ("gas_optics_sw_reduce1", "gas_optics_sw_reduce2"):
-        parts += [np.ascontiguousarray(f(r + ".weight").T).ravel(), f(r + ".bias")]
+        parts += [padc(f(r + ".weight"), 132), f(r + ".bias")]
     b4, b3, b2 = (int(round(l / 112 * ng)) for l in band_limits)
     idx = [3] * b4 + [2] * (b3 - b4) + [1] * (b2 - b3) + [0] * (ng - b2)
     parts.append(np.asarray(_SLINGO + _EBERT_CURRY, np.float32)[:, idx].ravel())
     blk = np.ascontiguousarray(np.concatenate([np.asarray(p, np.float32).ravel() for p in parts]), np.float32)
-    assert blk.size == 14352, blk.size
+    assert blk.size == 17648, blk.size
     return blk
 
 

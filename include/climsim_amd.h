@@ -442,10 +442,11 @@ int csa_phys_postprocess(csa_phys *h, int B, const float *out, const float *out_
  *                                humidity of the two largest regions of each level and averaged, reduced 112 -> 16; Slingo liquid
  *                                / Ebert-Curry ice cloud optics per region; the LW downward sweep reads the upward source (set
  *                                LATER_EXPORT for the `xdiv` slot only -- this flag wins for the source).  One more pointer at the
- *                                end: a block of 14352 floats = gas_optics_model_sw1.{xmin (7, padded to 8), xdiv (8)}, then for
- *                                sw1 and sw2 {mlp1.w (32,8 zero-padded), b (32), mlp2.w (32,32), b, mlp3.w (112,32), b, ystd (112),
- *                                ymean (112)}, gas_optics_sw_reduce1 {w TRANSPOSED (112,16), b (16)}, _reduce2 likewise, then the
- *                                cloud coefficients (12,16): Slingo A..F and Ebert-Curry a..f spread over the 16 g-points
+ *                                end: a block of 17648 floats = gas_optics_model_sw1.{xmin (7, padded to 8), xdiv (8)}, then for
+ *                                sw1 and sw2 {mlp1.w (32 rows of 12: 7 used), b (32), mlp2.w (32 rows of 36: 32 used), b, mlp3.w
+ *                                (128 rows of 36: 112 x 32 used), b (128), ystd (128), ymean (128)}, gas_optics_sw_reduce1 {w (16 rows
+ *                                of 132: 112 used), b (16)}, _reduce2 likewise -- all padding zero --, then the cloud coefficients
+ *                                (12,16): Slingo A..F and Ebert-Curry a..f spread over the 16 g-points
  *                                (climsim_amd/physrnn.py builds it; oracle/physrnn_rad_ref.py band_table has the band limits).
  *        CSA_PHYS_CLOUD_OPTICS_SW with SW_GAS and CLOUD_OPTICS_LW (num88741): SW cloud optics learned as well -- [extinction per unit
  *                                path (ReLU) | single-scattering albedo (sigmoid) | asymmetry (sigmoid)] x 16 g-points =
