@@ -16,10 +16,16 @@
 // (the contraction index m is the slow one), so the MFMA operand reads are lane-contiguous.
 #define TN_T 128
 #define TN_MK 16
+// WM x WN waves of NI x NJ MFMA tiles: (2, 2, 2, 2) = 128 x 128 per workgroup; (4, 1, 1, 5) = 128 x 160, for 128 < N2 <= 160
+// (the 144 inputs of rnn1: with 128-wide tiles the second tile column does a full tile of MFMAs for 16 columns -- 187 us
+// against 110 for the N2 = 128 contractions of the same step).
+template <int WM, int WN, int NI, int NJ>
 __global__ __launch_bounds__(256) void gemm_tn_partial_kernel(
     TnSegs segs, int lda, int ldb, float *__restrict__ Cpart, float *__restrict__ Csum,
     int M, int N1, int N2, int rows_per_split, int splits_per_seg, int conv_L, int conv_cin)
 {
+    static_assert(WM * WN == 4 && WM * NI * 32 == TN_T, "wave layout");
+    constexpr int TB = WN * NJ * 32, B4 = TB / 4, NB = (TN_MK * B4 + 255) / 256;      // B tile width; float4 per B row; B loads per thread
     // Csum (optional): partial column sums of A, Csum[split][n1] (the bias gradient rides on the rows this kernel
     // stages anyway; only the blockIdx.y == 0 workgroups keep them).
     // segs: up to TN_MAX_SEGS (A, B) pairs of M rows each, contracted into ONE result (the T_w time steps of a TBPTT
@@ -30,50 +36,58 @@ __global__ __launch_bounds__(256) void gemm_tn_partial_kernel(
     // 3*cin contiguous floats starting at X + (m-1)*ldb, first / last third masked on the first / last level of a
     // column (the weight gradient of Conv1D, cnn_train.hip); N2 = 3*cin.
     __shared__ float As[2][TN_MK][TN_T];     // double-buffered: one barrier per 16-row chunk
-    __shared__ float Bs[2][TN_MK][TN_T];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
-    const int n10 = blockIdx.x * TN_T, n20 = blockIdx.y * TN_T, split = blockIdx.z;
+    __shared__ float Bs[2][TN_MK][TB];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave / WN, wn = wave % WN;
+    const int n10 = blockIdx.x * TN_T, n20 = blockIdx.y * TB, split = blockIdx.z;
     const int m_begin = (split % splits_per_seg) * rows_per_split, m_end = min(M, m_begin + rows_per_split);
-    f32x16 acc[2][2];
+    f32x16 acc[NI][NJ];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < NI; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < NJ; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
-    // staging: 16 rows x 128 floats per operand = 512 float4, two per thread.  The global loads of chunk c+1 are
-    // issued before the MFMAs of chunk c (register prefetch), so their latency hides behind 2048 MFMA cycles.
+    // staging: 16 rows x 128 floats of A = 512 float4, two per thread; 16 rows x TB floats of B.  The global loads of chunk
+    // c+1 are issued before the MFMAs of chunk c (register prefetch), so their latency hides behind the MFMA cycles.
     const int sr = tid >> 5, sc = (tid & 31) * 4;
-    f32x4 va[2], vb[2], cs = {0, 0, 0, 0};
+    f32x4 va[2], vb[NB], cs = {0, 0, 0, 0};
     const bool do_cs = Csum != nullptr && blockIdx.y == 0;
     auto gload = [&](int m0) {
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             const int m = m0 + sr + 8 * h;
             va[h] = f32x4{0, 0, 0, 0};
-            vb[h] = f32x4{0, 0, 0, 0};
             if (m < m_end) {
                 const float *pa = A + (size_t)m * lda + n10 + sc;
-                const float *pb = conv_L > 0 ? Bm + ((long)m - 1) * ldb + n20 + sc : Bm + (size_t)m * ldb + n20 + sc;
                 if (n10 + sc + 3 < N1) va[h] = *(const f32x4 *)pa;
                 else for (int e = 0; e < 4; ++e) if (n10 + sc + e < N1) va[h][e] = pa[e];
+            }
+        }
+#pragma unroll
+        for (int h = 0; h < NB; ++h) {
+            const int idx = tid + 256 * h, br = idx / B4, bc = (idx - br * B4) * 4, m = m0 + br;
+            vb[h] = f32x4{0, 0, 0, 0};
+            if (br < TN_MK && m < m_end) {
+                const float *pb = conv_L > 0 ? Bm + ((long)m - 1) * ldb + n20 + bc : Bm + (size_t)m * ldb + n20 + bc;
                 bool okb = true;
                 if (conv_L > 0) {
-                    const int l = m % conv_L, c2 = n20 + sc;
+                    const int l = m % conv_L, c2 = n20 + bc;
                     okb = !((l == 0 && c2 < conv_cin) || (l == conv_L - 1 && c2 >= 2 * conv_cin));
                 }
                 if (okb) {
-                    if (n20 + sc + 3 < N2) vb[h] = *(const f32x4 *)pb;
-                    else for (int e = 0; e < 4; ++e) if (n20 + sc + e < N2) vb[h][e] = pb[e];
+                    if (n20 + bc + 3 < N2) vb[h] = *(const f32x4 *)pb;
+                    else for (int e = 0; e < 4; ++e) if (n20 + bc + e < N2) vb[h][e] = pb[e];
                 }
             }
         }
     };
     auto sstore = [&](int buf) {
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            *(f32x4 *)&As[buf][sr + 8 * h][sc] = va[h];
-            *(f32x4 *)&Bs[buf][sr + 8 * h][sc] = vb[h];
+        for (int h = 0; h < 2; ++h) *(f32x4 *)&As[buf][sr + 8 * h][sc] = va[h];
+#pragma unroll
+        for (int h = 0; h < NB; ++h) {
+            const int idx = tid + 256 * h, br = idx / B4, bc = (idx - br * B4) * 4;
+            if (br < TN_MK) *(f32x4 *)&Bs[buf][br][bc] = vb[h];
         }
         if (do_cs) cs += va[0] + va[1];      // here, not in gload: the loads are still in flight behind the MFMAs there
     };
@@ -89,25 +103,28 @@ __global__ __launch_bounds__(256) void gemm_tn_partial_kernel(
 #pragma unroll
         for (int kk = 0; kk < TN_MK / 2; ++kk) {
             const int kr = kk * 2 + (lane >> 5);
-            const float a0 = As[cur][kr][wm * 64 + (lane & 31)], a1 = As[cur][kr][wm * 64 + 32 + (lane & 31)];
-            const float b0 = Bs[cur][kr][wn * 64 + (lane & 31)], b1 = Bs[cur][kr][wn * 64 + 32 + (lane & 31)];
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+            float a[NI], b[NJ];
+#pragma unroll
+            for (int i = 0; i < NI; ++i) a[i] = As[cur][kr][(wm * NI + i) * 32 + (lane & 31)];
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) b[j] = Bs[cur][kr][(wn * NJ + j) * 32 + (lane & 31)];
+#pragma unroll
+            for (int i = 0; i < NI; ++i)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
         }
         if (more) sstore(cur ^ 1);
         __syncthreads();
     }
     float *C = Cpart + (size_t)split * N1 * N2;
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int c2 = n20 + wn * 64 + j * 32 + (lane & 31);
+    for (int j = 0; j < NJ; ++j) {
+        const int c2 = n20 + (wn * NJ + j) * 32 + (lane & 31);
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < NI; ++i)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int c1 = n10 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                const int c1 = n10 + (wm * NI + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                 if (c1 < N1 && c2 < N2) C[(size_t)c1 * N2 + c2] = acc[i][j][r];
             }
     }
@@ -156,8 +173,13 @@ int launch_gemm_tn_segs(const TnSegs &segs, int lda, int ldb, float *Cpart, int 
     const int sps = nsplit / segs.n;
     int rps = (M + sps - 1) / sps;
     rps = (rps + TN_MK - 1) / TN_MK * TN_MK;
-    dim3 grid((N1 + TN_T - 1) / TN_T, (N2 + TN_T - 1) / TN_T, nsplit);
-    hipLaunchKernelGGL(gemm_tn_partial_kernel, grid, dim3(256), 0, s, segs, lda, ldb, Cpart, Csum, M, N1, N2, rps, sps, conv_L, conv_cin);
+    if (N2 > TN_T && N2 <= 160 && conv_L == 0) {      // one 160-wide tile column instead of two 128-wide ones
+        dim3 grid((N1 + TN_T - 1) / TN_T, 1, nsplit);
+        hipLaunchKernelGGL((gemm_tn_partial_kernel<4, 1, 1, 5>), grid, dim3(256), 0, s, segs, lda, ldb, Cpart, Csum, M, N1, N2, rps, sps, conv_L, conv_cin);
+    } else {
+        dim3 grid((N1 + TN_T - 1) / TN_T, (N2 + TN_T - 1) / TN_T, nsplit);
+        hipLaunchKernelGGL((gemm_tn_partial_kernel<2, 2, 2, 2>), grid, dim3(256), 0, s, segs, lda, ldb, Cpart, Csum, M, N1, N2, rps, sps, conv_L, conv_cin);
+    }
     CSA_HIP_CHECK(hipGetLastError());
     return CSA_OK;
 }
