@@ -443,7 +443,7 @@ extern "C" int csa_train_create(const csa_config *cfg, const csa_params *p, cons
     h->dhc1 = dalloc<float>(h, 2 * Bm * nhm, rc); h->dhc2 = dalloc<float>(h, 2 * Bm * nhm, rc);
     if (rc == CSA_OK && (hipMemset(h->dhc1, 0, sizeof(float) * 2 * Bm * nhm) != hipSuccess ||
                          hipMemset(h->dhc2, 0, sizeof(float) * 2 * Bm * nhm) != hipSuccess)) rc = CSA_ERR_HIP;
-    h->nsplit = 64;
+    h->nsplit = 192;
     size_t pf = (size_t)h->nsplit * 4 * nhm * (nin1 > nhm ? nin1 : nhm);
     const size_t pcol = Bm * (size_t)std::max(head_bwd_partial_floats(c), prep_bwd_partial_floats(c));
     h->part_floats = pf > pcol ? pf : pcol;
