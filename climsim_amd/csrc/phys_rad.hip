@@ -346,21 +346,51 @@ __global__ __launch_bounds__(64 * SG_WAVES) void rad_sw_gas_kernel(const float *
         const RoW<4> h0 = ro_loada<4>(bB0 + n * SG_LD + 4 * half), h1 = ro_loada<4>(bB1 + n * SG_LD + 4 * half);
         const float *R = sw + SWG_RED + m * SWG_RED_FLOATS;
         const bool live = m == 0 ? n < 16 : n >= 16;
+        // layer 3 tile by tile, each tile reduced at once.  Pinned issue order (as in rad_optics_kernel): the (.)^8 epilogue of one
+        // variant's tile sits between the MFMAs of the other variant's tile / of the reduction, one accumulator element per MFMA;
+        // the next tile's first chain is issued while the last epilogue's LDS writes land.
+        RoW<4> w = ro_load<4>(W + SWG_W3 + n * SWG_LDK + 4 * half);
+        f32x16 a0 = ro_mma_r<4>(ro_zero(), h0, w);
 #pragma unroll
-        for (int t = 0; t < SWG_NKP / 32; ++t) {      // layer 3 tile t, reduced at once
-            const RoW<4> w = ro_load<4>(W + SWG_W3 + (t * 32 + n) * SWG_LDK + 4 * half);
-            const RoW<4> wr = ro_load<4>(R + (n & 15) * SWG_LDR + t * 32 + 4 * half);
+        for (int t = 0; t < SWG_NKP / 32; ++t) {
+            RoW<4> wr = ro_load<4>(R + (n & 15) * SWG_LDR + t * 32 + 4 * half);
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) wr.v[g][e] = live ? wr.v[g][e] : 0.0f;
             const float b = W[SWG_B3 + t * 32 + n], sd = W[SWG_YSTD + t * 32 + n], mn = W[SWG_YMEAN + t * 32 + n];
-            const f32x16 a0 = ro_mma_r<4>(ro_zero(), h0, w);
-            const f32x16 a1 = ro_mma_r<4>(ro_zero(), h1, w);
+            f32x16 a1 = ro_zero();
 #pragma unroll
-            for (int i = 0; i < 16; ++i) bA0[drow(i) * SG_LD + n] = cd0[i] * pr_pow8(sd * (a0[i] + b) + mn);
-            ro_fence();
-            tp0 = ro_mma<4>(tp0, bA0 + n * SG_LD + 4 * half, wr, live);
+            for (int g = 0; g < 4; ++g)
 #pragma unroll
-            for (int i = 0; i < 16; ++i) bA1[drow(i) * SG_LD + n] = cd1[i] * pr_pow8(sd * (a1[i] + b) + mn);
+                for (int e = 0; e < 4; ++e) {
+                    a1 = __builtin_amdgcn_mfma_f32_32x32x2f32(h1.v[g][e], w.v[g][e], a1, 0, 0, 0);
+                    const int i = 4 * g + e;
+                    bA0[drow(i) * SG_LD + n] = cd0[i] * pr_pow8(sd * (a0[i] + b) + mn);
+                    __builtin_amdgcn_sched_barrier(0x3F4);   // memory and scalar instructions may move; MFMA and VALU keep this order
+                }
             ro_fence();
-            tp1 = ro_mma<4>(tp1, bA1 + n * SG_LD + 4 * half, wr, live);
+            {
+                const RoW<4> x0 = ro_loada<4>(bA0 + n * SG_LD + 4 * half);
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        tp0 = __builtin_amdgcn_mfma_f32_32x32x2f32(x0.v[g][e], wr.v[g][e], tp0, 0, 0, 0);
+                        const int i = 4 * g + e;
+                        bA1[drow(i) * SG_LD + n] = cd1[i] * pr_pow8(sd * (a1[i] + b) + mn);
+                        __builtin_amdgcn_sched_barrier(0x3F4);
+                    }
+            }
+            ro_fence();
+            if (t + 1 < SWG_NKP / 32) {
+                w = ro_load<4>(W + SWG_W3 + ((t + 1) * 32 + n) * SWG_LDK + 4 * half);
+                a0 = ro_mma_r<4>(ro_zero(), h0, w);
+            }
+            {
+                const RoW<4> x1 = ro_loada<4>(bA1 + n * SG_LD + 4 * half);
+                tp1 = ro_mma_r<4>(tp1, x1, wr);
+            }
         }
         ro_fence();
     }
