@@ -293,6 +293,28 @@ int launch_reduce_partials(const float *part, int nsplit, int n, const int *map,
     return CSA_OK;
 }
 
+// rows of `rowf` floats (a multiple of 4, 16-byte aligned), `stride` floats apart in global memory -> consecutive rows of LDS
+// (row pitch `pitch` floats).  All J float4 loads of a thread are issued before the first LDS store: a rolled loop of
+// load -> store pairs pays one memory round trip per trip (this was 20-30 us of head_bwd / prep_bwd, three launches each per step).
+template <int J, int T>
+__device__ __forceinline__ void rows_to_lds(float *dst, int pitch, const float *__restrict__ src, size_t stride, int nrow, int rowf, int tid)
+{
+    const int q = rowf >> 2, total = nrow * q;
+    for (int base = 0; base < total; base += J * T) {
+        f32x4 v[J];
+        int r[J], c[J];
+#pragma unroll
+        for (int j = 0; j < J; ++j) {
+            const int idx = min(base + tid + T * j, total - 1);
+            r[j] = idx / q; c[j] = (idx - r[j] * q) * 4;
+            v[j] = *(const f32x4 *)(src + (size_t)r[j] * stride + c[j]);
+        }
+#pragma unroll
+        for (int j = 0; j < J; ++j)
+            if (base + tid + T * j < total) *(f32x4 *)(dst + r[j] * pitch + c[j]) = v[j];
+    }
+}
+
 // -------------------------------------------------------------------------------------------------
 // head backward, one workgroup per column (current generation, memory model):
 //   d_out (B,L,ny) [+ prune mask], d_out_sfc (B,nys), d_mem_out (L,B,nm)  ->  dH2 (L,B,nh2),
@@ -311,31 +333,48 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(
     float *hs = dos + L * ny;         // (L, nh2)
     const int b = blockIdx.x, tid = threadIdx.x;
     float *pp = part + (size_t)b * (ny * nm + ny + nm * nh2 + nm + nys * nh2 + nys);
-    for (int idx = tid; idx < L * ny; idx += 256) {
-        const int l = idx / ny, v = idx - l * ny;
-        float d = d_out[((size_t)b * L + l) * ny + v];
-        if (m.cfg.output_prune && l < 12 && v >= 1) d = 0.0f;
-        dos[idx] = d;
-    }
-    for (int idx = tid; idx < L * nm; idx += 256) {
-        const int l = idx / nm, j = idx - l * nm;
-        zs[idx] = Z[((size_t)l * B + b) * nm + j];
-    }
-    for (int idx = tid; idx < L * nh2; idx += 256) {
-        const int l = idx / nh2, k = idx - l * nh2;
-        hs[idx] = H2[((size_t)l * B + b) * nh2 + k];
+    if (((L * ny) | nm | nh2) & 3) {                 // generic widths: element-wise
+        for (int idx = tid; idx < L * ny; idx += 256) dos[idx] = d_out[(size_t)b * L * ny + idx];
+        for (int idx = tid; idx < L * nm; idx += 256) zs[idx] = Z[((size_t)(idx / nm) * B + b) * nm + idx % nm];
+        for (int idx = tid; idx < L * nh2; idx += 256) hs[idx] = H2[((size_t)(idx / nh2) * B + b) * nh2 + idx % nh2];
+    } else {                                          // the column's d_out block is contiguous; Z / H2 rows are B rows apart
+        rows_to_lds<2, 256>(dos, 0, d_out + (size_t)b * L * ny, 0, 1, L * ny, tid);
+        rows_to_lds<1, 256>(zs, nm, Z + (size_t)b * nm, (size_t)B * nm, L, nm, tid);
+        rows_to_lds<8, 256>(hs, nh2, H2 + (size_t)b * nh2, (size_t)B * nh2, L, nh2, tid);
     }
     __syncthreads();
-    // dz = W_out^T d_out + d_mem_out
-    for (int idx = tid; idx < L * nm; idx += 256) {
-        const int l = idx / nm, j = idx - l * nm;
-        float a = d_mem_out ? d_mem_out[((size_t)l * B + b) * nm + j] : 0.0f;
+    if (m.cfg.output_prune) {
+        for (int idx = tid; idx < 12 * ny; idx += 256) if (idx % ny >= 1) dos[idx] = 0.0f;
+        __syncthreads();
+    }
+    // dz = W_out^T d_out + d_mem_out.  Batches of four levels per thread: the d_mem_out loads of a batch are issued together, and
+    // when nm divides 256 a thread keeps one latent channel j, so its W_out column is loaded once.
+    {
+        constexpr int J = 4;
+        const bool fixj = (256 % nm) == 0;
         float w[8];
 #pragma unroll
-        for (int v = 0; v < 8; ++v) w[v] = m.out_w[min(v, ny - 1) * nm + j];      // ny <= 8 (launch check); clamped, weight 0 below
+        for (int v = 0; v < 8; ++v) w[v] = m.out_w[min(v, ny - 1) * nm + tid % nm];      // ny <= 8 (launch check); clamped, weight 0 below
+        for (int base = 0; base < L * nm; base += 256 * J) {
+            float dm[J];
 #pragma unroll
-        for (int v = 0; v < 8; ++v) a += (v < ny ? dos[l * ny + min(v, ny - 1)] : 0.0f) * w[v];
-        dz[idx] = a;
+            for (int q = 0; q < J; ++q) {
+                const int idx = min(base + tid + 256 * q, L * nm - 1), l = idx / nm, j = idx - l * nm;
+                dm[q] = d_mem_out ? d_mem_out[((size_t)l * B + b) * nm + j] : 0.0f;
+            }
+#pragma unroll
+            for (int q = 0; q < J; ++q) {
+                const int idx = base + tid + 256 * q, l = min(idx / nm, L - 1), j = idx - (idx / nm) * nm;
+                float a = dm[q];
+                if (!fixj) {
+#pragma unroll
+                    for (int v = 0; v < 8; ++v) w[v] = m.out_w[min(v, ny - 1) * nm + j];
+                }
+#pragma unroll
+                for (int v = 0; v < 8; ++v) a += (v < ny ? dos[l * ny + min(v, ny - 1)] : 0.0f) * w[v];
+                if (idx < L * nm) dz[idx] = a;
+            }
+        }
     }
     __syncthreads();
     // dH2 = W_lat^T dz (+ W_sfo^T d_out_sfc on the last level).  Thread -> hidden unit k is FIXED (k = tid mod nh2, 256 / nh2
@@ -388,11 +427,45 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(
         p[v] = a;
     }
     p += ny;
-    for (int idx = tid; idx < nm * nh2; idx += 256) {         // dW_lat[j][k] = sum_l dz[l][j] h2[l][k]
-        const int j = idx / nh2, k = idx - j * nh2;
-        float a = 0.0f;
-        for (int l = 0; l < L; ++l) a += dz[l * nm + j] * hs[l * nh2 + k];
-        p[idx] = a;
+    if (nm == 16 && (nh2 == 128 || nh2 == 256)) {             // dW_lat[j][k] = sum_l dz[l][j] h2[l][k]
+        // thread = (hidden unit k, group of 16 * nh2 / 256 latent channels): one h2 read and 1-2 broadcast float4 of dz feed 4-8
+        // accumulators per level (the element-wise form below runs 8 x L dependent two-read iterations per thread: 14 us)
+        const int k = tid % nh2, g = tid / nh2;
+        if (nh2 == 128) {
+            float a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll 4
+            for (int l = 0; l < L; ++l) {
+                const float h = hs[l * 128 + k];
+                const f32x4 z0 = *(const f32x4 *)(dz + l * 16 + g * 8), z1 = *(const f32x4 *)(dz + l * 16 + g * 8 + 4);
+                a[0] = fmaf(z0.x, h, a[0]); a[1] = fmaf(z0.y, h, a[1]); a[2] = fmaf(z0.z, h, a[2]); a[3] = fmaf(z0.w, h, a[3]);
+                a[4] = fmaf(z1.x, h, a[4]); a[5] = fmaf(z1.y, h, a[5]); a[6] = fmaf(z1.z, h, a[6]); a[7] = fmaf(z1.w, h, a[7]);
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) p[(g * 8 + q) * 128 + k] = a[q];
+        } else {
+            float a[16];
+#pragma unroll
+            for (int q = 0; q < 16; ++q) a[q] = 0.0f;
+#pragma unroll 2
+            for (int l = 0; l < L; ++l) {
+                const float h = hs[l * 256 + k];
+#pragma unroll
+                for (int q4 = 0; q4 < 4; ++q4) {
+                    const f32x4 z = *(const f32x4 *)(dz + l * 16 + q4 * 4);
+                    a[4 * q4] = fmaf(z.x, h, a[4 * q4]); a[4 * q4 + 1] = fmaf(z.y, h, a[4 * q4 + 1]);
+                    a[4 * q4 + 2] = fmaf(z.z, h, a[4 * q4 + 2]); a[4 * q4 + 3] = fmaf(z.w, h, a[4 * q4 + 3]);
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 16; ++q) p[q * 256 + k] = a[q];
+        }
+    } else {
+        for (int idx = tid; idx < nm * nh2; idx += 256) {
+            const int j = idx / nh2, k = idx - j * nh2;
+            float a = 0.0f;
+            for (int l = 0; l < L; ++l) a += dz[l * nm + j] * hs[l * nh2 + k];
+            p[idx] = a;
+        }
     }
     p += nm * nh2;
     for (int j = tid; j < nm; j += 256) {
@@ -431,7 +504,7 @@ int launch_head_bwd(const DevModel &m, int B, const float *d_out, const float *d
 //   d h0/c0 of rnn1), mlp_toa1/2 (from d h0/c0 of rnn2).
 // partial layout: [W_init nh1*nxp | b_init nh1 | W_s1 nh1*nxs | b_s1 nh1 | W_s2 nh1*nxs | b_s2 nh1 |
 //                  W_toa1 nh2*2 | b_toa1 nh2 | W_toa2 nh2*2 | b_toa2 nh2]
-#define PB_U 12
+#define PB_U 30            // levels per batch of independent global loads (12: 36.1 us per launch)
 __global__ __launch_bounds__(128) void prep_bwd_kernel(
     DevModel m, int B, const float *__restrict__ dX1, const float *__restrict__ X1, const float *__restrict__ X16,
     const float *__restrict__ xs_n, const float *__restrict__ hc0, const float *__restrict__ dhc1,
@@ -446,9 +519,14 @@ __global__ __launch_bounds__(128) void prep_bwd_kernel(
     float *x16 = smem;
     float *xs = x16 + L * 32;          // (nxs)
     const int b = blockIdx.x, tid = threadIdx.x;
-    for (int idx = tid; idx < L * 32; idx += 128) {
-        const int l = idx >> 5, v = idx & 31;
-        x16[idx] = v < nxp ? X16[((size_t)b * L + l) * nxp + v] : 0.0f;
+    if (nxp & 3) {
+        for (int idx = tid; idx < L * 32; idx += 128) {
+            const int l = idx >> 5, v = idx & 31;
+            x16[idx] = v < nxp ? X16[((size_t)b * L + l) * nxp + v] : 0.0f;
+        }
+    } else {                                          // batched float4 loads of the column's (L, nxp) block, then the zero padding
+        rows_to_lds<2, 128>(x16, 32, X16 + (size_t)b * L * nxp, nxp, L, nxp, tid);
+        for (int idx = tid; idx < L * 32; idx += 128) if ((idx & 31) >= nxp) x16[idx] = 0.0f;
     }
     for (int v = tid; v < nxs; v += 128) xs[v] = xs_n[(size_t)b * nxs + v];
     __syncthreads();
@@ -509,11 +587,22 @@ __global__ __launch_bounds__(128) void prep_bwd_kernel(
         }
     }
     // gradient w.r.t. the incoming memory (level order)
-    if (d_mem_in)
-        for (int idx = tid; idx < L * nm; idx += 128) {
-            const int t = idx / nm, k = idx - t * nm;
-            d_mem_in[((size_t)(m.cfg.add_stochastic_layer ? t : L - 1 - t) * B + b) * nm + k] = dX1[((size_t)t * B + b) * nin1 + nh1 + k];
+    if (d_mem_in) {
+        constexpr int J = 8;                          // eight independent loads in flight per thread (a rolled copy loop: one round trip per trip)
+        for (int base = 0; base < L * nm; base += 128 * J) {
+            float v[J];
+#pragma unroll
+            for (int j = 0; j < J; ++j) {
+                const int idx = min(base + tid + 128 * j, L * nm - 1), t = idx / nm, k = idx - t * nm;
+                v[j] = dX1[((size_t)t * B + b) * nin1 + nh1 + k];
+            }
+#pragma unroll
+            for (int j = 0; j < J; ++j) {
+                const int idx = base + tid + 128 * j, t = idx / nm, k = idx - t * nm;
+                if (idx < L * nm) d_mem_in[((size_t)(m.cfg.add_stochastic_layer ? t : L - 1 - t) * B + b) * nm + k] = v[j];
+            }
         }
+    }
 }
 
 int launch_prep_bwd(const DevModel &m, int B, const float *dX1, const float *X1, const float *X16, const float *xs_n,
