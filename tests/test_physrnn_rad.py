@@ -272,6 +272,27 @@ def test_hip_radiation_graph_errors_and_rollout_state():
 
 
 @pytest.mark.gpu
+def test_hip_sw_gas_optics_flags_are_validated():
+    """csa_phys_rad_create: the SW gas-optics block belongs to the 16-region physRad graphs (with the liquid-fraction head, or with both
+    learned cloud-optics layers); a state_dict that mixes the families is refused, not reinterpreted."""
+    from climsim_amd.physrnn import physical_RNN_autoreg
+    g, P = _load("physrad16_e3sm")
+    bad = {k: v for k, v in P.items() if not k.startswith("mlp_liq_frac_crm")}                  # Slingo / EC optics need the learned liquid fraction
+    with pytest.raises(RuntimeError):
+        physical_RNN_autoreg(bad, max_batch=8)
+    g2, P2 = _load("physrad16_e3sm_cld")
+    bad = {k: v for k, v in P2.items() if not k.startswith("cloud_optics_lw")}                  # learned SW cloud optics without the LW layer
+    with pytest.raises(RuntimeError):
+        physical_RNN_autoreg(bad, max_batch=8)
+    bad = dict(P)
+    bad["gas_optics_model_sw1.mlp1.weight"] = torch.zeros(16, 7)                               # not the shipped 7 -> 32 -> 32 -> 112 model
+    with pytest.raises(RuntimeError):
+        physical_RNN_autoreg(bad, max_batch=8)
+    m = _hip_model(P, 8)                                                                        # the untouched state_dict still builds
+    assert m.physrad
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("fixture", ["physrad16_a", "physrad16_b", "physrad16_c"])
 def test_hip_rnn3_steps_reproduce_the_artefact(fixture):
     g, P = _load(fixture)
@@ -309,7 +330,7 @@ def test_hip_stochastic_graph_noise_handling():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("fixture", ["physrnn_rad", "physrad16_b"])
+@pytest.mark.parametrize("fixture", ["physrnn_rad", "physrad16_b", "physrad16_e3sm"])
 def test_hip_radiation_graph_properties_at_shard_size(fixture):
     """2,700 columns (the per-GPU shard of the high-resolution grid): deterministic, finite, and a column's result does not
     depend on which other columns share the call (rows of a 640-column call = the same rows of the 2,700-column call, bit for
