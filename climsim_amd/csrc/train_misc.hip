@@ -293,28 +293,6 @@ int launch_reduce_partials(const float *part, int nsplit, int n, const int *map,
     return CSA_OK;
 }
 
-// rows of `rowf` floats (a multiple of 4, 16-byte aligned), `stride` floats apart in global memory -> consecutive rows of LDS
-// (row pitch `pitch` floats).  All J float4 loads of a thread are issued before the first LDS store: a rolled loop of
-// load -> store pairs pays one memory round trip per trip (this was 20-30 us of head_bwd / prep_bwd, three launches each per step).
-template <int J, int T>
-__device__ __forceinline__ void rows_to_lds(float *dst, int pitch, const float *__restrict__ src, size_t stride, int nrow, int rowf, int tid)
-{
-    const int q = rowf >> 2, total = nrow * q;
-    for (int base = 0; base < total; base += J * T) {
-        f32x4 v[J];
-        int r[J], c[J];
-#pragma unroll
-        for (int j = 0; j < J; ++j) {
-            const int idx = min(base + tid + T * j, total - 1);
-            r[j] = idx / q; c[j] = (idx - r[j] * q) * 4;
-            v[j] = *(const f32x4 *)(src + (size_t)r[j] * stride + c[j]);
-        }
-#pragma unroll
-        for (int j = 0; j < J; ++j)
-            if (base + tid + T * j < total) *(f32x4 *)(dst + r[j] * pitch + c[j]) = v[j];
-    }
-}
-
 // -------------------------------------------------------------------------------------------------
 // head backward, one workgroup per column (current generation, memory model):
 //   d_out (B,L,ny) [+ prune mask], d_out_sfc (B,nys), d_mem_out (L,B,nm)  ->  dH2 (L,B,nh2),
