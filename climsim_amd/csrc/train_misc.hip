@@ -218,21 +218,20 @@ __global__ void reduce_partials_kernel(const float *__restrict__ part, int nspli
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    // fixed summation order (s ascending within each of four interleaved chains, chains combined pairwise):
-    // deterministic, and the four loads per trip are independent (a single dependent chain costs nsplit L2 latencies)
-    float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
+    // fixed summation order (s ascending within each of eight interleaved chains, chains combined pairwise):
+    // deterministic, and the eight loads per trip are independent (a single dependent chain costs nsplit memory latencies;
+    // four chains: 16.4 us for 192 partials of 65,536 floats)
+    float a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     int s = 0;
-    for (; s + 3 < nsplit; s += 4) {
-        a0 += part[(size_t)s * n + i];
-        a1 += part[(size_t)(s + 1) * n + i];
-        a2 += part[(size_t)(s + 2) * n + i];
-        a3 += part[(size_t)(s + 3) * n + i];
+    for (; s + 7 < nsplit; s += 8) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) a[q] += part[(size_t)(s + q) * n + i];
     }
-    for (; s < nsplit; ++s) a0 += part[(size_t)s * n + i];
-    const float a = (a0 + a1) + (a2 + a3);
+    for (; s < nsplit; ++s) a[0] += part[(size_t)s * n + i];
+    const float a_ = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
     const int d = map ? map[i] : i;
-    if (d >= 0) grad[d] += a;
-    if (map2) { const int d2 = map2[i]; if (d2 >= 0) grad[d2] += a; }
+    if (d >= 0) grad[d] += a_;
+    if (map2) { const int d2 = map2[i]; if (d2 >= 0) grad[d2] += a_; }
 }
 // first stage for MANY partials (one per column: head / prep backward): chunk c of `chunks` sums its contiguous run of
 // partials into tmp[c][i]; the ordinary reduction then finishes over `chunks`.  Fixed order -> deterministic.
