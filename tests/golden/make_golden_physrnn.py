@@ -108,7 +108,10 @@ PHYSRAD = {"physrad16_a": "physRNN_physRad-16_nreg16_lr0.0007.neur128-128_xv4_mp
            # optics, learned liquid fraction; GRU 128/128 (the geometry of the frozen `*_wrapped` exports)
            "physrad16_e3sm": "physRNN_physRad-16_nreg16_lr0.0007.neur128-128_xv4_mp1_num94634_BEST_script_cpu.pt",
            # num88955's graph (learned cloud LW optics, GRU 112/112) with the SW gas-optics models and learned SW cloud optics
-           "physrad16_e3sm_cld": "physRNN_physRad-16_nreg16_lr0.0007.neur112-112_xv4_mp1_num88741_BEST_script_cpu.pt"}
+           "physrad16_e3sm_cld": "physRNN_physRad-16_nreg16_lr0.0007.neur112-112_xv4_mp1_num88741_BEST_script_cpu.pt",
+           # the `_script_gpu` twin of num55617_BEST: of the twelve unfrozen `_gpu` files the only one whose state_dict differs from its
+           # `_cpu` twin (rnn3 and the solar weights, a different checkpoint); loads and runs on the CPU with map_location
+           "physrad16_b_gpu": "physRNN_physRad-16_nreg16_lr0.0007.neur128-128_xv4_mp1_num55617_BEST_script_gpu.pt"}
 
 
 def staged_srnn(m, xm, xs, mem, seed, out_ref, sfc_ref, xd):

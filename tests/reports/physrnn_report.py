@@ -20,7 +20,8 @@ FIX = [("physrnn_hidden", "num14564_BEST", 2), ("physrnn_hidden_ep40", "num14564
        ("physrad4_a", "physRad-16_nreg4 neur112 num35741_BEST", 1), ("physrad4_b", "physRad-16_nreg4 neur112 num95220_BEST", 1),
        ("physrad16_nh112_cld", "physRad-16_nreg16 neur112 num88955_BEST", 1),
        ("physrad16_e3sm", "physRad-16_nreg16 neur128 num94634_BEST (physics_rad_e3sm)", 1),
-       ("physrad16_e3sm_cld", "physRad-16_nreg16 neur112 num88741_BEST (physics_rad_e3sm, learned cloud optics)", 1)]
+       ("physrad16_e3sm_cld", "physRad-16_nreg16 neur112 num88741_BEST (physics_rad_e3sm, learned cloud optics)", 1),
+       ("physrad16_b_gpu", "physRad-16_nreg16 num55617_BEST, the _script_gpu twin (another checkpoint)", 1)]
 print("fixture | artefact | case B | block: HIP-vs-artefact max|err| / max|ref| ; artefact-vs-float64 restatement (its own rounding) / max|ref|")
 for name, tag, ncase in FIX:
     g = np.load(os.path.join(ROOT, "tests", "golden", name + ".npz"))

@@ -79,7 +79,7 @@ def _noise_level(*realisations_then_exact):
 FIXTURES = [("physrnn_rad", 2), ("physrnn_rad_nomcica", 1), ("physrnn_rad_liqfrac", 1), ("physrnn_rad_stoch_a", 1),
             ("physrnn_rad_stoch_b", 1), ("physrnn_rad_stoch_c", 1), ("physrad16_a", 1), ("physrad16_b", 1), ("physrad16_c", 1),
             ("physrad16_nh96", 1), ("physrad16_nh112_a", 1), ("physrad16_nh112_b", 1),
-            ("physrad4_a", 1), ("physrad4_b", 1), ("physrad16_nh112_cld", 1), ("physrad16_e3sm", 1), ("physrad16_e3sm_cld", 1)]
+            ("physrad4_a", 1), ("physrad4_b", 1), ("physrad16_nh112_cld", 1), ("physrad16_e3sm", 1), ("physrad16_e3sm_cld", 1), ("physrad16_b_gpu", 1)]
 
 
 def _noise(g, i):
@@ -98,7 +98,7 @@ def _rnn3_step_inputs(P, r2, hx1, srnn, eps3):
     return x, h0, eps3.reshape(1, T * B, H)
 
 
-@pytest.mark.parametrize("fixture", ["physrad16_a", "physrad16_b", "physrad16_c"])
+@pytest.mark.parametrize("fixture", ["physrad16_a", "physrad16_b", "physrad16_c", "physrad16_b_gpu"])
 def test_restatement_rnn3_steps_reproduce_the_artefact(fixture):
     g, P = _load(fixture)
     B, seed = (int(v) for v in g["case0.cfg"])
@@ -293,7 +293,7 @@ def test_hip_sw_gas_optics_flags_are_validated():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("fixture", ["physrad16_a", "physrad16_b", "physrad16_c"])
+@pytest.mark.parametrize("fixture", ["physrad16_a", "physrad16_b", "physrad16_c", "physrad16_b_gpu"])
 def test_hip_rnn3_steps_reproduce_the_artefact(fixture):
     g, P = _load(fixture)
     m = _hip_model(P, 16)
