@@ -66,6 +66,7 @@ struct csa_phys {
     PhysDev d;
     int max_batch;
     float *wih1, *bias1, *bhn1, *whh1p, *whh1g, *wih2, *bias2, *bhn2, *whh2p, *whh2g, *whead, *bhead;
+    float *whh1m = nullptr, *whh2m = nullptr;     // gru_rec4m_kernel layout
     float *X1, *P, *H1, *H2, *hx, *HD;
     // radiation scheme: MLP weights (row-major (out, in), K padded to a multiple of 4) and per-call work arrays
     float *g_w1, *g_b1, *g_w2, *g_b2, *g_w3, *g_b3, *r1_w, *r1_b, *r2_w, *r2_b, *s1_w, *s1_b, *s2_w, *s2_b;

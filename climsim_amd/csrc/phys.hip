@@ -545,6 +545,11 @@ static int phys_build(int nx, int nfeat, int naux, int nx_sfc, int sfc_cut, int 
         rec_pack_weights(0, nh, w.r2_hh, pk.data()); h->whh2p = up(pk.data(), pk.size());
         gru2_pack_weights(nh, w.r1_hh, pk.data()); h->whh1g = up(pk.data(), pk.size());   // two-column kernel (B > 256)
         gru2_pack_weights(nh, w.r2_hh, pk.data()); h->whh2g = up(pk.data(), pk.size());
+        {   // matrix-pipe kernel (four columns per workgroup, from 544 columns)
+            std::vector<float> pm((size_t)4 * nh * nh);
+            gru4m_pack_weights(nh, w.r1_hh, pm.data()); h->whh1m = up(pm.data(), pm.size());
+            gru4m_pack_weights(nh, w.r2_hh, pm.data()); h->whh2m = up(pm.data(), pm.size());
+        }
     }
     // head GEMM: 11 decoder heads (mp_ncol rows each), mlp_latent (15 rows), then mlp_output_rad (1 row) or zero padding
     {
@@ -748,14 +753,17 @@ static int phys_forward_impl(csa_phys *h, int B, const float *x_main, const floa
     const int lsplit = B <= 1024 ? 4 : 1;
     hipLaunchKernelGGL(phys_prep_kernel, dim3(B, lsplit), dim3(128), 0, s, d, B, x_main, x_sfc, rnn_mem, h->X1, h->hx);
     CSA_HIP_CHECK(hipGetLastError());
-    auto rec = [&](const float *whh, const float *whg, const float *bhn, const float *h0, float *Hout, int reverse) {
+    // one column per workgroup up to 256 columns, two from there, four on the matrix pipe from 544 (the LSTM path's thresholds)
+    const bool four = gru4m_selected(nh, B);
+    auto rec = [&](const float *whh, const float *whg, const float *whm, const float *bhn, const float *h0, float *Hout, int reverse) {
         return B <= 256 ? launch_rec1_gru(nh, whh, bhn, h->P, h0, Hout, B, L, reverse, s)
+               : four   ? launch_rec4m_gru(nh, whm, bhn, h->P, h0, Hout, B, L, reverse, s)
                         : launch_rec2_gru(nh, whg, bhn, h->P, h0, Hout, B, L, reverse, s);
     };
     if ((rc = launch_proj_gemm(h->X1, h->wih1, h->bias1, h->P, M, 3 * nh, nh + 16, s, 0))) return rc;
-    if ((rc = rec(h->whh1p, h->whh1g, h->bhn1, h->hx, h->H1, 1))) return rc;
+    if ((rc = rec(h->whh1p, h->whh1g, h->whh1m, h->bhn1, h->hx, h->H1, 1))) return rc;
     if ((rc = launch_proj_gemm(h->H1, h->wih2, h->bias2, h->P, M, 3 * nh, nh, s, 0))) return rc;
-    if ((rc = rec(h->whh2p, h->whh2g, h->bhn2, hx2, h->H2, 0))) return rc;
+    if ((rc = rec(h->whh2p, h->whh2g, h->whh2m, h->bhn2, hx2, h->H2, 0))) return rc;
     const float *Hhead = h->H2, *Hlast = h->H2;      // the sequence the heads read; the sequence whose last state feeds the release head
     if (h->rnn3) {                                    // rnn2's output times the stochastic layer's output; last state: the layer's own
         if (srnn) CSA_HIP_CHECK(hipMemcpyAsync(h->H3, srnn, sizeof(float) * (size_t)M * nh, hipMemcpyDeviceToDevice, s));

@@ -640,6 +640,88 @@ __global__ __launch_bounds__(NH * 4, (NH / 16 + 3) / 4) void lstm_rec4m_kernel(
 }
 
 // ------------------------------------------------------------------------------------------------
+// GRU on the MATRIX pipe for LARGE batches: lstm_rec4m_kernel's mapping with three gate rows per block.  lane = 4*unit_in_wave + x
+// holds W_hh[gate x of the unit][k] (x = 0, 1, 2: r, z, n; x = 3: zeros -- a quarter of every 4x4x1 MFMA is padding) as A operand
+// and h_{t-1}[k] of column x as B operand; its D registers are W_hr h, W_hz h, W_hn h of (unit, column x), so
+//   r = sigma(x_r + D.x), z = sigma(x_z + D.y), n = tanh(x_n + r (D.z + b_hn)), h = (1 - z) n + z h
+// happen in the lane, no cross-lane traffic.  P rows are [r, z, n] per unit, unpadded: one 12-byte load per step.
+// Same arithmetic as gru_rec2_kernel up to the order of the k-sum.
+template <int NH, bool BLGP>
+__global__ __launch_bounds__(NH * 4, (NH / 16 + 3) / 4) void gru_rec4m_kernel(
+    const float *__restrict__ Wk, const float *__restrict__ bhn, const float *__restrict__ P,
+    const float *__restrict__ h0, float *__restrict__ Hout, int B, int L, int reverse_out)
+{
+    constexpr int NT = NH * 4;
+    static_assert(NH % 16 == 0, "nh must be a multiple of 16");
+    __shared__ __attribute__((aligned(16))) float hbuf[2][4 * NH];      // layout: see lstm_rec4m_kernel
+
+    const int tid = threadIdx.x, u = tid >> 2, x = tid & 3, lane = tid & 63;
+    int b = 4 * blockIdx.x + x;
+    const bool valid = b < B;
+    if (!valid) b = B - 1;
+
+    float w[NH];
+#pragma unroll
+    for (int k = 0; k < NH; ++k) w[k] = Wk[(size_t)k * NT + tid];
+
+    const float bn = bhn[u];
+    float h = h0[(size_t)b * NH + u];
+    const int hslot = (u >> 4) * 64 + ((((u & 15) >> 2) * 4 + x) << 2) + (u & 3);
+    hbuf[0][hslot] = h;
+    const float *Pb = P + (size_t)b * (3 * NH) + u * 3;
+    const size_t Pstep = (size_t)B * (3 * NH);
+    f32x3 preA = f32x3{Pb[0], Pb[1], Pb[2]}, preB = preA;
+    const int hoff = BLGP ? (((lane >> 4) * 4 + x) << 2) : (x << 2);
+    __syncthreads();
+
+#define MF4(ACC, K, HV, G)                                                                             \
+    ACC = __builtin_amdgcn_mfma_f32_4x4x1f32(w[(K)], HV.x, ACC, 0, 0, G);                              \
+    ACC##b = __builtin_amdgcn_mfma_f32_4x4x1f32(w[(K) + 1], HV.y, ACC##b, 0, 0, G);                    \
+    ACC##c = __builtin_amdgcn_mfma_f32_4x4x1f32(w[(K) + 2], HV.z, ACC##c, 0, 0, G);                    \
+    ACC##d = __builtin_amdgcn_mfma_f32_4x4x1f32(w[(K) + 3], HV.w, ACC##d, 0, 0, G);
+#define GRU4M_STEP(T, CUR, NXT)                                                                        \
+    {                                                                                                  \
+        const int t_ = (T);                                                                            \
+        {   /* unconditional prefetch + unconditional wait: see lstm_rec2_kernel */                     \
+            const float *pn = Pb + (size_t)(t_ + 1 < L ? t_ + 1 : L - 1) * Pstep;                      \
+            asm volatile("global_load_dwordx3 %0, %1, off" : "=&v"(NXT) : "v"(pn) : "memory");         \
+        }                                                                                              \
+        const float *hb = &hbuf[t_ & 1][0] + hoff;                                                     \
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f}, accb = acc, accc = acc, accd = acc;                          \
+        if (BLGP) {                                                                                    \
+            _Pragma("unroll") for (int q = 0; q < NH / 16; ++q) {                                      \
+                const f32x4 hv = *(const f32x4 *)(hb + 64 * q);                                        \
+                MF4(acc, 16 * q, hv, 4)                                                                \
+                MF4(acc, 16 * q + 4, hv, 5)                                                            \
+                MF4(acc, 16 * q + 8, hv, 6)                                                            \
+                MF4(acc, 16 * q + 12, hv, 7)                                                           \
+            }                                                                                          \
+        } else {                                                                                       \
+            _Pragma("unroll") for (int q = 0; q < NH / 4; ++q) {                                       \
+                const f32x4 hv = *(const f32x4 *)(hb + 64 * (q >> 2) + 16 * (q & 3));                   \
+                MF4(acc, 4 * q, hv, 0)                                                                 \
+            }                                                                                          \
+        }                                                                                              \
+        asm volatile("s_waitcnt vmcnt(1)" : "+v"(CUR));                                                \
+        acc = (acc + accb) + (accc + accd);                                                            \
+        const float rg = CSA_RCP(1.0f + CSA_EXP2(-1.44269504088896341f * (acc.x + CUR.x)));            \
+        const float zg = CSA_RCP(1.0f + CSA_EXP2(-1.44269504088896341f * (acc.y + CUR.y)));            \
+        const float tn = fminf(CSA_EXP2(-2.88539008177792681f * (CUR.z + rg * (acc.z + bn))), 1e30f);  \
+        const float n = (1.0f - tn) * CSA_RCP(1.0f + tn);                                              \
+        h = (1.0f - zg) * n + zg * h;                                                                  \
+        hbuf[(t_ & 1) ^ 1][hslot] = h;                                                                 \
+        if (valid) Hout[((size_t)(reverse_out ? L - 1 - t_ : t_) * B + b) * NH + u] = h;               \
+        LDS_BARRIER();                                                                                 \
+    }
+    for (int t = 0; t < L; t += 2) {
+        GRU4M_STEP(t, preA, preB)
+        if (t + 1 < L) GRU4M_STEP(t + 1, preB, preA)
+    }
+#undef GRU4M_STEP
+#undef MF4
+}
+
+// ------------------------------------------------------------------------------------------------
 // GRU kernel, second generation (inference): the lstm_rec2_kernel design with three accumulator slots.
 // Slot order per lane group (host packing, gru2_pack_weights): p<2 holds [r, hn, z], p>=2 holds [z, hn, r], so after
 //   r[s] = acc[s].x + xor1(acc[s].y);  v0 = r[0] + xor2(r[2]);  v1 = r[1] + xor2(r[1])
@@ -1041,6 +1123,43 @@ int launch_rec4m(int nh, const float *whh_m, const float *P, const float *h0, co
     return CSA_OK;
 }
 bool rec4m_selected(int use_lstm, int nh, int B) { return use_lstm && nh <= 128 && rec4_variant() != 0 && B >= rec4_min_batch(); }
+
+// GRU matrix-pipe kernel: Wk[k*NT + tid] = W_hh[gate (tid & 3) of unit (tid >> 2)][k] for the PyTorch gate rows (r, z, n); the
+// fourth row of every block is zero
+void gru4m_pack_weights(int nh, const float *w_hh, float *packed)
+{
+    const int NT = nh * 4;
+    for (int k = 0; k < nh; ++k)
+        for (int tid = 0; tid < NT; ++tid)
+            packed[(size_t)k * NT + tid] = (tid & 3) < 3 ? w_hh[(size_t)((tid & 3) * nh + (tid >> 2)) * nh + k] : 0.0f;
+}
+int launch_rec4m_gru(int nh, const float *whh_m, const float *bhn, const float *P, const float *h0, float *Hout, int B, int L,
+                     int reverse_out, hipStream_t s)
+{
+    const dim3 grid((B + 3) / 4), block(nh * 4);
+    const bool blgp = rec4_variant() != 1;
+#define G4M(NHv)                                                                                                                 \
+    if (blgp) hipLaunchKernelGGL((gru_rec4m_kernel<NHv, true>), grid, block, 0, s, whh_m, bhn, P, h0, Hout, B, L, reverse_out);  \
+    else hipLaunchKernelGGL((gru_rec4m_kernel<NHv, false>), grid, block, 0, s, whh_m, bhn, P, h0, Hout, B, L, reverse_out);
+    switch (nh) {
+    case 64: G4M(64) break;
+    case 96: G4M(96) break;
+    case 112: G4M(112) break;
+    case 128: G4M(128) break;
+    default:
+        csa_set_error_msg("gru_rec4m: hidden size not supported (64, 96, 112, 128)");
+        return CSA_ERR_UNSUPPORTED;
+    }
+#undef G4M
+    CSA_HIP_CHECK(hipGetLastError());
+    return CSA_OK;
+}
+// the GRU flavour of rec4m_selected (CSA_GRU4M=0 keeps the two-column kernel)
+bool gru4m_selected(int nh, int B)
+{
+    static const int on = getenv("CSA_GRU4M") ? atoi(getenv("CSA_GRU4M")) : 1;
+    return on && nh <= 128 && nh % 16 == 0 && rec4_variant() != 0 && B >= rec4_min_batch();
+}
 
 // smallest batch of a launch that uses the four-column kernel (env CSA_REC4_MIN_BATCH; 0 disables)
 static int rec4_min_batch()

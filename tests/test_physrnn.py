@@ -78,10 +78,10 @@ def test_hip_physrnn_matches_the_artefact(fixture, ncase):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("B", [1, 2, 301, 384])
+@pytest.mark.parametrize("B", [1, 2, 301, 384, 600])       # one / two columns per workgroup, and four on the matrix pipe (from 544)
 def test_hip_physrnn_matches_restatement(B):
     g, P = _load()
-    m = _hip_model(P, 384)
+    m = _hip_model(P, max(384, B))
     xm, xs, mem, xd = inputs(P, B, 50 + B)
     hx2 = torch.randn(B, 128, generator=torch.Generator().manual_seed(B))
     taps = {}

@@ -217,10 +217,14 @@ def test_hip_radiation_graph_matches_the_artefact(fixture, ncase):
                                        ("physrnn_rad_stoch_b", 301), ("physrnn_rad_stoch_c", 384), ("physrad16_a", 2),
                                        ("physrad16_a", 301), ("physrad16_a", 384), ("physrad16_nh96", 384),
                                        ("physrad16_nh112_a", 301), ("physrad16_nh112_b", 384), ("physrad4_a", 384), ("physrad4_b", 301),
-                                       ("physrad16_nh112_cld", 384)])
+                                       ("physrad16_nh112_cld", 384), ("physrad16_e3sm", 384),
+                                       # (num88741 is not in this list: on these synthetic inputs a 1e-7 relative input perturbation moves its SW surface
+                                       #  fluxes by 1e-2 in several columns of a 301-column batch -- no float32 bound holds; its parity is the B = 8 fixture)
+                                       # from 544 columns the GRUs run on the matrix-pipe four-column kernel (GRU 128 / 96 / 112)
+                                       ("physrnn_rad", 600), ("physrad16_e3sm", 600), ("physrad16_nh96", 600), ("physrad16_nh112_a", 600)])
 def test_hip_radiation_graph_matches_restatement(fixture, B):
     g, P = _load(fixture)
-    m = _hip_model(P, 384)
+    m = _hip_model(P, max(384, B))
     xm, xs, mem, xd = inputs_rad(P, B, 70 + B)
     hx2 = torch.randn(B, P["rnn2.weight_hh_l0"].shape[1], generator=torch.Generator().manual_seed(B))
     nz = _draw_noise(P, B, 900 + B)
