@@ -161,6 +161,14 @@ int upload_params(csa_emulator *h, const csa_params *p, bool first)
         rec4m_pack_weights(c.nh2, b_hh, packed.data());
         d.whh2m = U.up(packed);
     }
+    if (!c.use_lstm && c.nh1 <= 128 && c.nh2 <= 128 && c.nh1 % 16 == 0 && c.nh2 % 16 == 0) {     // GRU flavour of the matrix-pipe kernel
+        packed.resize((size_t)4 * c.nh1 * c.nh1);
+        gru4m_pack_weights(c.nh1, a_hh, packed.data());
+        d.whh1m = U.up(packed);
+        packed.resize((size_t)4 * c.nh2 * c.nh2);
+        gru4m_pack_weights(c.nh2, b_hh, packed.data());
+        d.whh2m = U.up(packed);
+    }
     d.whh1g = d.whh2g = nullptr;
     if (!c.use_lstm && c.nh1 <= 144 && c.nh2 <= 144) {    // second-generation two-column GRU kernel
         packed.resize((size_t)3 * c.nh1 * c.nh1);
@@ -370,6 +378,8 @@ static int launch_rec_auto(const csa_emulator *h, int layer, const float *P, con
         return launch_rec4m(nh, wm, P, h0, c0, Hout, B, L, reverse_out, s);
     if (!d.cfg.use_lstm && Bclass <= h->rec1_max_batch)
         return launch_rec1_gru(nh, layer == 1 ? d.whh1p : d.whh2p, layer == 1 ? d.bhn1 : d.bhn2, P, h0, Hout, B, L, reverse_out, s);
+    if (!d.cfg.use_lstm && wm && gru4m_selected(nh, Bclass))
+        return launch_rec4m_gru(nh, wm, layer == 1 ? d.bhn1 : d.bhn2, P, h0, Hout, B, L, reverse_out, s);
     const float *wg = layer == 1 ? d.whh1g : d.whh2g;
     if (!d.cfg.use_lstm && wg)
         return launch_rec2_gru(nh, wg, layer == 1 ? d.bhn1 : d.bhn2, P, h0, Hout, B, L, reverse_out, s);

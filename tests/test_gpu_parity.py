@@ -570,6 +570,28 @@ def test_gru_two_column_kernel_vs_reference_class_and_one_column():
         assert rel_err(a.cpu().numpy(), b.cpu().numpy()) <= 2e-6
 
 
+@pytest.mark.parametrize("B", [545, 1101])
+def test_gru_matrix_kernel_vs_two_column_kernel(B):
+    """gru_rec4m_kernel (four columns per workgroup on the matrix pipe, calls of 544 columns and more; B = 545 / 1101: a last
+    workgroup with one valid column) against the same rows computed in sub-batches small enough for the two-column packed-FMA
+    kernel: same arithmetic up to the order of the k-sum.  Deterministic; finite."""
+    import climsim_amd
+    consts, weights, flags = load_npz_model("cur_gru128")
+    model = climsim_amd.RNN_autoreg(consts, weights, max_batch=B, use_lstm=False, output_prune=bool(flags["output_prune"]))
+    g = torch.Generator().manual_seed(B)
+    xs = [0.8 * torch.randn(B, 60, model.emulator.cfg.nx, generator=g).cuda(), 0.8 * torch.randn(B, 19, generator=g).cuda(),
+          0.3 * torch.randn(60, B, 16, generator=g).cuda()]
+    big = [t.clone() for t in model(xs)]
+    again = [t.clone() for t in model(xs)]
+    assert all(torch.equal(a, b) for a, b in zip(big, again)) and all(torch.isfinite(a).all() for a in big)
+    n = 300                                              # 257..543 columns: gru_rec2_kernel
+    for lo in (0, B - n):
+        sub = model([xs[0][lo:lo + n].contiguous(), xs[1][lo:lo + n].contiguous(), xs[2][:, lo:lo + n].contiguous()])
+        for a, b, ax in zip(big, sub, (0, 0, 1)):
+            ref = a[lo:lo + n] if ax == 0 else a[:, lo:lo + n]
+            assert rel_err(ref.cpu().numpy(), b.cpu().numpy()) <= 1e-5
+
+
 @pytest.mark.parametrize("B", [1026, 1101, 2700])
 def test_four_column_matrix_kernel_vs_two_column_kernel_and_oracle(memory, B):
     """lstm_rec4m_kernel (four columns per workgroup on the matrix pipe, from 1,024 columns per call) against the same rows
