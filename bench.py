@@ -276,8 +276,8 @@ def aux_workload(a, rank, world, dist):
     from synth import synth_inputs
     B = int(a.workload.rsplit("_", 1)[1])        # columns per GPU are the workload's suffix
     g = torch.Generator().manual_seed(100 + rank)
-    if a.workload in ("cur_lstm144_384", "cur_gru128_384", "cur_lstm128_384"):
-        tag = a.workload[:-4]
+    if a.workload.rsplit("_", 1)[0] in ("cur_lstm144", "cur_gru128", "cur_lstm128"):       # any column count: cur_gru128_2700 ...
+        tag = a.workload.rsplit("_", 1)[0]
         consts, weights = load_model(tag)
         m = climsim_amd.model_wrapper(consts, weights, use_lstm="lstm" in tag, output_prune="lstm" in tag, max_batch=B)
         xm, xs = synth_inputs(consts, B, 9000 + rank)
@@ -414,7 +414,7 @@ def aux_workload(a, rank, world, dist):
             flush=True)
 
 
-AUX = ["cur_lstm144_384", "cur_lstm128_384", "cur_gru128_384", "mlp_384", "online_mlp_384", "physrnn_384", "physrnn_rad_384", "physrnn_2700", "physrnn_rad_2700", "physrnn_e3sm_384", "physrnn_e3sm_2700", "cnn_384", "cnn_train_384",
+AUX = ["cur_lstm144_384", "cur_lstm128_384", "cur_gru128_384", "mlp_384", "online_mlp_384", "physrnn_384", "physrnn_rad_384", "physrnn_2700", "physrnn_rad_2700", "physrnn_e3sm_384", "physrnn_e3sm_2700", "cur_gru128_2700", "cnn_384", "cnn_train_384",
        "cnn_train_512", "cnn_train_2700"]
 
 
