@@ -95,7 +95,9 @@ __device__ __forceinline__ f32x16 ro_zero()
     for (int i = 0; i < 16; ++i) z[i] = 0.0f;
     return z;
 }
-__device__ __forceinline__ float ro_softsign(float v) { return v / (1.0f + fabsf(v)); }
+// v / (1 + |v|) through v_rcp_f32 (1 ulp; an IEEE division is ~10 instructions, and the optics kernels spend a third of their wave
+// time issuing vector instructions: profiles/r2_physrnn_e3sm_384_sq_pmc.json)
+__device__ __forceinline__ float ro_softsign(float v) { return v * __builtin_amdgcn_rcpf(1.0f + fabsf(v)); }
 
 // One wave per workgroup and all LDS traffic wave-private: LDS executes one wave's instructions in order, so a write followed by
 // a read of other lanes' data needs no s_barrier, only a compiler fence (ro_fence).  Every tile's weights are requested one or two
@@ -416,7 +418,7 @@ __global__ __launch_bounds__(64 * SG_WAVES) void rad_sw_gas_kernel(const float *
         }
         const float tau = (t_abs + t_sca) + c_tau, sca = t_sca + c_sca;
         float *o = S2 + (size_t)row * 48;
-        o[g] = tau; o[16 + g] = sca / tau; o[32 + g] = (c_asy * c_sca) / sca;
+        o[g] = tau; o[16 + g] = sca * __builtin_amdgcn_rcpf(tau); o[32 + g] = (c_asy * c_sca) * __builtin_amdgcn_rcpf(sca);
     }
 }
 
