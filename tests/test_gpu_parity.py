@@ -570,6 +570,49 @@ def test_gru_two_column_kernel_vs_reference_class_and_one_column():
         assert rel_err(a.cpu().numpy(), b.cpu().numpy()) <= 2e-6
 
 
+def test_lstm144_two_column_kernel_vs_reference_class_and_oracle():
+    """lstm_rec2_kernel<144> (the reference's DEFAULT width, weight tail in LDS; chosen above 256 columns): (i) forced at the golden
+    batch sizes against the RNN_autoreg goldens (rnn/models/models.py:400-415 with nneur (144, 144)); (ii) at B = 300 / 384 / 301
+    against the C oracle (pinned on the same goldens by tests/test_oracle_golden.py) and against the one-column kernel."""
+    import climsim_amd
+    from oracle.pyoracle import OracleModel
+    consts, weights, flags = load_npz_model("cur_lstm144")
+    io = np.load(os.path.join(GOLDEN, "cur_lstm144_io.npz"))
+    kw = dict(use_lstm=True, output_prune=bool(flags["output_prune"]))
+    model = climsim_amd.RNN_autoreg(consts, weights, max_batch=384, **kw)
+    wrap = climsim_amd.model_wrapper(consts, weights, max_batch=384, snowhice_fix=True, **kw)
+    om = OracleModel(consts, weights, legacy=False, use_lstm=True, output_prune=bool(flags["output_prune"]), scrub_inf=True, snowhice_fix=True)
+    try:
+        model.emulator.set_rec1_max_batch(0)
+        for B in (2, 16):
+            for t in range(int(io[f"B{B}.nsteps"])):
+                p = f"B{B}.t{t}."
+                out, out_sfc, mem_out = model([_dev(io[p + "x_main_n"]), _dev(io[p + "x_sfc_n"]), _dev(io[p + "mem_in"])])
+                assert rel_err(out.cpu().numpy(), io[p + "out"]) <= 1e-5
+                assert rel_err(out_sfc.cpu().numpy(), io[p + "out_sfc"]) <= 1e-5
+                assert rel_err(mem_out.cpu().numpy(), io[p + "mem_out"]) <= 1e-5
+    finally:
+        model.emulator.set_rec1_max_batch(256)
+    g = np.random.Generator(np.random.PCG64(1440))
+    for B in (300, 301, 384):                             # automatic kernel choice: two columns per workgroup (301: one valid column in the last)
+        xm, xs = synth_inputs(consts, B, 70 + B)
+        mem = (0.3 * g.standard_normal((60, B, 16))).astype(np.float32)
+        o6, osf, mo = om.wrapper_forward_tuple(xm, xs, mem)
+        h6, hsf, hmo = wrap(_dev(xm), _dev(xs), _dev(mem))
+        for v in range(6):
+            assert rel_err(h6.cpu().numpy()[:, :, v], o6[:, :, v]) <= 1e-5, (B, v)
+        assert rel_err(hsf.cpu().numpy(), osf) <= 1e-5
+        assert rel_err(hmo.cpu().numpy(), mo) <= 1e-5
+        two = [t.clone() for t in (h6, hsf, hmo)]
+        try:
+            wrap.emulator.set_rec1_max_batch(4096)
+            one = [t.clone() for t in wrap(_dev(xm), _dev(xs), _dev(mem))]
+        finally:
+            wrap.emulator.set_rec1_max_batch(256)
+        for a, b in zip(two, one):
+            assert rel_err(a.cpu().numpy(), b.cpu().numpy()) <= 3e-6
+
+
 @pytest.mark.parametrize("B", [545, 1101])
 def test_gru_matrix_kernel_vs_two_column_kernel(B):
     """gru_rec4m_kernel (four columns per workgroup on the matrix pipe, calls of 544 columns and more; B = 545 / 1101: a last
