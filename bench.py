@@ -71,6 +71,23 @@ WORKLOADS = {
 }
 
 
+def workload_spec(name):
+    """(model npz, columns per GPU, FLOP per column, HBM bytes per column) of a forward workload; v4_memory_<B> / v4_stateless_<B>
+    exist at any column count (the strong-scaled shapes of --gpus N)."""
+    if name in WORKLOADS:
+        return WORKLOADS[name]
+    tag, B = name.rsplit("_", 1)
+    base = WORKLOADS[tag + "_384"]
+    return (base[0], int(B), base[2], base[3])
+
+
+def rec_kernel_name(B):
+    """Which recurrent kernel api.hip launches for a call of B columns (defaults: csa_set_rec1_max_batch 256, CSA_REC4M from 544)."""
+    if B <= 256:
+        return "lstm_rec1_kernel<128>"
+    return "lstm_rec4m_kernel<128>" if B >= 544 else "lstm_rec2_kernel<128,false,0>"
+
+
 def load_model(tag):
     d = np.load(os.path.join(ROOT, "tests", "golden", f"{tag}_model.npz"))
     consts = {k[2:]: d[k] for k in d.files if k.startswith("c.")}
@@ -204,7 +221,7 @@ def cpu_train_baseline(consts, weights, grid, B, Tw, args_cpu, budget_s=8.0):
                       f"(torch {torch.__version__} CPU, {cores} threads), {el:.1f} s"}
 
 
-def train_leg(a, rank, world, dist, steps, warmup, with_cpu):
+def train_leg(a, rank, world, dist, steps, warmup, with_cpu, B=384):
     """BASELINE.json configs[2]: one TBPTT optimiser step of the current-generation LSTM with memory (window T_w = 3, 384
     columns per GPU): 3 forwards with saved activations, loss, 3 backwards, ONE flat-buffer RCCL all-reduce, Adam.
     Unit: column-timesteps/s.  Returns the `train` object of the JSON line."""
@@ -212,7 +229,7 @@ def train_leg(a, rank, world, dist, steps, warmup, with_cpu):
     from synth import synth_inputs
     consts, weights = load_model("cur_lstm128")
     grid = np.load(os.path.join(ROOT, "tests", "golden", "grid_consts.npz"))
-    B, Tw = 384, 3
+    Tw = 3
     tr = Trainer(consts, weights, grid["hyai"], grid["hybi"], output_prune=True, max_batch=B, max_window=Tw)
     xm, xs = synth_inputs(consts, B, 7000 + rank)
     g = torch.Generator().manual_seed(rank)
@@ -248,13 +265,13 @@ def train_leg(a, rank, world, dist, steps, warmup, with_cpu):
         flop_step = 3 * 32.95e6                    # fwd + bwd ~ 3x forward FLOP per column-timestep
         out = {"metric": "train-step column-timesteps/sec (TBPTT window 3)", "value": value, "unit": "column-timesteps/s",
                "steps": steps, "warmup": warmup, "preheat_steps": pre, "ms_per_step": 1e3 * el / steps, "scaling": "weak", "dtype": "f32",
-               "config": {"workload": "train_tbptt3_384", "columns_per_gpu": B, "window": Tw,
+               "config": {"workload": f"train_tbptt3_{B}", "columns_per_gpu": B, "window": Tw,
                           "model": "RNN_autoreg LSTM 128/128, nh_mem 16, mp_mode 1; huber + energy + water loss; Adam",
                           "parallelism": f"columns sharded x{world}, one flat-gradient all-reduce per step"},
-               "roofline": {"bound": "fp32-vector (v_pk_fma_f32; same 157.3 TF peak as f32 MFMA)",
+               "roofline": {"bound": "mfma", "pipe": "v_pk_fma_f32 (fp32 vector peak = f32 MFMA peak, 157.3 TF: the two share the FMA lanes)",
                             "kernel": "lstm_bwd_rec_kernel<128> (one launch per LSTM per backward, 6 per step)",
                             "achieved": ach, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_FP32_TFLOPS,
-                            "traffic": pmc_traffic("train_tbptt3_384", "lstm_bwd_rec_kernel"),
+                            "traffic": pmc_traffic(f"train_tbptt3_{B}", "lstm_bwd_rec_kernel"),
                             "traffic_unit": "HBM bytes per launch (rocprofv3 PMC, profiles/)",
                             "algorithmic_hbm_bytes_per_launch": B * 60 * (2 * 4 * 128 + 2 * 128) * 4.0,
                             "flop_per_launch": flop, "avg_launch_ms": bwd_ms, "launches_timed": nb},
@@ -422,7 +439,7 @@ def forward_leg(a, workload, rank, world, dist, steps, warmup, with_cpu):
     """One forward workload: value (whole job), HIP-event kernel times, roofline of the recurrent kernel."""
     import climsim_amd
     from synth import synth_inputs
-    tag, B, flop_col, bytes_col = WORKLOADS[workload]
+    tag, B, flop_col, bytes_col = workload_spec(workload)
     consts, weights = load_model(tag)
     model = climsim_amd.NewModel_constraint(consts, weights, max_batch=B)
     stateful = model.stateful
@@ -460,7 +477,7 @@ def forward_leg(a, workload, rank, world, dist, steps, warmup, with_cpu):
     rec_ms = 0.5 * (prof["rec_rnn1"] + prof["rec_rnn2"])
     rec_flop = B * 60 * 2.0 * 4 * 128 * 128          # algorithmic FLOP of one recurrent launch
     achieved = rec_flop / (rec_ms * 1e-3) / 1e12 if rec_ms > 0 else 0.0
-    rec_name = "lstm_rec1_kernel<128>" if B <= 256 else ("lstm_rec4_kernel<128>" if B >= 1024 else "lstm_rec2_kernel<128,false,0>")
+    rec_name = rec_kernel_name(B)
     leg = {
         "value": value, "unit": "grid-columns/s", "steps": steps, "warmup": warmup, "preheat_steps": pre,
         "ms_per_step": 1e3 * el / steps,
@@ -468,7 +485,9 @@ def forward_leg(a, workload, rank, world, dist, steps, warmup, with_cpu):
                    "wrapper": "stateless v4 (rnn/v4_rnn_wrapper_constrained.pt weights)" if not stateful
                    else "stateful v4 memory wrapper (rnn/v4_rnn-memory_wrapper_constrained_huber.pt weights), rnn1_mem fed back",
                    "parallelism": f"columns sharded x{world}, no collective"},
-        "roofline": {"bound": "fp32-vector (v_pk_fma_f32; same 157.3 TF peak as f32 MFMA)",
+        "roofline": {"bound": "mfma",
+                     "pipe": "v_mfma_f32_4x4x1 (dense fp32 matrix peak 157.3 TF)" if "rec4m" in rec_name
+                     else "v_pk_fma_f32 (fp32 vector peak = f32 MFMA peak, 157.3 TF: the two share the FMA lanes)",
                      "kernel": rec_name + " (one launch per LSTM, 2 per step)",
                      "achieved": achieved, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
                      "frac": achieved / PEAK_FP32_TFLOPS, "traffic": pmc_traffic(workload, rec_name.split("<")[0]),
@@ -492,8 +511,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--workload", default="default", choices=["default"] + sorted(WORKLOADS) + ["train_tbptt3_384"] + AUX)
+    ap.add_argument("--workload", default="default",
+                    help="default | v4_stateless_<B> | v4_memory_<B> | train_tbptt3_<B> | " + " | ".join(AUX))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-shard", action="store_true", help="default line without the shard_2700 / strong_scaled objects")
     ap.add_argument("--halves", type=int, default=-1, help="1/0: force the two-stream column-half path on/off (default: library default)")
     a = ap.parse_args()
 
@@ -528,8 +549,8 @@ def main():
         return finish()
     with_cpu = not a.no_cpu_baseline and world == 1
     common = {"n_gpus": world, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic"}
-    if a.workload == "train_tbptt3_384":
-        t = train_leg(a, rank, world, dist, a.steps, a.warmup, with_cpu)
+    if a.workload.startswith("train_tbptt3_"):
+        t = train_leg(a, rank, world, dist, a.steps, a.warmup, with_cpu, B=int(a.workload.rsplit("_", 1)[1]))
         if rank == 0:
             print(json.dumps({**t, **common}), flush=True)
         return finish()
@@ -540,13 +561,52 @@ def main():
     if a.workload == "default":
         # the other half of BASELINE.json's metric and the north_star's target model, in the same line
         memleg = forward_leg(a, "v4_memory_384", rank, world, dist, a.steps, a.warmup, False)
-        train = train_leg(a, rank, world, dist, max(3, min(a.steps, 30)), max(2, min(a.warmup, 5)), with_cpu)
+        tsteps, twarm = max(3, min(a.steps, 30)), max(2, min(a.warmup, 5))
+        train = train_leg(a, rank, world, dist, tsteps, twarm, with_cpu)
         if rank == 0:
             line["memory_wrapper"] = {"metric": "grid-columns/sec emulator fwd", **memleg}
             line["train"] = train
+            if world > 1:
+                line["cpu_baseline"] = carried_cpu_baseline("cpu_baseline")
+                line["train"]["cpu_baseline"] = carried_cpu_baseline("train", "cpu_baseline")
+        if not a.no_shard:
+            # configs[3]/[4]: the share of ONE GPU when the 21,600-column high-resolution grid is split 8-way (2,700 columns per GPU,
+            # whatever N is here) -- ms_per_step of `forward` is config 5's latency per global time step of that share
+            sf = forward_leg(a, "v4_memory_2700", rank, world, dist, max(10, min(a.steps, 100)), max(2, min(a.warmup, 10)), False)
+            st = train_leg(a, rank, world, dist, max(3, min(a.steps, 10)), 2, False, B=2700)
+            # strong-scaled shapes of THIS run: the whole grid over the N GPUs that are here
+            strong = {}
+            shapes = [("hires_21600", 21600)] + ([("lowres_384", 384)] if world > 1 else [])
+            for name, total in shapes:
+                per = (total + world - 1) // world
+                leg = forward_leg(a, f"v4_memory_{per}", rank, world, dist, max(5, min(a.steps, 50)), 3, False)
+                if rank == 0:
+                    strong[name] = {"global_columns": total, "columns_per_gpu": per, "scaling": "strong",
+                                    "latency_ms_per_global_timestep": leg["ms_per_step"], "value": leg["value"], "unit": leg["unit"],
+                                    "whole_path": leg["whole_path"], "kernel_ms": leg["kernel_ms"], "rec_kernel": leg["roofline"]["kernel"]}
+            if rank == 0:
+                line["shard_2700"] = {"forward": {"metric": "grid-columns/sec emulator fwd", **sf},
+                                      "train": st}
+                line["strong_scaled"] = strong
     if rank == 0:
         print(json.dumps(line), flush=True)
     finish()
+
+
+def carried_cpu_baseline(*path):
+    """N > 1 lines: the CPU leg is timed on rank 0 of the N = 1 run only (it is a property of the host, not of N); carry the committed
+    N = 1 measurement (profiles/r*_bench_default.json, newest round) with its provenance instead of re-timing it."""
+    import glob
+    fs = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_default.json")))
+    if not fs:
+        return None
+    try:
+        d = json.load(open(fs[-1]))
+        for k in path:
+            d = d[k]
+        return {**d, "source": "N = 1 run, " + os.path.relpath(fs[-1], ROOT)}
+    except Exception:
+        return None
 
 
 if __name__ == "__main__":

@@ -47,9 +47,11 @@ class generator_xy:
         cfg.ny_sfc = data["output_sca"].shape[-1]
         cfg.remove_past_sfc_inputs, cfg.snowhice_fix = int(remove_past_sfc_inputs), int(snowhice_fix)
         cfg.rh_prune, cfg.qinput_prune, cfg.output_prune = int(rh_prune), int(qinput_prune), int(output_prune)
-        # rnn/utils.py:2183-2194: the conversion runs when rh_input_to_q is set; include_q_input selects append vs replace
-        # (train_rnn_rollout_torchscript_hydra.py:231-233 forces rh_input_to_q when include_q_input is configured)
-        cfg.q_mode = 0 if not (rh_input_to_q or include_q_input) else (1 if include_q_input else 2)
+        # rnn/utils.py:2183-2194: the conversion runs when rh_input_to_q is set; include_q_input then selects append vs replace and
+        # does nothing on its own (train_rnn_rollout_torchscript_hydra.py:231-233 forces rh_input_to_q when it is configured)
+        cfg.q_mode = 0 if not rh_input_to_q else (1 if include_q_input else 2)
+        if rh_input_to_q and (hyam is None or hybm is None):
+            raise NotImplementedError("Please provide hyam,hybm")
         cfg.cld_inp_transformation = _CLD[cld_inp_transformation]
         cfg.v4_to_v5_inputs = int(v4_to_v5_inputs)
         cfg.apply_new_input_scaling = int(xcoeffs is not None)

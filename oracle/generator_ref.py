@@ -1,10 +1,10 @@
 """numpy restatement of generator_xy.__getitem__ (rnn/utils.py:2238-2371) -- TEST INFRASTRUCTURE ONLY.
 
-rnn/utils.py cannot be imported in the build container (numba, h5py, torchmetrics absent at module top), so this
-follows the source line by line with the non-numba branches (the numba kernels :1795-1868 restate the same
-arithmetic).  Pinning: with the v4 defaults the input side is the wrapper pre-processing, which IS pinned by the
-shipped TorchScript artefacts (tests/test_generator.py checks that equality); the target construction and the
-float64 humidity conversion have no reference output to compare with -- "parity unpinned"."""
+Follows the source line by line with the non-numba branches (the numba kernels :1803-1868 restate the same arithmetic).  PINNED
+(round 3) by outputs of the reference class itself: tests/golden/make_golden_generator.py imports rnn/utils.py in the build
+container (inert placeholders for numba / h5py, in-memory datasets) and stores what generator_xy.__getitem__, eliq, eice and
+relative_to_specific_humidity_climsim return; tests/test_generator.py compares this restatement with those fixtures for every
+variant (mp_mode 0 / 1 / -1 / -2 targets, float64 RH -> q, v4_to_v5_inputs, re-normalisation, previous-step inputs)."""
 import numpy as np
 
 
@@ -37,7 +37,6 @@ def getitem(x_lev_b, x_sfc_b, y_lev_b, y_sfc_b, *, xcoeffs=None, ycoeffs=None, x
             output_prune=False, mp_mode=0, hybm=None, hyam=None, snowhice_fix=True):
     x_lev_b, x_sfc_b = np.array(x_lev_b, np.float32), np.array(x_sfc_b, np.float32)
     y_lev_b, y_sfc_b = np.array(y_lev_b, np.float32), np.array(y_sfc_b, np.float32)
-    rh_input_to_q = rh_input_to_q or include_q_input
     if xcoeffs_ref is not None:
         x_lev_b = x_lev_b * xcoeffs_ref[0][1] + xcoeffs_ref[0][0]
         x_sfc_b = x_sfc_b * xcoeffs_ref[1][1] + xcoeffs_ref[1][0]

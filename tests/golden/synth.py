@@ -63,3 +63,77 @@ def derived_inputs(hyam, hybm, N=500, nlev=60):
     q2 = r.uniform(0, 1e-4, (N, nlev)).astype(np.float32)
     q3 = r.uniform(0, 1e-4, (N, nlev)).astype(np.float32)
     return tair, pmid, q1, q2, q3
+
+
+# ---- inputs of the generator goldens (make_golden_generator.py), regenerated from seeds by tests/test_generator.py --------------
+def generator_chunk(consts, nt=3, nloc=7, seed=5, nx_sfc_in=24):
+    """An in-memory stand-in for one HDF5 training file: the four datasets of rnn/utils.py::generator_xy, (ntime, nloc, ...)."""
+    g = np.random.Generator(np.random.PCG64(seed))
+    xm, xs = synth_inputs(consts, nt * nloc, seed)
+    xm[:, :, 0] = np.linspace(170.0, 310.0, 60, dtype=np.float32)[None, :] + 0.01 * xm[:, :, 0]
+    if nx_sfc_in == 24:
+        xs24 = np.zeros((nt * nloc, 24), np.float32)
+        xs24[:, :17] = xs[:, :17]
+        xs24[:, 17:22] = g.standard_normal((nt * nloc, 5)).astype(np.float32)   # the five removed past-state scalars
+        xs24[:, 22:] = xs[:, 17:]
+        xs24[0, 22] = 3.0e10                                                    # snow/ice sentinel
+    else:
+        xs24 = xs.copy()
+        xs24[0, 17] = 3.0e10
+    xm[1, 5, 4] = np.nan
+    y = (g.standard_normal((nt * nloc, 60, 6)) * np.array([1e-5, 1e-8, 1e-9, 1e-9, 1e-5, 1e-5])).astype(np.float32)
+    ys = (g.random((nt * nloc, 8)) * 1e-6).astype(np.float32)
+    sh = lambda a: a.reshape((nt, nloc) + a.shape[1:])
+    return {"input_lev": sh(xm), "input_sca": sh(xs24), "output_lev": sh(y), "output_sca": sh(ys)}
+
+
+def generator_coeffs(consts, nx, ny, seed=2):
+    g = np.random.Generator(np.random.PCG64(seed))
+    xm, xd = consts["xmean_lev"], consts["xdiv_lev"].copy()
+    xd[xd == 0] = 1.0
+    if nx == 16:
+        qmean = np.geomspace(2e-6, 8e-3, 60).astype(np.float32)[:, None]
+        xm, xd = np.concatenate([xm, qmean], 1), np.concatenate([xd, 4 * qmean], 1)
+    ys = (10 ** g.uniform(3, 7, (60, ny))).astype(np.float32)
+    return ((xm, xd), (consts["xmean_sca"], consts["xdiv_sca"])), (ys, consts["yscale_sca"])
+
+
+GENERATOR_VARIANTS = {
+    "mp1": dict(mp_mode=1, remove_past_sfc_inputs=True),
+    "mp0_qin": dict(mp_mode=0, remove_past_sfc_inputs=True, rh_input_to_q=True, include_q_input=True, output_prune=True),
+    "mpm1_rh2q": dict(mp_mode=-1, remove_past_sfc_inputs=True, rh_input_to_q=True, rh_prune=True, qinput_prune=True),
+    "mpm2_v5": dict(mp_mode=-2, remove_past_sfc_inputs=True, rh_input_to_q=True, include_q_input=True, v4_to_v5_inputs=True),
+    "mp1_sqrt": dict(mp_mode=1, remove_past_sfc_inputs=False, cld_inp_transformation="sqrt", snowhice_fix=False, nx_sfc_in=19),
+    "mpm1_v5_prune": dict(mp_mode=-1, remove_past_sfc_inputs=True, v4_to_v5_inputs=True, qinput_prune=True),
+    "mp1_renorm": dict(mp_mode=1, remove_past_sfc_inputs=True, renorm=True),        # stored normalised with reference coefficients: undo, re-apply
+    "mp1_prev": dict(mp_mode=1, remove_past_sfc_inputs=True, include_prev_inputs=True, include_prev_outputs=True),
+}
+
+
+def generator_setup(consts, lbd_qn, tag):
+    """(in-memory datasets, constructor keywords of generator_xy) of one golden variant."""
+    kw = dict(GENERATOR_VARIANTS[tag])
+    data = generator_chunk(consts, nx_sfc_in=kw.pop("nx_sfc_in", 24))
+    nx = 16 if kw.get("include_q_input") else 15
+    ny = 5 if kw["mp_mode"] > 0 else 6
+    xco, yco = generator_coeffs(consts, nx, ny)
+    if kw.get("include_prev_inputs"):
+        g = np.random.Generator(np.random.PCG64(3))
+        xm = np.concatenate([xco[0][0], g.standard_normal((60, 11)).astype(np.float32)], 1)
+        xd = np.concatenate([xco[0][1], (1 + g.random((60, 11))).astype(np.float32)], 1)
+        xco = ((xm, xd), xco[1])
+    full = dict(xcoeffs=xco, ycoeffs=yco, lbd_qc=consts["lbd_qc"], lbd_qi=consts["lbd_qi"], lbd_qn=lbd_qn,
+                hyam=consts["hyam"], hybm=consts["hybm"], **kw)
+    if full.pop("renorm", False):
+        g = np.random.Generator(np.random.PCG64(11))
+        xr = ((g.standard_normal((60, 15)).astype(np.float32) * 0.1, (1 + g.random((60, 15))).astype(np.float32)),
+              (g.standard_normal(24).astype(np.float32) * 0.1, (1 + g.random(24)).astype(np.float32)))
+        yr = ((10 ** g.uniform(2, 5, (60, 6))).astype(np.float32), (10 ** g.uniform(2, 5, 8)).astype(np.float32))
+        # the file holds NORMALISED data: store (x - mean) / div and y * yscale of the physical chunk
+        with np.errstate(all="ignore"):
+            data["input_lev"] = ((data["input_lev"] - xr[0][0]) / xr[0][1]).astype(np.float32)
+            data["input_sca"] = ((data["input_sca"] - xr[1][0]) / xr[1][1]).astype(np.float32)
+            data["output_lev"] = (data["output_lev"] * yr[0]).astype(np.float32)
+            data["output_sca"] = (data["output_sca"] * yr[1]).astype(np.float32)
+        full["xcoeffs_ref"], full["ycoeffs_ref"] = xr, yr
+    return data, full
