@@ -49,7 +49,8 @@ SYMBOLS = ["csa_create", "csa_destroy", "csa_set_params", "csa_packed_width", "c
            "csa_online_create", "csa_online_destroy", "csa_online_dims", "csa_online_forward",
            "csa_stoch_gru5_create", "csa_stoch_lstm4_create", "csa_stoch_destroy", "csa_stoch_gru5_forward",
            "csa_stoch_lstm4_forward", "csa_stoch_enable_training", "csa_stoch_num_params", "csa_stoch_gru5_forward_train",
-           "csa_stoch_lstm4_forward_train", "csa_stoch_gru5_backward", "csa_stoch_lstm4_backward"]
+           "csa_stoch_lstm4_forward_train", "csa_stoch_gru5_backward", "csa_stoch_lstm4_backward", "csa_stoch_activation_floats",
+           "csa_stoch_set_activations"]
 
 
 class CsaConfig(ctypes.Structure):
@@ -206,6 +207,9 @@ def lib():
     L.csa_stoch_num_params.restype = ctypes.c_long
     L.csa_stoch_gru5_forward_train.argtypes = L.csa_stoch_gru5_forward.argtypes
     L.csa_stoch_lstm4_forward_train.argtypes = L.csa_stoch_lstm4_forward.argtypes
+    L.csa_stoch_activation_floats.argtypes = [H, i, i]
+    L.csa_stoch_activation_floats.restype = ctypes.c_long
+    L.csa_stoch_set_activations.argtypes = [H, _F, i, i]
     L.csa_stoch_gru5_backward.argtypes = [H, i, i] + [_F] * 7 + [ctypes.c_void_p]
     L.csa_stoch_lstm4_backward.argtypes = [H, i, i] + [_F] * 10 + [ctypes.c_void_p]
     L.csa_last_error.restype = ctypes.c_char_p

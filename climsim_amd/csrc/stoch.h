@@ -14,6 +14,7 @@ struct csa_stoch {
     float *w_ref_in = nullptr;        // GRU5: weight_ih (nx,3H); LSTM4: weight_encoder[:nx] (nx,5H)
     float *wT_a = nullptr, *wT_b = nullptr;   // BPTT packings: LSTM4 W_h^T; GRU5 W_zh^T (a), W_enc^T (b)
     float *Hseq = nullptr, *Cseq = nullptr, *ZN = nullptr, *Zs = nullptr, *EX = nullptr, *GZ = nullptr, *GPd = nullptr, *part = nullptr;
+    float *own[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // the handle's own XP, Hseq, Cseq, ZN, Zs, EX (csa_stoch_set_activations)
     std::vector<float> host_a, host_b;        // host copies of the recurrent matrices (reference layout) until training is enabled
     std::vector<void *> owned;
 };

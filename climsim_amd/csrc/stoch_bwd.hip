@@ -275,6 +275,32 @@ extern "C" int csa_stoch_enable_training(csa_stoch *h)
     float *hs = dev_alloc(h, R1 * nh, nullptr, rc);
     if (rc) return rc;
     h->Hseq = hs;
+    h->own[0] = h->XP; h->own[1] = h->Hseq; h->own[2] = h->Cseq; h->own[3] = h->ZN; h->own[4] = h->Zs; h->own[5] = h->EX;
+    return CSA_OK;
+}
+
+// sizes (floats) of the saved activations of one forward of T x B rows: XP | Hseq | Cseq (LSTM4)  or  XP | Hseq | ZN | Zs | EX (GRU5)
+extern "C" long csa_stoch_activation_floats(const csa_stoch *h, int T, int B)
+{
+    if (!h || T <= 0 || B <= 0) return CSA_ERR_ARG;
+    const long M = (long)T * B, M1 = (long)(T + 1) * B, nh = h->nh;
+    return h->kind == 1 ? M * 5 * nh + 2 * M1 * nh : M * 3 * nh + M1 * nh + 3 * M * nh;
+}
+
+extern "C" int csa_stoch_set_activations(csa_stoch *h, float *acts, int T, int B)
+{
+    if (!h || !h->own[1]) { csa_set_error_msg("csa_stoch_set_activations: call csa_stoch_enable_training first"); return CSA_ERR_ARG; }
+    if (!acts) {
+        h->XP = h->own[0]; h->Hseq = h->own[1]; h->Cseq = h->own[2]; h->ZN = h->own[3]; h->Zs = h->own[4]; h->EX = h->own[5];
+        return CSA_OK;
+    }
+    if (T <= 0 || B <= 0 || (long)T * B > h->max_rows) { csa_set_error_msg("csa_stoch_set_activations: bad shape"); return CSA_ERR_ARG; }
+    const size_t M = (size_t)T * B, M1 = (size_t)(T + 1) * B, nh = h->nh;
+    float *p = acts;
+    h->XP = p; p += M * (h->kind == 1 ? 5 : 3) * nh;
+    h->Hseq = p; p += M1 * nh;
+    if (h->kind == 1) { h->Cseq = p; }
+    else { h->ZN = p; p += M * nh; h->Zs = p; p += M * nh; h->EX = p; }
     return CSA_OK;
 }
 

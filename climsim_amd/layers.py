@@ -5,7 +5,8 @@ explicitly (eps=...) and is drawn on the GPU otherwise.  All arithmetic runs in 
 Like the reference's GPU path (FusedCUDAStochasticGRUSequence, :795-841) the layers are differentiable through a
 torch.autograd.Function whose backward is native code: with `requires_grad` inputs or `train()` mode the forward keeps the
 activations BPTT needs and `.backward()` fills the `.grad` of the layer's parameters (reference names and (in, out) layouts),
-of the input sequence and of the initial state.  After an optimiser step call `sync_params()` to re-pack the kernels' copies."""
+of the input sequence and of the initial state.  The kernels' packed weight copies follow in-place parameter updates by themselves
+(tensor version counters, checked per forward); `sync_params()` forces the re-pack."""
 import ctypes
 
 import numpy as np
@@ -27,12 +28,27 @@ def _host(a):
 
 
 class _StochFn(torch.autograd.Function):
-    """forward(x, h0, c0 | None, eps, layer, *params) -> out [, hT, cT]; backward = csa_stoch_*_backward."""
+    """forward(x, h0, c0 | None, eps, layer, *params) -> out [, hT, cT]; backward = csa_stoch_*_backward.
+
+    Every forward owns the activations its backward will consume (one torch buffer, installed in the native handle for the two
+    calls only), as the reference's autograd function keeps them in ctx (models_torch_kernels.py:795-841): several forwards may be
+    pending, inference calls in between do not disturb them.  The backward overwrites them in place, so a second backward through
+    the same forward (retain_graph) raises instead of returning wrong gradients, and so does a backward after sync_params()
+    re-packed different weights."""
 
     @staticmethod
     def forward(ctx, x, h0, c0, eps, layer, *params):
         ctx.layer, ctx.shape = layer, x.shape
-        out, hT, cT = layer._run(x, h0, c0, eps, train=True)
+        T, B, _ = x.shape
+        layer._enable_training()
+        L = _lib.lib()
+        ctx.acts = torch.empty(L.csa_stoch_activation_floats(layer._h, T, B), device=x.device)
+        ctx.generation, ctx.consumed = layer._generation, False
+        layer._set_acts(ctx.acts, T, B)
+        try:
+            out, hT, cT = layer._run(x, h0, c0, eps, train=True)
+        finally:
+            layer._set_acts(None, T, B)
         ctx.save_for_backward(x, eps)
         ctx.lstm = c0 is not None
         return (out, hT, cT) if ctx.lstm else out
@@ -40,6 +56,11 @@ class _StochFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, d_out, d_hT=None, d_cT=None):
         layer = ctx.layer
+        if ctx.consumed:
+            raise RuntimeError("the saved activations of this stochastic-layer forward were consumed by an earlier backward "
+                               "(the native BPTT overwrites them in place): call forward again instead of retain_graph")
+        if ctx.generation != layer._generation:
+            raise RuntimeError("sync_params() re-packed the layer's weights between this forward and its backward")
         x, eps = ctx.saved_tensors
         T, B, _ = ctx.shape
         H, L = layer.hidden_size, _lib.lib()
@@ -48,18 +69,25 @@ class _StochFn(torch.autograd.Function):
         d_h0 = torch.empty(B, H, device=x.device)
         d_eps = torch.empty_like(eps)
         flat = torch.zeros(L.csa_stoch_num_params(layer._h), device=x.device)
-        if ctx.lstm:
-            d_c0 = torch.empty(B, H, device=x.device)
-            rc = L.csa_stoch_lstm4_backward(layer._h, T, B, _ptr(x), _ptr(eps), _ptr(d_out),
-                                            _ptr(None if d_hT is None else d_hT.contiguous()),
-                                            _ptr(None if d_cT is None else d_cT.contiguous()), _ptr(d_x), _ptr(d_h0), _ptr(d_c0),
-                                            _ptr(d_eps), _ptr(flat), layer._stream())
-        else:
-            d_c0 = None
-            rc = L.csa_stoch_gru5_backward(layer._h, T, B, _ptr(x), _ptr(eps), _ptr(d_out), _ptr(d_x), _ptr(d_h0), _ptr(d_eps),
-                                           _ptr(flat), layer._stream())
+        ctx.consumed = True
+        layer._set_acts(ctx.acts, T, B)
+        try:
+            if ctx.lstm:
+                d_c0 = torch.empty(B, H, device=x.device)
+                rc = L.csa_stoch_lstm4_backward(layer._h, T, B, _ptr(x), _ptr(eps), _ptr(d_out),
+                                                _ptr(None if d_hT is None else d_hT.contiguous()),
+                                                _ptr(None if d_cT is None else d_cT.contiguous()), _ptr(d_x), _ptr(d_h0), _ptr(d_c0),
+                                                _ptr(d_eps), _ptr(flat), layer._stream())
+            else:
+                d_c0 = None
+                rc = L.csa_stoch_gru5_backward(layer._h, T, B, _ptr(x), _ptr(eps), _ptr(d_out), _ptr(d_x), _ptr(d_h0), _ptr(d_eps),
+                                               _ptr(flat), layer._stream())
+        finally:
+            layer._set_acts(None, T, B)
         if rc != 0:
             raise RuntimeError(f"csa_stoch backward failed ({rc}): {_lib.last_error()}")
+        ctx.acts.record_stream(torch.cuda.current_stream(x.device))
+        ctx.acts = None
         gp, off = [], 0
         for p in layer._param_list():
             gp.append(flat[off:off + p.numel()].view_as(p))
@@ -72,6 +100,7 @@ class _StochBase(torch.nn.Module):
         super().__init__()
         self._h = None
         self._training_enabled = False
+        self._generation = 0
         if not torch.cuda.is_available():
             raise RuntimeError("climsim_amd needs a HIP device: the product path has no CPU fallback")
         self.device = torch.device("cuda", torch.cuda.current_device())
@@ -86,6 +115,20 @@ class _StochBase(torch.nn.Module):
                 raise RuntimeError(f"csa_stoch_enable_training failed ({rc}): {_lib.last_error()}")
             self._training_enabled = True
 
+    def _set_acts(self, acts, T, B):
+        rc = _lib.lib().csa_stoch_set_activations(self._h, _ptr(acts), int(T), int(B))
+        if rc != 0:
+            raise RuntimeError(f"csa_stoch_set_activations failed ({rc}): {_lib.last_error()}")
+
+    def _versions(self):
+        return tuple((id(p), p._version) for p in self._param_list())
+
+    def _refresh(self):
+        """The kernels run on packed copies of the parameters: an in-place update (optimizer.step(), load_state_dict(), copy_)
+        bumps the tensors' version counters, and the copies are re-packed before the next forward (sync_params() does it by hand)."""
+        if self._versions() != self._packed_versions:
+            self.sync_params()
+
     def _wants_grad(self, *tensors):
         return torch.is_grad_enabled() and (any(t is not None and t.requires_grad for t in tensors)
                                             or any(p.requires_grad for p in self._param_list()))
@@ -96,7 +139,9 @@ class _StochBase(torch.nn.Module):
             _lib.lib().csa_stoch_destroy(self._h)
             self._h = None
         self._training_enabled = False
+        self._generation += 1
         self._create()
+        self._packed_versions = self._versions()
 
     def __del__(self):
         try:
@@ -120,6 +165,7 @@ class MyStochasticGRULayer5(_StochBase):
         self.input_size, self.hidden_size = self.weight_ih.shape[0], self.weight_zh.shape[0]
         self.max_rows = int(max_rows)
         self._create()
+        self._packed_versions = self._versions()
 
     def _param_list(self):
         return [self.weight_ih, self.weight_zh, self.weight_encoder] + ([self.bias_ih, self.bias_zh] if self.use_bias else [])
@@ -151,6 +197,7 @@ class MyStochasticGRULayer5(_StochBase):
         x = _check(input_seq, (T, B, self.input_size), "input_seq")
         h0 = _check(hidden, (B, H), "hidden")
         eps = torch.randn(T, B, H, device=self.device) if eps is None else _check(eps, (T, B, H), "eps")
+        self._refresh()
         if self._wants_grad(x, h0):
             return _StochFn.apply(x, h0, None, eps, self, *self._param_list())
         return self._run(x, h0, None, eps, train=False)[0]
@@ -170,6 +217,7 @@ class MyStochasticLSTMLayer4(_StochBase):
         self.weight_encoder = torch.nn.Parameter(w.to(self.device), requires_grad=requires_grad)
         self.max_rows = int(max_rows)
         self._create()
+        self._packed_versions = self._versions()
 
     def _param_list(self):
         return [self.weight_encoder]
@@ -201,6 +249,7 @@ class MyStochasticLSTMLayer4(_StochBase):
         x = _check(input_seq, (T, B, self.input_size), "input_seq")
         h0, c0 = _check(state[0], (B, H), "hx"), _check(state[1], (B, H), "cx")
         eps = torch.randn(T, B, H, device=self.device) if eps is None else _check(eps, (T, B, H), "eps")
+        self._refresh()
         if self._wants_grad(x, h0, c0):
             out, hT, cT = _StochFn.apply(x, h0, c0, eps, self, *self._param_list())
         else:

@@ -509,6 +509,12 @@ int csa_stoch_gru5_forward_train(csa_stoch *h, int T, int B, const float *x, con
                                  float *out, void *stream);
 int csa_stoch_lstm4_forward_train(csa_stoch *h, int T, int B, const float *x, const float *h0, const float *c0,
                                   const float *eps, float *out, float *hT, float *cT, void *stream);
+/* The activations *_forward_train saves and *_backward consumes (and overwrites) live in the handle's own buffers unless the caller
+ * supplies its own: `acts` = one device buffer of csa_stoch_activation_floats(h, T, B) floats per forward that is still awaiting its
+ * backward (the autograd layer of rnn/models_torch_kernels.py:795-841 saves them per call in ctx), NULL = back to the handle's own.
+ * Set before *_forward_train and again, with the same buffer, before the matching *_backward. */
+long csa_stoch_activation_floats(const csa_stoch *h, int T, int B);
+int csa_stoch_set_activations(csa_stoch *h, float *acts, int T, int B);
 int csa_stoch_gru5_backward(csa_stoch *h, int T, int B, const float *x, const float *eps, const float *d_out,
                             float *d_x, float *d_h0, float *d_eps, float *grads, void *stream);
 int csa_stoch_lstm4_backward(csa_stoch *h, int T, int B, const float *x, const float *eps, const float *d_out,

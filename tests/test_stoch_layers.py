@@ -103,3 +103,64 @@ def test_hip_stochastic_lstm4_backward_vs_reference_autograd(B):
     with torch.no_grad():
         out3, _ = layer(x, (h0, c0), eps=tg(f"B{B}.lstm4.eps").cuda())
     assert torch.equal(out3, out.detach())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["gru5b", "lstm4"])
+def test_pending_forwards_keep_their_own_activations(kind):
+    """The reference's TBPTT use of the autograd layer: several forwards of the SAME layer (window steps, a no_grad validation
+    forward in between) and THEN the backwards.  Every forward owns its saved activations (advisor finding, round 2): the gradients
+    of the first forward, taken after a second forward on other inputs and an inference call, equal the reference's autograd
+    goldens of that first forward; a second backward through a consumed forward raises; a backward after the weights were re-packed
+    raises; an in-place parameter update re-packs the kernels' weight copies by itself."""
+    from climsim_amd.layers import MyStochasticGRULayer5, MyStochasticLSTMLayer4
+    B, B2 = 6, 3
+    dev = lambda k: tg(k).cuda()
+    if kind == "lstm4":
+        layer = MyStochasticLSTMLayer4(G["lstm4.w.weight_encoder"], 128, max_rows=60 * 8, requires_grad=True)
+
+        def run(Bv, grad=True):
+            x, h0, c0 = (dev(f"B{Bv}.{n}").requires_grad_(grad) for n in ("x", "h0", "c0"))
+            out, (hT, cT) = layer(x, (h0, c0), eps=dev(f"B{Bv}.lstm4.eps"))
+            return (x, h0, c0), out, (out * dev(f"B{Bv}.dout")).sum() + (hT * dev(f"B{Bv}.dhT")).sum() + (cT * dev(f"B{Bv}.dcT")).sum()
+        names = ("dx", "dh0", "dc0")
+    else:
+        w = {k: G[f"{kind}.w.{k}"] for k in ("weight_ih", "weight_zh", "weight_encoder", "bias_ih", "bias_zh")}
+        layer = MyStochasticGRULayer5(w["weight_ih"], w["weight_zh"], w["weight_encoder"], w["bias_ih"], w["bias_zh"], max_rows=60 * 8, requires_grad=True)
+
+        def run(Bv, grad=True):
+            x, h0 = (dev(f"B{Bv}.{n}").requires_grad_(grad) for n in ("x", "h0"))
+            out = layer(x, h0, eps=dev(f"B{Bv}.{kind}.eps"))
+            return (x, h0), out, (out * dev(f"B{Bv}.dout")).sum()
+        names = ("dx", "dh0")
+    leaves1, out1, loss1 = run(B)
+    leaves2, out2, loss2 = run(B2)                    # a second forward of the same layer, other batch
+    with torch.no_grad():
+        run(B, grad=False)                            # and an inference forward: neither may disturb the first one's activations
+    loss1.backward(retain_graph=True)
+    for leaf, n in zip(leaves1, names):
+        assert rel_err(leaf.grad.cpu().numpy(), GR[f"B{B}.{kind}.{n}"]) <= 2e-5, n
+    for n, p in layer.named_parameters():
+        assert rel_err(p.grad.cpu().numpy(), GR[f"B{B}.{kind}.dw.{n}"]) <= 2e-5, n
+        p.grad = None
+    loss2.backward()                                  # the second forward's backward still has ITS activations
+    for leaf, n in zip(leaves2, names):
+        assert rel_err(leaf.grad.cpu().numpy(), GR[f"B{B2}.{kind}.{n}"]) <= 2e-5, n
+    for n, p in layer.named_parameters():
+        assert rel_err(p.grad.cpu().numpy(), GR[f"B{B2}.{kind}.dw.{n}"]) <= 2e-5, n
+    with pytest.raises(RuntimeError, match="consumed"):
+        loss1.backward()
+    # an in-place parameter update (what optimizer.step() does) is picked up by the next forward without sync_params()
+    _, out_a, loss_a = run(B)
+    with torch.no_grad():
+        for p in layer.parameters():
+            p.mul_(0.5)
+    _, out_b, _ = run(B)
+    assert not torch.equal(out_a, out_b)
+    import copy
+    fresh = copy.copy(layer)
+    fresh.sync_params()
+    _, out_c, _ = run(B)
+    assert torch.equal(out_b, out_c)
+    with pytest.raises(RuntimeError, match="re-packed"):
+        loss_a.backward()

@@ -178,7 +178,8 @@ def test_deferred_and_per_step_weight_gradients_agree_and_ragged_shards_sum_to_t
     for name, (o, r, c) in tr.layout.items():
         a, b = g_sum[o:o + r * c], g_full[o:o + r * c]
         assert float((a - b).abs().max()) <= 2e-6 * float(b.abs().max()) + 1e-30, name
-    assert float((torch.cat(dparts, 1) - d_mem).abs().max()) <= 1e-6 * float(d_mem.abs().max())
+    # the shard's loss gradient is the global one times B_local / B (one extra fp32 rounding per element, carried through BPTT)
+    assert float((torch.cat(dparts, 1) - d_mem).abs().max()) <= 4e-6 * float(d_mem.abs().max())
     for k in ("loss", "huber", "mse", "mae"):        # batch means; energy / water / precip are means of squares of window means: also linear in columns
         assert abs(sc_sum[k] - sc[k]) <= 5e-6 * abs(sc[k]) + 1e-30, k
     tr.close()
