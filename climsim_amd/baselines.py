@@ -176,13 +176,14 @@ class CNNTrainer:
         self._rc(_lib.lib().csa_cnn_train_adam(self._h, _ptr(self.grads), lr, beta1, beta2, eps, self.step_count, self._stream()),
                  "csa_cnn_train_adam")
 
-    def train_step(self, x, y_true, masks="draw", lr=1e-4, world_size=1):
+    def train_step(self, x, y_true, masks="draw", lr=1e-4, world_size=1, global_columns=None):
         """forward + loss + backward + ONE flat-gradient all-reduce (world_size > 1) + Adam; returns the loss tensor
-        (this rank's share of the global mean; summed over ranks by the same all-reduce call pattern)."""
+        (this rank's share of the global mean; summed over ranks by the same all-reduce call pattern).  Ragged shards: pass
+        `global_columns` so that the share is B_local / B_global instead of 1 / world_size."""
         if isinstance(masks, str):
             masks = self.draw_masks(x.shape[0])
         self.forward(x, masks)
-        self.backward(y_true, 1.0 / world_size)
+        self.backward(y_true, (x.shape[0] / float(global_columns)) if global_columns else 1.0 / world_size)
         if world_size > 1:
             import torch.distributed as dist
             dist.all_reduce(self.grads)
@@ -277,9 +278,9 @@ class MLPTrainer:
         self._rc(_lib.lib().csa_mlp_train_adam(self._h, _ptr(self.grads), lr, beta1, beta2, eps, self.step_count, self._stream()),
                  "csa_mlp_train_adam")
 
-    def train_step(self, x, y_true, lr=2.5e-4, world_size=1):
+    def train_step(self, x, y_true, lr=2.5e-4, world_size=1, global_columns=None):
         self.forward(x)
-        self.backward(y_true, 1.0 / world_size)
+        self.backward(y_true, (x.shape[0] / float(global_columns)) if global_columns else 1.0 / world_size)
         if world_size > 1:
             import torch.distributed as dist
             dist.all_reduce(self.grads)

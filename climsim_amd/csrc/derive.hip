@@ -47,8 +47,12 @@ __global__ __launch_bounds__(256) void derive_kernel(long n, const float *__rest
             const float t = T[i];
             // the reference forms omega in the array's own precision (float32: `tair - T00` with a python scalar)
             const float om = fminf(1.0f, fmaxf(0.0f, (t - 253.16f) / (273.16f - 253.16f)));
-            if (liq) liq[i] = om;
-            if (rh) {
+            // a missing cell stays missing: np.maximum / np.minimum propagate NaN (fmaxf / fminf drop it), and for +-inf the masked
+            // polynomial branches of eice give 0 * inf = NaN upstream
+            const bool finite = fabsf(t) <= 3.402823466e38f;
+            if (liq) liq[i] = (t != t) ? t : om;
+            if (rh && !finite) rh[i] = __builtin_nanf("");
+            else if (rh) {
                 const double esat = (double)om * eliq_d(t) + (double)(1.0f - om) * eice_d(t);
                 const double qvs = (287.0 * esat) / (double)(461.0f * pmid[i]);      // `Rv * pmid` stays float32 upstream
                 rh[i] = (float)((double)q1[i] / qvs);

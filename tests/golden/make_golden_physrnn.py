@@ -195,6 +195,7 @@ def check_float64():
     sys.path.insert(0, os.path.join(OUT, "..", ".."))
     from oracle import physrnn_rad_ref as R
     arts = [(n, ART_RAD.replace("num4050_BEST", t), False) for n, t in [("physrnn_rad", "num4050_BEST")] + list(RAD_FAMILY.items())]
+    f64 = {}
     for name, art, lm in arts + [(n, DIR + f, True) for n, f in PHYSRAD.items()]:
         m = torch.jit.load(art, map_location="cpu").eval()
         P = {k: v.detach().double() for k, v in m.state_dict().items()}
@@ -216,6 +217,11 @@ def check_float64():
             torch.set_default_dtype(torch.float32)
         print(name, "float64 artefact vs float64 restatement, relative to the block maximum:",
               ["%.1e" % ((a - b).abs().max() / b.abs().max()).item() for a, b in zip(got, ref)])
+        for k, v in zip(("out", "out_sfc", "mem_out"), ref):
+            f64[f"{name}.{k}"] = v.numpy()
+    # the artefacts' own float64 outputs travel as a fixture: tests/test_physrnn_rad.py::test_restatement_float64_formula_identity
+    # repeats this comparison on every CPU run (inputs and draws are regenerated from the seeds 77 / 5 as above)
+    np.savez_compressed(f"{OUT}/physrnn_f64.npz", **f64)
 
 
 if __name__ == "__main__":

@@ -62,6 +62,8 @@ def derived_inputs(hyam, hybm, N=500, nlev=60):
     q1 = (r.uniform(0, 1, (N, nlev)) * 2e-2 * (pmid / 1e5)).astype(np.float32)
     q2 = r.uniform(0, 1e-4, (N, nlev)).astype(np.float32)
     q3 = r.uniform(0, 1e-4, (N, nlev)).astype(np.float32)
+    # missing / fill cells: NaN and +-inf temperatures must propagate as they do through np.maximum / np.minimum / the masked sums
+    tair[3, 7], tair[4, 8], tair[5, 9] = np.nan, np.inf, -np.inf
     return tair, pmid, q1, q2, q3
 
 

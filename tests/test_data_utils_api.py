@@ -71,8 +71,11 @@ def test_derived_inputs_match_the_reference_formulas():
           "state_q0002_prvphy": d(q3), "state_q0003_prvphy": d(q2), "tm_state_q0002_prvphy": d(q2), "tm_state_q0003_prvphy": d(q2)}
     du.derive_inputs(ds)
     rh = ds["state_rh"].cpu().numpy().astype(np.float64)
-    assert np.abs(rh / gd["der.state_rh"] - 1).max() <= 2e-7            # float64 polynomials, one float32 rounding at the end
-    assert np.array_equal(ds["liq_partition"].cpu().numpy(), gd["der.liq_partition"])
+    # missing cells (NaN, +inf, -inf temperatures at [3,7], [4,8], [5,9]) propagate exactly as through the reference's numpy lines
+    ok = np.isfinite(gd["der.state_rh"])
+    assert (~ok).sum() == 3 and np.array_equal(np.isnan(rh), ~ok)
+    assert np.abs(rh[ok] / gd["der.state_rh"][ok] - 1).max() <= 2e-7    # float64 polynomials, one float32 rounding at the end
+    assert np.array_equal(ds["liq_partition"].cpu().numpy(), gd["der.liq_partition"], equal_nan=True)
     assert np.array_equal(ds["state_qn"].cpu().numpy(), gd["der.state_qn"])
     assert np.array_equal(ds["state_qn_prvphy"].cpu().numpy(), q3 + q2)
     assert np.array_equal(ds["tm_state_qn_prvphy"].cpu().numpy(), q2 + q2)

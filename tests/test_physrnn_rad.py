@@ -153,6 +153,34 @@ def test_restatement_reproduces_the_artefact(fixture, ncase):
         assert (ref[("out", 0)][:, :10] != 0).float().mean() > 0.9 and torch.all(ref[("out", 1)][:, :10] == 0)
 
 
+@pytest.mark.parametrize("fixture", [f for f, _ in FIXTURES])
+def test_restatement_float64_formula_identity(fixture):
+    """Formula identity free of rounding, as a STANDING guard of the loosest parity gate in the tree (round-2 review, item 10): the
+    artefact itself, converted to float64 and run with float64 default dtype in the build container
+    (tests/golden/make_golden_physrnn.py::check_float64 stored its outputs in physrnn_f64.npz), against the float64 restatement on
+    the same inputs and the same re-seeded draws.  Measured at generation time: 1e-14 on graphs without a cell near the two-stream
+    singularity k mu0 = 1 and without the third RNN, up to 5e-7 otherwise (the reference's 1e-7 guard of 1 - (k mu0)^2 leaves a
+    1e5-fold amplification of the last float64 digits there; the stochastic layer multiplies its noise by exp(z / 2)) -- a wrong
+    formula shows up at 1e-3 or worse.  Asserted: 2e-6 of every block's maximum."""
+    f64 = np.load(os.path.join(GOLDEN, "physrnn_f64.npz"))
+    g, P = _load(fixture)
+    P64 = {k: v.double() for k, v in P.items()}
+    xm, xs, mem, xd = (t.double() for t in inputs_rad(P, 8, 77))
+    torch.set_default_dtype(torch.float64)
+    try:
+        torch.manual_seed(5)
+        nh = P["rnn2.weight_hh_l0"].shape[1]
+        hx2 = torch.randn(8, nh)
+        kw = dict(hx1=torch.randn(8, nh), eps3=torch.randn(50, 8, nh)) if "rnn3.weight_ih" in P else {}
+        got = physrnn_rad_ref.forward(P64, xm, xs, mem, xd, hx2, **kw)
+    finally:
+        torch.set_default_dtype(torch.float32)
+    for k, a in zip(("out", "out_sfc", "mem_out"), got):
+        b = torch.from_numpy(f64[f"{fixture}.{k}"])
+        assert a.dtype == torch.float64 and a.shape == b.shape
+        assert ((a - b).abs().max() / b.abs().max()).item() <= 2e-6, k
+
+
 def test_subcolumn_sampling_properties():
     """physics_rad.py:533: every sub-column gets floor or ceil of p*G g-points, G in total, in sub-column order."""
     gen = torch.Generator().manual_seed(5)

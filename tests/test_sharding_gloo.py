@@ -155,3 +155,78 @@ def test_bench_spawns_its_own_ranks_before_touching_the_gpu():
         assert r.returncode != 0
         assert re.search(r"LOCAL_RANK [01] but only", r.stderr) or '"n_gpus": 2' in r.stdout, r.stderr[-2000:]
         assert "nproc" in r.stderr or "local_rank" in r.stderr or "torch.distributed" in r.stderr or "elastic" in r.stderr, r.stderr[-2000:]
+
+
+def _cnn_ens_worker(rank, world, port, q):
+    """CPU twins of tests/test_sharding_gpu.py through the oracle: (i) the Keras CNN's `mae_adjusted` and (ii) the ensemble score
+    CRPS are per-column quantities followed by a batch mean, so ragged shard gradients scaled by B_local / B_global and SUMMED by the
+    one flat all-reduce equal the unsharded gradient (CNNTrainer.train_step(world_size, global_columns),
+    Trainer.ensemble_window_step(world_size, global_columns))."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.set_num_threads(2)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle import torch_ref
+        from test_cnn_baseline import _arch
+        from test_train_bigbatch import _torch_crps
+        res = {}
+        # (i) CNN
+        depth, width, B = 2, 24, 7
+        ws, bs = _arch(depth, width, seed=3)
+        params = [t.clone().requires_grad_(True) for t in ws + bs]
+        g = torch.Generator().manual_seed(17)
+        x, yt = torch.randn(B, 60, 6, generator=g), torch.randn(B, 60, 10, generator=g)
+        lo, hi = sharding.shard_bounds(B, world, rank)
+
+        def cnn_loss(a, b):
+            y = torch_ref.cnn_ref(x[a:b], params[:len(ws)], params[len(ws):], depth=depth)
+            return torch_ref.mae_adjusted(yt[a:b], y)
+        (cnn_loss(lo, hi) * sharding.shard_loss_scale(hi - lo, B)).backward()
+        flat = torch.cat([p.grad.reshape(-1) for p in params])
+        sharding.allreduce_flat_(flat, world, average=False)
+        if rank == 0:
+            for p in params:
+                p.grad = None
+            cnn_loss(0, B).backward()
+            full = torch.cat([p.grad.reshape(-1) for p in params])
+            res["cnn"] = float((flat - full).abs().max() / full.abs().max())
+        # (ii) CRPS over an ensemble window
+        T, E, Bc = 2, 3, 5
+        y, ys = torch.randn(T * Bc, 60, 5, generator=g), torch.randn(T * Bc, 8, generator=g)
+        yp = torch.randn(T * E * Bc, 60, 5, generator=g).requires_grad_(True)
+        yps = torch.randn(T * E * Bc, 8, generator=g).requires_grad_(True)
+        lo, hi = sharding.shard_bounds(Bc, world, rank)
+        n = hi - lo
+        cut = lambda t, lead: t.reshape(lead + (Bc,) + t.shape[1:])[..., lo:hi, :, :].reshape((-1,) + t.shape[1:]) if t.dim() == 3 else \
+            t.reshape(lead + (Bc,) + t.shape[1:])[..., lo:hi, :].reshape((-1,) + t.shape[1:])
+        part = _torch_crps(cut(y, (T,)), cut(ys, (T,)), cut(yp, (T, E)), cut(yps, (T, E)), T) * sharding.shard_loss_scale(n, Bc)
+        part.backward()
+        flat = torch.cat([yp.grad.reshape(-1), yps.grad.reshape(-1)])
+        val = part.detach().reshape(1).clone()
+        sharding.allreduce_flat_(flat, world, average=False)
+        sharding.allreduce_flat_(val, world, average=False)
+        if rank == 0:
+            yp.grad = None; yps.grad = None
+            full_v = _torch_crps(y, ys, yp, yps, T)
+            full_v.backward()
+            full = torch.cat([yp.grad.reshape(-1), yps.grad.reshape(-1)])
+            res["crps_grad"] = float((flat - full).abs().max() / full.abs().max())
+            res["crps_val"] = abs(float(val) - float(full_v)) / abs(float(full_v))
+            q.put(res)
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_cnn_and_crps_shard_gradients_sum_to_the_unsharded_gradient():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_cnn_ens_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = q.get(timeout=300)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res["cnn"] <= 1e-5 and res["crps_grad"] <= 1e-5 and res["crps_val"] <= 1e-6, res
