@@ -107,74 +107,79 @@ __global__ __launch_bounds__(NH * 4, (NH / 16 + 3) / 4) void lstm_bwd_rec_kernel
     const size_t cidx = (size_t)b * NH + u;
     const size_t cstep = (size_t)B * NH;
 
-    // operands of the elementwise part are fetched one step ahead (they do not depend on the
-    // recurrence): saved gates, c_t (c_{t-1} of this step is c_t of the next), external dh
-    f32x4 g4 = {0, 0, 0, 0}, g4n = {0, 0, 0, 0};
-    float c_t = 0.f, c_p = 0.f, c_pn = 0.f, dhe = 0.f, dhen = 0.f;
-    if (cell) {
-        const int t = L - 1;
-        g4 = *(const f32x4 *)(GP + ((size_t)t * B + b) * (4 * NH) + u * 4);
-        c_t = Cseq[(size_t)(t + 1) * cstep + cidx];
-        c_p = Cseq[(size_t)t * cstep + cidx];
-        dhe = dH[((size_t)(rev ? L - 1 - t : t) * B + b) * NH + u];
+    // Operands of the elementwise part (saved gates, c_{t-1}, external dh: none depends on the recurrence) are fetched ONE STEP
+    // AHEAD with asm global loads into the other of two register sets and become valid behind `s_waitcnt vmcnt(3)` at the top of
+    // the step that uses them, exactly the scheme of the forward kernels (rec.hip): hipcc knows nothing of a load in flight, so
+    // it places no wait of its own.  Written as plain C++ loads (round 2) the compiler put `s_waitcnt vmcnt(0)` right behind the
+    // three loads it had just issued -- every step paid a full memory round trip plus the ack of the previous step's 16-byte dp
+    // store (SQ_WAIT_ANY 55 % of wave time, profiles/r3_train_tbptt3_384_sq_pmc_before.json).  In-order VMEM accounting per step:
+    // [3 loads for t-1] [dp store of t]; vmcnt(3) at the top of step t-1 leaves only that step's own three loads outstanding, so
+    // the store of step t has had a whole matvec to complete.  The prefetch is unconditional (step 0 re-reads its own row) and
+    // there is ONE wait statement per step with ONE count (tools/check_asm_prefetch.py lints the emitted ISA).
+    f32x4 g4A = {0, 0, 0, 0}, g4B = {0, 0, 0, 0};
+    float cpA = 0.f, cpB = 0.f, dheA = 0.f, dheB = 0.f, c_t = 0.f;
+    const float *GPu = GP + (size_t)b * (4 * NH) + u * 4;
+    const size_t GPstep = (size_t)B * (4 * NH);
+#define BWD_PREFETCH(TN, G4N, CPN, DHN)                                                                       \
+    {                                                                                                         \
+        const int tn_ = (TN);                                                                                 \
+        const float *pg = GPu + (size_t)tn_ * GPstep, *pc = Cseq + (size_t)tn_ * cstep + cidx;                \
+        const float *pd = dH + ((size_t)(rev ? L - 1 - tn_ : tn_) * B + b) * NH + u;                          \
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(G4N) : "v"(pg) : "memory");                    \
+        asm volatile("global_load_dword %0, %1, off" : "=&v"(CPN) : "v"(pc) : "memory");                      \
+        asm volatile("global_load_dword %0, %1, off" : "=&v"(DHN) : "v"(pd) : "memory");                      \
     }
+    if (cell) c_t = Cseq[(size_t)L * cstep + cidx];
+    BWD_PREFETCH(L - 1, g4A, cpA, dheA)
 
-    for (int t = L - 1; t >= 0; --t) {
-        const int cur = t & 1;
-        if (cell) {
-            if (t > 0) {
-                const int tn = t - 1;
-                g4n = *(const f32x4 *)(GP + ((size_t)tn * B + b) * (4 * NH) + u * 4);
-                c_pn = Cseq[(size_t)tn * cstep + cidx];
-                dhen = dH[((size_t)(rev ? L - 1 - tn : tn) * B + b) * NH + u];
-            }
-            const float dh = dhe + dh_rec;
-            const float tc = tanh_acc(c_t);
-            const float dc = dh * g4.w * (1.0f - tc * tc) + dc_carry;
-            f32x4 dp;
-            dp.x = dc * g4.y * g4.x * (1.0f - g4.x);             // i
-            dp.y = dc * g4.x * (1.0f - g4.y * g4.y);             // g~
-            dp.z = dc * c_p * g4.z * (1.0f - g4.z);              // f
-            dp.w = dh * tc * g4.w * (1.0f - g4.w);               // o
-            dc_carry = dc * g4.z;
-            if (valid) *(f32x4 *)(GP + ((size_t)t * B + b) * (4 * NH) + u * 4) = dp;
-            float *n = &dpbuf[cur][cslot + col], *sw = &dpbuf[cur][CPY + cslot + (1 - col)];
-            n[0] = dp.x; n[2] = dp.y; n[4] = dp.z; n[6] = dp.w;
-            sw[0] = dp.x; sw[2] = dp.y; sw[4] = dp.z; sw[6] = dp.w;
-        }
-        LDS_BARRIER();
-        if (t == 0) break;      // the matvec below would only produce dh for a step before the first
-
-        // recurrent matvec on dp[t]: feeds step t-1
-        f32x2 acc[4] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
-        const f32x4 *dpp = (const f32x4 *)&dpbuf[cur][rdoff];
-        BWD_MATVEC(acc, dpp)
-        float r[4];
-#pragma unroll
-        for (int s = 0; s < 4; ++s) r[s] = acc[s].x + dpp_mov<0xB1>(acc[s].y);     // xor 1
-        float v0 = r[0] + dpp_mov<0x4E>(r[2]);                                     // xor 2
-        float v1 = r[1] + dpp_mov<0x4E>(r[3]);
-        v0 += dpp_mov<0x124>(v0); v1 += dpp_mov<0x124>(v1);                        // row_ror:4
-        v0 += dpp_mov<0x128>(v0); v1 += dpp_mov<0x128>(v1);                        // row_ror:8
-        dh_rec = (rcq & 1) ? v1 : v0;
-        g4 = g4n; c_t = c_p; c_p = c_pn; dhe = dhen;
+    // one step: prefetch t-1, gate gradient of t (cell lanes), barrier, recurrent matvec on dp[t] -> dh_rec for step t-1
+    // (after step 0: dh_rec = W_hh^T dp[0] = the gradient w.r.t. the initial hidden state)
+#define BWD_STEP(T, G4C, CPC, DHC, G4N, CPN, DHN)                                                             \
+    {                                                                                                         \
+        const int t_ = (T), cur = t_ & 1;                                                                     \
+        BWD_PREFETCH(t_ > 0 ? t_ - 1 : 0, G4N, CPN, DHN)                                                      \
+        asm volatile("s_waitcnt vmcnt(3)" : "+v"(G4C), "+v"(CPC), "+v"(DHC));                                 \
+        if (cell) {                                                                                           \
+            const f32x4 g4 = G4C;                                                                             \
+            const float dh = DHC + dh_rec;                                                                    \
+            const float tc = tanh_acc(c_t);                                                                   \
+            const float dc = dh * g4.w * (1.0f - tc * tc) + dc_carry;                                         \
+            f32x4 dp;                                                                                         \
+            dp.x = dc * g4.y * g4.x * (1.0f - g4.x);             /* i  */                                     \
+            dp.y = dc * g4.x * (1.0f - g4.y * g4.y);             /* g~ */                                     \
+            dp.z = dc * CPC * g4.z * (1.0f - g4.z);              /* f  */                                     \
+            dp.w = dh * tc * g4.w * (1.0f - g4.w);               /* o  */                                     \
+            dc_carry = dc * g4.z;                                                                             \
+            c_t = CPC;                                                                                        \
+            float *n = &dpbuf[cur][cslot + col], *sw = &dpbuf[cur][CPY + cslot + (1 - col)];                  \
+            n[0] = dp.x; n[2] = dp.y; n[4] = dp.z; n[6] = dp.w;                                               \
+            sw[0] = dp.x; sw[2] = dp.y; sw[4] = dp.z; sw[6] = dp.w;                                           \
+            if (valid) *(f32x4 *)(GPu + (size_t)t_ * GPstep) = dp;                                            \
+        }                                                                                                     \
+        LDS_BARRIER();                                                                                        \
+        f32x2 acc[4] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};                                      \
+        const f32x4 *dpp = (const f32x4 *)&dpbuf[cur][rdoff];                                                 \
+        BWD_MATVEC(acc, dpp)                                                                                  \
+        float r[4];                                                                                           \
+        _Pragma("unroll") for (int s = 0; s < 4; ++s) r[s] = acc[s].x + dpp_mov<0xB1>(acc[s].y); /* xor 1 */  \
+        float v0 = r[0] + dpp_mov<0x4E>(r[2]);                                                   /* xor 2 */  \
+        float v1 = r[1] + dpp_mov<0x4E>(r[3]);                                                                \
+        v0 += dpp_mov<0x124>(v0); v1 += dpp_mov<0x124>(v1);                                      /* row_ror:4 */ \
+        v0 += dpp_mov<0x128>(v0); v1 += dpp_mov<0x128>(v1);                                      /* row_ror:8 */ \
+        dh_rec = (rcq & 1) ? v1 : v0;                                                                         \
     }
-    // gradient w.r.t. the initial state: dh_init = W_hh^T dp[0], dc_init = dc_carry
-    {
-        f32x2 acc[4] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
-        const f32x4 *dpp = (const f32x4 *)&dpbuf[0][rdoff];
-        BWD_MATVEC(acc, dpp)
-        float r[4];
-#pragma unroll
-        for (int s = 0; s < 4; ++s) r[s] = acc[s].x + dpp_mov<0xB1>(acc[s].y);
-        float v0 = r[0] + dpp_mov<0x4E>(r[2]);
-        float v1 = r[1] + dpp_mov<0x4E>(r[3]);
-        v0 += dpp_mov<0x124>(v0); v1 += dpp_mov<0x124>(v1);
-        v0 += dpp_mov<0x128>(v0); v1 += dpp_mov<0x128>(v1);
-        if (cell && valid) {
-            dh0[cidx] = (rcq & 1) ? v1 : v0;
-            dc0[cidx] = dc_carry;
-        }
+    int t = L - 1;
+    for (; t >= 1; t -= 2) {
+        BWD_STEP(t, g4A, cpA, dheA, g4B, cpB, dheB)
+        BWD_STEP(t - 1, g4B, cpB, dheB, g4A, cpA, dheA)
+    }
+    if (t == 0) BWD_STEP(0, g4A, cpA, dheA, g4B, cpB, dheB)
+#undef BWD_STEP
+#undef BWD_PREFETCH
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the last (unused) prefetch must not outlive the wave's registers
+    if (cell && valid) {      // gradient w.r.t. the initial state: dh_init = W_hh^T dp[0], dc_init = dc_carry
+        dh0[cidx] = dh_rec;
+        dc0[cidx] = dc_carry;
     }
 }
 

@@ -85,7 +85,10 @@ class generator_xy:
         self._h = h
         a, b, c = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
         _lib.lib().csa_gen_dims(h, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c))
-        self.nx, self.nx_sfc, self.ny, self.ny_sfc = a.value, b.value, c.value, cfg.ny_sfc
+        # widths of the tensors __getitem__ returns; the public nx / nx_sfc / ny / ny_sfc are, as in the reference class
+        # (rnn/utils.py:2003-2026), the widths of the stored datasets (nx with the previous-step columns added)
+        self.nx_out, self.nx_sfc_out, self.ny_out = a.value, b.value, c.value
+        self.nx, self.nx_sfc, self.ny, self.ny_sfc = nx_in, cfg.nx_sfc_in, data["output_lev"].shape[-1], cfg.ny_sfc
 
     def __len__(self):
         return self.ntimesteps * self.ncol
@@ -104,7 +107,7 @@ class generator_xy:
         yl = self._dev(y_lev_b).reshape(N, c.nlev, 6)
         ys = self._dev(y_sfc_b).reshape(N, c.ny_sfc)
         e = lambda *s: torch.empty(*s, device=self.device)
-        out = (e(N, c.nlev, self.nx), e(N, self.nx_sfc), e(N, c.nlev, self.ny), e(N, c.ny_sfc), e(N, c.nlev, self.nx),
+        out = (e(N, c.nlev, self.nx_out), e(N, self.nx_sfc_out), e(N, c.nlev, self.ny_out), e(N, c.ny_sfc), e(N, c.nlev, self.nx_out),
                e(N, c.nlev, 6), e(N, c.ny_sfc))
         P = lambda t: ctypes.c_void_p(t.data_ptr())
         rc = _lib.lib().csa_gen_batch(self._h, N, P(xl), P(xs), P(yl), P(ys), *[P(t) for t in out],

@@ -90,7 +90,8 @@ def test_cnn_train_step_two_ranks_equals_the_single_process_step():
     # both took ONE Keras-Adam step from the same parameters: the first step is lr * g / (|g| + eps) per element, so it is compared
     # where the gradient is resolved (|g| well above the 2e-6 agreement of the two gradients)
     big = g1.abs() > 1e-3 * g1.abs().max()
-    assert float((p2 - p1)[big].abs().max()) <= 1e-5 * 1e-3 and not torch.equal(p1, torch.zeros_like(p1))
+    # (parameters are O(0.5): one fp32 ulp of the parameter itself, 6e-8, is the resolution of the comparison)
+    assert float((p2 - p1)[big].abs().max()) <= 1e-5 * 1e-3 + 1.2e-7 and not torch.equal(p1, torch.zeros_like(p1))
 
 
 def _ens_case():
