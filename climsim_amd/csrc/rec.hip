@@ -729,11 +729,17 @@ __global__ __launch_bounds__(NH * 4, (NH / 16 + 3) / 4) void gru_rec4m_kernel(
 // 8 DPP adds per step (the all-reduce of rec_kernel<NH,3> needs 12 plus a select), 96 packed FMAs as before.
 // P rows are [r, z, n] per unit: lane group g reads the 8-byte pair at offset g -> (r,z) or (z,n); the p>=2 lanes own
 // h_t: they receive r over one DPP move, form n = tanh(x_n + r (W_hn h + b_hn)) and h = (1-z) n + z h.
-template <int NH>
+// TRAIN (round 3: the training forward of the GRU models, which ran on the first-generation rec_kernel<NH,3,true>): P rows are
+// the 4-padded rows of the training buffers; the owner lane ends a step with all of [r, z, n, W_hn h + b_hn] of its (unit,
+// column) and writes them IN PLACE over the row it consumed, h_t also goes to Hseq (L+1 slots, slot 0 = h_init) -- what
+// gru_bwd_rec_kernel reads.
+template <int NH, bool TRAIN = false>
 __global__ __launch_bounds__(NH * 4, (NH / 16 + 3) / 4) void gru_rec2_kernel(
-    const f32x4 *__restrict__ Wp4, const float *__restrict__ bhn, const float *__restrict__ P,
-    const float *__restrict__ h0, float *__restrict__ Hout, int B, int L, int reverse_out)
+    const f32x4 *__restrict__ Wp4, const float *__restrict__ bhn, const float *P,
+    const float *__restrict__ h0, float *__restrict__ Hout, int B, int L, int reverse_out,
+    float *Pw = nullptr, float *__restrict__ Hseq = nullptr)
 {
+    constexpr int PS = TRAIN ? 4 : 3;     // floats per unit of a P row
     constexpr int NT = NH * 4;
     constexpr int KC = NH / 4;
     constexpr int CH = 2 * KC + 4;
@@ -761,9 +767,10 @@ __global__ __launch_bounds__(NH * 4, (NH / 16 + 3) / 4) void gru_rec2_kernel(
     const int slotN = 2 * u + col + 4 * (u / KC);
     const int slotS = CPY + 2 * u + (1 - col) + 4 * (u / KC);
     if (owner) { hbuf[0][slotN] = h; hbuf[0][slotS] = h; }
+    if (TRAIN && owner && valid) Hseq[(size_t)b * NH + u] = h;
 
-    const float *Pb = P + (size_t)b * (3 * NH) + u * 3 + grp;      // rows are [r, z, n] per unit, unpadded: 4-byte-aligned pairs
-    const size_t Pstep = (size_t)B * (3 * NH);
+    const float *Pb = P + (size_t)b * (PS * NH) + u * PS + grp;    // rows are [r, z, n(, pad)] per unit: 4-byte-aligned pairs
+    const size_t Pstep = (size_t)B * (PS * NH);
     const int rdoff = col * CPY + p * CH;
     f32x2 preA = f32x2{Pb[0], Pb[1]}, preB = preA;
     __syncthreads();
@@ -797,6 +804,10 @@ __global__ __launch_bounds__(NH * 4, (NH / 16 + 3) / 4) void gru_rec2_kernel(
             hbuf[(t_ & 1) ^ 1][slotN] = h;                                                         \
             hbuf[(t_ & 1) ^ 1][slotS] = h;                                                         \
             if (valid) Hout[((size_t)(reverse_out ? L - 1 - t_ : t_) * B + b) * NH + u] = h;       \
+            if (TRAIN && valid) {                                                                  \
+                Hseq[((size_t)(t_ + 1) * B + b) * NH + u] = h;                                     \
+                *(f32x4 *)(Pw + ((size_t)t_ * B + b) * (4 * NH) + u * 4) = f32x4{rr, g0, n, hn}; \
+            }                                                                                      \
         }                                                                                          \
         LDS_BARRIER();                                                                             \
     }
@@ -1223,15 +1234,15 @@ int launch_rec_train(int nh, const float *whh_packed, float *P, const float *h0,
     return CSA_OK;
 }
 
-// GRU training forward: gates saved in place over P, h sequence into Hseq (L+1 slots)
+// GRU training forward: gates saved in place over P, h sequence into Hseq (L+1 slots).  whh_packed: gru2_pack_weights layout.
 int launch_rec_train_gru(int nh, const float *whh_packed, const float *bhn, float *P, const float *h0, float *Hout, int B, int L,
                          int reverse_out, float *Hseq, hipStream_t s)
 {
     const dim3 grid((B + 1) / 2), block(nh * 4);
     switch (nh) {
-    case 64:  hipLaunchKernelGGL((rec_kernel<64, 3, true>), grid, block, 0, s, (const f32x4 *)whh_packed, bhn, P, h0, (const float *)nullptr, Hout, B, L, reverse_out, P, Hseq); break;
-    case 96:  hipLaunchKernelGGL((rec_kernel<96, 3, true>), grid, block, 0, s, (const f32x4 *)whh_packed, bhn, P, h0, (const float *)nullptr, Hout, B, L, reverse_out, P, Hseq); break;
-    case 128: hipLaunchKernelGGL((rec_kernel<128, 3, true>), grid, block, 0, s, (const f32x4 *)whh_packed, bhn, P, h0, (const float *)nullptr, Hout, B, L, reverse_out, P, Hseq); break;
+    case 64:  hipLaunchKernelGGL((gru_rec2_kernel<64, true>), grid, block, 0, s, (const f32x4 *)whh_packed, bhn, P, h0, Hout, B, L, reverse_out, P, Hseq); break;
+    case 96:  hipLaunchKernelGGL((gru_rec2_kernel<96, true>), grid, block, 0, s, (const f32x4 *)whh_packed, bhn, P, h0, Hout, B, L, reverse_out, P, Hseq); break;
+    case 128: hipLaunchKernelGGL((gru_rec2_kernel<128, true>), grid, block, 0, s, (const f32x4 *)whh_packed, bhn, P, h0, Hout, B, L, reverse_out, P, Hseq); break;
     default:
         csa_set_error_msg("rec(train, GRU): hidden size not supported (64, 96, 128)");
         return CSA_ERR_UNSUPPORTED;

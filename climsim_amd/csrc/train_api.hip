@@ -327,7 +327,7 @@ extern "C" int csa_train_create(const csa_config *cfg, const csa_params *p, cons
         bias = add_gather(h, b1, &b2, rc);
         bhn = add_gather(h, ibhn, nullptr, rc);
         std::vector<float> ih = index_values((size_t)3 * nh * nh), pk(rec_packed_floats(0, nh));
-        rec_pack_weights(0, nh, ih.data(), pk.data());
+        gru2_pack_weights(nh, ih.data(), pk.data());            // the training forward is gru_rec2_kernel<NH, true> (round 3)
         whhp = add_gather(h, to_int(pk, o_whh), nullptr, rc);
         std::vector<float> pkT(bwd_rec_packed_floats_gru(nh));
         bwd_rec_pack_weights_gru(nh, ih.data(), pkT.data());

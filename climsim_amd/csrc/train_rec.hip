@@ -134,11 +134,17 @@ __global__ __launch_bounds__(NH * 4, (NH / 16 + 3) / 4) void lstm_bwd_rec_kernel
 
     // one step: prefetch t-1, gate gradient of t (cell lanes), barrier, recurrent matvec on dp[t] -> dh_rec for step t-1
     // (after step 0: dh_rec = W_hh^T dp[0] = the gradient w.r.t. the initial hidden state)
-#define BWD_STEP(T, G4C, CPC, DHC, G4N, CPN, DHN)                                                             \
+    // PF = 1: the paired steps of the loop (prefetch + vmcnt(3)); PF = 0: the unpaired last step of an odd L -- its prefetch would
+    // land in registers that are dead by then and that hipcc is free to re-use while the load is still in flight
+#define BWD_STEP(PF, T, G4C, CPC, DHC, G4N, CPN, DHN)                                                         \
     {                                                                                                         \
         const int t_ = (T), cur = t_ & 1;                                                                     \
-        BWD_PREFETCH(t_ > 0 ? t_ - 1 : 0, G4N, CPN, DHN)                                                      \
-        asm volatile("s_waitcnt vmcnt(3)" : "+v"(G4C), "+v"(CPC), "+v"(DHC));                                 \
+        if (PF) {                                                                                             \
+            BWD_PREFETCH(t_ > 0 ? t_ - 1 : 0, G4N, CPN, DHN)                                                  \
+            asm volatile("s_waitcnt vmcnt(3)" : "+v"(G4C), "+v"(CPC), "+v"(DHC));                             \
+        } else {                                                                                              \
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(G4C), "+v"(CPC), "+v"(DHC));                             \
+        }                                                                                                     \
         if (cell) {                                                                                           \
             const f32x4 g4 = G4C;                                                                             \
             const float dh = DHC + dh_rec;                                                                    \
@@ -170,13 +176,14 @@ __global__ __launch_bounds__(NH * 4, (NH / 16 + 3) / 4) void lstm_bwd_rec_kernel
     }
     int t = L - 1;
     for (; t >= 1; t -= 2) {
-        BWD_STEP(t, g4A, cpA, dheA, g4B, cpB, dheB)
-        BWD_STEP(t - 1, g4B, cpB, dheB, g4A, cpA, dheA)
+        BWD_STEP(1, t, g4A, cpA, dheA, g4B, cpB, dheB)
+        BWD_STEP(1, t - 1, g4B, cpB, dheB, g4A, cpA, dheA)
     }
-    if (t == 0) BWD_STEP(0, g4A, cpA, dheA, g4B, cpB, dheB)
+    if (t == 0) BWD_STEP(0, 0, g4A, cpA, dheA, g4B, cpB, dheB)
 #undef BWD_STEP
 #undef BWD_PREFETCH
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the last (unused) prefetch must not outlive the wave's registers
+    // the last (unused) prefetch of an even L must land before its registers may be re-used: the operands keep them live until here
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(g4A), "+v"(cpA), "+v"(dheA), "+v"(g4B), "+v"(cpB), "+v"(dheB) : : "memory");
     if (cell && valid) {      // gradient w.r.t. the initial state: dh_init = W_hh^T dp[0], dc_init = dc_carry
         dh0[cidx] = dh_rec;
         dc0[cidx] = dc_carry;
@@ -227,14 +234,21 @@ __global__ __launch_bounds__(NH * 4, 2) void gru_bwd_rec_kernel(
     float dh_rec = 0.0f, dh_dir = 0.0f;
     const size_t cidx = (size_t)b * NH + u, cstep = (size_t)B * NH;
 
-    f32x4 g4 = {0, 0, 0, 0}, g4n = {0, 0, 0, 0};
-    float hp = 0.f, hpn = 0.f, dhe = 0.f, dhen = 0.f;
-    if (cell) {
-        const int t = L - 1;
-        g4 = *(const f32x4 *)(GP + ((size_t)t * B + b) * (4 * NH) + u * 4);
-        hp = Hseq[(size_t)t * cstep + cidx];
-        dhe = dH[((size_t)(rev ? L - 1 - t : t) * B + b) * NH + u];
+    // operands of the gate gradient one step ahead through asm loads + ONE counted wait per step, as lstm_bwd_rec_kernel above
+    f32x4 g4A = {0, 0, 0, 0}, g4B = {0, 0, 0, 0};
+    float hpA = 0.f, hpB = 0.f, dheA = 0.f, dheB = 0.f;
+    const float *GPu = GP + (size_t)b * (4 * NH) + u * 4;
+    const size_t GPstep = (size_t)B * (4 * NH);
+#define GRU_PREFETCH(TN, G4N, HPN, DHN)                                                                       \
+    {                                                                                                         \
+        const int tn_ = (TN);                                                                                 \
+        const float *pg = GPu + (size_t)tn_ * GPstep, *ph = Hseq + (size_t)tn_ * cstep + cidx;                \
+        const float *pd = dH + ((size_t)(rev ? L - 1 - tn_ : tn_) * B + b) * NH + u;                          \
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(G4N) : "v"(pg) : "memory");                    \
+        asm volatile("global_load_dword %0, %1, off" : "=&v"(HPN) : "v"(ph) : "memory");                      \
+        asm volatile("global_load_dword %0, %1, off" : "=&v"(DHN) : "v"(pd) : "memory");                      \
     }
+    GRU_PREFETCH(L - 1, g4A, hpA, dheA)
 #define GRU_MATVEC(acc, dpp)                                                                       \
     _Pragma("unroll") for (int j = 0; j < RC / 2; ++j) {                                           \
         const f32x4 v = (dpp)[j];                                                                  \
@@ -242,44 +256,52 @@ __global__ __launch_bounds__(NH * 4, 2) void gru_bwd_rec_kernel(
         _Pragma("unroll") for (int s = 0; s < 4; ++s) PK_FMA_LO(acc[s], w[s][j], va);              \
         _Pragma("unroll") for (int s = 0; s < 4; ++s) PK_FMA_HI(acc[s], w[s][j], vb);              \
     }
-    for (int t = L - 1; t >= 0; --t) {
-        const int cur = t & 1;
-        if (cell) {
-            if (t > 0) {
-                const int tn = t - 1;
-                g4n = *(const f32x4 *)(GP + ((size_t)tn * B + b) * (4 * NH) + u * 4);
-                hpn = Hseq[(size_t)tn * cstep + cidx];
-                dhen = dH[((size_t)(rev ? L - 1 - tn : tn) * B + b) * NH + u];
-            }
-            const float dh = dhe + dh_rec;
-            const float r = g4.x, z = g4.y, n = g4.z, hn = g4.w;
-            const float dn = dh * (1.0f - z), dz = dh * (hp - n);
-            dh_dir = dh * z;
-            f32x4 dp;
-            dp.z = dn * (1.0f - n * n);              // dn~  (input-projection side)
-            dp.w = dp.z * r;                         // g_hn (recurrent side)
-            dp.x = dp.z * hn * r * (1.0f - r);       // dr~
-            dp.y = dz * z * (1.0f - z);              // dz~
-            if (valid) *(f32x4 *)(GP + ((size_t)t * B + b) * (4 * NH) + u * 4) = dp;
-            float *nn = &dpbuf[cur][cslot + col], *sw = &dpbuf[cur][CPY + cslot + (1 - col)];
-            nn[0] = dp.x; nn[2] = dp.y; nn[4] = dp.w;
-            sw[0] = dp.x; sw[2] = dp.y; sw[4] = dp.w;
-        }
-        LDS_BARRIER();
-        f32x2 acc[4] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
-        const f32x4 *dpp = (const f32x4 *)&dpbuf[cur][rdoff];
-        GRU_MATVEC(acc, dpp)
-        float rr[4];
-#pragma unroll
-        for (int s = 0; s < 4; ++s) rr[s] = acc[s].x + dpp_mov<0xB1>(acc[s].y);
-        float v0 = rr[0] + dpp_mov<0x4E>(rr[2]);
-        float v1 = rr[1] + dpp_mov<0x4E>(rr[3]);
-        v0 += dpp_mov<0x124>(v0); v1 += dpp_mov<0x124>(v1);
-        v0 += dpp_mov<0x128>(v0); v1 += dpp_mov<0x128>(v1);
-        dh_rec = ((rcq & 1) ? v1 : v0) + dh_dir;
-        g4 = g4n; hp = hpn; dhe = dhen;
+#define GRU_BWD_STEP(PF, T, G4C, HPC, DHC, G4N, HPN, DHN)                                                     \
+    {                                                                                                         \
+        const int t_ = (T), cur = t_ & 1;                                                                     \
+        if (PF) {                                                                                             \
+            GRU_PREFETCH(t_ > 0 ? t_ - 1 : 0, G4N, HPN, DHN)                                                  \
+            asm volatile("s_waitcnt vmcnt(3)" : "+v"(G4C), "+v"(HPC), "+v"(DHC));                             \
+        } else {                                                                                              \
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(G4C), "+v"(HPC), "+v"(DHC));                             \
+        }                                                                                                     \
+        if (cell) {                                                                                           \
+            const float dh = DHC + dh_rec;                                                                    \
+            const float r = G4C.x, z = G4C.y, n = G4C.z, hn = G4C.w;                                          \
+            const float dn = dh * (1.0f - z), dz = dh * (HPC - n);                                            \
+            dh_dir = dh * z;                                                                                  \
+            f32x4 dp;                                                                                         \
+            dp.z = dn * (1.0f - n * n);              /* dn~  (input-projection side) */                       \
+            dp.w = dp.z * r;                         /* g_hn (recurrent side) */                              \
+            dp.x = dp.z * hn * r * (1.0f - r);       /* dr~ */                                                \
+            dp.y = dz * z * (1.0f - z);              /* dz~ */                                                \
+            float *nn = &dpbuf[cur][cslot + col], *sw = &dpbuf[cur][CPY + cslot + (1 - col)];                 \
+            nn[0] = dp.x; nn[2] = dp.y; nn[4] = dp.w;                                                         \
+            sw[0] = dp.x; sw[2] = dp.y; sw[4] = dp.w;                                                         \
+            if (valid) *(f32x4 *)(GPu + (size_t)t_ * GPstep) = dp;                                            \
+        }                                                                                                     \
+        LDS_BARRIER();                                                                                        \
+        f32x2 acc[4] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};                                      \
+        const f32x4 *dpp = (const f32x4 *)&dpbuf[cur][rdoff];                                                 \
+        GRU_MATVEC(acc, dpp)                                                                                  \
+        float rr[4];                                                                                          \
+        _Pragma("unroll") for (int s = 0; s < 4; ++s) rr[s] = acc[s].x + dpp_mov<0xB1>(acc[s].y);             \
+        float v0 = rr[0] + dpp_mov<0x4E>(rr[2]);                                                              \
+        float v1 = rr[1] + dpp_mov<0x4E>(rr[3]);                                                              \
+        v0 += dpp_mov<0x124>(v0); v1 += dpp_mov<0x124>(v1);                                                   \
+        v0 += dpp_mov<0x128>(v0); v1 += dpp_mov<0x128>(v1);                                                   \
+        dh_rec = ((rcq & 1) ? v1 : v0) + dh_dir;                                                              \
     }
+    int t = L - 1;
+    for (; t >= 1; t -= 2) {
+        GRU_BWD_STEP(1, t, g4A, hpA, dheA, g4B, hpB, dheB)
+        GRU_BWD_STEP(1, t - 1, g4B, hpB, dheB, g4A, hpA, dheA)
+    }
+    if (t == 0) GRU_BWD_STEP(0, 0, g4A, hpA, dheA, g4B, hpB, dheB)
+#undef GRU_BWD_STEP
+#undef GRU_PREFETCH
 #undef GRU_MATVEC
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(g4A), "+v"(hpA), "+v"(dheA), "+v"(g4B), "+v"(hpB), "+v"(dheB) : : "memory");
     if (cell && valid) dh0[cidx] = dh_rec;       // gradient w.r.t. the initial hidden state
 }
 

@@ -68,7 +68,9 @@ def test_no_compiler_instruction_touches_an_in_flight_prefetch():
     r = subprocess.run([sys.executable, TOOL], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     # every asm-prefetch kernel family, every instantiated width, must have been seen by the lint
-    for fam in ("lstm_rec1_kernel", "lstm_rec2_kernel", "lstm_rec4_kernel", "lstm_rec4m_kernel", "gru_rec1_kernel", "gru_rec2_kernel"):
+    for fam in ("lstm_rec1_kernel", "lstm_rec2_kernel", "lstm_rec4_kernel", "lstm_rec4m_kernel", "gru_rec1_kernel", "gru_rec2_kernel",
+                "lstm_bwd_rec_kernel"):
         seen = [l for l in r.stdout.splitlines() if fam in l]
         assert len(seen) >= 3 and all(l.rstrip().endswith("OK") for l in seen), (fam, seen)
     assert sum("lstm_rec2_kernel" in l and "Lb1E" in l for l in r.stdout.splitlines()) == 4      # the TRAIN variants too
+    assert sum("gru_bwd_rec_kernel" in l and l.rstrip().endswith("OK") for l in r.stdout.splitlines()) == 2   # BPTT of the GRU (round 3)

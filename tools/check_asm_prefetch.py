@@ -9,9 +9,9 @@ copy, a `scratch_store` / `buffer_store` spill, a re-use of the register as a te
 
 This script compiles the source to gfx950 assembly and, per kernel, walks prologue -> loop body -> loop body (the back
 edge) -> epilogue with a small state machine:
-    asm load into D            -> D in flight, 0 waits seen
-    asm `s_waitcnt vmcnt`      -> every in-flight D: waits += 1; at 2 the data has landed
-    compiler instruction whose operands overlap an in-flight D -> FINDING
+    any VMEM instruction       -> appended to an in-order queue (asm loads with their destination registers D)
+    `s_waitcnt vmcnt(N)`       -> all but the newest N entries of the queue have landed (gfx9: loads and stores retire in order)
+    compiler instruction whose operands overlap the D of a queued asm load -> FINDING
 Instructions between `;;#ASMSTART` and `;;#ASMEND` are the hand-written ones and exempt.  Expected output: every kernel that
 uses the asm prefetch is listed with OK.  (A first version of lstm_rec4_kernel had a finding)
 
@@ -24,7 +24,7 @@ import sys
 import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-DEFAULT = [os.path.join(ROOT, "climsim_amd", "csrc", "rec.hip")]
+DEFAULT = [os.path.join(ROOT, "climsim_amd", "csrc", "rec.hip"), os.path.join(ROOT, "climsim_amd", "csrc", "train_rec.hip")]
 LOAD = re.compile(r"^\s*global_load_dword(?:x([234]))?\s+(v\[(\d+):(\d+)\]|v(\d+)),")
 REG = re.compile(r"\bv\[(\d+):(\d+)\]|\bv(\d+)\b")
 
@@ -72,31 +72,34 @@ def lint_kernel(name, body):
     order = list(range(len(tagged)))
     if loop:
         order = list(range(0, loop[1])) + list(range(loop[0], loop[1])) + list(range(loop[1], len(tagged)))
-    inflight, findings, dests = {}, [], set()
+    # in-order VMEM queue (gfx9 family: loads and stores retire in issue order, `s_waitcnt vmcnt(N)` leaves the newest N in flight)
+    queue, findings, dests = [], [], set()
+    VMEM = re.compile(r"^\s*(global|buffer|scratch|flat)_(load|store|atomic)")
     for i in order:
         a, l = tagged[i]
         ins = l.split("//")[0].split(";")[0].strip()
         if not ins or ins.endswith(":") or ins.startswith("."):
             continue
-        if a:
+        m = re.search(r"s_waitcnt.*vmcnt\((\d+)\)", ins)
+        if m:
+            n = int(m.group(1))
+            queue = queue[len(queue) - n:] if n else []
+            continue
+        if a and LOAD.match(l):
             m = LOAD.match(l)
-            if m:
-                d = (int(m.group(3)), int(m.group(4))) if m.group(3) is not None else (int(m.group(5)), int(m.group(5)))
-                inflight[d] = 0
-                dests.add(d)
-            elif "s_waitcnt" in ins and "vmcnt" in ins:
-                for d in list(inflight):
-                    inflight[d] += 1
-                    if inflight[d] >= 2:
-                        del inflight[d]
+            d = (int(m.group(3)), int(m.group(4))) if m.group(3) is not None else (int(m.group(5)), int(m.group(5)))
+            queue.append(d)
+            dests.add(d)
             continue
-        if "s_waitcnt" in ins and "vmcnt(0)" in ins:      # a compiler-issued full drain also lands everything
-            inflight.clear()
+        if a:
             continue
+        inflight = [d for d in queue if d is not None]
         for r in regs_of(ins.split(None, 1)[1] if " " in ins else ""):
             for d in inflight:
                 if overlap(r, d):
                     findings.append(f"line {i}: `{ins}` touches v[{d[0]}:{d[1]}] while its asm load is in flight")
+        if VMEM.match(l):
+            queue.append(None)          # a compiler-issued load / store occupies a slot of the counter too
     return sorted(dests), sorted(set(findings))
 
 
