@@ -221,16 +221,18 @@ def cpu_train_baseline(consts, weights, grid, B, Tw, args_cpu, budget_s=8.0):
                       f"(torch {torch.__version__} CPU, {cores} threads), {el:.1f} s"}
 
 
-def train_leg(a, rank, world, dist, steps, warmup, with_cpu, B=384):
+def train_leg(a, rank, world, dist, steps, warmup, with_cpu, B=384, tag="cur_lstm128"):
     """BASELINE.json configs[2]: one TBPTT optimiser step of the current-generation LSTM with memory (window T_w = 3, 384
     columns per GPU): 3 forwards with saved activations, loss, 3 backwards, ONE flat-buffer RCCL all-reduce, Adam.
     Unit: column-timesteps/s.  Returns the `train` object of the JSON line."""
     from climsim_amd.train import Trainer
     from synth import synth_inputs
-    consts, weights = load_model("cur_lstm128")
+    consts, weights = load_model(tag)
     grid = np.load(os.path.join(ROOT, "tests", "golden", "grid_consts.npz"))
     Tw = 3
-    tr = Trainer(consts, weights, grid["hyai"], grid["hybi"], output_prune=True, max_batch=B, max_window=Tw)
+    lstm = "lstm" in tag
+    nh, G = weights["rnn1.weight_hh_l0"].shape[1], (4 if lstm else 3)
+    tr = Trainer(consts, weights, grid["hyai"], grid["hybi"], use_lstm=lstm, output_prune=lstm, max_batch=B, max_window=Tw)
     xm, xs = synth_inputs(consts, B, 7000 + rank)
     g = torch.Generator().manual_seed(rank)
     xmt, xst = torch.from_numpy(xm), torch.from_numpy(xs)
@@ -259,21 +261,22 @@ def train_leg(a, rank, world, dist, steps, warmup, with_cpu, B=384):
     out = None
     if rank == 0:
         bwd_ms, nb = prof["bwd_rec"]
-        flop = B * 60 * 2.0 * 4 * 128 * 128       # W_hh^T . d(gates): algorithmic FLOP of one BPTT recurrence launch
+        flop = B * 60 * 2.0 * G * nh * nh         # W_hh^T . d(gates): algorithmic FLOP of one BPTT recurrence launch
         ach = flop / (bwd_ms * 1e-3) / 1e12 if bwd_ms > 0 else 0.0
         value = world * B * Tw * steps / el
-        flop_step = 3 * 32.95e6                    # fwd + bwd ~ 3x forward FLOP per column-timestep
+        # fwd + bwd ~ 3x forward FLOP per column-timestep (32.95 MFLOP forward for LSTM 128/128, nh_mem 16)
+        flop_step = 3 * (60 * (2.0 * G * nh * (nh + 16) + 2.0 * G * nh * nh + 2 * 2.0 * G * nh * nh + 4096 + 2 * 16 * nh + 160) + 11776)
         out = {"metric": "train-step column-timesteps/sec (TBPTT window 3)", "value": value, "unit": "column-timesteps/s",
                "steps": steps, "warmup": warmup, "preheat_steps": pre, "ms_per_step": 1e3 * el / steps, "scaling": "weak", "dtype": "f32",
-               "config": {"workload": f"train_tbptt3_{B}", "columns_per_gpu": B, "window": Tw,
-                          "model": "RNN_autoreg LSTM 128/128, nh_mem 16, mp_mode 1; huber + energy + water loss; Adam",
+               "config": {"workload": ("" if tag == "cur_lstm128" else tag[4:] + "_") + f"train_tbptt3_{B}", "columns_per_gpu": B, "window": Tw,
+                          "model": f"RNN_autoreg {'LSTM' if lstm else 'GRU'} {nh}/{nh}, nh_mem 16, mp_mode 1; huber + energy + water loss; Adam",
                           "parallelism": f"columns sharded x{world}, one flat-gradient all-reduce per step"},
                "roofline": {"bound": "mfma", "pipe": "v_pk_fma_f32 (fp32 vector peak = f32 MFMA peak, 157.3 TF: the two share the FMA lanes)",
-                            "kernel": "lstm_bwd_rec_kernel<128> (one launch per LSTM per backward, 6 per step)",
+                            "kernel": f"{'lstm' if lstm else 'gru'}_bwd_rec_kernel<{nh}> (one launch per RNN per backward, 6 per step)",
                             "achieved": ach, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_FP32_TFLOPS,
                             "traffic": pmc_traffic(f"train_tbptt3_{B}", "lstm_bwd_rec_kernel"),
                             "traffic_unit": "HBM bytes per launch (rocprofv3 PMC, profiles/)",
-                            "algorithmic_hbm_bytes_per_launch": B * 60 * (2 * 4 * 128 + 2 * 128) * 4.0,
+                            "algorithmic_hbm_bytes_per_launch": B * 60 * (2 * 4 * nh + 2 * nh) * 4.0,
                             "flop_per_launch": flop, "avg_launch_ms": bwd_ms, "launches_timed": nb},
                "whole_path": {"flop_per_column_timestep": flop_step, "achieved_tflops": value / world * flop_step / 1e12,
                               "frac_fp32_peak": value / world * flop_step / 1e12 / PEAK_FP32_TFLOPS},
@@ -549,8 +552,10 @@ def main():
         return finish()
     with_cpu = not a.no_cpu_baseline and world == 1
     common = {"n_gpus": world, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic"}
-    if a.workload.startswith("train_tbptt3_"):
-        t = train_leg(a, rank, world, dist, a.steps, a.warmup, with_cpu, B=int(a.workload.rsplit("_", 1)[1]))
+    if "train_tbptt3_" in a.workload and not a.workload.startswith("cnn"):      # train_tbptt3_<B>, lstm144_train_tbptt3_<B>, gru128_train_tbptt3_<B>
+        model = a.workload.split("train_tbptt3_")[0].rstrip("_")
+        t = train_leg(a, rank, world, dist, a.steps, a.warmup, with_cpu and not model, B=int(a.workload.rsplit("_", 1)[1]),
+                      tag="cur_" + (model or "lstm128"))
         if rank == 0:
             print(json.dumps({**t, **common}), flush=True)
         return finish()
