@@ -1,0 +1,256 @@
+"""TEST INFRASTRUCTURE ONLY (never imported by climsim_amd/): CPU restatement of the FROZEN physRNN exports
+`rnn/saved_models/physRNN_physRad-*_nx21_*_script_{cpu,gpu}_wrapped.pt` (82 of the 114 shipped files, the modules an E3SM host loads):
+rnn/utils.py::model_wrapper (:72-295: RH -> q appended as 21st level input, 1 - exp(-lambda q) cloud transforms, normalisation,
+NaN / Inf scrub; outputs de-normalised and the cloud tendency partitioned) around the "nx21" generation of
+rnn/models/models_phys.py::physical_RNN_autoreg (:1586-1823 forward, :414-748 microphysics_decode, :816-1270 rad_optical_props,
+:1272-1490 radiative_transfer), both inlined by torch.jit.freeze.  Signature of the export:
+
+    forward(x_main0 (B, 60, 20) raw, x_sfc0 (B, 19) raw, rnn1_mem (50, B, 16) level-major) -> (out_lev (B, 60, 6), out_sfc (B, 8), rnn1_mem)
+
+What this generation changes against the unfrozen physRad graphs (oracle/physrnn_rad_ref.py), as serialised:
+  * all nreg regions carry condensate (no clear-sky region), sub-grid temperature head, eddy heat flux zero at the surface,
+    per-region cloud liquid fraction (temperature ramp, or the learned head) shared by latent heating and cloud optics;
+  * the number of g-points equals nreg (12 / 14 / 16): g-point g sees region g;
+  * radiation reads the UN-updated grid-mean q_v (or, in some variants, the updated one: flag `rad_updated_qv`);
+  * SW gas optics: two small MLPs 7 -> 32 -> 32 -> ng (absorption, Rayleigh), tau = N_dry y^8 1e-17, evaluated for the humidity
+    of the two largest regions; per (level, column, g-point) ONE of the two is taken by a fair coin (`torch.rand_like(...) < 0.5`),
+    the uniform draw is an explicit argument here;
+  * Slingo liquid / Ebert-Curry ice cloud optics per g-point through a band map; the ICE optics are evaluated with the LIQUID
+    effective radius clamped to [13, 130] (as serialised -- kept);
+  * surface albedo and the SOLL / SOLS split of the two "mixed" g-points use learned weights (`mix_near`, `mix_vis`) or 0.5 / 0.5;
+  * the LW downward sweep has its own layer source; no relu on the SW fluxes; the first surface output is NET shortwave.
+PINNED by the artefacts themselves: tests/golden/make_golden_frozen.py runs one export per code variant (torch.jit.load, CPU) on
+seeded raw inputs, reproduces its internal draws by re-seeding, names its constants (tests/golden/frozen_extract.py) and stores
+weights + I/O; tests/test_physrnn_frozen.py checks this restatement against those outputs."""
+import torch
+import torch.nn.functional as F
+
+from .physrnn_ref import _gru, _lin, microphysics_decode, G
+from .physrnn_rad_ref import SIGMA, SLINGO, EBERT_CURRY, adding_sw, pow8, reitab, reltab, stochastic_gru, two_stream_sw
+
+A_LIQ = [-0.976195544e-15, -0.952447341e-13, 0.640689451e-10, 0.206739458e-7, 0.302950461e-5, 0.264847430e-3, 0.142986287e-1,
+         0.443987641, 6.11239921]
+A_ICE = [0.252751365e-14, 0.146898966e-11, 0.385852041e-9, 0.602588177e-7, 0.615021634e-5, 0.420895665e-3, 0.188439774e-1,
+         0.503160820, 6.11147274]
+
+
+def _horner(a, x):
+    o = torch.zeros_like(x)
+    for c in a:
+        o = o * x + c
+    return o
+
+
+def rh_to_q(rh, temp, pres):
+    """rnn/utils.py:134-180 (relative_to_specific_humidity_torch)."""
+    omega = ((temp - 253.16) / 20.000000000000028).clamp(0.0, 1.0)
+    eliq = _horner(A_LIQ, (temp - 273.16).clamp(min=-80.0)) * 100.0
+    b2 = _horner(A_ICE, temp - 273.16) * 100.0
+    tmp = (temp - 273.16).clamp(min=-100.0)
+    b3 = (0.00763685 + tmp * (0.000151069 + tmp * 7.48215e-07)) * 100.0
+    eice = torch.where(temp > 273.15, eliq, torch.where((temp <= 273.15) & (temp > 185.0), b2, b3))
+    esat = omega * eliq + (1.0 - omega) * eice
+    return rh * ((esat * 287.0) / (pres * 461.0))
+
+
+def wrapper_pre(P, x_main0, x_sfc0):
+    """-> x_main00 (B,60,21) raw with q appended, x_main_n (B,60,21), x_sfc_n (B,19)   (rnn/utils.py:182-217, 262-272)"""
+    pres = P["hyam"] * 100000.0 + x_sfc0[:, 0:1] * P["hybm"]
+    q = rh_to_q(x_main0[:, :, 1], x_main0[:, :, 0], pres)
+    x_main00 = torch.cat([x_main0, q.unsqueeze(2)], 2)
+    x = x_main00.clone()
+    xs = torch.where(x_sfc0 >= 1e10, torch.full_like(x_sfc0, -1.0), x_sfc0)
+    x[:, :, 2] = 1 - torch.exp(-x[:, :, 2] * P["lbd_qc"])
+    x[:, :, 3] = 1 - torch.exp(-x[:, :, 3] * P["lbd_qi"])
+    x = (x - P["xmean_lev"]) / P["xdiv_lev"]
+    xs = (xs - P["xmean_sca"]) / P["xdiv_sca"]
+    x = torch.where(torch.isnan(x), torch.zeros_like(x), x)
+    x = torch.where(torch.isinf(x), torch.zeros_like(x), x)
+    return x_main00, x, xs
+
+
+def wrapper_post(P, out_new, out_sfc, x_main00):
+    """de-normalise + mp constraint (models.py:273-339 with mp_mode 1) + NaN scrub -> (B,60,6), (B,8)"""
+    o = out_new / P["yscale_lev"]
+    os_ = out_sfc / P["yscale_sca"]
+    T_old, ql, qi = x_main00[:, :, 0:1], x_main00[:, :, 2:3], x_main00[:, :, 3:4]
+    T_new = T_old + o[:, :, 0:1] * 1200
+    lf = F.hardtanh((T_new - 253.16) * 0.05, 0.0, 1.0)
+    qn_new = (ql + qi) + o[:, :, 2:3] * 1200
+    dql = (lf * qn_new - ql) * 0.00083333333333333339
+    dqi = ((1 - lf) * qn_new - qi) * 0.00083333333333333339
+    y = torch.cat([o[:, :, 0:2], dql, dqi, o[:, :, 3:]], 2)
+    return torch.where(torch.isnan(y), torch.zeros_like(y), y), os_
+
+
+def cloud_optics(re, rows, lo, hi, idx):
+    y = torch.tensor(rows, dtype=re.dtype)[:, idx]
+    r = re.clamp(lo, hi)
+    return y[0] + y[1] / r, (1.0 - y[2] - r * y[3]).clamp(max=0.999999), y[4] + r * y[5]
+
+
+def gas_mlp(P, name, x):
+    h = F.softsign(_lin(P, name + ".mlp1", x))
+    h = F.softsign(_lin(P, name + ".mlp2", h))
+    return _lin(P, name + ".mlp3", h)
+
+
+def radiation(P, FL, aux, xd, play, plev, delta_plev, dec, T_new, qv_rad, mask_u, ilev_crm=10, taps=None):
+    """All arrays batch-first: xd (B,60,21) raw inputs, play / delta_plev (B,60,1), plev (B,61,1), dec = decoder state, T_new
+    (B,60,1) updated temperature, qv_rad (B,60,1) the humidity radiation sees, mask_u (B,60,ng) uniform draws.
+    -> dT_rad (B,60) scaled by yscale_lev[:,0], out_sfc_rad (B,6) scaled."""
+    B, nlev, _ = xd.shape
+    ng = P["gas_optics_lw_reduce1.weight"].shape[0]
+    area_frac, qn_crm, qv_crm, liq = dec["area_frac"], dec["qn_crm"], dec["qv_crm"], dec["liq_frac"]
+    vmr = qv_rad / (1.0 - qv_rad) * 1.608079364
+    fact = 1.0 / (1.0 + vmr)
+    m_air = (vmr + 0.04698) * fact
+    col_dry = (delta_plev * 10.0 * 6.02214076e23 * fact) / (m_air * 1000.0 * 100.0 * 9.80665)
+    o3 = xd[:, :, 12:13].sqrt().sqrt()
+    co2 = torch.full_like(T_new, 0.0003887)
+    T_low = T_new[:, ilev_crm:]
+    rei = reitab(T_low)
+    rel = reltab(T_low, aux[:, 13].view(B, 1, 1), aux[:, 12].view(B, 1, 1), aux[:, 15].view(B, 1, 1))
+    cwp = delta_plev[:, ilev_crm:] / G * 1000 * qn_crm                                        # (B,50,ng)
+    cwp_liq, cwp_ice = liq * cwp, (1.0 - liq) * cwp
+    # ---- LW gas + cloud optics -----------------------------------------------------------------------------------------------
+    xg = torch.cat([T_new, torch.log(play), vmr.sqrt().sqrt(), o3, co2, xd[:, :, 13:15], T_new.new_zeros(B, nlev, 11)], 2)
+    xg = torch.relu((xg - P["gas_optics_model_lw.xmin"]) / P["gas_optics_model_lw.xdiv"])
+    h = gas_mlp(P, "gas_optics_model_lw", xg)
+    nk = h.shape[2] // 2
+    tau_k = col_dry * pow8(P["gas_optics_model_lw.ystd"] * h[:, :, :nk] + P["gas_optics_model_lw.ymean"])
+    pfrac = torch.softmax(_lin(P, "gas_optics_lw_reduce2", h[:, :, nk:] ** 2), 2)
+    tau_lw = F.softplus(_lin(P, "gas_optics_lw_reduce1", tau_k)) * 0.01
+    ifr = cwp_ice / cwp.clamp(min=1e-8)
+    tau_cld = cwp * 0.090361 * (1.0 - ifr) + cwp * ifr * (1.0 / rei.clamp(13.0, 130.0) + 0.005)
+    pad = lambda t: torch.cat([t.new_zeros(B, ilev_crm, ng), t], 1)
+    tau_lw = tau_lw + pad(tau_cld)
+    # ---- LW sources + no-scattering solver (own downward source) ---------------------------------------------------------
+    tl, pl, ph = T_new.squeeze(2), play.squeeze(2), plev.squeeze(2)
+    tlev = torch.empty(B, nlev + 1, dtype=tl.dtype)
+    tlev[:, 0] = tl[:, 0] + (ph[:, 0] - pl[:, 0]) * (tl[:, 1] - tl[:, 0]) / (pl[:, 1] - pl[:, 0])
+    tlev[:, 1:nlev] = (pl[:, :-1] * tl[:, :-1] * (ph[:, 1:nlev] - pl[:, 1:]) + pl[:, 1:] * tl[:, 1:] * (pl[:, :-1] - ph[:, 1:nlev])) \
+        / (ph[:, 1:nlev] * (pl[:, :-1] - pl[:, 1:]))
+    tlev[:, nlev] = tl[:, -1] + (ph[:, nlev] - pl[:, -1]) * (tl[:, -1] - tl[:, -2]) / (pl[:, -1] - pl[:, -2])
+    blev = (tlev ** 4 * SIGMA).unsqueeze(2)
+    src_lev = torch.cat([pfrac * blev[:, :-1], pfrac[:, -1:] * blev[:, -1:]], 1)
+    src_sfc = pfrac[:, -1] * aux[:, 11:12]
+    od = tau_lw * 1.66
+    tr = torch.exp(-od)
+    c = od * 0.2
+    bmean = (src_lev[:, :-1] + src_lev[:, 1:]) * 0.5
+    s_up = (1.0 - tr) * (bmean + c * src_lev[:, :-1]) / (c + 1.0)
+    s_dn = (1.0 - tr) * (bmean + c * src_lev[:, 1:]) / (c + 1.0)
+    dn = [torch.zeros(B, ng, dtype=tr.dtype)]
+    for j in range(nlev):
+        dn.append(tr[:, j] * dn[-1] + s_dn[:, j])
+    up = [None] * (nlev + 1)
+    up[nlev] = src_sfc                                                                        # emissivity 1
+    for j in range(nlev - 1, -1, -1):
+        up[j] = tr[:, j] * up[j + 1] + s_up[:, j]
+    lw_dn, lw_up = torch.stack(dn, 1).sum(2), torch.stack(up, 1).sum(2)
+    # ---- SW gas optics on the humidity of the two largest regions ------------------------------------------------------------
+    qc = qv_crm.clamp(max=0.05)
+    vmr_c = qc / (1.0 - qc) * 1.608079364
+    v12 = torch.gather(vmr_c, 2, torch.topk(area_frac, 2, dim=2).indices)
+    v_top = vmr.sqrt().sqrt()[:, :ilev_crm]                         # as serialised: the levels above the CRM carry the FOURTH ROOT here
+    xmin, xdiv = P["gas_optics_model_sw1.xmin"], P["gas_optics_model_sw1.xdiv"]
+    taus = []
+    for j in range(2):
+        v = torch.cat([v_top, v12[:, :, j:j + 1]], 1)
+        f = 1.0 / (v + 1.0)
+        col = (delta_plev * 6.02214076e24 * f) / ((v + 0.04698) * f * 980665)
+        x = torch.cat([T_new, torch.log(play), v.sqrt().sqrt(), o3, co2, xd[:, :, 14:15], xd[:, :, 13:14]], 2)
+        x = (x - xmin) / xdiv
+        taus.append((col * pow8(gas_mlp(P, "gas_optics_model_sw1", x)) * 1e-17, col * pow8(gas_mlp(P, "gas_optics_model_sw2", x)) * 1e-17))
+    pick = mask_u < 0.5
+    tau_abs = torch.where(pick, taus[0][0], taus[1][0]).clamp(min=1e-9)
+    tau_sca = torch.where(pick, taus[0][1], taus[1][1])
+    # Slingo / Ebert-Curry band of every g-point (`band_to_gpt`: bucketize of the band limits, repeat_interleave) and the split of
+    # the g-points into near-infrared / mixed / visible (surface albedo, SOLL / SOLS): data of the variant
+    idx, n_ir, n_mx = list(FL["band_idx"]), FL["n_ir"], FL["n_mix_end"]
+    kl, wl, gl = cloud_optics(rel, SLINGO, 4.2, 16.0, idx)
+    ki, wi, gi = cloud_optics(rel, EBERT_CURRY, 13.0, 130.0, idx)                             # (the LIQUID radius: as serialised)
+    c_tau = pad(cwp_ice * ki + cwp_liq * kl)
+    c_sca0 = cwp_liq * (kl * wl) + cwp_ice * (ki * wi)
+    c_asy = pad((cwp_liq * (kl * wl * gl) + cwp_ice * (ki * wi * gi)) / (c_sca0 + 1e-7))
+    c_sca = pad(c_sca0)
+    tau_sw = (tau_abs + tau_sca) + c_tau
+    sca = (tau_sca + c_sca).clamp(min=1e-9)
+    asy = c_asy * c_sca / sca
+    ssa = sca / tau_sw
+    mu0 = aux[:, 6].clamp(min=1e-6).view(B, 1, 1).expand(B, nlev, ng)
+    R, T, Rdir, Tdd, Tdir = two_stream_sw(mu0, tau_sw, ssa, asy)
+    toa = aux[:, 1:2] * P["solar_weights"].view(1, -1)
+    wn, wv = (P["mix_near"], P["mix_vis"]) if "mix_near" in P else (torch.tensor([0.5]), torch.tensor([0.5]))
+    band = lambda near, vis: torch.cat([near.expand(B, n_ir), (wn * near + wv * vis).expand(B, n_mx - n_ir), vis.expand(B, ng - n_mx)], 1)
+    alb_dif, alb_dir = band(aux[:, 7:8], aux[:, 9:10]), band(aux[:, 8:9], aux[:, 10:11])
+    sw_up, sw_dif, sw_dir = adding_sw(toa, alb_dif, alb_dir, R, T, Rdir, Tdd, Tdir)
+
+    def split(f):
+        mix = f[:, n_ir:n_mx].sum(1, keepdim=True)
+        return f[:, :n_ir].sum(1, keepdim=True) + wn * mix, f[:, n_mx:].sum(1, keepdim=True) + wv * mix
+    SOLL, SOLS = split(sw_dir[:, -1])
+    SOLLD, SOLSD = split(sw_dif[:, -1])
+    sw_net = (sw_dif.sum(2) + sw_dir.sum(2)) - sw_up.sum(2)
+    day = (~(aux[:, 6] < 1e-6)).to(sw_net.dtype).view(B, 1)
+    sw_net, SOLL, SOLS, SOLLD, SOLSD = (v * day for v in (sw_net, SOLL, SOLS, SOLLD, SOLSD))
+    net = (lw_dn - lw_up) + sw_net
+    dT = -((net[:, 1:] - net[:, :-1]) / delta_plev.squeeze(2)) * 0.009761357302 * P["yscale_lev"][:, 0].view(1, -1)
+    out_sfc_rad = torch.cat([sw_net[:, -1:], lw_dn[:, -1:], SOLS, SOLL, SOLSD, SOLLD], 1) * P["yscale_sca_rad"]
+    if taps is not None:
+        taps.update(tau_lw=tau_lw, pfrac=pfrac, lw_dn=lw_dn, lw_up=lw_up, tau_sw=tau_sw, ssa=ssa, asy=asy, sw_net=sw_net)
+    return dT, out_sfc_rad
+
+
+def forward(P, FL, x_main0, x_sfc0, rnn1_mem, hx2, mask_u, hx1=None, eps3=None, srnn=None, ilev_crm=10, taps=None):
+    """x_main0 (B,60,20), x_sfc0 (B,19), rnn1_mem (50,B,16); hx2 (B,nh): rnn2's initial state; mask_u (60,B,ng) uniform draws of the
+    SW humidity coin; hx1 (B,nh), eps3 (50,B,nh): the stochastic third RNN's draws (variants with `rnn3`).
+    srnn (50,B,nh), if given, replaces the third RNN's output.
+    -> out_lev (B,60,6), out_sfc (B,8), rnn1_mem (50,B,16), as the export returns them."""
+    x_main00, xn, xsn = wrapper_pre(P, x_main0, x_sfc0)
+    B, nlev, _ = xn.shape
+    mp_ncol = P["mlp_qv_crm.weight"].shape[0]
+    nh_mem0 = P["mlp_latent.weight"].shape[0]
+    mem = rnn1_mem.transpose(0, 1)                                                            # (B,50,16)
+    hyam, hybm, hyai, hybi = (P[k].reshape(1, -1, 1) for k in ("hyam", "hybm", "hyai", "hybi"))
+    P_old = mem[:, -1, -1]
+    sp = xsn[:, 0:1].unsqueeze(1) * P["xdiv_sca"][0:1] + P["xmean_sca"][0:1]
+    play = hyam * 100000.0 + sp * hybm
+    plev = sp * hybi + hyai * 100000.0
+    delta_plev = sp * (hybi[:, 1:] - hybi[:, :-1]) + (hyai[:, 1:] - hyai[:, :-1]) * 100000.0
+    main0 = torch.cat([xn, torch.sqrt(play) / 314.0], 2)                                      # (B,60,22)
+    xin = torch.cat([main0[:, ilev_crm:, :-4], main0[:, ilev_crm:, -1:]], 2)                  # (B,50,19)
+    x = torch.tanh(_lin(P, "mlp_initial", xin))
+    rnn1_in = torch.flip(torch.cat([x, mem[:, :, :nh_mem0]], 2), [1])
+    hx = torch.tanh(_lin(P, "mlp_surface1", torch.cat([xsn[:, 0:6], xsn[:, 11:]], 1)))
+    rnn1out, _ = _gru(rnn1_in, hx, P["rnn1.weight_ih_l0"], P["rnn1.weight_hh_l0"], P["rnn1.bias_ih_l0"], P["rnn1.bias_hh_l0"])
+    rnn1out = torch.flip(rnn1out, [1])
+    rnn2out, last_h = _gru(rnn1out, hx2, P["rnn2.weight_ih_l0"], P["rnn2.weight_hh_l0"], P["rnn2.bias_ih_l0"], P["rnn2.bias_hh_l0"])
+    if taps is not None:
+        taps["rnn2raw"] = rnn2out
+    if "rnn3.weight_ih" in P:
+        if srnn is None:        # (srnn given: teacher forcing with the export's own third-RNN output, see tests/test_physrnn_frozen.py)
+            srnn = stochastic_gru(rnn2out.transpose(0, 1), hx1, eps3, P["rnn3.weight_ih"], P["rnn3.weight_zh"], P["rnn3.weight_encoder"])
+        if taps is not None:
+            taps["srnn"] = srnn
+        last_h = srnn[-1]
+        rnn2out = rnn2out * srnn.transpose(0, 1)
+    mem_new = _lin(P, "mlp_latent", rnn2out)
+    out = _lin(P, "mlp_output", mem_new)
+    dec = microphysics_decode(P, out, mem_new, rnn2out, last_h, x_main00, delta_plev, play, P_old, ilev_crm, mp_ncol,
+                              copy_dT=False, clear_sky=False, nx21=True)
+    out_new = dec["out_new"]
+    ys = P["yscale_lev"]
+    T_new = torch.relu(x_main00[:, :, 0:1] + out_new[:, :, 0:1] / ys[:, 0:1] * 1200)
+    qv = x_main00[:, :, -1:]
+    if FL["rad_updated_qv"]:
+        qv = torch.relu(qv + out_new[:, :, 1:2] / ys[:, 1:2] * 1200)
+    aux = xsn * P["xdiv_sca"] + P["xmean_sca"]
+    dT_rad, sfc_rad = radiation(P, FL, aux, x_main00, play, plev, delta_plev, dec, T_new, qv, mask_u.transpose(0, 1), ilev_crm, taps)
+    if taps is not None:
+        taps.update(out_mp=out_new.clone(), rnn2out=rnn2out)
+    out_new[:, :, 0] = out_new[:, :, 0] + dT_rad
+    out_sfc = torch.cat([sfc_rad[:, 0:2], dec["precsc"], dec["precc"], sfc_rad[:, 2:]], 1)
+    out_lev, out_sfc_d = wrapper_post(P, out_new, out_sfc, x_main00)
+    return out_lev, out_sfc_d, dec["mem_out"].transpose(0, 1).contiguous()

@@ -69,13 +69,17 @@ def forward(P, inputs_main, inputs_aux, rnn_mem, inputs_denorm, hx2, ilev_crm=10
 
 
 def microphysics_decode(P, out, mem_new, r2, last_h, inputs_denorm, delta_plev, play, P_old, ilev_crm, mp_ncol, copy_dT=True,
-                        clear_sky=False):
+                        clear_sky=False, nx21=False):
     """rnn/models/models_phys.py:414-748.  copy_dT: the nx = 21 graphs also pass the decoder's raw column-0 output of the
     levels below ilev_crm + 2 through to out_new; the radiation graphs (oracle/physrnn_rad_ref.py) do not.
     clear_sky (the physRNN_physRad-* graphs, `use_clear_sky_region`, no sub-grid temperature): region 0 holds no condensate
     (mlp_qn_crm / mlp_evap_cond_vapor_crm have mp_ncol - 1 outputs, a zero is prepended), temperature and eddy heat flux are
     those of the grid column (mlp_eddy_diff has one output, no mlp_t_crm), and the latent heating is formed from the
     area-summed condensation / evaporation.
+    nx21 (the generation of the frozen `*_wrapped` exports, oracle/physrnn_frozen_ref.py): the eddy heat flux is defined at layer
+    tops like the moisture fluxes (zero at the surface, where the Hidden graphs take -relu of it), and the cloud liquid fraction
+    is PER REGION -- the ramp on the region's own temperature after the flux divergence, or the learned `mlp_liq_frac_crm` head
+    -- both in the latent heating and, returned as `liq_frac`, in the radiation scheme's cloud water paths.
     -> dict with out_new, precc, precsc, mem_out and the updated sub-column state (T_crm, qv_crm, qn_crm, area_frac)."""
     B, nlev = inputs_denorm.shape[0], inputs_denorm.shape[1]
     x = out
@@ -108,8 +112,11 @@ def microphysics_decode(P, out, mem_new, r2, last_h, inputs_denorm, delta_plev, 
     zer = x.new_zeros(B, 1, mp_ncol)
     play_diff = play[:, ilev_crm:] - play[:, ilev_crm - 1:-1]
     fH = (eddy * (CP / G)) * T_crm * play_diff
-    fH = torch.cat([fH[:, :-1], -torch.relu(fH[:, -1:])], 1)
-    fH = torch.cat([zer[:, :, :fH.shape[2]], fH], 1)
+    if nx21:
+        fH = torch.cat([zer[:, :, :fH.shape[2]], fH[:, :-1], zer[:, :, :fH.shape[2]]], 1)
+    else:
+        fH = torch.cat([fH[:, :-1], -torch.relu(fH[:, -1:])], 1)
+        fH = torch.cat([zer[:, :, :fH.shape[2]], fH], 1)
     flux_t_dp = (fH[:, 1:] - fH[:, :-1]) / pres_diff * (-G / CP)
     f_qv = flux1 * 300000.0 * qv_crm
     f_qn = flux1 * 300000.0 * qn_crm
@@ -142,6 +149,12 @@ def microphysics_decode(P, out, mem_new, r2, last_h, inputs_denorm, delta_plev, 
         liq = F.hardtanh((temp - 253.16) * 0.05, 0.0, 1.0).unsqueeze(2)
         cond_s, evap_s = (area_frac * cond).sum(2, keepdim=True), (area_frac * evap_prec).sum(2, keepdim=True)
         net_cond = ((liq * LV + (1 - liq) * LS) * cond_s - evap_s * LV) * (1 / CP)
+    elif nx21:
+        if "mlp_liq_frac_crm.weight" in P:
+            liq = torch.sigmoid(_lin(P, "mlp_liq_frac_crm", r2))
+        else:
+            liq = F.hardtanh((T_crm + (flux_t_dp / ys0) * 1200 - 253.16) * 0.05, 0.0, 1.0)                  # (B,50,nreg)
+        net_cond = ((liq * LV + (1 - liq) * LS) * cond - evap_prec * LV) * 0.00099538143016403898
     else:
         temp = T_gcm.squeeze(2) + ((area_frac * flux_t_dp).sum(2) / ys[:, 0]) * 1200
         liq = F.hardtanh((temp - 253.16) * 0.05, 0.0, 1.0).unsqueeze(2)
@@ -165,6 +178,6 @@ def microphysics_decode(P, out, mem_new, r2, last_h, inputs_denorm, delta_plev, 
     snowfrac = F.hardtanh((-inputs_denorm[:, -1, 0:1] + 283.3) / 14.6, 0.0, 1.0)
     precsc = snowfrac * precc
     ys_ = lambda k: ys[:, k:k + 1]
-    return dict(out_new=out_new, precc=precc, precsc=precsc, mem_out=mem_out, area_frac=area_frac,
+    return dict(out_new=out_new, precc=precc, precsc=precsc, mem_out=mem_out, area_frac=area_frac, liq_frac=liq,
                 T_crm=torch.relu(T_crm + dT_crm * 1200 / ys_(0)), qv_crm=torch.relu(qv_crm + dqv_crm * 1200 / ys_(1)),
                 qn_crm=torch.relu(qn_crm + dqn_crm * 1200 / ys_(2)))
