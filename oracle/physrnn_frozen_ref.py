@@ -249,7 +249,7 @@ def forward(P, FL, x_main0, x_sfc0, rnn1_mem, hx2, mask_u, hx1=None, eps3=None, 
     aux = xsn * P["xdiv_sca"] + P["xmean_sca"]
     dT_rad, sfc_rad = radiation(P, FL, aux, x_main00, play, plev, delta_plev, dec, T_new, qv, mask_u.transpose(0, 1), ilev_crm, taps)
     if taps is not None:
-        taps.update(out_mp=out_new.clone(), rnn2out=rnn2out)
+        taps.update(out_mp=out_new.clone(), rnn2out=rnn2out, area_frac=dec["area_frac"])
     out_new[:, :, 0] = out_new[:, :, 0] + dT_rad
     out_sfc = torch.cat([sfc_rad[:, 0:2], dec["precsc"], dec["precc"], sfc_rad[:, 2:]], 1)
     out_lev, out_sfc_d = wrapper_post(P, out_new, out_sfc, x_main00)
