@@ -45,7 +45,7 @@ SYMBOLS = ["csa_create", "csa_destroy", "csa_set_params", "csa_packed_width", "c
            "csa_gen_create", "csa_gen_destroy", "csa_gen_dims", "csa_gen_batch",
            "csa_crps", "csa_crps_backward", "csa_spread_skill",
            "csa_eval_scratch_bytes", "csa_eval_metrics", "csa_eval_crps", "csa_derive_inputs",
-           "csa_phys_create", "csa_phys_destroy", "csa_phys_forward", "csa_phys_tap", "csa_phys_rad_create", "csa_phys_postprocess", "csa_phys_forward_noise", "csa_phys_debug_forward_srnn", "csa_phys_debug_rnn3",
+           "csa_phys_create", "csa_phys_destroy", "csa_phys_forward", "csa_phys_tap", "csa_phys_rad_create", "csa_phys_postprocess", "csa_phys_forward_noise", "csa_phys_debug_forward_srnn", "csa_phys_debug_rnn3", "csa_phys_wrapped_create", "csa_phys_wrapped_forward",
            "csa_online_create", "csa_online_destroy", "csa_online_dims", "csa_online_forward",
            "csa_stoch_gru5_create", "csa_stoch_lstm4_create", "csa_stoch_destroy", "csa_stoch_gru5_forward",
            "csa_stoch_lstm4_forward", "csa_stoch_enable_training", "csa_stoch_num_params", "csa_stoch_gru5_forward_train",
@@ -191,6 +191,8 @@ def lib():
     L.csa_phys_debug_forward_srnn.argtypes = [H, i, _F, _F, _F, _F, i, _F, _F, _F, _F, _F, ctypes.c_void_p]
     L.csa_phys_debug_rnn3.argtypes = [H, i, i, _F, _F, _F, _F, ctypes.c_void_p]
     L.csa_phys_destroy.argtypes = [H]
+    L.csa_phys_wrapped_create.argtypes = [i, i, i, PP, i, ctypes.POINTER(H)]
+    L.csa_phys_wrapped_forward.argtypes = [H, i] + [_F] * 11 + [ctypes.c_void_p]
     L.csa_phys_forward.argtypes = [H, i, _F, _F, _F, _F, i, _F, _F, _F, _F, ctypes.c_void_p]
     L.csa_phys_tap.argtypes = [H, i, i, _F, ctypes.c_void_p]
     L.csa_phys_postprocess.argtypes = [H, i, _F, _F, _F, i, _F, _F, ctypes.c_void_p]

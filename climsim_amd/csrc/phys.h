@@ -35,7 +35,28 @@ struct PhysDev {
     // physics_rad_e3sm generation (num94634): SW optical properties from two gas-optics MLPs + Slingo / Ebert-Curry cloud optics
     const float *swg;       // the packed block of include/climsim_amd.h (CSA_PHYS_SW_GAS), or null: SW head MLP
     const float *cld_sw_w, *cld_sw_b;   // learned SW cloud optics (48, 19), (48): cloud_optics_sw2 o cloud_optics_sw composed (num88741), or null
+    // the "nx21" generation of the frozen `*_wrapped` exports (csa_phys_wrapped_create):
+    int memlm;              // rnn_mem level-major (50, B, 16) in and out (physrad graphs and nx21)
+    int nx21;               // decoder: eddy heat flux zero at the surface, per-region liquid fraction shared with the cloud optics; radiation:
+                            // vapour mixing ratio q / (1 - q), 7-32-32-16 SW gas optics with the humidity coin (swg = the SWX_* block), ice SW
+                            // optics on the LIQUID radius (as serialised), no relu on the SW fluxes, NET shortwave as first surface output
+    int rad_qv_upd;         // 1: radiation reads the updated grid-mean q_v, 0: the un-updated one
+    int n_ir, n_mix;        // g-points [0, n_ir) near-infrared, [n_ir, n_mix) mixed, the rest visible (surface albedo, SOLL / SOLS split)
+    float mix_near, mix_vis;   // weights of the mixed g-points (learned in most variants; 0.5 / 0.5 otherwise and in the older graphs)
+    const float *cldtab;    // (12, 16): Slingo A..F then Ebert-Curry a..f per g-point
 };
+
+// layout of the nx21 SW gas-optics block (floats): input range (same offsets as SWG_XMIN / SWG_XDIV), then per model (absorption,
+// Rayleigh) W1 (32, 8: 7 inputs, zero-padded), b1, W2 (32, 32), b2, W3 (16, 32: ng rows, zero-padded), b3
+#define SWX_MODEL0 16
+#define SWX_W1 0
+#define SWX_B1 (SWX_W1 + 32 * 8)
+#define SWX_W2 (SWX_B1 + 32)
+#define SWX_B2 (SWX_W2 + 32 * 32)
+#define SWX_W3 (SWX_B2 + 32)
+#define SWX_B3 (SWX_W3 + 16 * 32)
+#define SWX_MODEL_FLOATS (SWX_B3 + 16)
+#define SWX_FLOATS (SWX_MODEL0 + 2 * SWX_MODEL_FLOATS)
 
 // layout of the CSA_PHYS_SW_GAS block (floats): input range, two gas-optics models, the two 112 -> 16 reductions, cloud-optics
 // coefficients per g-point.  The 112-wide axis is zero-padded to 128 (four 32-column MFMA tiles; a padded k-point has
@@ -75,6 +96,10 @@ struct csa_phys {
     // add_stochastic_layer graphs: rnn3 (MyStochasticGRULayer5 over rnn2's output), its output and the perturbed sequence
     struct csa_stoch *rnn3 = nullptr;
     float *H3 = nullptr, *H2p = nullptr;
+    // frozen `*_wrapped` exports: the wrapper's constants (rnn/utils.py:182-217) and the buffers between its two passes and the model
+    int ng = PH_NG;         // g-points of the export (= nreg: 12 / 14 / 16; the kernels run 16 with zero-weight padding)
+    float *wr_xmean = nullptr, *wr_xdiv = nullptr, *wr_lqc = nullptr, *wr_lqi = nullptr;
+    float *XM = nullptr, *XS = nullptr, *XD = nullptr, *O5 = nullptr, *OS = nullptr;
     std::vector<void *> owned;
 };
 
@@ -82,4 +107,4 @@ struct csa_phys {
 #define PH_XR_K 24
 
 // phys_rad.hip
-int launch_phys_radiation(csa_phys *h, int B, const float *x_sfc, float *out_lev, float *out_sfc, hipStream_t s);
+int launch_phys_radiation(csa_phys *h, int B, const float *x_sfc, float *out_lev, float *out_sfc, hipStream_t s, const float *mask_u = nullptr);

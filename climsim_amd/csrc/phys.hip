@@ -40,7 +40,7 @@ template <int N> __device__ __forceinline__ float ph_max(float v)
 // row of (column b, CRM level l) in rnn_mem / mem_out: (B, 50, 16), or level-major (50, B, 16) for the physRad graphs
 __device__ __forceinline__ size_t ph_mem_row(const PhysDev &d, int B, int b, int l)
 {
-    return d.physrad ? (size_t)l * B + b : (size_t)b * d.Lc + l;
+    return d.memlm ? (size_t)l * B + b : (size_t)b * d.Lc + l;
 }
 
 // one workgroup (128 threads = nh) per grid column: thread j owns hidden unit j of mlp_initial / mlp_surface1
@@ -134,6 +134,7 @@ __global__ __launch_bounds__(DT) void phys_decode_kernel(PhysDev d, int B, const
     __shared__ float s_out[LC][5], s_pv[LC], s_pd[LC], s_dprec[LC], s_red[8];
     __shared__ float s_area[LC * NC], s_qv[LC * NC], s_qn[LC * NC], s_fH[LC * NC], s_fqv[LC * NC], s_fqn[LC * NC], s_sed[LC * NC];
     __shared__ float s_T[LC * NC];                    // sub-column temperature (RAD: overwritten with its updated value)
+    __shared__ float s_liq[RAD ? LC * NC : 1];        // nx21: the region's cloud liquid fraction (latent heating AND cloud optics)
     __shared__ float s_o01[PH_L][2];                  // RAD: the decoder's dT, dqv of every level (zero above the CRM top)
     __shared__ float s_scal[16];
     constexpr int nm0 = 15;                           // enforced by csa_phys_create: compile-time trip counts (see phys_prep_kernel)
@@ -201,7 +202,7 @@ __global__ __launch_bounds__(DT) void phys_decode_kernel(PhysDev d, int B, const
         const float T_crm = xd[0] + (dT - ph_sum<NC>(dT * area));
         const float play = d.hyam[L] * 100000.0f + sp * d.hybm[L], play_up = d.hyam[L - 1] * 100000.0f + sp * d.hybm[L - 1];
         float fH = hd[H_EDDY * NC] * (CP / G) * T_crm * (play - play_up);
-        if (l == LC - 1) fH = -fmaxf(fH, 0.0f);
+        if (l == LC - 1 && !d.nx21) fH = -fmaxf(fH, 0.0f);     // (nx21: defined at layer tops like the moisture fluxes, zero at the surface)
         const float flux1 = hd[H_FLUX * NC] * 300000.0f;
         if (ok) {
             s_area[e] = area; s_qv[e] = qv; s_qn[e] = qn; s_fH[e] = fH; s_T[e] = T_crm;
@@ -220,7 +221,7 @@ __global__ __launch_bounds__(DT) void phys_decode_kernel(PhysDev d, int B, const
         const float *ys = d.yscale_lev + L * 5;
         const float pd = s_pd[lc], area = s_area[ec], qv = s_qv[ec], qn = s_qn[ec];
         const bool up = lc > 0, last = lc == LC - 1;
-        const float flux_t_dp = (s_fH[ec] - (up ? s_fH[ec - NC] : 0.0f)) / pd * (-G / CP);
+        const float flux_t_dp = ((last && d.nx21 ? 0.0f : s_fH[ec]) - (up ? s_fH[ec - NC] : 0.0f)) / pd * (-G / CP);
         const float flux_qv_dp = ((last ? 0.0f : s_fqv[ec]) - (up ? s_fqv[ec - NC] : 0.0f)) / pd * (-G);
         const float flux_qn_dp = ((last ? 0.0f : s_fqn[ec]) - (up ? s_fqn[ec - NC] : 0.0f)) / pd * (-G);
         const float sed_qn_dp = (s_sed[ec] - (up ? s_sed[ec - NC] : 0.0f)) / pd * (-G);
@@ -236,7 +237,12 @@ __global__ __launch_bounds__(DT) void phys_decode_kernel(PhysDev d, int B, const
         // physRad graphs: one temperature per level (flux_t_dp is the same in every region) and latent heating from the
         // area-summed rates; otherwise per sub-column
         const float temp = xd[0] + ((d.physrad ? flux_t_dp : ph_sum<NC>(area * flux_t_dp)) / ys[0]) * 1200.0f;
-        const float liq = fminf(fmaxf((temp - 253.16f) * 0.05f, 0.0f), 1.0f);
+        float liq = fminf(fmaxf((temp - 253.16f) * 0.05f, 0.0f), 1.0f);
+        if (RAD && d.nx21) {   // per region: the ramp on the region's own temperature after the flux divergence, or the learned head
+            liq = d.liq_off >= 0 ? 1.0f / (1.0f + expf(-HD[((size_t)(L - d.ltop) * B + b) * HDW + d.liq_off + c]))
+                                 : fminf(fmaxf(((s_T[ec] + (flux_t_dp / ys[0]) * 1200.0f) - 253.16f) * 0.05f, 0.0f), 1.0f);
+            if (ok) s_liq[e] = liq;
+        }
         const float cond_h = d.physrad ? ph_sum<NC>(area * cond) : cond, evap_h = d.physrad ? ph_sum<NC>(area * evap) : evap;
         const float net = ((liq * LV + (1.0f - liq) * LS) * cond_h - evap_h * LV) * (1.0f / CP);
         const float dT_crm = flux_t_dp + net / ys[1] * ys[0];
@@ -309,8 +315,8 @@ __global__ __launch_bounds__(DT) void phys_decode_kernel(PhysDev d, int B, const
             const float *xd = x_denorm + ((size_t)b * PH_L + L) * nxd;
             const float *ys = d.yscale_lev + L * 5;
             const float T_new = fmaxf(xd[0] + s_o01[L][0] / ys[0] * 1200.0f, 0.0f);
-            const float qv_new = fmaxf(xd[nxd - 1] + s_o01[L][1] / ys[1] * 1200.0f, 0.0f);
-            const float vmr = (d.physrad ? qv_new / (1.0f - qv_new) : qv_new) * 1.608079364f, fact = 1.0f / (1.0f + vmr), m_air = (vmr + 0.04698f) * fact;
+            const float qv_new = d.nx21 && !d.rad_qv_upd ? xd[nxd - 1] : fmaxf(xd[nxd - 1] + s_o01[L][1] / ys[1] * 1200.0f, 0.0f);
+            const float vmr = (d.physrad || d.nx21 ? qv_new / (1.0f - qv_new) : qv_new) * 1.608079364f, fact = 1.0f / (1.0f + vmr), m_air = (vmr + 0.04698f) * fact;
             const float pd = sp * (d.hybi[L + 1] - d.hybi[L]) + (d.hyai[L + 1] - d.hyai[L]) * 100000.0f;
             const float col_dry = (pd * 10.0f * 6.02214076e23f * fact) / (m_air * 1000.0f * 100.0f * 9.80665f);
             const float play = d.hyam[L] * 100000.0f + sp * d.hybm[L], lp = logf(play), v4 = sqrtf(sqrtf(vmr));
@@ -410,6 +416,7 @@ __global__ __launch_bounds__(DT) void phys_decode_kernel(PhysDev d, int B, const
                                                                                       //  un-shifted, as the serialised graph gathers it)
             float liq = fminf(fmaxf((T_g - 253.16f) * 0.05f, 0.0f), 1.0f);
             if (d.liq_off >= 0) liq = 1.0f / (1.0f + expf(-HD[((size_t)(L - d.ltop) * B + b) * HDW + d.liq_off + sub]));
+            if (d.nx21) liq = s_liq[l * NC + sub];
             const float cwp = s_pd[l] / G * qn_g * 1000.0f, cwp_ice = (1.0f - liq) * cwp;
             const float ifr = cwp_ice / fmaxf(cwp, 1e-8f);
             const float *xd = x_denorm + ((size_t)b * PH_L + L) * nxd;
@@ -454,11 +461,13 @@ __global__ __launch_bounds__(DT) void phys_decode_kernel(PhysDev d, int B, const
                 cs[16] = c_tau / (1.0f + expf(-o3[1]));
                 cs[32] = 1.0f / (1.0f + expf(-o3[2]));
             } else if (d.swg) {     // Slingo liquid / Ebert-Curry ice SW optics of region g (physics_rad_e3sm.py:98, :265)
-                const float *aux = x_sfc + (size_t)b * d.naux, *t = d.swg + SWG_CLD + g;
-                const float rl = fminf(fmaxf(ph_reltab(T_new, aux[13] * d.xdiv_sca[13] + d.xmean_sca[13], aux[12] * d.xdiv_sca[12] + d.xmean_sca[12],
-                                                       aux[15] * d.xdiv_sca[15] + d.xmean_sca[15]), 4.2f), 16.0f);
+                const float *aux = x_sfc + (size_t)b * d.naux, *t = (d.nx21 ? d.cldtab : d.swg + SWG_CLD) + g;
+                const float rl0 = ph_reltab(T_new, aux[13] * d.xdiv_sca[13] + d.xmean_sca[13], aux[12] * d.xdiv_sca[12] + d.xmean_sca[12],
+                                            aux[15] * d.xdiv_sca[15] + d.xmean_sca[15]);
+                const float rl = fminf(fmaxf(rl0, 4.2f), 16.0f);
+                const float ri = d.nx21 ? fminf(fmaxf(rl0, 13.0f), 130.0f) : rei;     // nx21: the ice optics see the LIQUID radius, as serialised
                 const float kl = t[0] + t[16] / rl, wl = fminf((1.0f - t[32]) - rl * t[48], 0.999999f), gl = t[64] + rl * t[80];
-                const float ki = t[96] + t[112] / rei, wi = fminf((1.0f - t[128]) - rei * t[144], 0.999999f), gi = t[160] + rei * t[176];
+                const float ki = t[96] + t[112] / ri, wi = fminf((1.0f - t[128]) - ri * t[144], 0.999999f), gi = t[160] + ri * t[176];
                 const float cwp_liq = liq * cwp, sl = kl * wl, si = ki * wi;
                 const float c_sca = cwp_liq * sl + cwp_ice * si;
                 float *cs = ro.CS + ((size_t)l * B + b) * 48 + g;
@@ -484,6 +493,9 @@ struct PhysHostW {           // host pointers of one state_dict, by role
     const float *cld_w, *cld_b;              // cloud_optics_lw (16, 19), optional
     const float *swg;                        // CSA_PHYS_SW_GAS block (SWG_FLOATS), optional
     const float *cld_sw_w, *cld_sw_b;        // composed learned SW cloud optics (48, 19), (48), optional
+    // nx21 generation (csa_phys_wrapped_create): SWX_* block, cloud-optics table (12, 16), [n_ir, n_mix, mix_near, mix_vis]
+    const float *swx = nullptr, *cldtab = nullptr, *misc = nullptr;
+    int rad_qv_upd = 0;
 };
 
 // ice effective radius (micron) against temperature, 137 K ... : E3SM's table as listed in rnn/models/physics_rad_e3sm.py:13-59
@@ -518,7 +530,7 @@ static int phys_build(int nx, int nfeat, int naux, int nx_sfc, int sfc_cut, int 
     d.nx = nx; d.nfeat = nfeat; d.naux = naux; d.nx_sfc = nx_sfc; d.sfc_cut = sfc_cut; d.sfc_skip = naux - nx_sfc;
     d.nh = nh; d.ilev = ilev_crm; d.nm0 = nh_mem0; d.Lc = PH_L - ilev_crm;
     d.ltop = rad ? ilev_crm : 0; d.Lr = PH_L - d.ltop;
-    d.ncol = mp_ncol; d.rad = rad; d.physrad = physrad;
+    d.ncol = mp_ncol; d.rad = rad; d.physrad = physrad; d.memlm = physrad;
     d.liq_off = w.liq_w ? PH_NHEAD * mp_ncol + 16 : -1;
     d.hdw = rad ? ((PH_NHEAD * mp_ncol + nh_mem0 + (w.liq_w ? 1 + mp_ncol : 0) + 3) / 4) * 4 : PH_NHEAD * mp_ncol + nh_mem0 + 1;
     d.hyam = up(w.hyam, 60); d.hybm = up(w.hybm, 60); d.hyai = up(w.hyai, 61); d.hybi = up(w.hybi, 61);
@@ -584,7 +596,7 @@ static int phys_build(int nx, int nfeat, int naux, int nx_sfc, int sfc_cut, int 
     h->X1 = up(nullptr, rows * (nh + 16)); h->P = up(nullptr, rows * 4 * nh); h->H1 = up(nullptr, rows * nh);
     h->H2 = up(nullptr, rows * nh); h->hx = up(nullptr, (size_t)max_batch * nh); h->HD = up(nullptr, rows * d.hdw);
     if (rad) {
-        d.xmean_sca = up(w.xms, naux); d.xdiv_sca = up(w.xds, naux); d.lbd_qn = up(w.lbd_qn, 60);
+        d.xmean_sca = up(w.xms, naux); d.xdiv_sca = up(w.xds, naux); d.lbd_qn = w.lbd_qn ? up(w.lbd_qn, 60) : nullptr;
         {   // normalisation range of the gas-optics inputs: xmax - xmin (float, as the reference subtracts) or the stored `xdiv`
             float rg[18];
             for (int k = 0; k < 18; ++k) rg[k] = lw_dn ? w.g_xmax[k] : w.g_xmax[k] - w.g_xmin[k];
@@ -592,6 +604,7 @@ static int phys_build(int nx, int nfeat, int naux, int nx_sfc, int sfc_cut, int 
         }
         // (num94634, the SW gas-optics graph with the Slingo / Ebert-Curry cloud optics, carries `xdiv` too but views the upward source twice again)
         d.lw_dn = lw_dn && !(w.swg && !w.cld_sw_w);
+        d.n_ir = 11; d.n_mix = 13; d.mix_near = 0.5f; d.mix_vis = 0.5f;      // round(0.7143 * 16), round(0.7946 * 16)
         d.cld_w = w.cld_w ? up(w.cld_w, PH_NG * 19) : nullptr;
         d.cld_b = w.cld_w ? up(w.cld_b, PH_NG) : nullptr;
         d.g_xmin = up(w.g_xmin, 18); d.g_ymean = up(w.g_ymean, 128); d.g_ystd = up(w.g_ystd, 128);
@@ -601,7 +614,7 @@ static int phys_build(int nx, int nfeat, int naux, int nx_sfc, int sfc_cut, int 
             for (int g = 0; g < PH_NG; ++g) { sq[g] = physrad ? w.solar_w[g] : w.solar_w[g] * w.solar_w[g]; m = sq[g] > m ? sq[g] : m; }
             for (int g = 0; g < PH_NG; ++g) { e[g] = expf(sq[g] - m); sum += e[g]; }
             for (int g = 0; g < PH_NG; ++g) e[g] /= sum;
-            d.toa_spec = up(e, PH_NG);
+            d.toa_spec = w.swx ? up(w.solar_w, PH_NG) : up(e, PH_NG);     // (frozen exports: the weights arrive as the folded constant)
         }
         auto padK = [&](const float *src, int n, int k, int kp) {
             std::vector<float> t((size_t)n * kp, 0.0f);
@@ -613,7 +626,12 @@ static int phys_build(int nx, int nfeat, int naux, int nx_sfc, int sfc_cut, int 
         h->g_w3 = up(w.g_w3, 256 * 64); h->g_b3 = up(w.g_b3, 256);
         h->r1_w = up(w.r1_w, 16 * 128); h->r1_b = up(w.r1_b, 16);
         h->r2_w = up(w.r2_w, 16 * 128); h->r2_b = up(w.r2_b, 16);
-        if (w.swg) {
+        if (w.swx) {          // the nx21 generation of the frozen exports
+            d.swg = up(w.swx, SWX_FLOATS); d.cldtab = up(w.cldtab, 12 * PH_NG);
+            h->CS = up(nullptr, (size_t)d.Lc * max_batch * 48);
+            d.nx21 = 1; d.memlm = 1; d.lw_dn = 1; d.rad_qv_upd = w.rad_qv_upd;
+            d.n_ir = (int)w.misc[0]; d.n_mix = (int)w.misc[1]; d.mix_near = w.misc[2]; d.mix_vis = w.misc[3];
+        } else if (w.swg) {
             d.swg = up(w.swg, SWG_FLOATS);
             h->CS = up(nullptr, (size_t)d.Lc * max_batch * 48);
             if (w.cld_sw_w) { d.cld_sw_w = up(w.cld_sw_w, 48 * 19); d.cld_sw_b = up(w.cld_sw_b, 48); }
@@ -714,6 +732,109 @@ extern "C" int csa_phys_rad_create(int nx, int naux, int nh, int ilev_crm, int m
     return phys_build(nx, nx - 3, naux, naux - 5, 6, nh, ilev_crm, mp_ncol, nh_mem0, 1, physrad ? 1 : 0, (flags & CSA_PHYS_LATER_EXPORT) ? 1 : 0, v, max_batch, out);
 }
 
+// ---- the frozen `*_wrapped` exports: rnn/utils.py::model_wrapper (:72-295) inlined around the nx21 generation of the model ----------
+// Wrapper pre-processing (:134-217, :262-272): q = RH * Rd esat(T) / (Rv p) appended as 21st level input, snow / ice sentinel -> -1,
+// 1 - exp(-lambda q) on the two cloud inputs, (x - mean) / div, NaN and Inf -> 0.  One thread per (column, level); the raw row with
+// q (what the model calls inputs_denorm) and the normalised row are both written.
+__device__ __forceinline__ float ph_horner9(const float *a, float x)
+{
+    float o = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) o = o * x + a[i];       // the reference's loop: out = out * x + c (unfused, as torch evaluates it)
+    return o;
+}
+__global__ __launch_bounds__(256) void phys_wrap_pre_kernel(PhysDev d, int B, const float *__restrict__ x_main0, const float *__restrict__ x_sfc0,
+                                                            const float *__restrict__ xmean, const float *__restrict__ xdiv,
+                                                            const float *__restrict__ lqc, const float *__restrict__ lqi,
+                                                            float *__restrict__ XM, float *__restrict__ XS, float *__restrict__ XD)
+{
+#pragma clang fp contract(off)
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < B * PH_L) {
+        const int b = i / PH_L, L = i - b * PH_L;
+        const float *x = x_main0 + (size_t)i * 20;
+        const float a_liq[9] = {-0.976195544e-15f, -0.952447341e-13f, 0.640689451e-10f, 0.206739458e-7f, 0.302950461e-5f, 0.264847430e-3f,
+                                0.142986287e-1f, 0.443987641f, 6.11239921f};
+        const float a_ice[9] = {0.252751365e-14f, 0.146898966e-11f, 0.385852041e-9f, 0.602588177e-7f, 0.615021634e-5f, 0.420895665e-3f,
+                                0.188439774e-1f, 0.503160820f, 6.11147274f};
+        const float temp = x[0], rh = x[1];
+        const float pres = d.hyam[L] * 100000.0f + x_sfc0[(size_t)b * d.naux] * d.hybm[L];
+        const float omega = fminf(fmaxf((temp - 253.16f) / 20.000000000000028f, 0.0f), 1.0f);
+        const float eliq = ph_horner9(a_liq, fmaxf(temp - 273.16f, -80.0f)) * 100.0f;
+        const float b2 = ph_horner9(a_ice, temp - 273.16f) * 100.0f;
+        const float tmp = fmaxf(temp - 273.16f, -100.0f);
+        const float b3 = (0.00763685f + tmp * (0.000151069f + tmp * 7.48215e-07f)) * 100.0f;
+        const float eice = temp > 273.15f ? eliq : (temp > 185.0f ? b2 : b3);
+        const float esat = omega * eliq + (1.0f - omega) * eice;
+        const float q = rh * ((esat * 287.0f) / (pres * 461.0f));
+        float *xd = XD + (size_t)i * 21, *xm = XM + (size_t)i * 21;
+#pragma unroll
+        for (int k = 0; k < 21; ++k) {
+            const float raw = k < 20 ? x[k] : q;
+            xd[k] = raw;
+            float v = raw;
+            if (k == 2) v = 1.0f - expf(-raw * lqc[L]);
+            if (k == 3) v = 1.0f - expf(-raw * lqi[L]);
+            v = (v - xmean[L * 21 + k]) / xdiv[L * 21 + k];
+            xm[k] = (v != v || fabsf(v) > 3.402823466e38f) ? 0.0f : v;
+        }
+    }
+    if (i < B * d.naux) {
+        const int k = i % d.naux;
+        const float v = x_sfc0[i];
+        XS[i] = ((v >= 1.0e10f ? -1.0f : v) - d.xmean_sca[k]) / d.xdiv_sca[k];
+    }
+}
+
+// pointer order: see include/climsim_amd.h (csa_phys_wrapped_create)
+extern "C" int csa_phys_wrapped_create(int nh, int ng, int flags, const float *const *w, int max_batch, csa_phys **out)
+{
+    if (!w || !out || max_batch <= 0 || (flags & ~(CSA_PHYS_LIQ_FRAC_HEAD | CSA_PHYS_STOCHASTIC | CSA_PHYS_RAD_UPDATED_QV))) {
+        csa_set_error_msg("csa_phys_wrapped_create: bad argument");
+        return CSA_ERR_ARG;
+    }
+    if (nh != 128 || !(ng == 12 || ng == 14 || ng == 16)) {
+        csa_set_error_msg("csa_phys_wrapped_create: built for the shipped exports (GRU 128/128; 12, 14 or 16 regions = g-points)");
+        return CSA_ERR_UNSUPPORTED;
+    }
+    PhysHostW v{};
+    const float *const *p = w;
+    v.hyam = *p++; v.hybm = *p++; v.hyai = *p++; v.hybi = *p++; v.ysl = *p++; v.yss = *p++; v.xds = *p++; v.xms = *p++;
+    v.init_w = *p++; v.init_b = *p++; v.s1_w = *p++; v.s1_b = *p++;
+    v.r1_ih = *p++; v.r1_hh = *p++; v.r1_bih = *p++; v.r1_bhh = *p++; v.r2_ih = *p++; v.r2_hh = *p++; v.r2_bih = *p++; v.r2_bhh = *p++;
+    v.lat_w = *p++; v.lat_b = *p++; v.out_w = *p++; v.out_b = *p++; v.rel_w = *p++; v.rel_b = *p++;
+    v.heads = p; p += 2 * PH_NHEAD;
+    v.ys_rad = *p++; v.solar_w = *p++; v.g_xmin = *p++; v.g_xmax = *p++; v.g_ymean = *p++; v.g_ystd = *p++;
+    v.g_w1 = *p++; v.g_b1 = *p++; v.g_w2 = *p++; v.g_b2 = *p++; v.g_w3 = *p++; v.g_b3 = *p++;
+    v.r1_w = *p++; v.r1_b = *p++; v.r2_w = *p++; v.r2_b = *p++;
+    v.swx = *p++; v.cldtab = *p++; v.misc = *p++;
+    const float *xmean_lev = *p++, *xdiv_lev = *p++, *lqc = *p++, *lqi = *p++;
+    if (flags & CSA_PHYS_LIQ_FRAC_HEAD) { v.liq_w = *p++; v.liq_b = *p++; }
+    if (flags & CSA_PHYS_STOCHASTIC) { v.s3_ih = *p++; v.s3_zh = *p++; v.s3_enc = *p++; }
+    for (const float *const *q = w; q != p; ++q)
+        if (!*q) { csa_set_error_msg("csa_phys_wrapped_create: null weight pointer"); return CSA_ERR_ARG; }
+    v.rad_qv_upd = (flags & CSA_PHYS_RAD_UPDATED_QV) ? 1 : 0;
+    // the model behind the wrapper: 21 level inputs (18 + pressure feed mlp_initial), 19 surface inputs (0:6 and 11:19 feed mlp_surface1),
+    // 16 regions (the caller zero-pads 12 / 14), 15 + 1 memory channels, later-export LW scheme
+    int rc = phys_build(21, 18, 19, 14, 6, nh, 10, 16, 15, 1, 0, 1, v, max_batch, out);
+    if (rc) return rc;
+    csa_phys *h = *out;
+    h->ng = ng;
+    auto up = [&](const float *src, size_t n) {
+        void *q = nullptr;
+        if (hipMalloc(&q, sizeof(float) * n) != hipSuccess) { rc = CSA_ERR_NOMEM; return (float *)nullptr; }
+        h->owned.push_back(q);
+        if (src && hipMemcpy(q, src, sizeof(float) * n, hipMemcpyHostToDevice) != hipSuccess) rc = CSA_ERR_HIP;
+        return (float *)q;
+    };
+    h->wr_xmean = up(xmean_lev, 60 * 21); h->wr_xdiv = up(xdiv_lev, 60 * 21); h->wr_lqc = up(lqc, 60); h->wr_lqi = up(lqi, 60);
+    const size_t M = (size_t)PH_L * max_batch;
+    h->XM = up(nullptr, M * 21); h->XD = up(nullptr, M * 21); h->XS = up(nullptr, (size_t)max_batch * 19);
+    h->O5 = up(nullptr, M * 5); h->OS = up(nullptr, (size_t)max_batch * 8);
+    if (rc) { csa_phys_destroy(h); *out = nullptr; }
+    return rc;
+}
+
 extern "C" int csa_phys_destroy(csa_phys *h)
 {
     if (!h) return CSA_ERR_ARG;
@@ -734,7 +855,7 @@ __global__ __launch_bounds__(256) void phys_mul_kernel(const f32x4 *__restrict__
 // initial state, and eps3 (Lr,B,nh), the layer's noise.  -> out_lev (B,60,5), out_sfc (B,8), mem_out (B,50,16)
 static int phys_forward_impl(csa_phys *h, int B, const float *x_main, const float *x_sfc, const float *rnn_mem,
                              const float *x_denorm, int nxd, const float *hx2, const float *hx1, const float *eps3, const float *srnn,
-                             float *out_lev, float *out_sfc, float *mem_out, void *stream)
+                             float *out_lev, float *out_sfc, float *mem_out, void *stream, const float *mask_u = nullptr)
 {
     if (!h || !x_main || !x_sfc || !rnn_mem || !x_denorm || !hx2 || !out_lev || !out_sfc || !mem_out || B <= 0 || B > h->max_batch || nxd < 5 ||
         (h->d.rad && nxd < 16)) {
@@ -784,7 +905,7 @@ static int phys_forward_impl(csa_phys *h, int B, const float *x_main, const floa
             hipLaunchKernelGGL((phys_decode_kernel<16, 512, true>), dim3(B), dim3(512), 0, s, d, B, h->HD, Hlast, x_sfc, rnn_mem, x_denorm, nxd,
                                out_lev, out_sfc, mem_out, ro);
         CSA_HIP_CHECK(hipGetLastError());
-        return launch_phys_radiation(h, B, x_sfc, out_lev, out_sfc, s);
+        return launch_phys_radiation(h, B, x_sfc, out_lev, out_sfc, s, mask_u);
     }
     hipLaunchKernelGGL((phys_decode_kernel<16, 512, false>), dim3(B), dim3(512), 0, s, d, B, h->HD, Hlast, x_sfc, rnn_mem, x_denorm, nxd,
                        out_lev, out_sfc, mem_out, PhysRadOut{});
@@ -829,7 +950,7 @@ extern "C" int csa_phys_debug_rnn3(csa_phys *h, int T, int B, const float *x, co
 // out (B,60,5) [dT, dqv, dqn, du, dv] normalised -> out6 (B,60,6) [dT, dqv, dqliq, dqice, du, dv] physical; out_sfc / yscale_sca.
 __global__ __launch_bounds__(256) void phys_post_kernel(PhysDev d, int B, const float *__restrict__ out, const float *__restrict__ out_sfc,
                                                         const float *__restrict__ x_denorm, int nxd, float *__restrict__ out6,
-                                                        float *__restrict__ out_sfc_d)
+                                                        float *__restrict__ out_sfc_d, int scrub_nan = 0)
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i < B * PH_L) {
@@ -846,6 +967,10 @@ __global__ __launch_bounds__(256) void phys_post_kernel(PhysDev d, int B, const 
         r[2] = (lf * qn_new - xd[2]) * 0.0008333333333333334f;
         r[3] = ((1.0f - lf) * qn_new - xd[3]) * 0.0008333333333333334f;
         r[4] = v[3]; r[5] = v[4];
+        if (scrub_nan) {      // the wrapper's last line (rnn/utils.py:293): NaN -> 0 on the level outputs
+#pragma unroll
+            for (int k = 0; k < 6; ++k) r[k] = r[k] != r[k] ? 0.0f : r[k];
+        }
     }
     if (i < B * 8) out_sfc_d[i] = out_sfc[i] / d.yscale_sca[i & 7];
 }
@@ -859,6 +984,29 @@ extern "C" int csa_phys_postprocess(csa_phys *h, int B, const float *out, const 
     }
     hipLaunchKernelGGL(phys_post_kernel, dim3((B * PH_L + 255) / 256), dim3(256), 0, (hipStream_t)stream, h->d, B, out, out_sfc, x_denorm, nxd,
                        out6, out_sfc_denorm);
+    CSA_HIP_CHECK(hipGetLastError());
+    return CSA_OK;
+}
+
+// The frozen export's call: raw x_main0 (B,60,20), x_sfc0 (B,19), rnn1_mem (50,B,16) -> out_lev (B,60,6) physical, out_sfc (B,8) physical,
+// rnn1_mem (50,B,16).  The draws the export makes inside forward are arguments: hx2 (B,nh), with CSA_PHYS_STOCHASTIC hx1 (B,nh) and eps3
+// (50,B,nh), and mask_u (60,B,ng): the uniform field of the SW humidity coin (< 0.5: the largest region's humidity).  srnn (test hook,
+// nullable): the third RNN's output supplied.
+extern "C" int csa_phys_wrapped_forward(csa_phys *h, int B, const float *x_main0, const float *x_sfc0, const float *rnn1_mem, const float *hx2,
+                                        const float *hx1, const float *eps3, const float *mask_u, const float *srnn, float *out_lev,
+                                        float *out_sfc, float *mem_out, void *stream)
+{
+    if (!h || !h->XM || !x_main0 || !x_sfc0 || !rnn1_mem || !hx2 || !mask_u || !out_lev || !out_sfc || !mem_out || B <= 0 || B > h->max_batch) {
+        csa_set_error_msg("csa_phys_wrapped_forward: bad argument (or not a csa_phys_wrapped_create handle)");
+        return CSA_ERR_ARG;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(phys_wrap_pre_kernel, dim3((B * PH_L + 255) / 256), dim3(256), 0, s, h->d, B, x_main0, x_sfc0, h->wr_xmean, h->wr_xdiv,
+                       h->wr_lqc, h->wr_lqi, h->XM, h->XS, h->XD);
+    CSA_HIP_CHECK(hipGetLastError());
+    int rc = phys_forward_impl(h, B, h->XM, h->XS, rnn1_mem, h->XD, 21, hx2, hx1, eps3, srnn, h->O5, h->OS, mem_out, stream, mask_u);
+    if (rc) return rc;
+    hipLaunchKernelGGL(phys_post_kernel, dim3((B * PH_L + 255) / 256), dim3(256), 0, s, h->d, B, h->O5, h->OS, h->XD, 21, out_lev, out_sfc, 1);
     CSA_HIP_CHECK(hipGetLastError());
     return CSA_OK;
 }

