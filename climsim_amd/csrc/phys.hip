@@ -1014,6 +1014,16 @@ extern "C" int csa_phys_wrapped_forward(csa_phys *h, int B, const float *x_main0
 // taps for tests: level-major (Lr, B, nh) outputs of rnn1 (level order) and rnn2 of the last call
 extern "C" int csa_phys_tap(csa_phys *h, int which, int B, float *dst, void *stream)
 {
+    if (h && dst && B > 0 && B <= h->max_batch && which >= 3 && which <= 8 && h->d.rad) {
+        // radiation work arrays of the last call (level-major rows): 3 CS (50 B, 48), 4 CL (50 B, 16), 5 XR (60 B, 24), 6 S2 (60 B, 48),
+        // 7 RS (60 B, 2), 8 TP (60 B, 32)
+        const float *src[] = {h->CS, h->CL, h->XR, h->S2, h->RS, h->TP};
+        const size_t n[] = {(size_t)h->d.Lc * B * 48, (size_t)h->d.Lc * B * PH_NG, (size_t)PH_L * B * PH_XR_K, (size_t)PH_L * B * 48,
+                            (size_t)PH_L * B * 2, (size_t)PH_L * B * 32};
+        if (!src[which - 3]) return CSA_ERR_ARG;
+        CSA_HIP_CHECK(hipMemcpyAsync(dst, src[which - 3], sizeof(float) * n[which - 3], hipMemcpyDeviceToDevice, (hipStream_t)stream));
+        return CSA_OK;
+    }
     if (!h || !dst || B <= 0 || B > h->max_batch || which < 1 || which > 2) return CSA_ERR_ARG;
     CSA_HIP_CHECK(hipMemcpyAsync(dst, which == 1 ? h->H1 : h->H2, sizeof(float) * (size_t)h->d.Lr * B * h->d.nh, hipMemcpyDeviceToDevice,
                                  (hipStream_t)stream));

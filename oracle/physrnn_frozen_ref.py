@@ -89,10 +89,20 @@ def cloud_optics(re, rows, lo, hi, idx):
     return y[0] + y[1] / r, (1.0 - y[2] - r * y[3]).clamp(max=0.999999), y[4] + r * y[5]
 
 
+_JITTER = None      # test-only: a torch.Generator -> every layer output below is multiplied by (1 + 1.2e-7 U(-1, 1)), i.e. re-rounded in
+                    # its last bit as another valid float32 summation order would round it (an independent realisation of the rounding)
+
+
+def _jit(t):
+    if _JITTER is None:
+        return t
+    return t * (1.0 + 1.2e-7 * (2.0 * torch.rand(t.shape, generator=_JITTER, dtype=t.dtype) - 1.0))
+
+
 def gas_mlp(P, name, x):
-    h = F.softsign(_lin(P, name + ".mlp1", x))
-    h = F.softsign(_lin(P, name + ".mlp2", h))
-    return _lin(P, name + ".mlp3", h)
+    h = F.softsign(_jit(_lin(P, name + ".mlp1", x)))
+    h = F.softsign(_jit(_lin(P, name + ".mlp2", h)))
+    return _jit(_lin(P, name + ".mlp3", h))
 
 
 def radiation(P, FL, aux, xd, play, plev, delta_plev, dec, T_new, qv_rad, mask_u, ilev_crm=10, taps=None):
@@ -199,7 +209,8 @@ def radiation(P, FL, aux, xd, play, plev, delta_plev, dec, T_new, qv_rad, mask_u
     dT = -((net[:, 1:] - net[:, :-1]) / delta_plev.squeeze(2)) * 0.009761357302 * P["yscale_lev"][:, 0].view(1, -1)
     out_sfc_rad = torch.cat([sw_net[:, -1:], lw_dn[:, -1:], SOLS, SOLL, SOLSD, SOLLD], 1) * P["yscale_sca_rad"]
     if taps is not None:
-        taps.update(tau_lw=tau_lw, pfrac=pfrac, lw_dn=lw_dn, lw_up=lw_up, tau_sw=tau_sw, ssa=ssa, asy=asy, sw_net=sw_net)
+        taps.update(tau_lw=tau_lw, pfrac=pfrac, lw_dn=lw_dn, lw_up=lw_up, tau_sw=tau_sw, ssa=ssa, asy=asy, sw_net=sw_net, c_tau=c_tau,
+                    tau_abs=tau_abs, tau_sca=tau_sca, tau_cld_lw=tau_cld, T_new=T_new, v12=v12, cwp=cwp, liq=liq)
     return dT, out_sfc_rad
 
 

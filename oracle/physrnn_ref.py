@@ -16,6 +16,14 @@ import torch.nn.functional as F
 
 CP, G, LV, LS, ONE_OVER_G = 1004.64, 9.80665, 2510400.0, 2844000.0, 0.1019716213
 
+_JITTER = None      # test-only (tests/test_physrnn_frozen.py): a torch.Generator -> the sub-grid tendencies are re-rounded in their last bit
+
+
+def _jit(t):
+    if _JITTER is None:
+        return t
+    return t * (1.0 + 1.2e-7 * (2.0 * torch.rand(t.shape, generator=_JITTER, dtype=t.dtype) - 1.0))
+
 
 def _gru(x, h0, w_ih, w_hh, b_ih, b_hh):
     """nn.GRU, batch_first, one layer: gates r, z, n."""
@@ -142,8 +150,10 @@ def microphysics_decode(P, out, mem_new, r2, last_h, inputs_denorm, delta_plev, 
     cond = torch.maximum(cond, -(ys2 * qn_crm / 1200) - flux_qn_dp + dqn_aa - sed_qn_dp)
     evap_prec = torch.maximum(evap_prec, -(ys1 * qv_crm / 1200) - flux_qv_dp + cond)
     dqn_aa = torch.maximum(dqn_aa, flux_qn_dp + cond + sed_qn_dp - ys2 * (-qn_crm + 0.0006) / 1200)
-    dqv_crm = flux_qv_dp - cond + evap_prec
-    dqn_crm = flux_qn_dp + cond - dqn_aa + sed_qn_dp
+    # (the clamps above make q + dq * 1200 / yscale EXACTLY zero where they bind; in float32 a residue of either sign is left, relu keeps
+    #  the positive ones, and the radiation scheme takes the FOURTH ROOT of the vapour residue: _jit lets a test realise that rounding)
+    dqv_crm = _jit(flux_qv_dp - cond + evap_prec)
+    dqn_crm = _jit(flux_qn_dp + cond - dqn_aa + sed_qn_dp)
     if clear_sky:
         temp = T_gcm.squeeze(2) + (flux_t_dp.squeeze(2) / ys[:, 0]) * 1200
         liq = F.hardtanh((temp - 253.16) * 0.05, 0.0, 1.0).unsqueeze(2)

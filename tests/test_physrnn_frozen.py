@@ -12,6 +12,7 @@ import torch
 
 from conftest import GOLDEN
 from oracle import physrnn_frozen_ref as R
+from oracle import physrnn_ref as D
 
 FIX = sorted(os.path.basename(f)[:-4] for f in glob.glob(os.path.join(GOLDEN, "frozen_*.npz")))
 NAMES = ("out_lev", "out_sfc", "mem_out")
@@ -114,12 +115,23 @@ def test_hip_frozen_export_matches_the_artefact(fixture):
         got = m(d(x), d(s), d(mem), hx2=d(dr["hx2"]), hx1=d(dr.get("hx1")), eps3=d(dr.get("eps3")), mask_u=d(dr["mask_u"]), _srnn=d(dr.get("srnn")))
         got = [t.cpu() for t in got]
         assert all(torch.isfinite(t).all() for t in got)
-        got32 = R.forward(P, FL, x, s, mem, dr["hx2"], dr["mask_u"], **{k: dr[k] for k in ("hx1", "eps3", "srnn") if k in dr})
+        kw = {k: dr[k] for k in ("hx1", "eps3", "srnn") if k in dr}
+        got32 = R.forward(P, FL, x, s, mem, dr["hx2"], dr["mask_u"], **kw)
         got64 = _f64(P, FL, x, s, mem, dr)
+        # Rounding level of a block: the export and the float32 restatement share torch's matmul, so their roundings of the gas-optics
+        # MLPs coincide and the pair under-estimates the level of blocks that amplify those (tau = N y^8, then exp(-tau / mu0): one
+        # SOLL reached 10 x the pair's level).  Two more float32 realisations re-round every MLP layer output in its last bit.
+        jit = []
+        for sd in (1, 2):
+            R._JITTER = D._JITTER = torch.Generator().manual_seed(sd)
+            try:
+                jit.append(_blocks(*R.forward(P, FL, x, s, mem, dr["hx2"], dr["mask_u"], **kw)))
+            finally:
+                R._JITTER = D._JITTER = None
         b_ref, bh, b32, b64 = _blocks(*ref), _blocks(*got), _blocks(*got32), _blocks(*got64)
         for key in b_ref:
             scale = b_ref[key].abs().max().item()
-            noise = max((b_ref[key].double() - b64[key]).abs().max().item(), (b32[key].double() - b64[key]).abs().max().item())
+            noise = max((r[key].double() - b64[key]).abs().max().item() for r in (b_ref, b32, jit[0], jit[1]))
             tol = max(1e-5 * scale, 6 * noise) + 1e-30
             assert (bh[key].double() - b64[key]).abs().max().item() <= tol, (fixture, i, key, "vs float64 restatement")
             assert (bh[key] - b_ref[key]).abs().max().item() <= tol + noise, (fixture, i, key, "vs the export")
