@@ -16,7 +16,11 @@ import re
 import torch
 
 C = r"CONSTANTS\.c(\d+)"
-LIN = r"torch\.add\(torch\.matmul\((\w+), " + C + r"\), " + C + r"\)"
+LIN0 = r"torch\.add\(torch\.matmul\((\w+), " + C + r"\), " + C + r"\)"
+# the `_gpu` exports were frozen with horizontally fused Linear layers: ONE matmul against the concatenated weights of all heads that
+# share an input, sliced afterwards -- `torch.slice(torch.add(torch.matmul(x, cW), cB), -1, a, b)` is head columns a:b of (cW, cB)
+LIN = r"(?:torch\.slice\()?" + LIN0 + r"(?:, -1, (\d+), (\d+)\))?"
+NG_LIN = 5          # groups per LIN: input, weight, bias, slice begin, slice end
 
 
 def parse(code):
@@ -74,9 +78,15 @@ class Extractor:
         if m is None:
             return False
         g = m.groups()
-        w, b = self.c(g[3 * lin_index + 1]), self.c(g[3 * lin_index + 2])
-        self.P[name + ".weight"], self.P[name + ".bias"] = w.t().contiguous(), b.reshape(-1)
+        self.P[name + ".weight"], self.P[name + ".bias"] = self.lin_wb(g[NG_LIN * lin_index + 1:NG_LIN * lin_index + 5])
         return True
+
+    def lin_wb(self, g):
+        """(weight constant, bias constant, slice begin | None, slice end | None) -> weight (out, in), bias (out)"""
+        w, b = self.c(g[0]), self.c(g[1]).reshape(-1)
+        if g[2] is not None:
+            w, b = w[:, int(g[2]):int(g[3])], b[int(g[2]):int(g[3])]
+        return w.t().contiguous(), b.contiguous()
 
     def const(self, name, lhs_re, rhs_re, group=1, required=True, which=0):
         m = self.find(lhs_re, rhs_re, which, required)
@@ -123,8 +133,8 @@ class Extractor:
         self.linear("mlp_surface1", r"hx\d*", r"torch\.tanh\({LIN}\)")
         m = re.search(r"torch\.add\(torch\.matmul\(" + LIN + rf", {C}\), {C}\)", "\n".join(r for _, r in self.named) + "\n".join(self.sinks))
         g = m.groups()
-        P["mlp_latent.weight"], P["mlp_latent.bias"] = self.c(g[1]).t().contiguous(), self.c(g[2])
-        P["mlp_output.weight"], P["mlp_output.bias"] = self.c(g[3]).t().contiguous(), self.c(g[4])
+        P["mlp_latent.weight"], P["mlp_latent.bias"] = self.lin_wb(g[1:5])
+        P["mlp_output.weight"], P["mlp_output.bias"] = self.c(g[5]).t().contiguous(), self.c(g[6])
         # ---- decoder heads (models_phys.py:414-748) ------------------------------------------------------------------------
         self.linear("mlp_qv_crm", r"qv_crm", r"torch\.softplus\({LIN}, 1\., 20\.\)")
         if not self.linear("mlp_qn_crm", r"qn_crm", r"torch\.softplus\({LIN}, 1\., 20\.\)", required=False):
@@ -159,7 +169,7 @@ class Extractor:
         self.linear("gas_optics_model_lw.mlp2", r"x\d+", soft, which=1)
         m = re.search(r"tau\d*, pfrac\d*,? = torch\.chunk\((_\d+), 2, -1\)", code)
         mm = re.search(LIN, expand(self.temps[m.group(1)], self.temps))
-        P["gas_optics_model_lw.mlp3.weight"], P["gas_optics_model_lw.mlp3.bias"] = self.c(mm.group(2)).t().contiguous(), self.c(mm.group(3))
+        P["gas_optics_model_lw.mlp3.weight"], P["gas_optics_model_lw.mlp3.bias"] = self.lin_wb(mm.groups()[1:5])
         m = self.find(r"tau\d+", rf"torch\.mul\(col_dry\d*, torch\.pow\(torch\.add\(torch\.mul\({C}, tau\d*\), {C}\), 8\)\)")
         P["gas_optics_model_lw.ystd"], P["gas_optics_model_lw.ymean"] = self.c(m.group(1)), self.c(m.group(2))
         self.linear("gas_optics_lw_reduce2", r"pfrac\d+", r"torch\.softmax\({LIN}, 2\)")
@@ -177,8 +187,7 @@ class Extractor:
         taus = [(l, r) for l, r in self.named if re.fullmatch(r"tau\d+", l) and re.search(r"torch\.mul\(col_dry_crm_1\d*, torch\.pow\(" + LIN + r", 8\)\)", r)]
         for i, (l, r) in enumerate(taus[:2]):
             mm = re.search(LIN, r)
-            P[f"gas_optics_model_sw{i + 1}.mlp3.weight"] = self.c(mm.group(2)).t().contiguous()
-            P[f"gas_optics_model_sw{i + 1}.mlp3.bias"] = self.c(mm.group(3))
+            P[f"gas_optics_model_sw{i + 1}.mlp3.weight"], P[f"gas_optics_model_sw{i + 1}.mlp3.bias"] = self.lin_wb(mm.groups()[1:5])
         F["sw_gas_reduce"] = self.linear("gas_optics_sw_reduce1", r"tau_sw\w*", r"torch\.softplus\({LIN}, 1\., 20\.\)", required=False)
         if F["sw_gas_reduce"]:
             self.linear("gas_optics_sw_reduce2", r"tau_sw_scat\w*", r"torch\.softplus\({LIN}, 1\., 20\.\)")

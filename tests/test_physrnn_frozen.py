@@ -153,3 +153,19 @@ def test_hip_rnn3_of_the_frozen_export_end_to_end_is_finite_and_reproducible(fix
     assert a[2].shape == (50, x.shape[0], 16) and torch.equal(a[2][0, :, 15], a[2][49, :, 15])
     c = m(d(x), d(s), d(mem))                       # all draws made on the device
     assert all(torch.isfinite(u).all() for u in c)
+
+
+def test_index_of_the_frozen_exports_is_consistent_with_the_fixtures():
+    """tests/golden/frozen_index.json (make_frozen_index.py): all 82 shipped exports classified by serialised code; every `_cpu` file
+    marked built belongs to a variant with a fixture (which the two tests above hold to its own outputs); the `_gpu` files are twins
+    of built variants with identical constants, or listed with the reason they are not covered."""
+    import json
+    idx = json.load(open(os.path.join(GOLDEN, "frozen_index.json")))
+    assert len(idx) == 82
+    built = {f[7:] for f in FIX}
+    cpu_built = [k for k, v in idx.items() if v["status"] == "built"]
+    assert cpu_built and all(idx[k]["code"] in built for k in cpu_built)
+    assert {idx[k]["code"] for k in cpu_built} == built
+    twins = [k for k, v in idx.items() if v["status"].startswith("twin of a built variant")]
+    assert all(idx[k]["cpu_twin_code"] in built for k in twins)
+    assert len(cpu_built) == 38 and len(twins) == 21
