@@ -153,7 +153,7 @@ int upload_params(csa_emulator *h, const csa_params *p, bool first)
         d.whh2q = U.up(packed);
     }
     d.whh1m = d.whh2m = nullptr;
-    if (c.use_lstm && c.nh1 <= 128 && c.nh2 <= 128) {     // matrix-pipe four-column kernel (large batches)
+    if (c.use_lstm && c.nh1 <= 144 && c.nh2 <= 144 && c.nh1 % 16 == 0 && c.nh2 % 16 == 0) {     // matrix-pipe four-column kernel (large batches)
         packed.resize((size_t)4 * c.nh1 * c.nh1);
         rec4m_pack_weights(c.nh1, a_hh, packed.data());
         d.whh1m = U.up(packed);

@@ -125,6 +125,8 @@ int launch_rec_train_gru(int nh, const float *whh_packed, const float *bhn, floa
                          int reverse_out, float *Hseq, hipStream_t s);
 // matrix-pipe four-column LSTM kernel (large batches): packing, selection (env CSA_REC4_KERNEL / CSA_REC4_MIN_BATCH), launch
 void rec4m_pack_weights(int nh, const float *w_hh, float *packed);
+int launch_rec4m_train(int nh, const float *whh_m, float *P, const float *h0, const float *c0, float *Hout, int B, int L,
+                       int reverse_out, float *Hseq, float *Cseq, hipStream_t s);
 void gru4m_pack_weights(int nh, const float *w_hh, float *packed);
 int launch_rec4m_gru(int nh, const float *whh_m, const float *bhn, const float *P, const float *h0, float *Hout, int B, int L,
                      int reverse_out, hipStream_t s);

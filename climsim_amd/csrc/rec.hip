@@ -546,31 +546,47 @@ __global__ __launch_bounds__(NH * 4, (NH / 16 + 3) / 4) void lstm_rec4_kernel(
 // k-quad of its column, and `blgp:4+g` makes the matrix pipe take B from lane group g for all four groups (16 KB of LDS
 // return traffic per wave and step instead of 64 KB).
 // Same arithmetic as the other LSTM kernels up to the order of the k-sum (four interleaved accumulator chains).
-template <int NH, bool BLGP>
+// TRAIN (round 3): the training forward at shard size -- the lane already ends a step with all four activated gates of its (unit,
+// column): they are written IN PLACE over the projection row [i, g~, f, o], c_t to Cseq and h_t to Hseq (L+1 slots, slot 0 = the
+// initial state), exactly what lstm_rec2_kernel<NH, true> saves and lstm_bwd_rec_kernel reads.
+// NWL > 0 (nh = 144, the reference's default width): 9 waves put three on one SIMD, so a wave may hold 168 VGPRs and 144 weights +
+// the working set do not fit; the weights of the LAST NWL k-values live in dynamic LDS (NWL/4 float4 per lane, consecutive lanes
+// 16 bytes apart: conflict-free) and pass through four temporaries per 16-k block.
+#ifndef REC4M_NWL144
+#define REC4M_NWL144 32      /* k-values of the nh = 144 weight run kept in LDS */
+#endif
+template <int NH, bool BLGP, bool TRAIN = false, int NWL = 0>
 __global__ __launch_bounds__(NH * 4, (NH / 16 + 3) / 4) void lstm_rec4m_kernel(
-    const float *__restrict__ Wk, const float *__restrict__ P,
+    const float *__restrict__ Wk, float *P,
     const float *__restrict__ h0, const float *__restrict__ c0, float *__restrict__ Hout,
-    int B, int L, int reverse_out)
+    int B, int L, int reverse_out, float *__restrict__ Hseq = nullptr, float *__restrict__ Cseq = nullptr)
 {
-    constexpr int NT = NH * 4;
-    static_assert(NH % 16 == 0, "nh must be a multiple of 16");
+    constexpr int NT = NH * 4, NR = NH - NWL;
+    static_assert(NH % 16 == 0 && NWL % 16 == 0, "nh and the LDS-resident tail must be multiples of 16");
     // h_{t-1} in LDS as [k / 16][(k % 16) / 4][column][k % 4]: the sixteen 16-byte chunks one ds_read_b128 of a wave touches
     // (4 lane groups x 4 columns) are 256 CONTIGUOUS bytes -> conflict-free however the hardware splits the wave
     // (a [column][k] layout with padded rows measured 50 % SQ_LDS_BANK_CONFLICT, profiles/r2_v4_memory_2700_sq_pmc.json)
     __shared__ __attribute__((aligned(16))) float hbuf[2][4 * NH];
+    extern __shared__ f32x4 wl4[];        // NWL > 0: [NWL / 4][NT] float4
+    static_assert(NWL == 0 || BLGP, "the LDS weight tail is written for the blgp operand-broadcast variant");
 
     const int tid = threadIdx.x, u = tid >> 2, x = tid & 3, lane = tid & 63;
     int b = 4 * blockIdx.x + x;
     const bool valid = b < B;
     if (!valid) b = B - 1;
 
-    float w[NH];
+    float w[NR];
 #pragma unroll
-    for (int k = 0; k < NH; ++k) w[k] = Wk[(size_t)k * NT + tid];
+    for (int k = 0; k < NR; ++k) w[k] = Wk[(size_t)k * NT + tid];
+#pragma unroll
+    for (int q = 0; q < NWL / 4; ++q)
+        wl4[q * NT + tid] = f32x4{Wk[(size_t)(NR + 4 * q) * NT + tid], Wk[(size_t)(NR + 4 * q + 1) * NT + tid],
+                                  Wk[(size_t)(NR + 4 * q + 2) * NT + tid], Wk[(size_t)(NR + 4 * q + 3) * NT + tid]};
 
     float h = h0[(size_t)b * NH + u], c = c0[(size_t)b * NH + u];
     const int hslot = (u >> 4) * 64 + ((((u & 15) >> 2) * 4 + x) << 2) + (u & 3);      // where (k = u, column x) lives
     hbuf[0][hslot] = h;
+    if (TRAIN && valid) { Hseq[(size_t)b * NH + u] = h; Cseq[(size_t)b * NH + u] = c; }
     const float *Pb = P + (size_t)b * (4 * NH) + u * 4;
     const size_t Pstep = (size_t)B * (4 * NH);
     f32x4 preA = *(const f32x4 *)Pb, preB = preA;
@@ -598,6 +614,11 @@ __global__ __launch_bounds__(NH * 4, (NH / 16 + 3) / 4) void lstm_rec4m_kernel(
     ACC##b = __builtin_amdgcn_mfma_f32_4x4x1f32(w[(K) + 1], HV.y, ACC##b, 0, 0, G);                    \
     ACC##c = __builtin_amdgcn_mfma_f32_4x4x1f32(w[(K) + 2], HV.z, ACC##c, 0, 0, G);                    \
     ACC##d = __builtin_amdgcn_mfma_f32_4x4x1f32(w[(K) + 3], HV.w, ACC##d, 0, 0, G);
+#define MF4L(ACC, WV, HV, G)                                                                           \
+    ACC = __builtin_amdgcn_mfma_f32_4x4x1f32(WV.x, HV.x, ACC, 0, 0, G);                                \
+    ACC##b = __builtin_amdgcn_mfma_f32_4x4x1f32(WV.y, HV.y, ACC##b, 0, 0, G);                          \
+    ACC##c = __builtin_amdgcn_mfma_f32_4x4x1f32(WV.z, HV.z, ACC##c, 0, 0, G);                          \
+    ACC##d = __builtin_amdgcn_mfma_f32_4x4x1f32(WV.w, HV.w, ACC##d, 0, 0, G);
 #define LSTM4M_STEP(T, CUR, NXT)                                                                       \
     {                                                                                                  \
         const int t_ = (T);                                                                            \
@@ -608,12 +629,21 @@ __global__ __launch_bounds__(NH * 4, (NH / 16 + 3) / 4) void lstm_rec4m_kernel(
         const float *hb = &hbuf[t_ & 1][0] + hoff;                                                     \
         f32x4 acc = {0.f, 0.f, 0.f, 0.f}, accb = acc, accc = acc, accd = acc;                          \
         if (BLGP) {                                                                                    \
-            _Pragma("unroll") for (int q = 0; q < NH / 16 / REC4M_EXP_MFMA_DIV; ++q) {                 \
+            _Pragma("unroll") for (int q = 0; q < NR / 16 / REC4M_EXP_MFMA_DIV; ++q) {                 \
                 const f32x4 hv = *(const f32x4 *)(hb + 64 * q);                                        \
                 MF4(acc, 16 * q, hv, 4)                                                                \
                 MF4(acc, 16 * q + 4, hv, 5)                                                            \
                 MF4(acc, 16 * q + 8, hv, 6)                                                            \
                 MF4(acc, 16 * q + 12, hv, 7)                                                           \
+            }                                                                                          \
+            _Pragma("unroll") for (int q = 0; q < NWL / 16; ++q) {      /* the LDS-resident weight tail */ \
+                const f32x4 hv = *(const f32x4 *)(hb + 64 * (NR / 16 + q));                            \
+                const f32x4 w0 = wl4[(4 * q) * NT + tid], w1 = wl4[(4 * q + 1) * NT + tid];            \
+                const f32x4 w2 = wl4[(4 * q + 2) * NT + tid], w3 = wl4[(4 * q + 3) * NT + tid];        \
+                MF4L(acc, w0, hv, 4)                                                                   \
+                MF4L(acc, w1, hv, 5)                                                                   \
+                MF4L(acc, w2, hv, 6)                                                                   \
+                MF4L(acc, w3, hv, 7)                                                                   \
             }                                                                                          \
         } else {                                                                                       \
             _Pragma("unroll") for (int q = 0; q < NH / 4; ++q) {                                       \
@@ -628,6 +658,11 @@ __global__ __launch_bounds__(NH * 4, (NH / 16 + 3) / 4) void lstm_rec4m_kernel(
         REC4M_GATES                                                                                    \
         hbuf[(t_ & 1) ^ 1][hslot] = h;                                                                 \
         if (valid) Hout[((size_t)(reverse_out ? L - 1 - t_ : t_) * B + b) * NH + u] = h;               \
+        if (TRAIN && valid) {                                                                          \
+            Hseq[((size_t)(t_ + 1) * B + b) * NH + u] = h;                                             \
+            Cseq[((size_t)(t_ + 1) * B + b) * NH + u] = c;                                             \
+            *(f32x4 *)(P + ((size_t)t_ * B + b) * (4 * NH) + u * 4) = f32x4{ig, gg, fg, og};           \
+        }                                                                                              \
         LDS_BARRIER();                                                                                 \
     }
     for (int t = 0; t < L; t += 2) {
@@ -636,6 +671,7 @@ __global__ __launch_bounds__(NH * 4, (NH / 16 + 3) / 4) void lstm_rec4m_kernel(
     }
 #undef LSTM4M_STEP
 #undef MF4
+#undef MF4L
 #undef REC4M_GATES
 }
 
@@ -1119,21 +1155,52 @@ int launch_rec4m(int nh, const float *whh_m, const float *P, const float *h0, co
     const dim3 grid((B + 3) / 4), block(nh * 4);
     const bool blgp = rec4_variant() == 2;
 #define L4M(NHv)                                                                                                             \
-    if (blgp) hipLaunchKernelGGL((lstm_rec4m_kernel<NHv, true>), grid, block, 0, s, whh_m, P, h0, c0, Hout, B, L, reverse_out);   \
-    else hipLaunchKernelGGL((lstm_rec4m_kernel<NHv, false>), grid, block, 0, s, whh_m, P, h0, c0, Hout, B, L, reverse_out);
+    if (blgp) hipLaunchKernelGGL((lstm_rec4m_kernel<NHv, true>), grid, block, 0, s, whh_m, (float *)P, h0, c0, Hout, B, L, reverse_out, (float *)nullptr, (float *)nullptr);   \
+    else hipLaunchKernelGGL((lstm_rec4m_kernel<NHv, false>), grid, block, 0, s, whh_m, (float *)P, h0, c0, Hout, B, L, reverse_out, (float *)nullptr, (float *)nullptr);
     switch (nh) {
     case 64: L4M(64) break;
     case 96: L4M(96) break;
     case 128: L4M(128) break;
+    case 144: {
+        constexpr size_t shm = (size_t)(REC4M_NWL144 / 4) * 144 * 4 * sizeof(f32x4);
+        auto kern = lstm_rec4m_kernel<144, true, false, REC4M_NWL144>;
+        CSA_SET_DYN_LDS_ONCE(kern, shm);
+        hipLaunchKernelGGL(kern, grid, block, shm, s, whh_m, (float *)P, h0, c0, Hout, B, L, reverse_out, (float *)nullptr, (float *)nullptr);
+        break;
+    }
     default:
-        csa_set_error_msg("rec4m: hidden size not supported (64, 96, 128)");
+        csa_set_error_msg("rec4m: hidden size not supported (64, 96, 128, 144)");
         return CSA_ERR_UNSUPPORTED;
     }
 #undef L4M
     CSA_HIP_CHECK(hipGetLastError());
     return CSA_OK;
 }
-bool rec4m_selected(int use_lstm, int nh, int B) { return use_lstm && nh <= 128 && rec4_variant() != 0 && B >= rec4_min_batch(); }
+
+// training forward on the matrix pipe (from CSA_REC4_MIN_BATCH columns): gates saved in place over P, c / h sequences (L+1 slots)
+int launch_rec4m_train(int nh, const float *whh_m, float *P, const float *h0, const float *c0, float *Hout, int B, int L,
+                       int reverse_out, float *Hseq, float *Cseq, hipStream_t s)
+{
+    const dim3 grid((B + 3) / 4), block(nh * 4);
+    switch (nh) {
+    case 64:  hipLaunchKernelGGL((lstm_rec4m_kernel<64, true, true>), grid, block, 0, s, whh_m, P, h0, c0, Hout, B, L, reverse_out, Hseq, Cseq); break;
+    case 96:  hipLaunchKernelGGL((lstm_rec4m_kernel<96, true, true>), grid, block, 0, s, whh_m, P, h0, c0, Hout, B, L, reverse_out, Hseq, Cseq); break;
+    case 128: hipLaunchKernelGGL((lstm_rec4m_kernel<128, true, true>), grid, block, 0, s, whh_m, P, h0, c0, Hout, B, L, reverse_out, Hseq, Cseq); break;
+    case 144: {
+        constexpr size_t shm = (size_t)(REC4M_NWL144 / 4) * 144 * 4 * sizeof(f32x4);
+        auto kern = lstm_rec4m_kernel<144, true, true, REC4M_NWL144>;
+        CSA_SET_DYN_LDS_ONCE(kern, shm);
+        hipLaunchKernelGGL(kern, grid, block, shm, s, whh_m, P, h0, c0, Hout, B, L, reverse_out, Hseq, Cseq);
+        break;
+    }
+    default:
+        csa_set_error_msg("rec4m(train): hidden size not supported (64, 96, 128, 144)");
+        return CSA_ERR_UNSUPPORTED;
+    }
+    CSA_HIP_CHECK(hipGetLastError());
+    return CSA_OK;
+}
+bool rec4m_selected(int use_lstm, int nh, int B) { return use_lstm && (nh <= 128 || (nh == 144 && rec4_variant() == 2)) && rec4_variant() != 0 && B >= rec4_min_batch(); }
 
 // GRU matrix-pipe kernel: Wk[k*NT + tid] = W_hh[gate (tid & 3) of unit (tid >> 2)][k] for the PyTorch gate rows (r, z, n); the
 // fourth row of every block is zero

@@ -275,7 +275,7 @@ extern "C" int csa_train_create(const csa_config *cfg, const csa_params *p, cons
     }
     std::vector<int> rowmap1, rowmap2;   // permuted row n' -> PyTorch gate row, per LSTM
     auto lstm_pack = [&](int nh, int K, int o_wih, int o_whh, int o_bih, int o_bhh, const float *&wih, const float *&bias,
-                         const float *&whhp, float *&whhTp, float *&wihT, std::vector<int> &rowmap) {
+                         const float *&whhp, float *&whhTp, float *&wihT, std::vector<int> &rowmap, const float *&whhm) {
         std::vector<float> w, b, bhn;
         std::vector<float> iw = index_values((size_t)4 * nh * K), ib = index_values((size_t)4 * nh);
         pack_ih(1, nh, K, iw.data(), ib.data(), ib.data(), w, b, bhn);      // b = 2*index (b_ih+b_hh of equal indices)
@@ -287,6 +287,12 @@ extern "C" int csa_train_create(const csa_config *cfg, const csa_params *p, cons
         std::vector<float> ih = index_values((size_t)4 * nh * nh), pk(rec_packed_floats(1, nh));
         rec_pack_weights(1, nh, ih.data(), pk.data());
         whhp = add_gather(h, to_int(pk, o_whh), nullptr, rc);
+        whhm = nullptr;
+        if (nh % 16 == 0) {      // matrix-pipe training forward (lstm_rec4m_kernel<NH, true, true>, from 544 columns per call)
+            std::vector<float> pm((size_t)4 * nh * nh);
+            rec4m_pack_weights(nh, ih.data(), pm.data());
+            whhm = add_gather(h, to_int(pm, o_whh), nullptr, rc);
+        }
         std::vector<float> pkT(bwd_rec_packed_floats(nh));
         bwd_rec_pack_weights(nh, ih.data(), pkT.data());
         whhTp = (float *)add_gather(h, to_int(pkT, o_whh), nullptr, rc);
@@ -339,9 +345,9 @@ extern "C" int csa_train_create(const csa_config *cfg, const csa_params *p, cons
     auto ON = [&](const std::string &n) { return O(n.c_str()); };
     if (lstm) {
         lstm_pack(nh1, nin1, ON(la + ".weight_ih_l0"), ON(la + ".weight_hh_l0"), ON(la + ".bias_ih_l0"), ON(la + ".bias_hh_l0"),
-                  d.wih1, d.bias1, d.whh1p, h->whh1Tp, h->wih1T, rowmap1);
+                  d.wih1, d.bias1, d.whh1p, h->whh1Tp, h->wih1T, rowmap1, d.whh1m);
         lstm_pack(nh2, nh1, ON(lb + ".weight_ih_l0"), ON(lb + ".weight_hh_l0"), ON(lb + ".bias_ih_l0"), ON(lb + ".bias_hh_l0"),
-                  d.wih2, d.bias2, d.whh2p, h->whh2Tp, h->wih2T, rowmap2);
+                  d.wih2, d.bias2, d.whh2p, h->whh2Tp, h->wih2T, rowmap2, d.whh2m);
     } else {
         gru_pack(nh1, nin1, O("rnn1.weight_ih_l0"), O("rnn1.weight_hh_l0"), O("rnn1.bias_ih_l0"), O("rnn1.bias_hh_l0"),
                  d.wih1, d.bias1, d.bhn1, d.whh1p, h->whh1Tp, h->wih1T, gm1);
@@ -500,6 +506,15 @@ extern "C" int csa_train_copy_state(csa_trainer *h, int which, int dir, float *b
 }
 extern "C" int csa_train_sync_params(csa_trainer *h, void *stream) { return h ? repack(h, (hipStream_t)stream) : CSA_ERR_ARG; }
 
+// training forward of one LSTM: two columns per workgroup (packed FMA), or four on the matrix pipe from CSA_REC4_MIN_BATCH columns
+// per call (the kernel classes differ in the order of the k-sum only; what they save for BPTT has the same layout)
+static int rec_train_lstm(int nh, const float *whhp, const float *whhm, float *P, const float *h0, const float *c0, float *Hout, int B, int L,
+                          int reverse_out, float *Hseq, float *Cseq, hipStream_t s)
+{
+    if (whhm && rec4m_selected(1, nh, B)) return launch_rec4m_train(nh, whhm, P, h0, c0, Hout, B, L, reverse_out, Hseq, Cseq, s);
+    return launch_rec_train(nh, whhp, P, h0, c0, Hout, B, L, reverse_out, Hseq, Cseq, s);
+}
+
 extern "C" int csa_train_forward(csa_trainer *h, int slot, int B, const float *x_main_n, const float *x_sfc_n,
                                  const float *mem_in, float *out, float *out_sfc, float *mem_out, void *stream)
 {
@@ -520,7 +535,7 @@ extern "C" int csa_train_forward(csa_trainer *h, int slot, int B, const float *x
     }
     {
         StageTimer tm(h, 0, s);
-        if (c.use_lstm) rc = launch_rec_train(nh1, h->dm.whh1p, S.GP1, S.hc0, S.hc0 + (size_t)B * nhm, S.H1lev, B, L, 1, S.H1seq, S.C1, s);
+        if (c.use_lstm) rc = rec_train_lstm(nh1, h->dm.whh1p, h->dm.whh1m, S.GP1, S.hc0, S.hc0 + (size_t)B * nhm, S.H1lev, B, L, 1, S.H1seq, S.C1, s);
         else rc = launch_rec_train_gru(nh1, h->dm.whh1p, h->dm.bhn1, S.GP1, S.hc0, S.H1lev, B, L, 1, S.H1seq, s);
         if (rc) return rc;
     }
@@ -530,8 +545,8 @@ extern "C" int csa_train_forward(csa_trainer *h, int slot, int B, const float *x
     }
     {   // rnn2: level order == sequence order, so the hidden sequence itself carries the extra slot 0
         StageTimer tm(h, 0, s);
-        if (c.use_lstm) rc = launch_rec_train(nh2, h->dm.whh2p, S.GP2, S.hc0 + (size_t)2 * B * nhm, S.hc0 + (size_t)3 * B * nhm,
-                                              S.H2 + (size_t)B * nh2, B, L, 0, S.H2, S.C2, s);
+        if (c.use_lstm) rc = rec_train_lstm(nh2, h->dm.whh2p, h->dm.whh2m, S.GP2, S.hc0 + (size_t)2 * B * nhm, S.hc0 + (size_t)3 * B * nhm,
+                                            S.H2 + (size_t)B * nh2, B, L, 0, S.H2, S.C2, s);
         else rc = launch_rec_train_gru(nh2, h->dm.whh2p, h->dm.bhn2, S.GP2, S.hc0 + (size_t)2 * B * nhm, S.H2 + (size_t)B * nh2, B, L, 0,
                                        S.H2, s);
         if (rc) return rc;
@@ -560,9 +575,9 @@ extern "C" int csa_train_forward_noise(csa_trainer *h, int slot, int B, const fl
     if ((rc = launch_prep_train(h->dm, B, 1, x_main_n, x_sfc_n, mem_in, S.X1, S.hc0, S.X16, S.xs, s))) return rc;
     if ((rc = launch_proj_gemm(S.X1, h->dm.wih1, h->dm.bias1, S.GP1, L * B, 4 * nh, nh + nm, s))) return rc;
     // rnn0 runs downward over the level-ordered rows; its output is stored flipped = the sequence order of the upward rnn1
-    if ((rc = launch_rec_train(nh, h->dm.whh1p, S.GP1, hx0, cx0, S.H1lev, B, L, 1, S.H1seq, S.C1, s))) return rc;
+    if ((rc = rec_train_lstm(nh, h->dm.whh1p, h->dm.whh1m, S.GP1, hx0, cx0, S.H1lev, B, L, 1, S.H1seq, S.C1, s))) return rc;
     if ((rc = launch_proj_gemm(S.H1lev, h->dm.wih2, h->dm.bias2, S.GP2, L * B, 4 * nh, nh, s))) return rc;
-    if ((rc = launch_rec_train(nh, h->dm.whh2p, S.GP2, S.hc0, S.hc0 + (size_t)B * nh, S.Hb, B, L, 1, S.H2, S.C2, s))) return rc;
+    if ((rc = rec_train_lstm(nh, h->dm.whh2p, h->dm.whh2m, S.GP2, S.hc0, S.hc0 + (size_t)B * nh, S.Hb, B, L, 1, S.H2, S.C2, s))) return rc;
     csa_stoch *st = h->stoch;
     st->XP = S.sXP; st->Hseq = S.sH; st->Cseq = S.sC;
     if ((rc = csa_stoch_lstm4_forward_train(st, L, B, S.Hb, S.hc0 + (size_t)2 * B * nh, S.hc0 + (size_t)3 * B * nh, eps, S.Zs, nullptr,

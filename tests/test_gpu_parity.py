@@ -613,6 +613,36 @@ def test_lstm144_two_column_kernel_vs_reference_class_and_oracle():
             assert rel_err(a.cpu().numpy(), b.cpu().numpy()) <= 3e-6
 
 
+@pytest.mark.parametrize("B", [545, 2700])
+def test_lstm144_matrix_kernel_vs_oracle_and_two_column_kernel(B):
+    """lstm_rec4m_kernel<144, .., NWL = 32> (round 3: the reference's default width on the matrix pipe -- the last 32 k-values of the
+    weight run live in LDS): calls of 544 columns and more, against the C oracle (pinned on the cur_lstm144 goldens) and against
+    sub-batches that run the two-column kernel; B = 545: a last workgroup with one valid column.  Deterministic."""
+    import climsim_amd
+    from oracle.pyoracle import OracleModel
+    consts, weights, flags = load_npz_model("cur_lstm144")
+    kw = dict(use_lstm=True, output_prune=bool(flags["output_prune"]))
+    wrap = climsim_amd.model_wrapper(consts, weights, max_batch=B, snowhice_fix=True, **kw)
+    om = OracleModel(consts, weights, legacy=False, use_lstm=True, output_prune=bool(flags["output_prune"]), scrub_inf=True, snowhice_fix=True)
+    g = np.random.Generator(np.random.PCG64(14400 + B))
+    xm, xs = synth_inputs(consts, B, 170 + B)
+    mem = (0.3 * g.standard_normal((60, B, 16))).astype(np.float32)
+    big = [t.clone() for t in wrap(_dev(xm), _dev(xs), _dev(mem))]
+    again = wrap(_dev(xm), _dev(xs), _dev(mem))
+    assert all(torch.equal(a, b) for a, b in zip(big, again))
+    n = 600 if B > 600 else 300
+    o6, osf, mo = om.wrapper_forward_tuple(xm[:n], xs[:n], mem[:, :n])
+    for v in range(6):
+        assert rel_err(big[0][:n].cpu().numpy()[:, :, v], o6[:, :, v]) <= 1e-5, (B, v)
+    assert rel_err(big[1][:n].cpu().numpy(), osf) <= 1e-5
+    assert rel_err(big[2][:, :n].cpu().numpy(), mo) <= 1e-5
+    for lo in (0, B - 300):                               # 300 columns: lstm_rec2_kernel<144>
+        sub = wrap(_dev(xm[lo:lo + 300]), _dev(xs[lo:lo + 300]), _dev(np.ascontiguousarray(mem[:, lo:lo + 300])))
+        for a, b, ax in zip(big, sub, (0, 0, 1)):
+            ref = a[lo:lo + 300] if ax == 0 else a[:, lo:lo + 300]
+            assert rel_err(ref.cpu().numpy(), b.cpu().numpy()) <= 1e-5
+
+
 @pytest.mark.parametrize("B", [545, 1101])
 def test_gru_matrix_kernel_vs_two_column_kernel(B):
     """gru_rec4m_kernel (four columns per workgroup on the matrix pipe, calls of 544 columns and more; B = 545 / 1101: a last
