@@ -567,7 +567,7 @@ def main():
             dist.barrier()
             dist.destroy_process_group()
 
-    if a.workload in AUX:
+    if a.workload in AUX or a.workload.rsplit("_", 1)[0] in {w.rsplit("_", 1)[0] for w in AUX}:      # any column count: cur_lstm144_2700 ...
         aux_workload(a, rank, world, dist)
         return finish()
     with_cpu = not a.no_cpu_baseline and world == 1
