@@ -11,7 +11,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libclimsim_amd.so")
-SOURCES = ["api.hip", "prep.hip", "gemm.hip", "rec.hip", "head.hip", "mlp_api.hip", "mlp_train.hip", "cnn_api.hip", "cnn_train.hip", "gen.hip", "crps.hip", "evalm.hip", "derive.hip", "online.hip", "phys.hip", "phys_rad.hip", "stoch.hip", "stoch_bwd.hip", "train_api.hip", "train_rec.hip", "train_misc.hip"]
+SOURCES = ["api.hip", "prep.hip", "gemm.hip", "rec.hip", "head.hip", "mlp_api.hip", "mlp_train.hip", "cnn_api.hip", "cnn_train.hip", "gen.hip", "crps.hip", "evalm.hip", "derive.hip", "online.hip", "phys.hip", "phys_rad.hip", "phys_train.hip", "stoch.hip", "stoch_bwd.hip", "train_api.hip", "train_rec.hip", "train_misc.hip"]
 HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "train.h"), os.path.join(CSRC, "pack.h"), os.path.join(CSRC, "rh_to_q.h"), os.path.join(CSRC, "stoch.h"), os.path.join(CSRC, "phys.h"),
            os.path.join(HERE, "..", "include", "climsim_amd.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")

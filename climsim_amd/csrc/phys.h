@@ -100,11 +100,47 @@ struct csa_phys {
     int ng = PH_NG;         // g-points of the export (= nreg: 12 / 14 / 16; the kernels run 16 with zero-weight padding)
     float *wr_xmean = nullptr, *wr_xdiv = nullptr, *wr_lqc = nullptr, *wr_lqi = nullptr;
     float *XM = nullptr, *XS = nullptr, *XD = nullptr, *O5 = nullptr, *OS = nullptr;
+    // training (phys_train.hip; non-radiative graph): the trainable tensors as given at create, and the state csa_phys_train_enable builds
+    std::vector<float> host_params;
+    struct PhysTrain *tr = nullptr;
     std::vector<void *> owned;
 };
 
 #define PH_XG_K 24          // 18 gas-optics inputs, zero-padded to a multiple of 8 (two k-quads per MFMA group)
 #define PH_XR_K 24
+
+// head-GEMM column order
+enum { H_QV = 0, H_QN, H_T, H_AREA, H_FLUX, H_EDDY, H_QICE, H_SED, H_EVAP, H_COND, H_AA };
+
+#ifdef __HIPCC__
+__device__ __forceinline__ float ph_softplus(float x) { return x > 20.0f ? x : log1pf(expf(x)); }   // torch.softplus(beta 1, threshold 20)
+template <int N> __device__ __forceinline__ float ph_sum(float v)
+{
+#pragma unroll
+    for (int o = N / 2; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+template <int N> __device__ __forceinline__ float ph_max(float v)
+{
+#pragma unroll
+    for (int o = N / 2; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+}
+
+// row of (column b, CRM level l) in rnn_mem / mem_out: (B, 50, 16), or level-major (50, B, 16) for the physRad graphs
+__device__ __forceinline__ size_t ph_mem_row(const PhysDev &d, int B, int b, int l)
+{
+    return d.memlm ? (size_t)l * B + b : (size_t)b * d.Lc + l;
+}
+
+#endif
+
+// phys.hip: the two kernels the training forward shares with inference
+int launch_phys_prep(const PhysDev &d, int B, const float *x_main, const float *x_sfc, const float *mem, float *X1, float *hx, hipStream_t s);
+int launch_phys_decode_hidden(const PhysDev &d, int B, const float *HD, const float *Hlast, const float *x_sfc, const float *mem,
+                              const float *x_denorm, int nxd, float *out_lev, float *out_sfc, float *mem_out, hipStream_t s);
+// phys_train.hip
+void phys_train_free(struct PhysTrain *t);
 
 // phys_rad.hip
 int launch_phys_radiation(csa_phys *h, int B, const float *x_sfc, float *out_lev, float *out_sfc, hipStream_t s, const float *mask_u = nullptr);

@@ -23,26 +23,6 @@
 //           decoder (num4050)
 #include "phys.h"
 #include "stoch.h"
-__device__ __forceinline__ float ph_softplus(float x) { return x > 20.0f ? x : log1pf(expf(x)); }   // torch.softplus(beta 1, threshold 20)
-template <int N> __device__ __forceinline__ float ph_sum(float v)
-{
-#pragma unroll
-    for (int o = N / 2; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    return v;
-}
-template <int N> __device__ __forceinline__ float ph_max(float v)
-{
-#pragma unroll
-    for (int o = N / 2; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
-    return v;
-}
-
-// row of (column b, CRM level l) in rnn_mem / mem_out: (B, 50, 16), or level-major (50, B, 16) for the physRad graphs
-__device__ __forceinline__ size_t ph_mem_row(const PhysDev &d, int B, int b, int l)
-{
-    return d.memlm ? (size_t)l * B + b : (size_t)b * d.Lc + l;
-}
-
 // one workgroup (128 threads = nh) per grid column: thread j owns hidden unit j of mlp_initial / mlp_surface1
 __global__ __launch_bounds__(128) void phys_prep_kernel(PhysDev d, int B, const float *__restrict__ x_main, const float *__restrict__ x_sfc,
                                                         const float *__restrict__ mem, float *__restrict__ X1, float *__restrict__ hx)
@@ -96,8 +76,6 @@ __global__ __launch_bounds__(128) void phys_prep_kernel(PhysDev d, int B, const 
     }
 }
 
-// head-GEMM column order
-enum { H_QV = 0, H_QN, H_T, H_AREA, H_FLUX, H_EDDY, H_QICE, H_SED, H_EVAP, H_COND, H_AA };
 
 // E3SM's ice effective radius table and liquid effective radius rule (rnn/models/physics_rad_e3sm.py:13, :62)
 __device__ __forceinline__ float ph_reitab(const float *__restrict__ tab, float t)
@@ -669,7 +647,18 @@ extern "C" int csa_phys_create(int nx, int nx_sfc, int nh, int ilev_crm, int mp_
     v.lat_w = *p++; v.lat_b = *p++; v.out_w = *p++; v.out_b = *p++; v.sfo_w = *p++; v.sfo_b = *p++; v.rad_w = *p++; v.rad_b = *p++;
     v.rel_w = *p++; v.rel_b = *p++;
     v.heads = p;
-    return phys_build(nx, nx, nx_sfc, nx_sfc, nx_sfc, nh, ilev_crm, mp_ncol, nh_mem0, 0, 0, 0, v, max_batch, out);
+    int rc = phys_build(nx, nx, nx_sfc, nx_sfc, nx_sfc, nh, ilev_crm, mp_ncol, nh_mem0, 0, 0, 0, v, max_batch, out);
+    if (rc != CSA_OK) return rc;
+    // the trainable tensors in state_dict order (csa_phys_train_param_info): kept on the host until csa_phys_train_enable
+    std::vector<float> &hp = (*out)->host_params;
+    auto app = [&](const float *src, size_t n) { hp.insert(hp.end(), src, src + n); };
+    app(v.init_w, (size_t)nh * (nx + 1)); app(v.init_b, nh); app(v.s1_w, (size_t)nh * nx_sfc); app(v.s1_b, nh);
+    app(v.r1_ih, (size_t)3 * nh * (nh + nh_mem0)); app(v.r1_hh, (size_t)3 * nh * nh); app(v.r1_bih, 3 * nh); app(v.r1_bhh, 3 * nh);
+    app(v.r2_ih, (size_t)3 * nh * nh); app(v.r2_hh, (size_t)3 * nh * nh); app(v.r2_bih, 3 * nh); app(v.r2_bhh, 3 * nh);
+    app(v.lat_w, (size_t)nh_mem0 * nh); app(v.lat_b, nh_mem0); app(v.out_w, 5 * nh_mem0); app(v.out_b, 5);
+    app(v.sfo_w, 6 * nh); app(v.sfo_b, 6); app(v.rad_w, nh); app(v.rad_b, 1); app(v.rel_w, nh); app(v.rel_b, 1);
+    for (int k = 0; k < PH_NHEAD; ++k) { app(v.heads[2 * k], (size_t)mp_ncol * nh); app(v.heads[2 * k + 1], mp_ncol); }
+    return CSA_OK;
 }
 
 // The radiation graphs (num4050): see include/climsim_amd.h for the pointer order
@@ -835,9 +824,26 @@ extern "C" int csa_phys_wrapped_create(int nh, int ng, int flags, const float *c
     return rc;
 }
 
+int launch_phys_prep(const PhysDev &d, int B, const float *x_main, const float *x_sfc, const float *mem, float *X1, float *hx, hipStream_t s)
+{
+    hipLaunchKernelGGL(phys_prep_kernel, dim3(B, B <= 1024 ? 4 : 1), dim3(128), 0, s, d, B, x_main, x_sfc, mem, X1, hx);
+    CSA_HIP_CHECK(hipGetLastError());
+    return CSA_OK;
+}
+
+int launch_phys_decode_hidden(const PhysDev &d, int B, const float *HD, const float *Hlast, const float *x_sfc, const float *mem,
+                              const float *x_denorm, int nxd, float *out_lev, float *out_sfc, float *mem_out, hipStream_t s)
+{
+    hipLaunchKernelGGL((phys_decode_kernel<16, 512, false>), dim3(B), dim3(512), 0, s, d, B, HD, Hlast, x_sfc, mem, x_denorm, nxd,
+                       out_lev, out_sfc, mem_out, PhysRadOut{});
+    CSA_HIP_CHECK(hipGetLastError());
+    return CSA_OK;
+}
+
 extern "C" int csa_phys_destroy(csa_phys *h)
 {
     if (!h) return CSA_ERR_ARG;
+    if (h->tr) phys_train_free(h->tr);
     if (h->rnn3) csa_stoch_destroy(h->rnn3);
     for (void *p : h->owned) (void)hipFree(p);
     delete h;

@@ -221,6 +221,96 @@ class physical_RNN_autoreg(torch.nn.Module):
 
 
 # ---- the frozen `*_wrapped` exports ---------------------------------------------------------------------------------------------------
+class physical_RNN_trainer:
+    """Training of the non-radiative physRNN graph on the device (C-ABI csa_phys_train_*; reference: the model the training script
+    builds at rnn/train_rnn_rollout_torchscript_hydra.py:553-554 and differentiates with autograd).  The parameters live in ONE flat
+    device vector in state_dict order; `forward` keeps the activations, `backward` takes the loss gradients w.r.t. the three outputs,
+    accumulates into `self.grads` and returns the gradient w.r.t. the incoming memory (the link of a TBPTT window)."""
+
+    def __init__(self, model):
+        if model.use_physrad:
+            raise RuntimeError("physical_RNN_trainer: built for the non-radiative graph")
+        self.model, self._h, self.device = model, model._h, model.device
+        L = _lib.lib()
+        rc = L.csa_phys_train_enable(self._h)
+        if rc != 0:
+            raise RuntimeError(f"csa_phys_train_enable failed ({rc}): {_lib.last_error()}")
+        nt, nf = ctypes.c_int(), ctypes.c_int()
+        L.csa_phys_train_num_params(self._h, ctypes.byref(nt), ctypes.byref(nf))
+        self.nparam, self.info = nf.value, []
+        for i in range(nt.value):
+            name, off, rows, cols = ctypes.c_char_p(), ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+            L.csa_phys_train_param_info(self._h, i, ctypes.byref(name), ctypes.byref(off), ctypes.byref(rows), ctypes.byref(cols))
+            self.info.append((name.value.decode(), off.value, rows.value, cols.value))
+        self.grads = torch.zeros(self.nparam, device=self.device)
+        self._pending = None
+
+    def _stream(self):
+        return ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def named(self, flat):
+        """name -> view of a flat vector, shaped like the reference's state_dict entry"""
+        return {n: (flat[o:o + r * c].view(r, c) if "weight" in n else flat[o:o + r * c]) for n, o, r, c in self.info}
+
+    def params(self):
+        flat = torch.empty(self.nparam, device=self.device)
+        rc = _lib.lib().csa_phys_train_get_params(self._h, _ptr(flat), self._stream())
+        if rc != 0:
+            raise RuntimeError(f"csa_phys_train_get_params failed ({rc}): {_lib.last_error()}")
+        return flat
+
+    def set_params(self, flat):
+        flat = _check(flat, (self.nparam,), "params")
+        rc = _lib.lib().csa_phys_train_set_params(self._h, _ptr(flat), self._stream())
+        if rc != 0:
+            raise RuntimeError(f"csa_phys_train_set_params failed ({rc}): {_lib.last_error()}")
+
+    def state_dict(self):
+        return {k: v.clone() for k, v in self.named(self.params()).items()}
+
+    def zero_grad(self):
+        self.grads.zero_()
+
+    def forward(self, inp_list, hx2=None):
+        m = self.model
+        x_main, x_sfc, rnn_mem, x_denorm = inp_list[0], inp_list[1], inp_list[2], inp_list[3]
+        B = x_main.shape[0]
+        x_main = _check(x_main, (B, m.nlev, m.nx), "inputs_main")
+        x_sfc = _check(x_sfc, (B, m.nx_sfc), "inputs_aux")
+        rnn_mem = _check(rnn_mem, (B, m.nlev_mem, m.nh_mem), "rnn_mem")
+        x_denorm = _check(x_denorm, (B, m.nlev, x_denorm.shape[-1]), "inputs_denorm")
+        hx2 = torch.randn(B, m.nh, device=self.device) if hx2 is None else _check(hx2, (B, m.nh), "hx2")
+        out, out_sfc = torch.empty(B, m.nlev, 5, device=self.device), torch.empty(B, 8, device=self.device)
+        mem_out = torch.empty(B, m.nlev_mem, m.nh_mem, device=self.device)
+        rc = _lib.lib().csa_phys_train_forward(self._h, B, _ptr(x_main), _ptr(x_sfc), _ptr(rnn_mem), _ptr(x_denorm), int(x_denorm.shape[-1]),
+                                               _ptr(hx2), _ptr(out), _ptr(out_sfc), _ptr(mem_out), self._stream())
+        if rc != 0:
+            raise RuntimeError(f"csa_phys_train_forward failed ({rc}): {_lib.last_error()}")
+        self._pending = (B, x_main, x_sfc, rnn_mem, x_denorm)
+        return out, out_sfc, mem_out
+
+    def backward(self, d_out, d_out_sfc, d_mem_out):
+        if self._pending is None:
+            raise RuntimeError("physical_RNN_trainer.backward: no pending forward")
+        B, x_main, x_sfc, rnn_mem, x_denorm = self._pending
+        m = self.model
+        d_out, d_out_sfc = _check(d_out, (B, m.nlev, 5), "d_out"), _check(d_out_sfc, (B, 8), "d_out_sfc")
+        d_mem_out = _check(d_mem_out, (B, m.nlev_mem, m.nh_mem), "d_mem_out")
+        d_mem_in = torch.empty(B, m.nlev_mem, m.nh_mem, device=self.device)
+        rc = _lib.lib().csa_phys_train_backward(self._h, B, _ptr(x_main), _ptr(x_sfc), _ptr(rnn_mem), _ptr(x_denorm), int(x_denorm.shape[-1]),
+                                                _ptr(d_out), _ptr(d_out_sfc), _ptr(d_mem_out), _ptr(d_mem_in), _ptr(self.grads), self._stream())
+        if rc != 0:
+            raise RuntimeError(f"csa_phys_train_backward failed ({rc}): {_lib.last_error()}")
+        self._pending = None
+        return d_mem_in
+
+    def adam_step(self, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01):
+        rc = _lib.lib().csa_phys_train_adam_step(self._h, _ptr(self.grads), float(lr), float(betas[0]), float(betas[1]), float(eps),
+                                                 float(weight_decay), self._stream())
+        if rc != 0:
+            raise RuntimeError(f"csa_phys_train_adam_step failed ({rc}): {_lib.last_error()}")
+
+
 _W_ORDER = (["hyam", "hybm", "hyai", "hybi", "yscale_lev", "yscale_sca", "xdiv_sca", "xmean_sca",
              "mlp_initial.weight", "mlp_initial.bias", "mlp_surface1.weight", "mlp_surface1.bias"]
             + [f"rnn{r}.{n}_l0" for r in (1, 2) for n in ("weight_ih", "weight_hh", "bias_ih", "bias_hh")]

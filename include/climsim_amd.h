@@ -510,6 +510,32 @@ int csa_phys_wrapped_forward(csa_phys *h, int B, const float *x_main0, const flo
                              const float *hx1, const float *eps3, const float *mask_u, const float *srnn, float *out_lev,
                              float *out_sfc, float *mem_out, void *stream);
 
+/* ---- physRNN training (the trainable model of rnn/train_rnn_rollout_torchscript_hydra.py:553-554) ----------
+ * Backward of the non-radiative Hidden graph (csa_phys_create handles): rnn/models_phys.py:226-412 (forward) and :414-748
+ * (microphysics_decode), differentiated by hand; pinned by torch autograd through oracle/physrnn_ref.py (tests/test_physrnn_train.py).
+ * csa_phys_train_enable  builds the training state from the weights given at create: a flat parameter vector in state_dict order
+ *                        (csa_phys_train_param_info: name, offset, rows, cols of tensor i), Adam moments, the kernel layouts gathered
+ *                        from it, and the activation buffers for max_batch columns.
+ * csa_phys_train_forward as csa_phys_forward (same arguments), keeping the GRU gates / hidden sequences / head-GEMM output.
+ * csa_phys_train_backward given dLoss/d(out_lev) (B,60,5), dLoss/d(out_sfc) (B,8), dLoss/d(mem_out) (B,50,16) and the forward's own
+ *                        inputs: grads (nparam floats) += dLoss/dparams, d_mem_in (B,50,16) = dLoss/d(rnn_mem).  Deterministic
+ *                        (fixed-order partial sums, no atomics).
+ * csa_phys_train_adam_step torch.optim.AdamW update of the flat vector, then the kernel layouts re-packed (one gather launch).
+ * get / set_params copy the flat vector (device pointers).  The inference entry points of the same handle keep the weights given at
+ * create: build a new handle from the trained state_dict to serve it. */
+int csa_phys_train_enable(csa_phys *h);
+int csa_phys_train_num_params(csa_phys *h, int *n_tensors, int *n_floats);
+int csa_phys_train_param_info(csa_phys *h, int i, const char **name, int *offset, int *rows, int *cols);
+int csa_phys_train_get_params(csa_phys *h, float *dst, void *stream);
+int csa_phys_train_set_params(csa_phys *h, const float *src, void *stream);
+int csa_phys_train_forward(csa_phys *h, int B, const float *x_main, const float *x_sfc, const float *rnn_mem, const float *x_denorm,
+                           int nxd, const float *hx2, float *out_lev, float *out_sfc, float *mem_out, void *stream);
+int csa_phys_train_backward(csa_phys *h, int B, const float *x_main, const float *x_sfc, const float *rnn_mem, const float *x_denorm,
+                            int nxd, const float *d_out, const float *d_out_sfc, const float *d_mem_out, float *d_mem_in,
+                            float *grads, void *stream);
+int csa_phys_train_adam_step(csa_phys *h, const float *grads, float lr, float beta1, float beta2, float eps, float weight_decay,
+                             void *stream);
+
 /* ---- stochastic recurrent layers ---------------------------------------------------
  * MyStochasticGRULayer5  rnn/models_torch_kernels.py:834-891 (its GPU path = the repo's inline CUDA, :29-252)
  * MyStochasticLSTMLayer4 rnn/models_torch_kernels.py:1474-1531

@@ -1,0 +1,152 @@
+"""physRNN training step (verdict item: "backward of the physRNN path").
+
+The reference differentiates physical_RNN_autoreg with torch autograd (rnn/train_rnn_rollout_torchscript_hydra.py:553-554 builds
+it as the trainable model, rnn/utils.py:1070-1137 drives it).  The product differentiates by hand (csrc/phys_train.hip: decoder
+backward, BPTT through both GRUs, split-M weight-gradient GEMMs).  Oracle: autograd through oracle/physrnn_ref.py -- the restatement
+the forward tests pin to the shipped artefacts -- in float64.
+
+Tolerance per gradient tensor: max(2e-5 * max|g64|, 6 x noise), noise = |autograd float32 - autograd float64| of the restatement
+itself: the decoder's clamps (torch.maximum / relu) are sub-gradient switches, the rescalings divide by region means, and float32
+autograd of the same formulas is that far from exact arithmetic.  A wrong term (a missed path through a clamp, a flux divergence
+applied to the wrong neighbour) shows up at 1e-2 .. 1 relative."""
+import os
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN
+from make_golden_physrnn import inputs
+from oracle import physrnn_ref
+from test_physrnn import _load
+
+REPORT = os.environ.get("CSA_PARITY_REPORT")
+
+
+def _upstream(B, seed):
+    g = torch.Generator().manual_seed(900 + seed)
+    d_out = torch.randn(B, 60, 5, generator=g)
+    d_sfc = torch.randn(B, 8, generator=g)
+    d_mem = 0.2 * torch.randn(B, 50, 16, generator=g)
+    return d_out, d_sfc, d_mem
+
+
+def _autograd(P, xm, xs, mem, xd, hx2, ups, dtype):
+    names = [k for k in P if k.split(".")[0].startswith(("mlp", "rnn"))]
+    Pd = {k: v.to(dtype) for k, v in P.items()}
+    leaves = {k: Pd[k].clone().requires_grad_(True) for k in names}
+    Pd.update(leaves)
+    mem = mem.to(dtype).clone().requires_grad_(True)
+    out, out_sfc, mem_out = physrnn_ref.forward(Pd, xm.to(dtype), xs.to(dtype), mem, xd.to(dtype), hx2.to(dtype))
+    loss = (out * ups[0].to(dtype)).sum() + (out_sfc * ups[1].to(dtype)).sum() + (mem_out * ups[2].to(dtype)).sum()
+    loss.backward()
+    g = {k: v.grad.detach() for k, v in leaves.items()}
+    g["rnn_mem"] = mem.grad.detach()
+    return (out.detach(), out_sfc.detach(), mem_out.detach()), g
+
+
+def _trainer(P, max_batch):
+    from climsim_amd.physrnn import physical_RNN_autoreg, physical_RNN_trainer
+    m = physical_RNN_autoreg(P, max_batch=max_batch)
+    return m, physical_RNN_trainer(m)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B", [3, 64, 385])
+def test_hip_physrnn_gradients_match_autograd_of_the_restatement(B):
+    g, P = _load()
+    xm, xs, mem, xd = inputs(P, B, 70 + B)
+    hx2 = torch.randn(B, 128, generator=torch.Generator().manual_seed(B))
+    ups = _upstream(B, B)
+    fw64, g64 = _autograd(P, xm, xs, mem, xd, hx2, ups, torch.float64)
+    fw32, g32 = _autograd(P, xm, xs, mem, xd, hx2, ups, torch.float32)
+    m, tr = _trainer(P, max(B, 8))
+    # the flat vector is the state_dict, in order
+    named = tr.named(tr.params())
+    for k, v in named.items():
+        assert torch.equal(v.cpu().reshape(P[k].shape), P[k]), k
+    assert set(named) == set(g64) - {"rnn_mem"}
+    inp = [xm.cuda(), xs.cuda(), mem.cuda(), xd.cuda()]
+    out = tr.forward(inp, hx2=hx2.cuda())
+    # the training forward is the inference forward through other layouts: same outputs to rounding
+    ref = m(inp, hx2=hx2.cuda())
+    for a, b, r in zip(out, ref, fw64):
+        assert (a - b).abs().max().item() <= 2e-5 * r.abs().max().item() + 1e-6
+    d_mem_in = tr.backward(ups[0].cuda(), ups[1].cuda(), ups[2].cuda())
+    got = {k: v.cpu().reshape(g64[k].shape) for k, v in tr.named(tr.grads).items()}
+    got["rnn_mem"] = d_mem_in.cpu()
+    lines, worst = [], 0.0
+    for k in sorted(g64):
+        scale = g64[k].abs().max().item()
+        noise = (g32[k].double() - g64[k]).abs().max().item()
+        err = (got[k].double() - g64[k]).abs().max().item()
+        tol = max(2e-5 * scale, 6 * noise)
+        lines.append(f"B={B:4d} {k:40s} max|g|={scale:9.3e} noise={noise:9.3e} err={err:9.3e} err/tol={err / tol:6.3f}")
+        worst = max(worst, err / tol)
+    if REPORT:
+        with open(REPORT, "a") as f:
+            f.write("\n".join(lines) + "\n")
+    bad = [l for l in lines if float(l.rsplit("=", 1)[1]) > 1.0]
+    assert not bad, "\n".join(bad)
+    with pytest.raises(RuntimeError, match="no pending forward"):
+        tr.backward(ups[0].cuda(), ups[1].cuda(), ups[2].cuda())
+
+
+@pytest.mark.gpu
+def test_hip_physrnn_gradients_accumulate_and_are_deterministic():
+    g, P = _load()
+    B = 96
+    xm, xs, mem, xd = (t.cuda() for t in inputs(P, B, 5))
+    hx2 = torch.randn(B, 128, generator=torch.Generator().manual_seed(1)).cuda()
+    ups = [t.cuda() for t in _upstream(B, 1)]
+    m, tr = _trainer(P, B)
+    runs = []
+    for _ in range(2):
+        tr.zero_grad()
+        tr.forward([xm, xs, mem, xd], hx2=hx2)
+        dm = tr.backward(*ups)
+        runs.append((tr.grads.clone(), dm.clone()))
+    assert torch.equal(runs[0][0], runs[1][0]) and torch.equal(runs[0][1], runs[1][1])
+    tr.forward([xm, xs, mem, xd], hx2=hx2)
+    tr.backward(*ups)                                      # no zero_grad: the second pass adds
+    assert torch.allclose(tr.grads, 2 * runs[0][0], rtol=1e-6, atol=1e-9)
+
+
+@pytest.mark.gpu
+def test_hip_physrnn_adam_step_matches_torch_adamw_and_repacks():
+    g, P = _load()
+    B = 32
+    xm, xs, mem, xd = inputs(P, B, 9)
+    hx2 = torch.randn(B, 128, generator=torch.Generator().manual_seed(2))
+    ups = _upstream(B, 2)
+    m, tr = _trainer(P, B)
+    inp = [xm.cuda(), xs.cuda(), mem.cuda(), xd.cuda()]
+    p0 = tr.params().clone()
+    tr.forward(inp, hx2=hx2.cuda())
+    tr.backward(*(u.cuda() for u in ups))
+    ref = torch.nn.Parameter(p0.clone())
+    ref.grad = tr.grads.clone()
+    opt = torch.optim.AdamW([ref], lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01)
+    opt.step()
+    tr.adam_step(1e-3)
+    p1 = tr.params()
+    assert (p1 - ref.detach()).abs().max().item() <= 2e-7
+    assert (p1 - p0).abs().max().item() > 1e-4
+    # the kernel layouts follow the update: the training forward equals the restatement run on the new state_dict
+    sd = {k: v.cpu() for k, v in tr.state_dict().items()}
+    P1 = dict(P)
+    P1.update({k: v.reshape(P[k].shape) for k, v in sd.items()})
+    out = tr.forward(inp, hx2=hx2.cuda())
+    P64 = {k: v.double() for k, v in P1.items()}
+    r64 = physrnn_ref.forward(P64, xm.double(), xs.double(), mem.double(), xd.double(), hx2.double())
+    r32 = physrnn_ref.forward(P1, xm, xs, mem, xd, hx2)
+    for a, r, q in zip(out, r64, r32):
+        noise = (q.double() - r).abs().max().item()
+        assert (a.cpu().double() - r).abs().max().item() <= max(1e-5 * r.abs().max().item(), 6 * noise)
+
+
+def test_training_entry_points_are_declared_and_exported():
+    from climsim_amd import _lib
+    hdr = open(os.path.join(os.path.dirname(GOLDEN), "..", "include", "climsim_amd.h")).read()
+    for s in ("csa_phys_train_enable", "csa_phys_train_forward", "csa_phys_train_backward", "csa_phys_train_adam_step",
+              "csa_phys_train_param_info", "csa_phys_train_get_params", "csa_phys_train_set_params", "csa_phys_train_num_params"):
+        assert s in _lib.SYMBOLS and ("int " + s + "(") in hdr
