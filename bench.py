@@ -360,6 +360,31 @@ def aux_workload(a, rank, world, dist):
         flop_col = (50 * (2.0 * 20 * 128 + 2.0 * 384 * (143 + 128) + 2.0 * 384 * 256 + 2.0 * 192 * 128) + 50 * 16 * 150.0
                     + 60 * 2.0 * (18 * 64 + 64 * 64 + 64 * 256 + 2 * 128 * 16 + 4 * (7 * 32 + 32 * 32 + 32 * 16)) + 60 * 16 * 250.0)
         what = "frozen physRNN export (model_wrapper + nx21 physical_RNN_autoreg: BiGRU 128/128 over 50 levels, 16-region decoder, LW/SW gas optics, two-stream solver), weights of num13483"
+    elif a.workload.startswith("physrnn_train_"):
+        import numpy as np
+        sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests", "golden"))
+        from make_golden_physrnn import inputs as phys_inputs
+        from climsim_amd.physrnn import physical_RNN_autoreg, physical_RNN_trainer
+        gz = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests", "golden", "physrnn_hidden.npz"))
+        Pw = {k[2:]: torch.from_numpy(gz[k]) for k in gz.files if k.startswith("w.")}
+        m = physical_RNN_autoreg(Pw, max_batch=B)
+        tr = physical_RNN_trainer(m)
+        xs_ = [t.cuda() for t in phys_inputs(Pw, B, 300 + rank)]
+        hx2 = torch.randn(B, 128, generator=g).cuda()
+        tgt = [torch.randn(B, 60, 5, generator=g).cuda() * 0.1, torch.randn(B, 8, generator=g).cuda() * 0.1]
+        d_mem = torch.zeros(B, 50, 16, device="cuda")
+        n_out = float(world * B * (60 * 5 + 8))
+
+        def step():   # forward, MSE gradient (two elementwise torch ops: the loss is not part of this path), backward, all-reduce, Adam
+            tr.zero_grad()
+            o, osfc, _ = tr.forward(xs_, hx2=hx2)
+            tr.backward((o - tgt[0]) * (2.0 / n_out), (osfc - tgt[1]) * (2.0 / n_out), d_mem)
+            if world > 1:
+                dist.all_reduce(tr.grads)
+            tr.adam_step(1e-5)
+        flop_col = 3 * (60 * (2.0 * 22 * 128 + 2.0 * 384 * (143 + 128) + 2.0 * 384 * 256 + 2.0 * 192 * 128) + 50 * 16 * 150.0)
+        what = ("physRNN-Hidden training step: forward with saved activations, MSE gradient, hand-written backward (decoder, BPTT through both GRUs, "
+                "weight-gradient GEMMs), Adam + re-pack; fwd+bwd = 3x forward FLOP")
     elif a.workload.startswith("physrnn_") and not a.workload.startswith("physrnn_rad_"):
         import numpy as np
         sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests", "golden"))
@@ -449,12 +474,12 @@ def aux_workload(a, rank, world, dist):
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * el / a.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": a.workload, "columns_per_gpu": B, "what": what,
-                       "parallelism": f"columns sharded x{world}, no collective"},
+                       "parallelism": f"columns sharded x{world}, " + ("one flat-gradient all-reduce per step" if "train" in a.workload else "no collective")},
             "whole_path": {"flop_per_column": flop_col, "achieved_tflops": tf, "frac_fp32_peak": tf / PEAK_FP32_TFLOPS}}),
             flush=True)
 
 
-AUX = ["cur_lstm144_384", "cur_lstm128_384", "cur_gru128_384", "mlp_384", "online_mlp_384", "physrnn_384", "physrnn_rad_384", "physrnn_2700", "physrnn_rad_2700", "physrnn_e3sm_384", "physrnn_e3sm_2700", "physrnn_wrapped_384", "physrnn_wrapped_2700", "cur_gru128_2700", "cnn_384", "cnn_train_384",
+AUX = ["cur_lstm144_384", "cur_lstm128_384", "cur_gru128_384", "mlp_384", "online_mlp_384", "physrnn_384", "physrnn_rad_384", "physrnn_2700", "physrnn_rad_2700", "physrnn_e3sm_384", "physrnn_e3sm_2700", "physrnn_wrapped_384", "physrnn_wrapped_2700", "physrnn_train_384", "physrnn_train_2700", "cur_gru128_2700", "cnn_384", "cnn_train_384",
        "cnn_train_512", "cnn_train_2700"]
 
 

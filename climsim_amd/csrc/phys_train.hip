@@ -683,7 +683,7 @@ extern "C" int csa_phys_train_backward(csa_phys *h, int B, const float *x_main, 
     return CSA_OK;
 }
 
-// AdamW step on the flat parameter vector (torch.optim.AdamW semantics, as csa_train_adam_step), then the kernel layouts re-packed
+// Adam step on the flat parameter vector (torch.optim.Adam semantics, as csa_train_adam), then the kernel layouts re-packed
 extern "C" int csa_phys_train_adam_step(csa_phys *h, const float *grads, float lr, float beta1, float beta2, float eps, float weight_decay,
                                         void *stream)
 {

@@ -304,7 +304,8 @@ class physical_RNN_trainer:
         self._pending = None
         return d_mem_in
 
-    def adam_step(self, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01):
+    def adam_step(self, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+        """torch.optim.Adam (the reference's default, train_rnn_rollout_torchscript_hydra.py:678); weight_decay is its L2 term."""
         rc = _lib.lib().csa_phys_train_adam_step(self._h, _ptr(self.grads), float(lr), float(betas[0]), float(betas[1]), float(eps),
                                                  float(weight_decay), self._stream())
         if rc != 0:

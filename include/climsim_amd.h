@@ -520,7 +520,8 @@ int csa_phys_wrapped_forward(csa_phys *h, int B, const float *x_main0, const flo
  * csa_phys_train_backward given dLoss/d(out_lev) (B,60,5), dLoss/d(out_sfc) (B,8), dLoss/d(mem_out) (B,50,16) and the forward's own
  *                        inputs: grads (nparam floats) += dLoss/dparams, d_mem_in (B,50,16) = dLoss/d(rnn_mem).  Deterministic
  *                        (fixed-order partial sums, no atomics).
- * csa_phys_train_adam_step torch.optim.AdamW update of the flat vector, then the kernel layouts re-packed (one gather launch).
+ * csa_phys_train_adam_step torch.optim.Adam update of the flat vector (the reference's default optimiser, :678; weight_decay is Adam's L2
+ *                        term), then the kernel layouts re-packed (one gather launch).
  * get / set_params copy the flat vector (device pointers).  The inference entry points of the same handle keep the weights given at
  * create: build a new handle from the trained state_dict to serve it. */
 int csa_phys_train_enable(csa_phys *h);

@@ -79,7 +79,7 @@ def test_hip_physrnn_gradients_match_autograd_of_the_restatement(B):
         scale = g64[k].abs().max().item()
         noise = (g32[k].double() - g64[k]).abs().max().item()
         err = (got[k].double() - g64[k]).abs().max().item()
-        tol = max(2e-5 * scale, 6 * noise)
+        tol = max(2e-5 * scale, 6 * noise, 1e-30)
         lines.append(f"B={B:4d} {k:40s} max|g|={scale:9.3e} noise={noise:9.3e} err={err:9.3e} err/tol={err / tol:6.3f}")
         worst = max(worst, err / tol)
     if REPORT:
@@ -112,7 +112,7 @@ def test_hip_physrnn_gradients_accumulate_and_are_deterministic():
 
 
 @pytest.mark.gpu
-def test_hip_physrnn_adam_step_matches_torch_adamw_and_repacks():
+def test_hip_physrnn_adam_step_matches_torch_adam_and_repacks():
     g, P = _load()
     B = 32
     xm, xs, mem, xd = inputs(P, B, 9)
@@ -125,7 +125,7 @@ def test_hip_physrnn_adam_step_matches_torch_adamw_and_repacks():
     tr.backward(*(u.cuda() for u in ups))
     ref = torch.nn.Parameter(p0.clone())
     ref.grad = tr.grads.clone()
-    opt = torch.optim.AdamW([ref], lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01)
+    opt = torch.optim.Adam([ref], lr=1e-3)        # the reference's default optimiser (train_rnn_rollout_torchscript_hydra.py:678)
     opt.step()
     tr.adam_step(1e-3)
     p1 = tr.params()
