@@ -2,8 +2,11 @@
 
 The reference differentiates physical_RNN_autoreg with torch autograd (rnn/train_rnn_rollout_torchscript_hydra.py:553-554 builds
 it as the trainable model, rnn/utils.py:1070-1137 drives it).  The product differentiates by hand (csrc/phys_train.hip: decoder
-backward, BPTT through both GRUs, split-M weight-gradient GEMMs).  Oracle: autograd through oracle/physrnn_ref.py -- the restatement
-the forward tests pin to the shipped artefacts -- in float64.
+backward, BPTT through both GRUs, split-M weight-gradient GEMMs).  Oracle chain:
+  autograd through the shipped TorchScript artefact itself, run in the build container (tests/golden/physrnn_hidden_grads.npz,
+  B = 8 / 37: every parameter gradient and d(rnn_mem))
+    -> CPU: autograd through the restatement oracle/physrnn_ref.py reproduces those gradients          (pins the gradient oracle)
+    -> GPU: the HIP backward reproduces them too, and matches float64 autograd of the restatement at B = 3 / 64 / 385.
 
 Tolerance per gradient tensor: max(2e-5 * max|g64|, 6 x noise), noise = |autograd float32 - autograd float64| of the restatement
 itself: the decoder's clamps (torch.maximum / relu) are sub-gradient switches, the rescalings divide by region means, and float32
@@ -42,6 +45,62 @@ def _autograd(P, xm, xs, mem, xd, hx2, ups, dtype):
     g = {k: v.grad.detach() for k, v in leaves.items()}
     g["rnn_mem"] = mem.grad.detach()
     return (out.detach(), out_sfc.detach(), mem_out.detach()), g
+
+
+def _artefact_grads():
+    return np.load(os.path.join(GOLDEN, "physrnn_hidden_grads.npz"))
+
+
+def _case_of(G, i):
+    B, seed = (int(v) for v in G[f"case{i}.cfg"])
+    ref = {k[len(f"case{i}.g."):]: torch.from_numpy(G[k]) for k in G.files if k.startswith(f"case{i}.g.")}
+    return B, seed, torch.from_numpy(G[f"case{i}.hx2"]), ref
+
+
+@pytest.mark.parametrize("i", [0, 1])
+def test_restatement_autograd_reproduces_the_artefacts_gradients(i):
+    """Pins the gradient oracle: autograd through the restatement = autograd through the shipped TorchScript graph (fixture made by
+    tests/golden/make_golden_physrnn_grads.py), every parameter and d(rnn_mem); float64 autograd of the restatement is the yardstick
+    for the two float32 results."""
+    g, P = _load()
+    B, seed, hx2, ref = _case_of(_artefact_grads(), i)
+    xm, xs, mem, xd = inputs(P, B, seed)
+    ups = _upstream(B, seed)
+    _, g32 = _autograd(P, xm, xs, mem, xd, hx2, ups, torch.float32)
+    _, g64 = _autograd(P, xm, xs, mem, xd, hx2, ups, torch.float64)
+    assert set(ref) == set(g64)
+    for k in sorted(ref):
+        scale = g64[k].abs().max().item()
+        noise = max((g32[k].double() - g64[k]).abs().max().item(), (ref[k].double() - g64[k]).abs().max().item())
+        assert (g32[k] - ref[k]).abs().max().item() <= max(2e-5 * scale, 3 * noise), k
+        assert (ref[k].double() - g64[k]).abs().max().item() <= 2e-3 * scale + 1e-12, (k, scale)     # same formulas: float32 rounding only
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("i", [0, 1])
+def test_hip_physrnn_gradients_match_the_artefacts_autograd(i):
+    g, P = _load()
+    B, seed, hx2, ref = _case_of(_artefact_grads(), i)
+    xm, xs, mem, xd = inputs(P, B, seed)
+    ups = _upstream(B, seed)
+    _, g64 = _autograd(P, xm, xs, mem, xd, hx2, ups, torch.float64)
+    m, tr = _trainer(P, 64)
+    tr.forward([xm.cuda(), xs.cuda(), mem.cuda(), xd.cuda()], hx2=hx2.cuda())
+    d_mem_in = tr.backward(*(u.cuda() for u in ups))
+    got = {k: v.cpu().reshape(ref[k].shape) for k, v in tr.named(tr.grads).items()}
+    got["rnn_mem"] = d_mem_in.cpu()
+    lines = []
+    for k in sorted(ref):
+        scale = ref[k].abs().max().item()
+        noise = (ref[k].double() - g64[k]).abs().max().item()          # the artefact's own float32 rounding
+        err = (got[k] - ref[k]).abs().max().item()
+        tol = max(2e-5 * scale, 6 * noise, 1e-30)
+        lines.append(f"artefact B={B:3d} {k:40s} max|g|={scale:9.3e} noise={noise:9.3e} err={err:9.3e} err/tol={err / tol:6.3f}")
+    if REPORT:
+        with open(REPORT, "a") as f:
+            f.write("\n".join(lines) + "\n")
+    bad = [l for l in lines if float(l.rsplit("=", 1)[1]) > 1.0]
+    assert not bad, "\n".join(bad)
 
 
 def _trainer(P, max_batch):
