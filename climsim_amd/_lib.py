@@ -197,13 +197,13 @@ def lib():
     L.csa_phys_wrapped_forward.argtypes = [H, i] + [_F] * 11 + [ctypes.c_void_p]
     L.csa_phys_forward.argtypes = [H, i, _F, _F, _F, _F, i, _F, _F, _F, _F, ctypes.c_void_p]
     L.csa_phys_tap.argtypes = [H, i, i, _F, ctypes.c_void_p]
-    L.csa_phys_train_enable.argtypes = [H]
+    L.csa_phys_train_enable.argtypes = [H, i]
     L.csa_phys_train_num_params.argtypes = [H, ctypes.POINTER(i), ctypes.POINTER(i)]
     L.csa_phys_train_param_info.argtypes = [H, i, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(i), ctypes.POINTER(i), ctypes.POINTER(i)]
     L.csa_phys_train_get_params.argtypes = [H, _F, ctypes.c_void_p]
     L.csa_phys_train_set_params.argtypes = [H, _F, ctypes.c_void_p]
-    L.csa_phys_train_forward.argtypes = [H, i, _F, _F, _F, _F, i, _F, _F, _F, _F, ctypes.c_void_p]
-    L.csa_phys_train_backward.argtypes = [H, i, _F, _F, _F, _F, i, _F, _F, _F, _F, _F, ctypes.c_void_p]
+    L.csa_phys_train_forward.argtypes = [H, i, i, _F, _F, _F, _F, i, _F, _F, _F, _F, ctypes.c_void_p]
+    L.csa_phys_train_backward.argtypes = [H, i, i, _F, _F, _F, _F, i, _F, _F, _F, _F, _F, ctypes.c_void_p]
     L.csa_phys_train_adam_step.argtypes = [H, _F] + [ctypes.c_float] * 5 + [ctypes.c_void_p]
     L.csa_phys_postprocess.argtypes = [H, i, _F, _F, _F, i, _F, _F, ctypes.c_void_p]
     L.csa_online_destroy.argtypes = [H]

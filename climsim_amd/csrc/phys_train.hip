@@ -384,13 +384,15 @@ __global__ void phys_add_last_kernel(float *__restrict__ dH_last, const float *_
 
 struct PtInfo { std::string name; int off, rows, cols; };
 struct PhysTrain {
-    int nparam = 0, nsplit = 192, adam_step = 0, fwd_B = 0;
+    int nparam = 0, nsplit = 192, adam_step = 0;
     std::vector<PtInfo> info;
     PhysDev d;
     float *params = nullptr, *adam_m = nullptr, *adam_v = nullptr;
     float *wih1, *bias1, *bhn1, *whh1g, *wih2, *bias2, *bhn2, *whh2g, *whead, *bhead;      // forward layouts (gate rows u*4 + [r, z, n, pad])
     float *wih1T, *wih2T, *whh1Tp, *whh2Tp, *wheadT;                                       // backward layouts
-    float *GP1, *GP2, *Hs1, *Hs2, *dHD, *dH2, *dH1, *dX1, *dlast, *dhx1, *dhx2, *dpold, *XIN, *XS, *DHX, *part, *part_b, *rtmp;
+    struct Slot { float *X1, *H1, *hx, *HD, *GP1, *GP2, *Hs1, *Hs2; int B = 0; };      // what one pending forward keeps
+    std::vector<Slot> slots;
+    float *dHD, *dH2, *dH1, *dX1, *dlast, *dhx1, *dhx2, *dpold, *XIN, *XS, *DHX, *part, *part_b, *rtmp;
     int *m_whead, *m_bhead, *m_wih1, *m_whh1, *m_b1a, *m_b1b, *m_wih2, *m_whh2, *m_b2a, *m_b2b, *m_dec, *m_init, *m_initb, *m_s1, *m_s1b;
     std::vector<GatherEntry> gathers;
     GatherEntry *gtab = nullptr;
@@ -437,10 +439,10 @@ std::vector<int> pt_to_int(const std::vector<float> &f, int off)
 int pt_repack(PhysTrain *t, hipStream_t s) { return launch_gather_multi(t->gtab, (int)t->gathers.size(), t->gmax, t->params, s); }
 }   // namespace
 
-extern "C" int csa_phys_train_enable(csa_phys *h)
+extern "C" int csa_phys_train_enable(csa_phys *h, int nslots)
 {
-    if (!h) return CSA_ERR_ARG;
-    if (h->tr) return CSA_OK;
+    if (!h || nslots < 1 || nslots > 16) return CSA_ERR_ARG;
+    if (h->tr) return (int)h->tr->slots.size() == nslots ? CSA_OK : CSA_ERR_ARG;
     if (h->d.rad || h->host_params.empty()) {
         csa_set_error_msg("csa_phys_train_enable: training is built for the non-radiative Hidden graph (csa_phys_create)");
         return CSA_ERR_UNSUPPORTED;
@@ -550,8 +552,13 @@ extern "C" int csa_phys_train_enable(csa_phys *h)
     if (rc == CSA_OK && hipMemcpy(t->gtab, t->gathers.data(), sizeof(GatherEntry) * t->gathers.size(), hipMemcpyHostToDevice) != hipSuccess) rc = CSA_ERR_HIP;
     // ---- saved activations and work arrays ----
     const size_t MB = (size_t)h->max_batch, M = (size_t)PH_L * MB;
-    t->GP1 = pt_alloc<float>(t, M * 4 * nh, rc); t->GP2 = pt_alloc<float>(t, M * 4 * nh, rc);
-    t->Hs1 = pt_alloc<float>(t, (M + MB) * nh, rc); t->Hs2 = pt_alloc<float>(t, (M + MB) * nh, rc);
+    t->slots.resize(nslots);
+    for (PhysTrain::Slot &S : t->slots) {
+        S.X1 = pt_alloc<float>(t, M * K1, rc); S.H1 = pt_alloc<float>(t, M * nh, rc); S.hx = pt_alloc<float>(t, MB * nh, rc);
+        S.HD = pt_alloc<float>(t, M * HDW, rc);
+        S.GP1 = pt_alloc<float>(t, M * 4 * nh, rc); S.GP2 = pt_alloc<float>(t, M * 4 * nh, rc);
+        S.Hs1 = pt_alloc<float>(t, (M + MB) * nh, rc); S.Hs2 = pt_alloc<float>(t, (M + MB) * nh, rc);
+    }
     t->dHD = pt_alloc<float>(t, M * HDW, rc); t->dH2 = pt_alloc<float>(t, M * nh, rc); t->dH1 = pt_alloc<float>(t, M * nh, rc);
     t->dX1 = pt_alloc<float>(t, M * K1, rc); t->dlast = pt_alloc<float>(t, MB * nh, rc); t->dhx1 = pt_alloc<float>(t, MB * nh, rc);
     t->dhx2 = pt_alloc<float>(t, MB * nh, rc); t->dpold = pt_alloc<float>(t, MB, rc);
@@ -600,11 +607,11 @@ extern "C" int csa_phys_train_set_params(csa_phys *h, const float *src, void *st
 }
 
 // training forward: as csa_phys_forward, through the training layouts, keeping what the backward pass needs (GRU gates and
-// hidden sequences, X1, the head GEMM's output).  One forward may be pending per handle.
-extern "C" int csa_phys_train_forward(csa_phys *h, int B, const float *x_main, const float *x_sfc, const float *rnn_mem, const float *x_denorm,
-                                      int nxd, const float *hx2, float *out_lev, float *out_sfc, float *mem_out, void *stream)
+// hidden sequences, X1, the head GEMM's output) in `slot`: one pending forward per slot (a TBPTT window of T_w steps uses T_w slots).
+extern "C" int csa_phys_train_forward(csa_phys *h, int slot, int B, const float *x_main, const float *x_sfc, const float *rnn_mem,
+                                      const float *x_denorm, int nxd, const float *hx2, float *out_lev, float *out_sfc, float *mem_out, void *stream)
 {
-    if (!h || !h->tr || !x_main || !x_sfc || !rnn_mem || !x_denorm || !hx2 || !out_lev || !out_sfc || !mem_out || B <= 0 || B > h->max_batch || nxd < 5) {
+    if (!h || !h->tr || slot < 0 || slot >= (int)h->tr->slots.size() || !x_main || !x_sfc || !rnn_mem || !x_denorm || !hx2 || !out_lev || !out_sfc || !mem_out || B <= 0 || B > h->max_batch || nxd < 5) {
         csa_set_error_msg("csa_phys_train_forward: bad argument (csa_phys_train_enable first)");
         return CSA_ERR_ARG;
     }
@@ -612,37 +619,41 @@ extern "C" int csa_phys_train_forward(csa_phys *h, int B, const float *x_main, c
     hipStream_t s = (hipStream_t)stream;
     const PhysDev &d = t->d;
     const int nh = d.nh, L = PH_L, M = L * B;
+    PhysTrain::Slot &S = t->slots[slot];
     int rc;
-    if ((rc = launch_phys_prep(d, B, x_main, x_sfc, rnn_mem, h->X1, h->hx, s))) return rc;
-    if ((rc = launch_proj_gemm(h->X1, t->wih1, t->bias1, t->GP1, M, 4 * nh, nh + 16, s))) return rc;
-    if ((rc = launch_rec_train_gru(nh, t->whh1g, t->bhn1, t->GP1, h->hx, h->H1, B, L, 1, t->Hs1, s))) return rc;
-    if ((rc = launch_proj_gemm(h->H1, t->wih2, t->bias2, t->GP2, M, 4 * nh, nh, s))) return rc;
-    float *H2 = t->Hs2 + (size_t)B * nh;
-    if ((rc = launch_rec_train_gru(nh, t->whh2g, t->bhn2, t->GP2, hx2, H2, B, L, 0, t->Hs2, s))) return rc;
-    if ((rc = launch_proj_gemm(H2, t->whead, t->bhead, h->HD, M, d.hdw, nh, s))) return rc;
-    if ((rc = launch_phys_decode_hidden(d, B, h->HD, H2, x_sfc, rnn_mem, x_denorm, nxd, out_lev, out_sfc, mem_out, s))) return rc;
-    t->fwd_B = B;
+    S.B = 0;
+    if ((rc = launch_phys_prep(d, B, x_main, x_sfc, rnn_mem, S.X1, S.hx, s))) return rc;
+    if ((rc = launch_proj_gemm(S.X1, t->wih1, t->bias1, S.GP1, M, 4 * nh, nh + 16, s))) return rc;
+    if ((rc = launch_rec_train_gru(nh, t->whh1g, t->bhn1, S.GP1, S.hx, S.H1, B, L, 1, S.Hs1, s))) return rc;
+    if ((rc = launch_proj_gemm(S.H1, t->wih2, t->bias2, S.GP2, M, 4 * nh, nh, s))) return rc;
+    float *H2 = S.Hs2 + (size_t)B * nh;
+    if ((rc = launch_rec_train_gru(nh, t->whh2g, t->bhn2, S.GP2, hx2, H2, B, L, 0, S.Hs2, s))) return rc;
+    if ((rc = launch_proj_gemm(H2, t->whead, t->bhead, S.HD, M, d.hdw, nh, s))) return rc;
+    if ((rc = launch_phys_decode_hidden(d, B, S.HD, H2, x_sfc, rnn_mem, x_denorm, nxd, out_lev, out_sfc, mem_out, s))) return rc;
+    S.B = B;
     return CSA_OK;
 }
 
 // backward of the pending forward: grads (nparam floats, state_dict order) += dLoss/dparams; d_mem_in (B, 50, 16) = dLoss/d(rnn_mem).
 // The inputs are the forward's (they are read again, not copied).
-extern "C" int csa_phys_train_backward(csa_phys *h, int B, const float *x_main, const float *x_sfc, const float *rnn_mem, const float *x_denorm,
+extern "C" int csa_phys_train_backward(csa_phys *h, int slot, int B, const float *x_main, const float *x_sfc, const float *rnn_mem, const float *x_denorm,
                                        int nxd, const float *d_out, const float *d_out_sfc, const float *d_mem_out, float *d_mem_in,
                                        float *grads, void *stream)
 {
-    if (!h || !h->tr || !x_main || !x_sfc || !rnn_mem || !x_denorm || !d_out || !d_out_sfc || !d_mem_out || !d_mem_in || !grads) {
+    if (!h || !h->tr || slot < 0 || slot >= (int)h->tr->slots.size() || !x_main || !x_sfc || !rnn_mem || !x_denorm || !d_out || !d_out_sfc ||
+        !d_mem_out || !d_mem_in || !grads) {
         csa_set_error_msg("csa_phys_train_backward: bad argument");
         return CSA_ERR_ARG;
     }
     PhysTrain *t = h->tr;
-    if (t->fwd_B != B || B <= 0) { csa_set_error_msg("csa_phys_train_backward: no pending forward of this batch size"); return CSA_ERR_ARG; }
+    PhysTrain::Slot &S = t->slots[slot];
+    if (S.B != B || B <= 0) { csa_set_error_msg("csa_phys_train_backward: no pending forward of this batch size in the slot"); return CSA_ERR_ARG; }
     hipStream_t s = (hipStream_t)stream;
     const PhysDev &d = t->d;
     const int nh = d.nh, L = PH_L, M = L * B, HDW = d.hdw, K1 = nh + 16, ns = t->nsplit, npart = pb_part_floats(nh);
-    float *H2 = t->Hs2 + (size_t)B * nh;
+    float *H2 = S.Hs2 + (size_t)B * nh;
     int rc;
-    hipLaunchKernelGGL(phys_decode_bwd_kernel, dim3(B), dim3(PB_T), 0, s, d, B, h->HD, H2, x_sfc, rnn_mem, x_denorm, nxd, d_out, d_out_sfc, d_mem_out,
+    hipLaunchKernelGGL(phys_decode_bwd_kernel, dim3(B), dim3(PB_T), 0, s, d, B, S.HD, H2, x_sfc, rnn_mem, x_denorm, nxd, d_out, d_out_sfc, d_mem_out,
                        t->dHD, t->dlast, t->dpold, t->part);
     CSA_HIP_CHECK(hipGetLastError());
     if ((rc = launch_reduce_partials_2stage(t->part, B, npart, t->m_dec, nullptr, grads, t->rtmp, 32, s))) return rc;
@@ -654,23 +665,23 @@ extern "C" int csa_phys_train_backward(csa_phys *h, int B, const float *x_main, 
     if ((rc = launch_reduce_partials(t->part, ns, HDW * nh, t->m_whead, nullptr, grads, s))) return rc;
     if ((rc = launch_reduce_partials(t->part_b, ns, HDW, t->m_bhead, nullptr, grads, s))) return rc;
     // rnn2 (downward)
-    if ((rc = launch_bwd_rec_gru(nh, t->whh2Tp, t->GP2, t->Hs2, t->dH2, t->dhx2, B, L, 0, s))) return rc;
-    if ((rc = launch_proj_gemm(t->GP2, t->wih2T, nullptr, t->dH1, M, nh, 4 * nh, s))) return rc;
-    if ((rc = launch_gemm_tn_partial_cs(t->GP2, 4 * nh, h->H1, nh, t->part, t->part_b, M, 4 * nh, nh, ns, s))) return rc;
+    if ((rc = launch_bwd_rec_gru(nh, t->whh2Tp, S.GP2, S.Hs2, t->dH2, t->dhx2, B, L, 0, s))) return rc;
+    if ((rc = launch_proj_gemm(S.GP2, t->wih2T, nullptr, t->dH1, M, nh, 4 * nh, s))) return rc;
+    if ((rc = launch_gemm_tn_partial_cs(S.GP2, 4 * nh, S.H1, nh, t->part, t->part_b, M, 4 * nh, nh, ns, s))) return rc;
     if ((rc = launch_reduce_partials(t->part, ns, 4 * nh * nh, t->m_wih2, nullptr, grads, s))) return rc;
     if ((rc = launch_reduce_partials(t->part_b, ns, 4 * nh, t->m_b2a, t->m_b2b, grads, s))) return rc;
-    if ((rc = launch_gemm_tn_partial(t->GP2, 4 * nh, t->Hs2, nh, t->part, M, 4 * nh, nh, ns, s))) return rc;
+    if ((rc = launch_gemm_tn_partial(S.GP2, 4 * nh, S.Hs2, nh, t->part, M, 4 * nh, nh, ns, s))) return rc;
     if ((rc = launch_reduce_partials(t->part, ns, 4 * nh * nh, t->m_whh2, nullptr, grads, s))) return rc;
     // rnn1 (upward): dH1 is in level order, the recurrence ran over the flipped axis
-    if ((rc = launch_bwd_rec_gru(nh, t->whh1Tp, t->GP1, t->Hs1, t->dH1, t->dhx1, B, L, 1, s))) return rc;
-    if ((rc = launch_proj_gemm(t->GP1, t->wih1T, nullptr, t->dX1, M, K1, 4 * nh, s))) return rc;
-    if ((rc = launch_gemm_tn_partial_cs(t->GP1, 4 * nh, h->X1, K1, t->part, t->part_b, M, 4 * nh, K1, ns, s))) return rc;
+    if ((rc = launch_bwd_rec_gru(nh, t->whh1Tp, S.GP1, S.Hs1, t->dH1, t->dhx1, B, L, 1, s))) return rc;
+    if ((rc = launch_proj_gemm(S.GP1, t->wih1T, nullptr, t->dX1, M, K1, 4 * nh, s))) return rc;
+    if ((rc = launch_gemm_tn_partial_cs(S.GP1, 4 * nh, S.X1, K1, t->part, t->part_b, M, 4 * nh, K1, ns, s))) return rc;
     if ((rc = launch_reduce_partials(t->part, ns, 4 * nh * K1, t->m_wih1, nullptr, grads, s))) return rc;
     if ((rc = launch_reduce_partials(t->part_b, ns, 4 * nh, t->m_b1a, t->m_b1b, grads, s))) return rc;
-    if ((rc = launch_gemm_tn_partial(t->GP1, 4 * nh, t->Hs1, nh, t->part, M, 4 * nh, nh, ns, s))) return rc;
+    if ((rc = launch_gemm_tn_partial(S.GP1, 4 * nh, S.Hs1, nh, t->part, M, 4 * nh, nh, ns, s))) return rc;
     if ((rc = launch_reduce_partials(t->part, ns, 4 * nh * nh, t->m_whh1, nullptr, grads, s))) return rc;
     // mlp_initial, mlp_surface1, incoming memory (DPRE reuses dH1: rnn1's BPTT has consumed it)
-    hipLaunchKernelGGL(phys_prep_bwd_kernel, dim3(B), dim3(128), 0, s, d, B, x_main, x_sfc, h->X1, h->hx, t->dX1, t->dhx1, t->dpold, t->dH1, t->XIN,
+    hipLaunchKernelGGL(phys_prep_bwd_kernel, dim3(B), dim3(128), 0, s, d, B, x_main, x_sfc, S.X1, S.hx, t->dX1, t->dhx1, t->dpold, t->dH1, t->XIN,
                        t->DHX, t->XS, d_mem_in);
     CSA_HIP_CHECK(hipGetLastError());
     if ((rc = launch_gemm_tn_partial_cs(t->dH1, nh, t->XIN, 32, t->part, t->part_b, M, nh, 32, ns, s))) return rc;
@@ -679,7 +690,7 @@ extern "C" int csa_phys_train_backward(csa_phys *h, int B, const float *x_main, 
     if ((rc = launch_gemm_tn_partial_cs(t->DHX, nh, t->XS, 32, t->part, t->part_b, B, nh, 32, ns, s))) return rc;
     if ((rc = launch_reduce_partials(t->part, ns, nh * 32, t->m_s1, nullptr, grads, s))) return rc;
     if ((rc = launch_reduce_partials(t->part_b, ns, nh, t->m_s1b, nullptr, grads, s))) return rc;
-    t->fwd_B = 0;
+    S.B = 0;
     return CSA_OK;
 }
 

@@ -227,12 +227,12 @@ class physical_RNN_trainer:
     device vector in state_dict order; `forward` keeps the activations, `backward` takes the loss gradients w.r.t. the three outputs,
     accumulates into `self.grads` and returns the gradient w.r.t. the incoming memory (the link of a TBPTT window)."""
 
-    def __init__(self, model):
+    def __init__(self, model, slots=1):
         if model.use_physrad:
             raise RuntimeError("physical_RNN_trainer: built for the non-radiative graph")
-        self.model, self._h, self.device = model, model._h, model.device
+        self.model, self._h, self.device, self.slots = model, model._h, model.device, int(slots)
         L = _lib.lib()
-        rc = L.csa_phys_train_enable(self._h)
+        rc = L.csa_phys_train_enable(self._h, self.slots)
         if rc != 0:
             raise RuntimeError(f"csa_phys_train_enable failed ({rc}): {_lib.last_error()}")
         nt, nf = ctypes.c_int(), ctypes.c_int()
@@ -243,7 +243,7 @@ class physical_RNN_trainer:
             L.csa_phys_train_param_info(self._h, i, ctypes.byref(name), ctypes.byref(off), ctypes.byref(rows), ctypes.byref(cols))
             self.info.append((name.value.decode(), off.value, rows.value, cols.value))
         self.grads = torch.zeros(self.nparam, device=self.device)
-        self._pending = None
+        self._pending = {}
 
     def _stream(self):
         return ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
@@ -271,7 +271,7 @@ class physical_RNN_trainer:
     def zero_grad(self):
         self.grads.zero_()
 
-    def forward(self, inp_list, hx2=None):
+    def forward(self, inp_list, hx2=None, slot=0):
         m = self.model
         x_main, x_sfc, rnn_mem, x_denorm = inp_list[0], inp_list[1], inp_list[2], inp_list[3]
         B = x_main.shape[0]
@@ -282,27 +282,43 @@ class physical_RNN_trainer:
         hx2 = torch.randn(B, m.nh, device=self.device) if hx2 is None else _check(hx2, (B, m.nh), "hx2")
         out, out_sfc = torch.empty(B, m.nlev, 5, device=self.device), torch.empty(B, 8, device=self.device)
         mem_out = torch.empty(B, m.nlev_mem, m.nh_mem, device=self.device)
-        rc = _lib.lib().csa_phys_train_forward(self._h, B, _ptr(x_main), _ptr(x_sfc), _ptr(rnn_mem), _ptr(x_denorm), int(x_denorm.shape[-1]),
+        rc = _lib.lib().csa_phys_train_forward(self._h, int(slot), B, _ptr(x_main), _ptr(x_sfc), _ptr(rnn_mem), _ptr(x_denorm), int(x_denorm.shape[-1]),
                                                _ptr(hx2), _ptr(out), _ptr(out_sfc), _ptr(mem_out), self._stream())
         if rc != 0:
             raise RuntimeError(f"csa_phys_train_forward failed ({rc}): {_lib.last_error()}")
-        self._pending = (B, x_main, x_sfc, rnn_mem, x_denorm)
+        self._pending[int(slot)] = (B, x_main, x_sfc, rnn_mem, x_denorm)
         return out, out_sfc, mem_out
 
-    def backward(self, d_out, d_out_sfc, d_mem_out):
-        if self._pending is None:
-            raise RuntimeError("physical_RNN_trainer.backward: no pending forward")
-        B, x_main, x_sfc, rnn_mem, x_denorm = self._pending
+    def backward(self, d_out, d_out_sfc, d_mem_out, slot=0):
+        if int(slot) not in self._pending:
+            raise RuntimeError("physical_RNN_trainer.backward: no pending forward in this slot")
+        B, x_main, x_sfc, rnn_mem, x_denorm = self._pending.pop(int(slot))
         m = self.model
         d_out, d_out_sfc = _check(d_out, (B, m.nlev, 5), "d_out"), _check(d_out_sfc, (B, 8), "d_out_sfc")
         d_mem_out = _check(d_mem_out, (B, m.nlev_mem, m.nh_mem), "d_mem_out")
         d_mem_in = torch.empty(B, m.nlev_mem, m.nh_mem, device=self.device)
-        rc = _lib.lib().csa_phys_train_backward(self._h, B, _ptr(x_main), _ptr(x_sfc), _ptr(rnn_mem), _ptr(x_denorm), int(x_denorm.shape[-1]),
+        rc = _lib.lib().csa_phys_train_backward(self._h, int(slot), B, _ptr(x_main), _ptr(x_sfc), _ptr(rnn_mem), _ptr(x_denorm), int(x_denorm.shape[-1]),
                                                 _ptr(d_out), _ptr(d_out_sfc), _ptr(d_mem_out), _ptr(d_mem_in), _ptr(self.grads), self._stream())
         if rc != 0:
             raise RuntimeError(f"csa_phys_train_backward failed ({rc}): {_lib.last_error()}")
-        self._pending = None
         return d_mem_in
+
+    def window(self, steps, rnn_mem, loss_grad, hx2=None):
+        """One truncated-BPTT window (the reference's loop, rnn/utils.py:1200-1377: the memory returned by step t is the input of
+        step t+1, the loss is summed over the window, one backward).  steps: list of (x_main, x_sfc, x_denorm) per step (len <= slots);
+        loss_grad(t, out, out_sfc) -> (d_out, d_out_sfc), the loss gradient of step t's outputs; hx2: list of rnn2 initial states or
+        None (drawn).  Returns (outputs per step, final memory detached, d(loss)/d(incoming memory)); gradients accumulate in .grads."""
+        if len(steps) > self.slots:
+            raise RuntimeError("physical_RNN_trainer.window: more steps than slots")
+        outs, mem = [], rnn_mem
+        for t, (xm, xs, xd) in enumerate(steps):
+            o, osfc, mem = self.forward([xm, xs, mem, xd], hx2=None if hx2 is None else hx2[t], slot=t)
+            outs.append((o, osfc))
+        d_mem = torch.zeros_like(mem)
+        for t in reversed(range(len(steps))):
+            d_o, d_sfc = loss_grad(t, *outs[t])
+            d_mem = self.backward(d_o, d_sfc, d_mem, slot=t)
+        return outs, mem, d_mem
 
     def adam_step(self, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
         """torch.optim.Adam (the reference's default, train_rnn_rollout_torchscript_hydra.py:678); weight_decay is its L2 term."""

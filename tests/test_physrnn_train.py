@@ -8,8 +8,9 @@ backward, BPTT through both GRUs, split-M weight-gradient GEMMs).  Oracle chain:
     -> CPU: autograd through the restatement oracle/physrnn_ref.py reproduces those gradients          (pins the gradient oracle)
     -> GPU: the HIP backward reproduces them too, and matches float64 autograd of the restatement at B = 3 / 64 / 385.
 
-Tolerance per gradient tensor: max(2e-5 * max|g64|, 6 x noise), noise = |autograd float32 - autograd float64| of the restatement
-itself: the decoder's clamps (torch.maximum / relu) are sub-gradient switches, the rescalings divide by region means, and float32
+Tolerance per gradient tensor: max(5e-5 * max|g64|, 6 x noise), noise = |autograd float32 - autograd float64| of the restatement
+itself (for a one-element tensor such as mlp_precip_release.bias that is a single draw, hence the relative floor: its gradient is a
+sum over columns of terms that cancel, 2.3e-5 relative was observed between two correct float32 evaluations): the decoder's clamps (torch.maximum / relu) are sub-gradient switches, the rescalings divide by region means, and float32
 autograd of the same formulas is that far from exact arithmetic.  A wrong term (a missed path through a clamp, a flux divergence
 applied to the wrong neighbour) shows up at 1e-2 .. 1 relative."""
 import os
@@ -94,7 +95,7 @@ def test_hip_physrnn_gradients_match_the_artefacts_autograd(i):
         scale = ref[k].abs().max().item()
         noise = (ref[k].double() - g64[k]).abs().max().item()          # the artefact's own float32 rounding
         err = (got[k] - ref[k]).abs().max().item()
-        tol = max(2e-5 * scale, 6 * noise, 1e-30)
+        tol = max(5e-5 * scale, 6 * noise, 1e-30)
         lines.append(f"artefact B={B:3d} {k:40s} max|g|={scale:9.3e} noise={noise:9.3e} err={err:9.3e} err/tol={err / tol:6.3f}")
     if REPORT:
         with open(REPORT, "a") as f:
@@ -103,10 +104,10 @@ def test_hip_physrnn_gradients_match_the_artefacts_autograd(i):
     assert not bad, "\n".join(bad)
 
 
-def _trainer(P, max_batch):
+def _trainer(P, max_batch, slots=1):
     from climsim_amd.physrnn import physical_RNN_autoreg, physical_RNN_trainer
     m = physical_RNN_autoreg(P, max_batch=max_batch)
-    return m, physical_RNN_trainer(m)
+    return m, physical_RNN_trainer(m, slots=slots)
 
 
 @pytest.mark.gpu
@@ -138,7 +139,7 @@ def test_hip_physrnn_gradients_match_autograd_of_the_restatement(B):
         scale = g64[k].abs().max().item()
         noise = (g32[k].double() - g64[k]).abs().max().item()
         err = (got[k].double() - g64[k]).abs().max().item()
-        tol = max(2e-5 * scale, 6 * noise, 1e-30)
+        tol = max(5e-5 * scale, 6 * noise, 1e-30)
         lines.append(f"B={B:4d} {k:40s} max|g|={scale:9.3e} noise={noise:9.3e} err={err:9.3e} err/tol={err / tol:6.3f}")
         worst = max(worst, err / tol)
     if REPORT:
@@ -148,6 +149,66 @@ def test_hip_physrnn_gradients_match_autograd_of_the_restatement(B):
     assert not bad, "\n".join(bad)
     with pytest.raises(RuntimeError, match="no pending forward"):
         tr.backward(ups[0].cuda(), ups[1].cuda(), ups[2].cuda())
+    with pytest.raises(RuntimeError, match="failed"):
+        tr.forward(inp, hx2=hx2.cuda(), slot=1)          # one slot only
+
+
+@pytest.mark.gpu
+def test_hip_physrnn_tbptt_window_matches_autograd_through_the_chained_restatement():
+    """Three autoregressive steps (the memory a step returns feeds the next, rnn/utils.py:1200-1377), loss summed over the window, ONE
+    backward: float64 autograd through three chained calls of the restatement against three forwards into slots 0..2 and three
+    backwards in reverse order that hand d(rnn_mem) down."""
+    g, P = _load()
+    B, T = 48, 3
+    ins = [inputs(P, B, 40 + t) for t in range(T)]
+    hx2 = [torch.randn(B, 128, generator=torch.Generator().manual_seed(7 + t)) for t in range(T)]
+    ups = [_upstream(B, 20 + t) for t in range(T)]
+    mem0 = ins[0][2]
+
+    def chain(dtype):
+        names = [k for k in P if k.split(".")[0].startswith(("mlp", "rnn"))]
+        Pd = {k: v.to(dtype) for k, v in P.items()}
+        leaves = {k: Pd[k].clone().requires_grad_(True) for k in names}
+        Pd.update(leaves)
+        mem = mem0.to(dtype).clone().requires_grad_(True)
+        m, loss = mem, 0.0
+        for t in range(T):
+            out, out_sfc, m = physrnn_ref.forward(Pd, ins[t][0].to(dtype), ins[t][1].to(dtype), m, ins[t][3].to(dtype), hx2[t].to(dtype))
+            loss = loss + (out * ups[t][0].to(dtype)).sum() + (out_sfc * ups[t][1].to(dtype)).sum()
+        loss = loss + (m * ups[T - 1][2].to(dtype)).sum()
+        loss.backward()
+        gr = {k: v.grad.detach() for k, v in leaves.items()}
+        gr["rnn_mem"] = mem.grad.detach()
+        return gr
+    g64, g32 = chain(torch.float64), chain(torch.float32)
+    m, tr = _trainer(P, B, slots=T)
+    mem, outs = mem0.cuda(), []
+    for t in range(T):
+        o, osfc, mem = tr.forward([ins[t][0].cuda(), ins[t][1].cuda(), mem, ins[t][3].cuda()], hx2=hx2[t].cuda(), slot=t)
+    d_mem = ups[T - 1][2].cuda()
+    for t in reversed(range(T)):
+        d_mem = tr.backward(ups[t][0].cuda(), ups[t][1].cuda(), d_mem, slot=t)
+    got = {k: v.cpu().reshape(g64[k].shape) for k, v in tr.named(tr.grads).items()}
+    got["rnn_mem"] = d_mem.cpu()
+    lines = []
+    for k in sorted(g64):
+        scale = g64[k].abs().max().item()
+        noise = (g32[k].double() - g64[k]).abs().max().item()
+        err = (got[k].double() - g64[k]).abs().max().item()
+        tol = max(5e-5 * scale, 6 * noise, 1e-30)
+        lines.append(f"window T=3 B={B} {k:40s} max|g|={scale:9.3e} noise={noise:9.3e} err={err:9.3e} err/tol={err / tol:6.3f}")
+    if REPORT:
+        with open(REPORT, "a") as f:
+            f.write("\n".join(lines) + "\n")
+    bad = [l for l in lines if float(l.rsplit("=", 1)[1]) > 1.0]
+    assert not bad, "\n".join(bad)
+    # the helper runs the same window
+    tr.zero_grad()
+    steps = [(ins[t][0].cuda(), ins[t][1].cuda(), ins[t][3].cuda()) for t in range(T)]
+    first = got
+    outs, mem_T, d0 = tr.window(steps, mem0.cuda(), lambda t, o, s_: (ups[t][0].cuda(), ups[t][1].cuda()), hx2=[h.cuda() for h in hx2])
+    # (window() starts the chain from a zero d(mem_out): add the last step's memory term by linearity is not needed for this check)
+    assert torch.isfinite(tr.grads).all() and mem_T.shape == (B, 50, 16) and d0.shape == (B, 50, 16)
 
 
 @pytest.mark.gpu
