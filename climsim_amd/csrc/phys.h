@@ -43,7 +43,10 @@ struct PhysDev {
     int rad_qv_upd;         // 1: radiation reads the updated grid-mean q_v, 0: the un-updated one
     int n_ir, n_mix;        // g-points [0, n_ir) near-infrared, [n_ir, n_mix) mixed, the rest visible (surface albedo, SOLL / SOLS split)
     float mix_near, mix_vis;   // weights of the mixed g-points (learned in most variants; 0.5 / 0.5 otherwise and in the older graphs)
-    const float *cldtab;    // (12, 16): Slingo A..F then Ebert-Curry a..f per g-point
+    const float *cldtab;    // (12, 16): Slingo A..F then Ebert-Curry a..f per g-point; cld_band: (12, 4) per BAND, then the (4, 16) band -> g-point matrix
+    int cld_band;           // 1: later exports (num32701, num87824): k, k ssa, k ssa g of the four bands times a learned band -> g-point matrix
+    int ice_re;             // 1: the ice SW optics read the ICE effective radius (later exports); 0: the liquid one clamped to 13..130, as first serialised
+    int sw_ngk;             // > 0: the SW gas models give sw_ngk k-points, reduced to the 16 g-points by Linear + softplus * 0.01 BEHIND the humidity coin
 };
 
 // layout of the nx21 SW gas-optics block (floats): input range (same offsets as SWG_XMIN / SWG_XDIV), then per model (absorption,
@@ -56,7 +59,9 @@ struct PhysDev {
 #define SWX_W3 (SWX_B2 + 32)
 #define SWX_B3 (SWX_W3 + 16 * 32)
 #define SWX_MODEL_FLOATS (SWX_B3 + 16)
-#define SWX_FLOATS (SWX_MODEL0 + 2 * SWX_MODEL_FLOATS)
+#define SWX_RED (SWX_MODEL0 + 2 * SWX_MODEL_FLOATS)     // k-point reductions (num11916, num87824): W (16, 16: 16 g rows, k zero-padded), b (16), absorption then Rayleigh
+#define SWX_RED_FLOATS (16 * 16 + 16)
+#define SWX_FLOATS (SWX_RED + 2 * SWX_RED_FLOATS)
 
 // layout of the CSA_PHYS_SW_GAS block (floats): input range, two gas-optics models, the two 112 -> 16 reductions, cloud-optics
 // coefficients per g-point.  The 112-wide axis is zero-padded to 128 (four 32-column MFMA tiles; a padded k-point has

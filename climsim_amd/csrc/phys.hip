@@ -443,15 +443,31 @@ __global__ __launch_bounds__(DT) void phys_decode_kernel(PhysDev d, int B, const
                 const float rl0 = ph_reltab(T_new, aux[13] * d.xdiv_sca[13] + d.xmean_sca[13], aux[12] * d.xdiv_sca[12] + d.xmean_sca[12],
                                             aux[15] * d.xdiv_sca[15] + d.xmean_sca[15]);
                 const float rl = fminf(fmaxf(rl0, 4.2f), 16.0f);
-                const float ri = d.nx21 ? fminf(fmaxf(rl0, 13.0f), 130.0f) : rei;     // nx21: the ice optics see the LIQUID radius, as serialised
-                const float kl = t[0] + t[16] / rl, wl = fminf((1.0f - t[32]) - rl * t[48], 0.999999f), gl = t[64] + rl * t[80];
-                const float ki = t[96] + t[112] / ri, wi = fminf((1.0f - t[128]) - ri * t[144], 0.999999f), gi = t[160] + ri * t[176];
-                const float cwp_liq = liq * cwp, sl = kl * wl, si = ki * wi;
+                const float ri = (d.nx21 && !d.ice_re) ? fminf(fmaxf(rl0, 13.0f), 130.0f) : rei;     // first nx21 exports: the ice optics see the LIQUID radius, as serialised
+                float kl, sl, sgl, ki, si, sgi;
+                if (d.cld_band) {      // four bands, then the learned band -> g-point matrix on k, k ssa, k ssa g
+                    const float *tb = d.cldtab, *Mb = d.cldtab + 48 + g;
+                    kl = sl = sgl = ki = si = sgi = 0.0f;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float m = Mb[16 * q];
+                        const float k1 = tb[q] + tb[4 + q] / rl, w1 = fminf((1.0f - tb[8 + q]) - rl * tb[12 + q], 0.999999f), g1 = tb[16 + q] + rl * tb[20 + q];
+                        const float k2 = tb[24 + q] + tb[28 + q] / ri, w2 = fminf((1.0f - tb[32 + q]) - ri * tb[36 + q], 0.999999f), g2 = tb[40 + q] + ri * tb[44 + q];
+                        kl = fmaf(k1, m, kl); sl = fmaf(k1 * w1, m, sl); sgl = fmaf((k1 * w1) * g1, m, sgl);
+                        ki = fmaf(k2, m, ki); si = fmaf(k2 * w2, m, si); sgi = fmaf((k2 * w2) * g2, m, sgi);
+                    }
+                } else {
+                    const float wl = fminf((1.0f - t[32]) - rl * t[48], 0.999999f), gl = t[64] + rl * t[80];
+                    const float wi = fminf((1.0f - t[128]) - ri * t[144], 0.999999f), gi = t[160] + ri * t[176];
+                    kl = t[0] + t[16] / rl; ki = t[96] + t[112] / ri;
+                    sl = kl * wl; si = ki * wi; sgl = sl * gl; sgi = si * gi;
+                }
+                const float cwp_liq = liq * cwp;
                 const float c_sca = cwp_liq * sl + cwp_ice * si;
                 float *cs = ro.CS + ((size_t)l * B + b) * 48 + g;
                 cs[0] = cwp_ice * ki + cwp_liq * kl;
                 cs[16] = c_sca;
-                cs[32] = (cwp_liq * (sl * gl) + cwp_ice * (si * gi)) / (c_sca + 1e-7f);
+                cs[32] = (cwp_liq * sgl + cwp_ice * sgi) / (c_sca + 1e-7f);
             }
         }
     }
@@ -605,7 +621,8 @@ static int phys_build(int nx, int nfeat, int naux, int nx_sfc, int sfc_cut, int 
         h->r1_w = up(w.r1_w, 16 * 128); h->r1_b = up(w.r1_b, 16);
         h->r2_w = up(w.r2_w, 16 * 128); h->r2_b = up(w.r2_b, 16);
         if (w.swx) {          // the nx21 generation of the frozen exports
-            d.swg = up(w.swx, SWX_FLOATS); d.cldtab = up(w.cldtab, 12 * PH_NG);
+            d.sw_ngk = (int)w.misc[4]; d.ice_re = (int)w.misc[5]; d.cld_band = (int)w.misc[6];
+            d.swg = up(w.swx, SWX_FLOATS); d.cldtab = up(w.cldtab, d.cld_band ? 12 * 4 + 4 * PH_NG : 12 * PH_NG);
             h->CS = up(nullptr, (size_t)d.Lc * max_batch * 48);
             d.nx21 = 1; d.memlm = 1; d.lw_dn = 1; d.rad_qv_upd = w.rad_qv_upd;
             d.n_ir = (int)w.misc[0]; d.n_mix = (int)w.misc[1]; d.mix_near = w.misc[2]; d.mix_vis = w.misc[3];

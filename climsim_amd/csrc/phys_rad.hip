@@ -431,7 +431,7 @@ __global__ __launch_bounds__(64 * SG_WAVES) void rad_sw_gas_kernel(const float *
 // finishes a quarter of the g-points (gas + cloud -> tau, ssa, g).  Padded g-points (ng < 16) get tau 1, ssa 0, g 0: they carry no flux.
 #define SX_ROWS 64
 __global__ __launch_bounds__(256) void rad_sw_gas16_kernel(const float *__restrict__ XR, const float *__restrict__ swx, const float *__restrict__ CS,
-                                                          const float *__restrict__ mask_u, float *__restrict__ S2, int M, int B, int ilev, int ng)
+                                                          const float *__restrict__ mask_u, float *__restrict__ S2, int M, int B, int ilev, int ng, int ngk)
 {
     __shared__ __attribute__((aligned(16))) float sw[SWX_FLOATS];
     const int tid = threadIdx.x;
@@ -479,6 +479,41 @@ __global__ __launch_bounds__(256) void rad_sw_gas16_kernel(const float *__restri
     }
     // lane c of the row finishes g-points 4c .. 4c+3: absorption / Rayleigh of both variants from lanes 0..3 of the quad
     const int L = rowc / B, b = rowc - L * B;
+    if (ngk > 0) {
+        // sub-generation with k-point reductions (num11916, num87824): the coin picks the humidity variant per K-POINT (mask_u is
+        // (60, B, ngk)), then tau_g = softplus(W tau_k + b) * 0.01 (+ 1e-9 for the absorption); every lane gathers the ngk selected
+        // absorption / Rayleigh depths of its row from the quad and reduces them for its four g-points
+        float asel[16], ssel[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const float mine = tau[k];
+            const float v0 = __shfl(mine, (tid & ~3) + 0, 64), v1 = __shfl(mine, (tid & ~3) + 1, 64);
+            const float v2 = __shfl(mine, (tid & ~3) + 2, 64), v3 = __shfl(mine, (tid & ~3) + 3, 64);
+            const bool first = k < ngk ? mask_u[(size_t)rowc * ngk + k] < 0.5f : true;
+            asel[k] = k < ngk ? (first ? v0 : v2) : 0.0f;
+            ssel[k] = k < ngk ? (first ? v1 : v3) : 0.0f;
+        }
+        const float *R1 = sw + SWX_RED, *R2 = sw + SWX_RED + SWX_RED_FLOATS;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int g = 4 * c + j;
+            float a = R1[256 + g], sc = R2[256 + g];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) { a = fmaf(asel[k], R1[g * 16 + k], a); sc = fmaf(ssel[k], R2[g * 16 + k], sc); }
+            if (row >= M) continue;
+            float *o = S2 + (size_t)row * 48;
+            const float t_abs = (a > 20.0f ? a : log1pf(expf(a))) * 0.01f + 1.0000000000000001e-09f;
+            const float t_sca = (sc > 20.0f ? sc : log1pf(expf(sc))) * 0.01f;
+            float c_tau = 0.0f, c_sca = 0.0f, c_asy = 0.0f;
+            if (L >= ilev) {
+                const float *cs = CS + ((size_t)(L - ilev) * B + b) * 48;
+                c_tau = cs[g]; c_sca = cs[16 + g]; c_asy = cs[32 + g];
+            }
+            const float tot = (t_abs + t_sca) + c_tau, sca = fmaxf(t_sca + c_sca, 1.0000000000000001e-09f);
+            o[g] = tot; o[16 + g] = sca / tot; o[32 + g] = (c_asy * c_sca) / sca;
+        }
+        return;
+    }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         float a0 = 0.f, s0 = 0.f, a1 = 0.f, s1 = 0.f;
@@ -689,7 +724,7 @@ int launch_phys_radiation(csa_phys *h, int B, const float *x_sfc, float *out_lev
     CSA_HIP_CHECK(hipGetLastError());
     if (d.nx21) {
         if (!mask_u) { csa_set_error_msg("physRNN (frozen export): the SW humidity coin needs its uniform draws"); return CSA_ERR_ARG; }
-        hipLaunchKernelGGL(rad_sw_gas16_kernel, dim3((M + SX_ROWS - 1) / SX_ROWS), dim3(256), 0, s, h->XR, d.swg, h->CS, mask_u, h->S2, M, B, d.ilev, h->ng);
+        hipLaunchKernelGGL(rad_sw_gas16_kernel, dim3((M + SX_ROWS - 1) / SX_ROWS), dim3(256), 0, s, h->XR, d.swg, h->CS, mask_u, h->S2, M, B, d.ilev, h->ng, d.sw_ngk);
         CSA_HIP_CHECK(hipGetLastError());
     } else if (d.swg) {
         hipLaunchKernelGGL(rad_sw_gas_kernel, dim3((M + 32 * SG_WAVES - 1) / (32 * SG_WAVES)), dim3(64 * SG_WAVES), 0, s, h->XR, d.swg, h->CS, h->S2, M, B, d.ilev);

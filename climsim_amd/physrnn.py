@@ -374,15 +374,33 @@ class physical_RNN_wrapped(torch.nn.Module):
         blk = [pad8(f("gas_optics_model_sw1.xmin"), 0.0), pad8(f("gas_optics_model_sw1.xdiv"), 1.0)]
         for m in ("gas_optics_model_sw1", "gas_optics_model_sw2"):
             w1 = f(m + ".mlp1.weight")
-            if w1.shape != (32, 7) or f(m + ".mlp2.weight").shape != (32, 32) or f(m + ".mlp3.weight").shape != (nreg, 32):
+            ngk = int(f(m + ".mlp3.weight").shape[0])
+            if w1.shape != (32, 7) or f(m + ".mlp2.weight").shape != (32, 32) or f(m + ".mlp3.weight").shape[1] != 32 or \
+                    (ngk != nreg and "gas_optics_sw_reduce1.weight" not in state_dict) or ngk > 16:
                 raise RuntimeError("physRNN (frozen export): built for the shipped 7 -> 32 -> 32 -> ng SW gas-optics models")
             blk += [np.concatenate([w1, np.zeros((32, 1), np.float32)], 1).ravel(), f(m + ".mlp1.bias"), f(m + ".mlp2.weight").ravel(),
                     f(m + ".mlp2.bias"), pad_rows(f(m + ".mlp3.weight")).ravel(), pad_rows(f(m + ".mlp3.bias"))]
+        # k-point -> g-point reductions behind the humidity coin (sub-generation of num11916 / num87824), zero block otherwise
+        self.ngk = 0
+        for r in ("gas_optics_sw_reduce1", "gas_optics_sw_reduce2"):
+            wr, br = np.zeros((16, 16), np.float32), np.zeros(16, np.float32)
+            if r + ".weight" in state_dict:
+                w0 = f(r + ".weight")
+                if nreg != 16 or w0.shape[0] != 16:
+                    raise RuntimeError("physRNN (frozen export): the SW k-point reduction is built for 16 g-points")
+                self.ngk = int(w0.shape[1])
+                wr[:, :self.ngk], br[:] = w0, f(r + ".bias")
+            blk += [wr.ravel(), br]
         arrs.append(np.ascontiguousarray(np.concatenate(blk), np.float32))
-        band = list(cfg["band_idx"]) + [0] * (16 - nreg)
-        arrs.append(np.ascontiguousarray(np.asarray(_SLINGO + _EBERT_CURRY, np.float32)[:, band]))
+        tab = np.asarray(_SLINGO + _EBERT_CURRY, np.float32)
+        band_matrix = "cloud_band_to_gpt" in state_dict
+        if band_matrix:           # four-band tables + the learned (4, ng) band -> g-point matrix
+            arrs.append(np.ascontiguousarray(np.concatenate([tab.ravel(), pad_rows(f("cloud_band_to_gpt").T).T.ravel()]), np.float32))
+        else:
+            arrs.append(np.ascontiguousarray(tab[:, list(cfg["band_idx"]) + [0] * (16 - nreg)]))
         mix = (float(f("mix_near").reshape(-1)[0]), float(f("mix_vis").reshape(-1)[0])) if "mix_near" in state_dict else (0.5, 0.5)
-        arrs.append(np.asarray([cfg["n_ir"], cfg["n_mix_end"], mix[0], mix[1]], np.float32))
+        arrs.append(np.asarray([cfg["n_ir"], cfg["n_mix_end"], mix[0], mix[1], self.ngk, int(bool(cfg.get("ice_optics_on_ice_radius"))),
+                                int(band_matrix), 0], np.float32))
         arrs += [f("xmean_lev"), f("xdiv_lev"), f("lbd_qc"), f("lbd_qi")]
         flags = (2 if liq_head else 0) | (4 if self.stochastic else 0) | (256 if cfg.get("rad_updated_qv") else 0)
         if liq_head:
@@ -409,7 +427,8 @@ class physical_RNN_wrapped(torch.nn.Module):
             eps3 = torch.randn(50, B, nh, device=dev) if eps3 is None else _check(eps3, (50, B, nh), "eps3")
         else:
             hx1 = eps3 = None
-        mask_u = torch.rand(60, B, self.ng, device=dev) if mask_u is None else _check(mask_u, (60, B, self.ng), "mask_u")
+        nm = self.ngk or self.ng          # the coin is drawn per k-point of the SW gas models (= g-points unless the export reduces them)
+        mask_u = torch.rand(60, B, nm, device=dev) if mask_u is None else _check(mask_u, (60, B, nm), "mask_u")
         if _srnn is not None:
             _srnn = _check(_srnn, (50, B, nh), "srnn")
         out_lev, out_sfc, mem_out = torch.empty(B, 60, 6, device=dev), torch.empty(B, 8, device=dev), torch.empty(50, B, 16, device=dev)

@@ -496,13 +496,17 @@ int csa_phys_debug_rnn3(csa_phys *h, int T, int B, const float *x, const float *
  *    mlp_evap_prec_crm, mlp_evap_cond_vapor_crm, mlp_mp_aa_crm}.{w (16,nh), b (16)},
  *   yscale_sca_rad (6), solar weights (16, as folded into the export: they sum to 1), gas_optics_model_lw.{xmin (18), xdiv (18),
  *   ymean (128), ystd (128), mlp1.{w (64,18), b}, mlp2.{w (64,64), b}, mlp3.{w (256,64), b}}, gas_optics_lw_reduce1.{w (16,128), b},
- *   gas_optics_lw_reduce2.{w (16,128), b}, the SW gas-optics block (csrc/phys.h SWX_*: input range, two 7-32-32-16 models), the
- *   Slingo / Ebert-Curry table per g-point (12,16), misc [n_ir, n_mix_end, mix_near, mix_vis] (4 floats: the split of the g-points into
- *   near-infrared | mixed | visible and the weights of the mixed ones), then the wrapper's xmean_lev (60,21), xdiv_lev (60,21),
+ *   gas_optics_lw_reduce2.{w (16,128), b}, the SW gas-optics block (csrc/phys.h SWX_*: input range, two 7-32-32-16 models whose last
+ *   layer may give ngk <= 16 k-points, then gas_optics_sw_reduce1 / 2 as (16,16) + (16), zero when the export has no reduction), the
+ *   Slingo / Ebert-Curry table per g-point (12,16) -- or, when misc[6] = 1, per BAND (12,4) followed by the learned band -> g-point
+ *   matrix (4,16) --, misc (8 floats) [n_ir, n_mix_end, mix_near, mix_vis: the split of the g-points into near-infrared | mixed |
+ *   visible and the weights of the mixed ones; ngk: k-points behind the SW coin that the reduction maps to the g-points, 0 = none;
+ *   1 = the ice SW optics read the ice effective radius (0: the liquid one, as first serialised); 1 = band matrix; 0], then the
+ *   wrapper's xmean_lev (60,21), xdiv_lev (60,21),
  *   lbd_qc (60), lbd_qi (60)   (71 pointers); with CSA_PHYS_LIQ_FRAC_HEAD mlp_liq_frac_crm.{w (16,nh), b}, with CSA_PHYS_STOCHASTIC
  *   rnn3.{weight_ih, weight_zh, weight_encoder}.  CSA_PHYS_RAD_UPDATED_QV: radiation reads the updated grid-mean q_v.
  * csa_phys_wrapped_forward: the random draws the export makes inside forward are ARGUMENTS (device pointers): hx2 (B,nh) rnn2's initial
- * state; hx1 (B,nh), eps3 (50,B,nh) the stochastic third RNN's state and noise (CSA_PHYS_STOCHASTIC, else null); mask_u (60,B,ng) the
+ * state; hx1 (B,nh), eps3 (50,B,nh) the stochastic third RNN's state and noise (CSA_PHYS_STOCHASTIC, else null); mask_u (60,B,ngk or ng) the
  * uniform field of the SW humidity coin (`torch.rand_like(tau) < 0.5` picks the largest region's humidity).  srnn: test hook, null in
  * production (the third RNN's output supplied: that layer is chaotic on synthetic inputs, see tests/test_physrnn_frozen.py). */
 int csa_phys_wrapped_create(int nh, int ng, int flags, const float *const *w, int max_batch, csa_phys **out);

@@ -173,17 +173,31 @@ def radiation(P, FL, aux, xd, play, plev, delta_plev, dec, T_new, qv_rad, mask_u
         x = torch.cat([T_new, torch.log(play), v.sqrt().sqrt(), o3, co2, xd[:, :, 14:15], xd[:, :, 13:14]], 2)
         x = (x - xmin) / xdiv
         taus.append((col * pow8(gas_mlp(P, "gas_optics_model_sw1", x)) * 1e-17, col * pow8(gas_mlp(P, "gas_optics_model_sw2", x)) * 1e-17))
-    pick = mask_u < 0.5
-    tau_abs = torch.where(pick, taus[0][0], taus[1][0]).clamp(min=1e-9)
+    pick = mask_u < 0.5                                                 # (B,60,k-points of the gas models: ng, or 14 / 12 with the reduction)
+    tau_abs = torch.where(pick, taus[0][0], taus[1][0])
     tau_sca = torch.where(pick, taus[0][1], taus[1][1])
+    if "gas_optics_sw_reduce1.weight" in P:      # sub-generation with k-point -> g-point reductions behind the coin (num11916, num87824)
+        tau_abs = F.softplus(_jit(_lin(P, "gas_optics_sw_reduce1", tau_abs))) * 0.01 + 1e-9
+        tau_sca = F.softplus(_jit(_lin(P, "gas_optics_sw_reduce2", tau_sca))) * 0.01
+    else:
+        tau_abs = tau_abs.clamp(min=1e-9)
     # Slingo / Ebert-Curry band of every g-point (`band_to_gpt`: bucketize of the band limits, repeat_interleave) and the split of
     # the g-points into near-infrared / mixed / visible (surface albedo, SOLL / SOLS): data of the variant
     idx, n_ir, n_mx = list(FL["band_idx"]), FL["n_ir"], FL["n_mix_end"]
-    kl, wl, gl = cloud_optics(rel, SLINGO, 4.2, 16.0, idx)
-    ki, wi, gi = cloud_optics(rel, EBERT_CURRY, 13.0, 130.0, idx)                             # (the LIQUID radius: as serialised)
+    r_ice = rei if FL.get("ice_optics_on_ice_radius") else rel       # (first exports: the LIQUID radius, as serialised)
+    if "cloud_band_to_gpt" in P:                 # learned (4, ng) band -> g-point matrix applied to k, k ssa, k ssa g of the four bands
+        Mb, b4 = P["cloud_band_to_gpt"], [0, 1, 2, 3]
+        kl, wl, gl = cloud_optics(rel, SLINGO, 4.2, 16.0, b4)
+        ki, wi, gi = cloud_optics(r_ice, EBERT_CURRY, 13.0, 130.0, b4)
+        kl, sl, sgl = kl @ Mb, (kl * wl) @ Mb, (kl * wl * gl) @ Mb
+        ki, si, sgi = ki @ Mb, (ki * wi) @ Mb, (ki * wi * gi) @ Mb
+    else:
+        kl, wl, gl = cloud_optics(rel, SLINGO, 4.2, 16.0, idx)
+        ki, wi, gi = cloud_optics(r_ice, EBERT_CURRY, 13.0, 130.0, idx)
+        sl, sgl, si, sgi = kl * wl, kl * wl * gl, ki * wi, ki * wi * gi
     c_tau = pad(cwp_ice * ki + cwp_liq * kl)
-    c_sca0 = cwp_liq * (kl * wl) + cwp_ice * (ki * wi)
-    c_asy = pad((cwp_liq * (kl * wl * gl) + cwp_ice * (ki * wi * gi)) / (c_sca0 + 1e-7))
+    c_sca0 = cwp_liq * sl + cwp_ice * si
+    c_asy = pad((cwp_liq * sgl + cwp_ice * sgi) / (c_sca0 + 1e-7))
     c_sca = pad(c_sca0)
     tau_sw = (tau_abs + tau_sca) + c_tau
     sca = (tau_sca + c_sca).clamp(min=1e-9)

@@ -212,11 +212,34 @@ class Extractor:
             wav = [1e4 / float(v) for v in m2.group(1).split(",")]
             sidx = [bisect.bisect_right([0.7, 1.25, 2.38], w) for w in wav]
             F["band_idx"] = [b for b, r in zip(sidx, F["band_repeats"]) for _ in range(r)]
+        else:
+            # a later form of the same map: columns of the 4-band coefficient stack copied into slices of an empty (6, ng) tensor
+            cp = re.findall(r"torch\.copy_\(torch\.slice\(torch\.slice\(y\), 1, (\d+)(?:, (\d+))?\), torch\.slice\(torch\.slice\(x\d+\), 1, (\d+), \d+\)\)",
+                            "\n".join(self.sinks))
+            ng = P["gas_optics_lw_reduce1.weight"].shape[0]
+            if cp:
+                idx = [None] * ng
+                for a, b, band in cp:
+                    for g in range(int(a), int(b) if b else ng):
+                        idx[g] = int(band)
+                F["band_idx"] = idx if None not in idx else None
+        # yet another: the band quantities multiplied by a learned (4, ng) band -> g-point matrix (ONE constant for liquid and ice)
+        mm = re.findall(rf"torch\.matmul\((?:k\d*|kscag?_sw_cld_\w+), {C}\)", code)
+        F["cld_band_matrix"] = bool(mm)
+        if mm:
+            if len(set(mm)) != 1 or len(mm) != 6:
+                raise KeyError("cloud band matrix: expected one constant used six times")
+            P["cloud_band_to_gpt"] = self.c(mm[0])
+        # the ice SW optics read the ICE effective radius (later exports) or, as first serialised, the liquid one clamped to 13..130
+        F["ice_optics_on_ice_radius"] = not bool(re.search(r"re_um\d* = torch\.clamp\(liq_eff_rad\d*, 13\., 130\.\)", code))
         # g-points [0, n_ir) take the near-infrared surface albedo, [n_ir, n_mix_end) the mixed one, the rest the visible one
         a1 = re.search(r"torch\.slice\(albedo_surf_dir_sw, 0, 0, (\d+)\)", code)
         a2 = re.search(r"torch\.slice\(albedo_surf_dir_sw, 0, %s, (\d+)\)" % (a1.group(1) if a1 else "x"), code)
         if a1 and a2:
             F["n_ir"], F["n_mix_end"] = int(a1.group(1)), int(a2.group(1))
+        # the 4-band Slingo / Ebert-Curry coefficient lists as serialised (compared with the tables of the restatement by the golden script)
+        F["cloud_tables"] = [[float(v) for v in m_.group(1).split(",")] for m_ in re.finditer(r"^  _\d+ = \[([-\d.e, ]+)\]$", code, re.M)
+                             if len(m_.group(1).split(",")) == 4]
         F["mem_channels"] = int(re.search(r"torch\.slice\(torch\.slice\(torch\.slice\(rnn\w*_mem\w*\), 1\), 2, 0, (\d+)\)", code).group(1)) + 1
         F["unnamed"] = sorted(int(k[1:]) for k in self.cm if int(k[1:]) not in self.used)
         return P, F

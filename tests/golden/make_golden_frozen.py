@@ -19,7 +19,7 @@ from frozen_extract import Extractor  # noqa: E402
 
 DIR = "/root/reference/rnn/saved_models/"
 KEEP = ("rnn1.", "rnn2.", "rnn3.", "mlp_", "gas_optics_", "cloud_optics_", "xmean_", "xdiv_", "lbd_", "hyam", "hybm", "hyai", "hybi",
-        "yscale_lev", "yscale_sca", "yscale_sca_rad", "solar_weights", "mix_near", "mix_vis")
+        "yscale_lev", "yscale_sca", "yscale_sca_rad", "solar_weights", "mix_near", "mix_vis", "cloud_band_to_gpt")
 DROP = ("hyam_m", "hybm_m", "yscale_lev_3d")
 
 
@@ -67,7 +67,7 @@ def draws(Fl, B, seed):
     if Fl["rnn3"]:
         d["hx1"] = torch.randn(B, nh)
         d["eps3"] = torch.randn(50, B, nh)
-    d["mask_u"] = torch.rand(60, B, ng)
+    d["mask_u"] = torch.rand(60, B, Fl["sw_ng_gas"] if Fl.get("sw_gas_reduce") else ng)     # rand_like(tau_sw1): the gas models' k-points
     return d
 
 
@@ -124,8 +124,8 @@ def main(only=None):
             print(h, os.path.basename(f), "constants not named:", repr(e)[:120])
             seen[h] = None
             continue
-        if Fl["unnamed"] or Fl["sw_gas_reduce"] or Fl["band_repeats"] is None:
-            print(h, os.path.basename(f), "variant outside the built family:", {k: Fl[k] for k in ("unnamed", "sw_gas_reduce", "band_repeats")})
+        if Fl["unnamed"] or Fl.get("band_idx") is None and not Fl["cld_band_matrix"]:
+            print(h, os.path.basename(f), "variant outside the built family:", {k: Fl.get(k) for k in ("unnamed", "band_idx", "cld_band_matrix")})
             seen[h] = None
             continue
         seen[h] = f
@@ -134,7 +134,12 @@ def main(only=None):
             if isinstance(v, (bool, int)):
                 d["flag." + k] = np.array(int(v), np.int64)
         d["flag.n_ir"], d["flag.n_mix_end"] = np.array(Fl["n_ir"], np.int64), np.array(Fl["n_mix_end"], np.int64)
-        d["cfg.band_idx"] = np.array(Fl["band_idx"], np.int64)
+        d["cfg.band_idx"] = np.array(Fl["band_idx"] if Fl.get("band_idx") else [0] * Fl["nreg"], np.int64)
+        sys.path.insert(0, os.path.join(OUT, "..", ".."))
+        from oracle.physrnn_rad_ref import SLINGO, EBERT_CURRY      # the serialised 4-band tables are the restatement's
+        ser = [[np.float32(v) for v in row] for row in Fl["cloud_tables"]]
+        for row in list(SLINGO) + list(EBERT_CURRY):
+            assert [np.float32(v) for v in row] in ser or "torch.tensor([%s]" % ", ".join(repr(float(v)) for v in row) in m.code, (h, row)
         d["artefact"] = np.array(os.path.basename(f))
         for i, (B, seed) in enumerate(((8, 71), (37, 72))):
             x, s, mem = inputs_wrapped(P, B, seed)
