@@ -46,6 +46,9 @@ struct PhysDev {
     const float *cldtab;    // (12, 16): Slingo A..F then Ebert-Curry a..f per g-point; cld_band: (12, 4) per BAND, then the (4, 16) band -> g-point matrix
     int cld_band;           // 1: later exports (num32701, num87824): k, k ssa, k ssa g of the four bands times a learned band -> g-point matrix
     int ice_re;             // 1: the ice SW optics read the ICE effective radius (later exports); 0: the liquid one clamped to 13..130, as first serialised
+    int rad_qn_upd;         // SW head MLP of the earlier nx21 exports: 1 = it sees the UPDATED grid-mean cloud water
+    int sfc_sw_down;        // nx21: 1 = the first surface output is the DOWNWARD shortwave (num82174), 0 = the net one
+    int cld_liq_upd;        // nx21: 1 = cloud LW optics take the liquid fraction of the UPDATED sub-grid temperature (num82174)
     int sw_ngk;             // > 0: the SW gas models give sw_ngk k-points, reduced to the 16 g-points by Linear + softplus * 0.01 BEHIND the humidity coin
 };
 

@@ -113,7 +113,7 @@ __global__ __launch_bounds__(DT) void phys_decode_kernel(PhysDev d, int B, const
     __shared__ float s_area[LC * NC], s_qv[LC * NC], s_qn[LC * NC], s_fH[LC * NC], s_fqv[LC * NC], s_fqn[LC * NC], s_sed[LC * NC];
     __shared__ float s_T[LC * NC];                    // sub-column temperature (RAD: overwritten with its updated value)
     __shared__ float s_liq[RAD ? LC * NC : 1];        // nx21: the region's cloud liquid fraction (latent heating AND cloud optics)
-    __shared__ float s_o01[PH_L][2];                  // RAD: the decoder's dT, dqv of every level (zero above the CRM top)
+    __shared__ float s_o01[PH_L][3];                  // RAD: the decoder's dT, dqv, dqn of every level (zero above the CRM top)
     __shared__ float s_scal[16];
     constexpr int nm0 = 15;                           // enforced by csa_phys_create: compile-time trip counts (see phys_prep_kernel)
     const int nh = d.nh;
@@ -236,7 +236,7 @@ __global__ __launch_bounds__(DT) void phys_decode_kernel(PhysDev d, int B, const
             float *o = out_lev + ((size_t)b * PH_L + L) * 5;
             if (RAD) {
                 o[0] = sT;
-                s_o01[L][0] = sT; s_o01[L][1] = sqv;
+                s_o01[L][0] = sT; s_o01[L][1] = sqv; s_o01[L][2] = sqn;
             } else {
                 const float dT_rad = HD[((size_t)L * B + b) * HDW + HDW - 1];
                 o[0] = ((l >= 2 ? s_out[l][0] : 0.0f) + sT) + dT_rad;
@@ -254,7 +254,7 @@ __global__ __launch_bounds__(DT) void phys_decode_kernel(PhysDev d, int B, const
         float *o = out_lev + ((size_t)b * PH_L + L) * 5;
         o[0] = RAD ? 0.0f : HD[((size_t)L * B + b) * HDW + HDW - 1];
         o[1] = 0.0f; o[2] = 0.0f; o[3] = 0.0f; o[4] = 0.0f;
-        if (RAD) { s_o01[L][0] = 0.0f; s_o01[L][1] = 0.0f; }
+        if (RAD) { s_o01[L][0] = 0.0f; s_o01[L][1] = 0.0f; s_o01[L][2] = 0.0f; }
     }
     __syncthreads();
 
@@ -338,7 +338,8 @@ __global__ __launch_bounds__(DT) void phys_decode_kernel(PhysDev d, int B, const
             xr[0] = (lp - 0.00515f) / 11.59485f;
             xr[1] = (T_new - 160.0f) / 180.0f;
             xr[2] = sqrtf(sqrtf(qv_new * 1.608079364f)) / 0.497653f;
-            xr[3] = 1.0f - expf(-(xd[2] + xd[3]) * d.lbd_qn[L]);
+            const float qn_rad = d.rad_qn_upd ? fmaxf((xd[2] + xd[3]) + s_o01[L][2] / ys[2] * 1200.0f, 0.0f) : xd[2] + xd[3];
+            xr[3] = 1.0f - expf(-qn_rad * d.lbd_qn[L]);
             xr[4] = xm[12]; xr[5] = xm[13]; xr[6] = xm[14];
             float rel = 0.0f, rei = 0.0f;
             if (L >= ilev) {
@@ -394,7 +395,7 @@ __global__ __launch_bounds__(DT) void phys_decode_kernel(PhysDev d, int B, const
                                                                                       //  un-shifted, as the serialised graph gathers it)
             float liq = fminf(fmaxf((T_g - 253.16f) * 0.05f, 0.0f), 1.0f);
             if (d.liq_off >= 0) liq = 1.0f / (1.0f + expf(-HD[((size_t)(L - d.ltop) * B + b) * HDW + d.liq_off + sub]));
-            if (d.nx21) liq = s_liq[l * NC + sub];
+            if (d.nx21 && !d.cld_liq_upd) liq = s_liq[l * NC + sub];
             const float cwp = s_pd[l] / G * qn_g * 1000.0f, cwp_ice = (1.0f - liq) * cwp;
             const float ifr = cwp_ice / fmaxf(cwp, 1e-8f);
             const float *xd = x_denorm + ((size_t)b * PH_L + L) * nxd;
@@ -489,7 +490,7 @@ struct PhysHostW {           // host pointers of one state_dict, by role
     const float *cld_sw_w, *cld_sw_b;        // composed learned SW cloud optics (48, 19), (48), optional
     // nx21 generation (csa_phys_wrapped_create): SWX_* block, cloud-optics table (12, 16), [n_ir, n_mix, mix_near, mix_vis]
     const float *swx = nullptr, *cldtab = nullptr, *misc = nullptr;
-    int rad_qv_upd = 0;
+    int rad_qv_upd = 0, nx21 = 0;
 };
 
 // ice effective radius (micron) against temperature, 137 K ... : E3SM's table as listed in rnn/models/physics_rad_e3sm.py:13-59
@@ -608,7 +609,7 @@ static int phys_build(int nx, int nfeat, int naux, int nx_sfc, int sfc_cut, int 
             for (int g = 0; g < PH_NG; ++g) { sq[g] = physrad ? w.solar_w[g] : w.solar_w[g] * w.solar_w[g]; m = sq[g] > m ? sq[g] : m; }
             for (int g = 0; g < PH_NG; ++g) { e[g] = expf(sq[g] - m); sum += e[g]; }
             for (int g = 0; g < PH_NG; ++g) e[g] /= sum;
-            d.toa_spec = w.swx ? up(w.solar_w, PH_NG) : up(e, PH_NG);     // (frozen exports: the weights arrive as the folded constant)
+            d.toa_spec = w.nx21 ? up(w.solar_w, PH_NG) : up(e, PH_NG);     // (frozen exports: the weights arrive as the folded constant)
         }
         auto padK = [&](const float *src, int n, int k, int kp) {
             std::vector<float> t((size_t)n * kp, 0.0f);
@@ -620,10 +621,17 @@ static int phys_build(int nx, int nfeat, int naux, int nx_sfc, int sfc_cut, int 
         h->g_w3 = up(w.g_w3, 256 * 64); h->g_b3 = up(w.g_b3, 256);
         h->r1_w = up(w.r1_w, 16 * 128); h->r1_b = up(w.r1_b, 16);
         h->r2_w = up(w.r2_w, 16 * 128); h->r2_b = up(w.r2_b, 16);
-        if (w.swx) {          // the nx21 generation of the frozen exports
+        if (w.nx21) {         // the nx21 generation of the frozen exports
+            const int bits = (int)w.misc[7];
             d.sw_ngk = (int)w.misc[4]; d.ice_re = (int)w.misc[5]; d.cld_band = (int)w.misc[6];
-            d.swg = up(w.swx, SWX_FLOATS); d.cldtab = up(w.cldtab, d.cld_band ? 12 * 4 + 4 * PH_NG : 12 * PH_NG);
-            h->CS = up(nullptr, (size_t)d.Lc * max_batch * 48);
+            d.sfc_sw_down = bits & 1; d.cld_liq_upd = (bits >> 1) & 1; d.rad_qn_upd = (bits >> 2) & 1;
+            if (w.swx) {      // SW gas-optics MLPs + Slingo / Ebert-Curry cloud optics
+                d.swg = up(w.swx, SWX_FLOATS); d.cldtab = up(w.cldtab, d.cld_band ? 12 * 4 + 4 * PH_NG : 12 * PH_NG);
+                h->CS = up(nullptr, (size_t)d.Lc * max_batch * 48);
+            } else {          // earlier sub-generation: the SW head MLP (24 -> 32 -> 3 x 16) of the unfrozen num4050 family
+                h->s1_w = up(w.sw1_w, 32 * PH_XR_K); h->s1_b = up(w.sw1_b, 32);
+                h->s2_w = up(w.sw2_w, 48 * 32); h->s2_b = up(w.sw2_b, 48);
+            }
             d.nx21 = 1; d.memlm = 1; d.lw_dn = 1; d.rad_qv_upd = w.rad_qv_upd;
             d.n_ir = (int)w.misc[0]; d.n_mix = (int)w.misc[1]; d.mix_near = w.misc[2]; d.mix_vis = w.misc[3];
         } else if (w.swg) {
@@ -795,7 +803,7 @@ __global__ __launch_bounds__(256) void phys_wrap_pre_kernel(PhysDev d, int B, co
 // pointer order: see include/climsim_amd.h (csa_phys_wrapped_create)
 extern "C" int csa_phys_wrapped_create(int nh, int ng, int flags, const float *const *w, int max_batch, csa_phys **out)
 {
-    if (!w || !out || max_batch <= 0 || (flags & ~(CSA_PHYS_LIQ_FRAC_HEAD | CSA_PHYS_STOCHASTIC | CSA_PHYS_RAD_UPDATED_QV))) {
+    if (!w || !out || max_batch <= 0 || (flags & ~(CSA_PHYS_LIQ_FRAC_HEAD | CSA_PHYS_STOCHASTIC | CSA_PHYS_RAD_UPDATED_QV | CSA_PHYS_SW_HEAD))) {
         csa_set_error_msg("csa_phys_wrapped_create: bad argument");
         return CSA_ERR_ARG;
     }
@@ -813,7 +821,10 @@ extern "C" int csa_phys_wrapped_create(int nh, int ng, int flags, const float *c
     v.ys_rad = *p++; v.solar_w = *p++; v.g_xmin = *p++; v.g_xmax = *p++; v.g_ymean = *p++; v.g_ystd = *p++;
     v.g_w1 = *p++; v.g_b1 = *p++; v.g_w2 = *p++; v.g_b2 = *p++; v.g_w3 = *p++; v.g_b3 = *p++;
     v.r1_w = *p++; v.r1_b = *p++; v.r2_w = *p++; v.r2_b = *p++;
-    v.swx = *p++; v.cldtab = *p++; v.misc = *p++;
+    v.nx21 = 1;
+    if (flags & CSA_PHYS_SW_HEAD) { v.sw1_w = *p++; v.sw1_b = *p++; v.sw2_w = *p++; v.sw2_b = *p++; v.lbd_qn = *p++; }
+    else { v.swx = *p++; v.cldtab = *p++; }
+    v.misc = *p++;
     const float *xmean_lev = *p++, *xdiv_lev = *p++, *lqc = *p++, *lqi = *p++;
     if (flags & CSA_PHYS_LIQ_FRAC_HEAD) { v.liq_w = *p++; v.liq_b = *p++; }
     if (flags & CSA_PHYS_STOCHASTIC) { v.s3_ih = *p++; v.s3_zh = *p++; v.s3_enc = *p++; }

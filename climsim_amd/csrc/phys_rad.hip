@@ -696,7 +696,7 @@ __global__ __launch_bounds__(RS_T) void phys_rad_solve_kernel(PhysDev d, int B, 
                 if (g < d.n_ir) { dir_ir += a; dif_ir += c; } else if (g < d.n_mix) { dir_mix += a; dif_mix += c; } else { dir_vis += a; dif_vis += c; }
             }
             float *os = out_sfc + (size_t)b * 8;
-            os[0] = (day ? (d.nx21 ? sw_dn - up : sw_dn) : 0.0f) * d.ys_rad[0];     // (the exports return the NET surface shortwave)
+            os[0] = (day ? (d.nx21 && !d.sfc_sw_down ? sw_dn - up : sw_dn) : 0.0f) * d.ys_rad[0];     // (most exports return the NET surface shortwave)
             os[1] = ldn * d.ys_rad[1];
             os[4] = (day ? dir_vis + d.mix_vis * dir_mix : 0.0f) * d.ys_rad[2];      // SOLS
             os[5] = (day ? dir_ir + d.mix_near * dir_mix : 0.0f) * d.ys_rad[3];      // SOLL
@@ -722,7 +722,7 @@ int launch_phys_radiation(csa_phys *h, int B, const float *x_sfc, float *out_lev
     // grid y: 0 = LW gas optics, 1 = SW head (absent in the SW gas-optics generation, which has its own kernel)
     hipLaunchKernelGGL(rad_optics_kernel, dim3((M + 32 * RO_WAVES - 1) / (32 * RO_WAVES), d.swg ? 1 : 2), dim3(64 * RO_WAVES), 0, s, a);
     CSA_HIP_CHECK(hipGetLastError());
-    if (d.nx21) {
+    if (d.nx21 && d.swg) {
         if (!mask_u) { csa_set_error_msg("physRNN (frozen export): the SW humidity coin needs its uniform draws"); return CSA_ERR_ARG; }
         hipLaunchKernelGGL(rad_sw_gas16_kernel, dim3((M + SX_ROWS - 1) / SX_ROWS), dim3(256), 0, s, h->XR, d.swg, h->CS, mask_u, h->S2, M, B, d.ilev, h->ng, d.sw_ngk);
         CSA_HIP_CHECK(hipGetLastError());

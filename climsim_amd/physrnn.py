@@ -369,7 +369,36 @@ class physical_RNN_wrapped(torch.nn.Module):
         arrs += [f("yscale_sca_rad"), pad_rows(f("solar_weights").reshape(-1))] + [f(k) for k in _W_LW]
         arrs += [pad_rows(f("gas_optics_lw_reduce1.weight")), pad_rows(f("gas_optics_lw_reduce1.bias")),
                  pad_rows(f("gas_optics_lw_reduce2.weight")), pad_rows(f("gas_optics_lw_reduce2.bias"), -1.0e30)]
-        # SW gas-optics block (csrc/phys.h SWX_*)
+        sw_head = "mlp_sw_optprops1.weight" in state_dict      # earlier sub-generation: SW optical properties from one two-layer MLP
+        self.ngk = 0
+        if sw_head:
+            if nreg != 16 or f("mlp_sw_optprops1.weight").shape != (32, 24) or f("mlp_sw_optprops2.weight").shape != (48, 32):
+                raise RuntimeError("physRNN (frozen export): the SW head is built for 24 -> 32 -> 3 x 16")
+            arrs += [f("mlp_sw_optprops1.weight"), f("mlp_sw_optprops1.bias"), f("mlp_sw_optprops2.weight"), f("mlp_sw_optprops2.bias"),
+                     np.ascontiguousarray(f("lbd_qn").reshape(-1))]
+        else:
+            self._sw_gas_arrays(arrs, f, state_dict, cfg, nreg, pad_rows)
+        band_matrix = "cloud_band_to_gpt" in state_dict
+        mix = (float(f("mix_near").reshape(-1)[0]), float(f("mix_vis").reshape(-1)[0])) if "mix_near" in state_dict else (0.5, 0.5)
+        bits = (1 if cfg.get("sfc_sw_down") else 0) | (2 if cfg.get("cld_liq_from_updated_T") else 0) | (4 if cfg.get("rad_updated_qn") else 0)
+        arrs.append(np.asarray([cfg["n_ir"], cfg["n_mix_end"], mix[0], mix[1], self.ngk, int(bool(cfg.get("ice_optics_on_ice_radius"))),
+                                int(band_matrix), bits], np.float32))
+        arrs += [f("xmean_lev"), f("xdiv_lev"), f("lbd_qc"), f("lbd_qi")]
+        flags = (2 if liq_head else 0) | (4 if self.stochastic else 0) | (256 if cfg.get("rad_updated_qv") else 0) | (512 if sw_head else 0)
+        if liq_head:
+            arrs += [pad_rows(f("mlp_liq_frac_crm.weight")), pad_rows(f("mlp_liq_frac_crm.bias"))]
+        if self.stochastic:
+            arrs += [f("rnn3.weight_ih"), f("rnn3.weight_zh"), f("rnn3.weight_encoder")]
+        FP = ctypes.POINTER(ctypes.c_float)
+        warr = (FP * len(arrs))(*[a.ctypes.data_as(FP) for a in arrs])
+        h = ctypes.c_void_p()
+        rc = _lib.lib().csa_phys_wrapped_create(self.nh, nreg, flags, warr, int(max_batch), ctypes.byref(h))
+        if rc != 0:
+            raise RuntimeError(f"csa_phys_wrapped_create failed ({rc}): {_lib.last_error()}")
+        self._h, self.max_batch = h, max_batch
+
+    def _sw_gas_arrays(self, arrs, f, state_dict, cfg, nreg, pad_rows):
+        """SW gas-optics block (csrc/phys.h SWX_*) and the cloud-optics table of the later sub-generations"""
         pad8 = lambda v, fill: np.concatenate([v.reshape(-1), np.full(8 - v.size, fill, np.float32)])
         blk = [pad8(f("gas_optics_model_sw1.xmin"), 0.0), pad8(f("gas_optics_model_sw1.xdiv"), 1.0)]
         for m in ("gas_optics_model_sw1", "gas_optics_model_sw2"):
@@ -398,22 +427,6 @@ class physical_RNN_wrapped(torch.nn.Module):
             arrs.append(np.ascontiguousarray(np.concatenate([tab.ravel(), pad_rows(f("cloud_band_to_gpt").T).T.ravel()]), np.float32))
         else:
             arrs.append(np.ascontiguousarray(tab[:, list(cfg["band_idx"]) + [0] * (16 - nreg)]))
-        mix = (float(f("mix_near").reshape(-1)[0]), float(f("mix_vis").reshape(-1)[0])) if "mix_near" in state_dict else (0.5, 0.5)
-        arrs.append(np.asarray([cfg["n_ir"], cfg["n_mix_end"], mix[0], mix[1], self.ngk, int(bool(cfg.get("ice_optics_on_ice_radius"))),
-                                int(band_matrix), 0], np.float32))
-        arrs += [f("xmean_lev"), f("xdiv_lev"), f("lbd_qc"), f("lbd_qi")]
-        flags = (2 if liq_head else 0) | (4 if self.stochastic else 0) | (256 if cfg.get("rad_updated_qv") else 0)
-        if liq_head:
-            arrs += [pad_rows(f("mlp_liq_frac_crm.weight")), pad_rows(f("mlp_liq_frac_crm.bias"))]
-        if self.stochastic:
-            arrs += [f("rnn3.weight_ih"), f("rnn3.weight_zh"), f("rnn3.weight_encoder")]
-        FP = ctypes.POINTER(ctypes.c_float)
-        warr = (FP * len(arrs))(*[a.ctypes.data_as(FP) for a in arrs])
-        h = ctypes.c_void_p()
-        rc = _lib.lib().csa_phys_wrapped_create(self.nh, nreg, flags, warr, int(max_batch), ctypes.byref(h))
-        if rc != 0:
-            raise RuntimeError(f"csa_phys_wrapped_create failed ({rc}): {_lib.last_error()}")
-        self._h, self.max_batch = h, max_batch
 
     def forward(self, x_main0, x_sfc0, rnn1_mem, hx2=None, hx1=None, eps3=None, mask_u=None, _srnn=None):
         B = x_main0.shape[0]

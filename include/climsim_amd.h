@@ -466,7 +466,7 @@ int csa_phys_postprocess(csa_phys *h, int B, const float *out, const float *out_
  * csa_phys_forward_noise: csa_phys_forward + hx1 (B,nh), rnn3's initial state, and eps3 (50,B,nh), its noise: the two further
  * N(0,1) draws the reference makes inside forward (both nullable for a handle without rnn3). */
 enum { CSA_PHYS_MCICA = 1, CSA_PHYS_LIQ_FRAC_HEAD = 2, CSA_PHYS_STOCHASTIC = 4, CSA_PHYS_PHYSRAD = 8, CSA_PHYS_LATER_EXPORT = 16,
-       CSA_PHYS_CLOUD_OPTICS_LW = 32, CSA_PHYS_SW_GAS = 64, CSA_PHYS_CLOUD_OPTICS_SW = 128, CSA_PHYS_RAD_UPDATED_QV = 256 };
+       CSA_PHYS_CLOUD_OPTICS_LW = 32, CSA_PHYS_SW_GAS = 64, CSA_PHYS_CLOUD_OPTICS_SW = 128, CSA_PHYS_RAD_UPDATED_QV = 256, CSA_PHYS_SW_HEAD = 512 };
 int csa_phys_rad_create(int nx, int naux, int nh, int ilev_crm, int mp_ncol, int nh_mem0, int ng, int flags,
                         const float *const *w, int max_batch, csa_phys **out);
 int csa_phys_forward_noise(csa_phys *h, int B, const float *x_main, const float *x_sfc, const float *rnn_mem,
@@ -501,7 +501,10 @@ int csa_phys_debug_rnn3(csa_phys *h, int T, int B, const float *x, const float *
  *   Slingo / Ebert-Curry table per g-point (12,16) -- or, when misc[6] = 1, per BAND (12,4) followed by the learned band -> g-point
  *   matrix (4,16) --, misc (8 floats) [n_ir, n_mix_end, mix_near, mix_vis: the split of the g-points into near-infrared | mixed |
  *   visible and the weights of the mixed ones; ngk: k-points behind the SW coin that the reduction maps to the g-points, 0 = none;
- *   1 = the ice SW optics read the ice effective radius (0: the liquid one, as first serialised); 1 = band matrix; 0], then the
+ *   1 = the ice SW optics read the ice effective radius (0: the liquid one, as first serialised); 1 = band matrix; bit mask: 1 the
+ *   first surface output is the downward (not net) shortwave, 2 cloud LW optics on the liquid fraction of the updated sub-grid
+ *   temperature, 4 the SW head sees the updated cloud water].  With CSA_PHYS_SW_HEAD (earlier exports: num8701, num75599, num82174)
+ *   the SW block and the cloud table are replaced by mlp_sw_optprops1.{w (32,24), b}, mlp_sw_optprops2.{w (48,32), b}, lbd_qn (60).  Then the
  *   wrapper's xmean_lev (60,21), xdiv_lev (60,21),
  *   lbd_qc (60), lbd_qi (60)   (71 pointers); with CSA_PHYS_LIQ_FRAC_HEAD mlp_liq_frac_crm.{w (16,nh), b}, with CSA_PHYS_STOCHASTIC
  *   rnn3.{weight_ih, weight_zh, weight_encoder}.  CSA_PHYS_RAD_UPDATED_QV: radiation reads the updated grid-mean q_v.

@@ -105,7 +105,7 @@ def gas_mlp(P, name, x):
     return _jit(_lin(P, name + ".mlp3", h))
 
 
-def radiation(P, FL, aux, xd, play, plev, delta_plev, dec, T_new, qv_rad, mask_u, ilev_crm=10, taps=None):
+def radiation(P, FL, aux, xd, play, plev, delta_plev, dec, T_new, qv_rad, mask_u, ilev_crm=10, taps=None, qn_rad=None, xn=None, mem_new=None):
     """All arrays batch-first: xd (B,60,21) raw inputs, play / delta_plev (B,60,1), plev (B,61,1), dec = decoder state, T_new
     (B,60,1) updated temperature, qv_rad (B,60,1) the humidity radiation sees, mask_u (B,60,ng) uniform draws.
     -> dT_rad (B,60) scaled by yscale_lev[:,0], out_sfc_rad (B,6) scaled."""
@@ -122,6 +122,8 @@ def radiation(P, FL, aux, xd, play, plev, delta_plev, dec, T_new, qv_rad, mask_u
     rei = reitab(T_low)
     rel = reltab(T_low, aux[:, 13].view(B, 1, 1), aux[:, 12].view(B, 1, 1), aux[:, 15].view(B, 1, 1))
     cwp = delta_plev[:, ilev_crm:] / G * 1000 * qn_crm                                        # (B,50,ng)
+    if FL.get("cld_liq_from_updated_T"):         # (num82174) the ramp on the sub-grid temperature AFTER the whole tendency
+        liq = F.hardtanh((dec["T_crm"] - 253.16) * 0.05, 0.0, 1.0)
     cwp_liq, cwp_ice = liq * cwp, (1.0 - liq) * cwp
     # ---- LW gas + cloud optics -----------------------------------------------------------------------------------------------
     xg = torch.cat([T_new, torch.log(play), vmr.sqrt().sqrt(), o3, co2, xd[:, :, 13:15], T_new.new_zeros(B, nlev, 11)], 2)
@@ -159,6 +161,17 @@ def radiation(P, FL, aux, xd, play, plev, delta_plev, dec, T_new, qv_rad, mask_u
     for j in range(nlev - 1, -1, -1):
         up[j] = tr[:, j] * up[j + 1] + s_up[:, j]
     lw_dn, lw_up = torch.stack(dn, 1).sum(2), torch.stack(up, 1).sum(2)
+    if "mlp_sw_optprops1.weight" in P:
+        # ---- earlier sub-generation (num8701, num75599, num82174): SW optical properties of the g-points from one two-layer MLP ----
+        top0 = T_new.new_zeros(B, ilev_crm, 1)
+        mem60 = torch.cat([T_new.new_zeros(B, ilev_crm, mem_new.shape[2]), mem_new], 1)
+        xr = torch.cat([(torch.log(play) - 0.00515) / 11.59485, (T_new - 160.0) / 180.0, (qv_rad * 1.608079364).sqrt().sqrt() / 0.497653,
+                        1.0 - torch.exp(-qn_rad * P["lbd_qn"].view(1, -1, 1)), xn[:, :, 12:15],
+                        torch.cat([top0, rel / 13.5], 1), torch.cat([top0, rei / 250.0], 1), mem60], 2)
+        o = _jit(_lin(P, "mlp_sw_optprops2", F.softsign(_jit(_lin(P, "mlp_sw_optprops1", xr))))).view(B, nlev, 3, ng)
+        tau_sw = (pow8(o[:, :, 0]) * (col_dry * 1e-23)).clamp(1e-6, 40.0)
+        ssa, asy = torch.sigmoid(o[:, :, 1]), torch.sigmoid(o[:, :, 2])
+        return _sw_solve_and_finish(P, FL, aux, delta_plev, tau_sw, ssa, asy, lw_dn, lw_up, taps, dict(tau_lw=tau_lw, pfrac=pfrac, T_new=T_new, xr=xr))
     # ---- SW gas optics on the humidity of the two largest regions ------------------------------------------------------------
     qc = qv_crm.clamp(max=0.05)
     vmr_c = qc / (1.0 - qc) * 1.608079364
@@ -183,7 +196,7 @@ def radiation(P, FL, aux, xd, play, plev, delta_plev, dec, T_new, qv_rad, mask_u
         tau_abs = tau_abs.clamp(min=1e-9)
     # Slingo / Ebert-Curry band of every g-point (`band_to_gpt`: bucketize of the band limits, repeat_interleave) and the split of
     # the g-points into near-infrared / mixed / visible (surface albedo, SOLL / SOLS): data of the variant
-    idx, n_ir, n_mx = list(FL["band_idx"]), FL["n_ir"], FL["n_mix_end"]
+    idx = list(FL["band_idx"])
     r_ice = rei if FL.get("ice_optics_on_ice_radius") else rel       # (first exports: the LIQUID radius, as serialised)
     if "cloud_band_to_gpt" in P:                 # learned (4, ng) band -> g-point matrix applied to k, k ssa, k ssa g of the four bands
         Mb, b4 = P["cloud_band_to_gpt"], [0, 1, 2, 3]
@@ -203,6 +216,14 @@ def radiation(P, FL, aux, xd, play, plev, delta_plev, dec, T_new, qv_rad, mask_u
     sca = (tau_sca + c_sca).clamp(min=1e-9)
     asy = c_asy * c_sca / sca
     ssa = sca / tau_sw
+    return _sw_solve_and_finish(P, FL, aux, delta_plev, tau_sw, ssa, asy, lw_dn, lw_up, taps,
+                                dict(tau_lw=tau_lw, pfrac=pfrac, c_tau=c_tau, tau_abs=tau_abs, tau_sca=tau_sca, tau_cld_lw=tau_cld, T_new=T_new, v12=v12,
+                                     cwp=cwp, liq=liq))
+
+
+def _sw_solve_and_finish(P, FL, aux, delta_plev, tau_sw, ssa, asy, lw_dn, lw_up, taps, extra):
+    B, nlev, ng = tau_sw.shape
+    n_ir, n_mx = FL["n_ir"], FL["n_mix_end"]
     mu0 = aux[:, 6].clamp(min=1e-6).view(B, 1, 1).expand(B, nlev, ng)
     R, T, Rdir, Tdd, Tdir = two_stream_sw(mu0, tau_sw, ssa, asy)
     toa = aux[:, 1:2] * P["solar_weights"].view(1, -1)
@@ -221,10 +242,10 @@ def radiation(P, FL, aux, xd, play, plev, delta_plev, dec, T_new, qv_rad, mask_u
     sw_net, SOLL, SOLS, SOLLD, SOLSD = (v * day for v in (sw_net, SOLL, SOLS, SOLLD, SOLSD))
     net = (lw_dn - lw_up) + sw_net
     dT = -((net[:, 1:] - net[:, :-1]) / delta_plev.squeeze(2)) * 0.009761357302 * P["yscale_lev"][:, 0].view(1, -1)
-    out_sfc_rad = torch.cat([sw_net[:, -1:], lw_dn[:, -1:], SOLS, SOLL, SOLSD, SOLLD], 1) * P["yscale_sca_rad"]
+    sw_sfc = (sw_dif.sum(2) + sw_dir.sum(2))[:, -1:] * day if FL.get("sfc_sw_down") else sw_net[:, -1:]
+    out_sfc_rad = torch.cat([sw_sfc, lw_dn[:, -1:], SOLS, SOLL, SOLSD, SOLLD], 1) * P["yscale_sca_rad"]
     if taps is not None:
-        taps.update(tau_lw=tau_lw, pfrac=pfrac, lw_dn=lw_dn, lw_up=lw_up, tau_sw=tau_sw, ssa=ssa, asy=asy, sw_net=sw_net, c_tau=c_tau,
-                    tau_abs=tau_abs, tau_sca=tau_sca, tau_cld_lw=tau_cld, T_new=T_new, v12=v12, cwp=cwp, liq=liq)
+        taps.update(lw_dn=lw_dn, lw_up=lw_up, tau_sw=tau_sw, ssa=ssa, asy=asy, sw_net=sw_net, **extra)
     return dT, out_sfc_rad
 
 
@@ -271,8 +292,12 @@ def forward(P, FL, x_main0, x_sfc0, rnn1_mem, hx2, mask_u, hx1=None, eps3=None, 
     qv = x_main00[:, :, -1:]
     if FL["rad_updated_qv"]:
         qv = torch.relu(qv + out_new[:, :, 1:2] / ys[:, 1:2] * 1200)
+    qn = x_main00[:, :, 2:3] + x_main00[:, :, 3:4]                     # grid-mean cloud water the SW head MLP sees (earlier sub-generation)
+    if FL.get("rad_updated_qn"):
+        qn = torch.relu(qn + out_new[:, :, 2:3] / ys[:, 2:3] * 1200)
     aux = xsn * P["xdiv_sca"] + P["xmean_sca"]
-    dT_rad, sfc_rad = radiation(P, FL, aux, x_main00, play, plev, delta_plev, dec, T_new, qv, mask_u.transpose(0, 1), ilev_crm, taps)
+    dT_rad, sfc_rad = radiation(P, FL, aux, x_main00, play, plev, delta_plev, dec, T_new, qv, None if mask_u is None else mask_u.transpose(0, 1),
+                                ilev_crm, taps, qn_rad=qn, xn=xn, mem_new=mem_new[:, :, :nh_mem0])
     if taps is not None:
         taps.update(out_mp=out_new.clone(), rnn2out=rnn2out, area_frac=dec["area_frac"])
     out_new[:, :, 0] = out_new[:, :, 0] + dT_rad

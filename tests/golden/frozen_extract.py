@@ -176,7 +176,17 @@ class Extractor:
         self.linear("gas_optics_lw_reduce1", r"tau_lw\d*", r"torch\.mul\(torch\.softplus\({LIN}, 1\., 20\.\), 0\.01\)")
         F["cloud_optics_lw"] = self.linear("cloud_optics_lw", r"tau_lw_cld\d*", r"torch\.relu\({LIN}\)", required=False)
         # ---- SW gas optics --------------------------------------------------------------------------------------------------
-        m = self.find(r"x_gas_1\d*", rf"torch\.div\(torch\.sub\(x_gas_1\d*, {C}\), {C}\)")
+        m = self.find(r"x_gas_1\d*", rf"torch\.div\(torch\.sub\(x_gas_1\d*, {C}\), {C}\)", required=False)
+        F["sw_mlp"] = m is None
+        if m is None:
+            # earlier sub-generation: SW optical properties of every g-point from ONE two-layer MLP on (pressure, T, q_v, cloud water,
+            # three gases, effective radii, the 15 new latent channels) -- models_phys.py's mlp_sw_optprops, as in the unfrozen num4050 family
+            self.linear("mlp_sw_optprops1", r"sw_optprops", soft)
+            self.linear("mlp_sw_optprops2", r"sw_optprops\d+", r"torch\.reshape\({LIN}, ")
+            self.const("lbd_qn", r"qn_new", rf"torch\.add\(torch\.neg\(torch\.exp\(torch\.mul\(torch\.neg\(qn\d*\), {C}\)\)\), 1\)")
+            F["sw_gas_reduce"], F["sw_ng_gas"], F["sw_random_mask"] = False, 0, False
+            F["rad_updated_qn"] = bool(re.search(r"qn0 = torch\.relu\(torch\.add\(qn, dqn0\)\)", code))
+            return self._tail(P, F, code)
         P["gas_optics_model_sw1.xmin"], P["gas_optics_model_sw1.xdiv"] = self.c(m.group(1)), self.c(m.group(2))
         m = re.search(rf"torch\.div\(torch\.sub\(vmr_h2o_2\d*, {C}\), {C}\)", code)
         if m:
@@ -193,6 +203,11 @@ class Extractor:
             self.linear("gas_optics_sw_reduce2", r"tau_sw_scat\w*", r"torch\.softplus\({LIN}, 1\., 20\.\)")
         F["sw_ng_gas"] = P["gas_optics_model_sw1.mlp3.weight"].shape[0]
         F["sw_random_mask"] = "torch.rand_like(tau_sw1)" in code
+        return self._tail(P, F, code)
+
+    def _tail(self, P, F, code):
+        F["sfc_sw_down"] = "flux_sw_dn_sfc" in code              # first surface output: downward (num82174) instead of net shortwave
+        F["cld_liq_from_updated_T"] = bool(re.search(r"torch\.sub\(torch\.squeeze\(T_crm\d*\), 253\.16", code))   # cloud LW optics: ramp on the UPDATED T_crm
         F["rad_updated_qv"] = bool(re.search(r"qv0 = torch\.relu\(torch\.add\(qv, dqv0\)\)", code))
         self.const("solar_weights", r"incoming_toa\d+", rf"torch\.mul\(incoming_toa\d*, {C}\)")
         a = self.find(r"SOLL", rf"torch\.mul\({C}, sw_dir_dn_\w+\)", required=False)

@@ -16,7 +16,7 @@ sys.path.insert(0, OUT)
 from frozen_extract import Extractor  # noqa: E402
 from make_golden_frozen import DIR, code_hash  # noqa: E402
 
-FLAGS = ("nreg", "rnn3", "pred_subgrid_liq_frac", "rad_updated_qv", "albedo_mix_learned", "sw_gas_reduce", "cld_band_matrix", "ice_optics_on_ice_radius")
+FLAGS = ("nreg", "rnn3", "pred_subgrid_liq_frac", "rad_updated_qv", "albedo_mix_learned", "sw_gas_reduce", "cld_band_matrix", "ice_optics_on_ice_radius", "sw_mlp")
 
 
 def main():
@@ -30,7 +30,7 @@ def main():
             h = code_hash(m.code)
             try:
                 P, F = Extractor(m).run()
-                if F["unnamed"] or (F.get("band_idx") is None and not F["cld_band_matrix"]):
+                if F["unnamed"] or (F.get("band_idx") is None and not F["cld_band_matrix"] and not F["sw_mlp"]):
                     P, why = None, "outside the built family: " + ", ".join(f"{k}={F[k]}" for k in ("unnamed",) if F[k]) + (
                         "" if F.get("band_idx") else " other cloud-optics band code")
                 else:

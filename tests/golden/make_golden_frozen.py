@@ -124,7 +124,7 @@ def main(only=None):
             print(h, os.path.basename(f), "constants not named:", repr(e)[:120])
             seen[h] = None
             continue
-        if Fl["unnamed"] or Fl.get("band_idx") is None and not Fl["cld_band_matrix"]:
+        if Fl["unnamed"] or (Fl.get("band_idx") is None and not Fl["cld_band_matrix"] and not Fl["sw_mlp"]):
             print(h, os.path.basename(f), "variant outside the built family:", {k: Fl.get(k) for k in ("unnamed", "band_idx", "cld_band_matrix")})
             seen[h] = None
             continue
@@ -138,7 +138,7 @@ def main(only=None):
         sys.path.insert(0, os.path.join(OUT, "..", ".."))
         from oracle.physrnn_rad_ref import SLINGO, EBERT_CURRY      # the serialised 4-band tables are the restatement's
         ser = [[np.float32(v) for v in row] for row in Fl["cloud_tables"]]
-        for row in list(SLINGO) + list(EBERT_CURRY):
+        for row in ([] if Fl["sw_mlp"] else list(SLINGO) + list(EBERT_CURRY)):
             assert [np.float32(v) for v in row] in ser or "torch.tensor([%s]" % ", ".join(repr(float(v)) for v in row) in m.code, (h, row)
         d["artefact"] = np.array(os.path.basename(f))
         for i, (B, seed) in enumerate(((8, 71), (37, 72))):
