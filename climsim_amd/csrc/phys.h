@@ -46,6 +46,13 @@ struct PhysDev {
     const float *cldtab;    // (12, 16): Slingo A..F then Ebert-Curry a..f per g-point; cld_band: (12, 4) per BAND, then the (4, 16) band -> g-point matrix
     int cld_band;           // 1: later exports (num32701, num87824): k, k ssa, k ssa g of the four bands times a learned band -> g-point matrix
     int ice_re;             // 1: the ice SW optics read the ICE effective radius (later exports); 0: the liquid one clamped to 13..130, as first serialised
+    int gridT, clear0;      // decoder: no sub-grid temperature (grid temperature in the eddy flux and the liquid ramp, latent heating from the
+                            // area-summed rates) / region 0 holds no condensate.  Both = physrad in the unfrozen graphs; the exports num45826 /
+                            // num74834 have the first without the second
+    int dec21;              // nx21-style decoder (heat flux at layer tops, zero at the surface; per-region liquid fraction): nx21 && !gridT
+    int cld_qn_old;         // 1: the radiation scheme's cloud water paths take the sub-grid cloud water BEFORE the step (num45826 / num74834)
+    int sw_e3sm;            // nx21 wrapper + solver around the unfrozen physics_rad_e3sm SW gas optics (112 k-points, mean of the two humidity
+                            // variants, reductions): swg = the SWG_* block, cldtab = the cloud table / band matrix
     int rad_qn_upd;         // SW head MLP of the earlier nx21 exports: 1 = it sees the UPDATED grid-mean cloud water
     int sfc_sw_down;        // nx21: 1 = the first surface output is the DOWNWARD shortwave (num82174), 0 = the net one
     int cld_liq_upd;        // nx21: 1 = cloud LW optics take the liquid fraction of the UPDATED sub-grid temperature (num82174)

@@ -171,7 +171,7 @@ __global__ __launch_bounds__(DT) void phys_decode_kernel(PhysDev d, int B, const
         const float a_raw = hd[H_AREA * NC];
         const float am = ph_max<NC>(a_raw), ae = expf(a_raw - am), area = ae / ph_sum<NC>(ae);
         float qv = ph_softplus(hd[H_QV * NC]), qn = ph_softplus(hd[H_QN * NC]), qi = ph_softplus(hd[H_QICE * NC]);
-        if (d.physrad && c == 0) qn = 0.0f;           // clear-sky region (its condensation head row is zero too: see phys_build)
+        if (d.clear0 && c == 0) qn = 0.0f;           // clear-sky region (its condensation head row is zero too: see phys_build)
         const float mqv = ph_sum<NC>(qv * area), mqn = ph_sum<NC>(qn * area), mqi = ph_sum<NC>(qi * area);
         qv *= mqv == 0.0f ? 1.0f : xd[nxd - 1] / mqv;
         qn *= mqn == 0.0f ? 1.0f : (xd[2] + xd[3]) / mqn;
@@ -180,7 +180,7 @@ __global__ __launch_bounds__(DT) void phys_decode_kernel(PhysDev d, int B, const
         const float T_crm = xd[0] + (dT - ph_sum<NC>(dT * area));
         const float play = d.hyam[L] * 100000.0f + sp * d.hybm[L], play_up = d.hyam[L - 1] * 100000.0f + sp * d.hybm[L - 1];
         float fH = hd[H_EDDY * NC] * (CP / G) * T_crm * (play - play_up);
-        if (l == LC - 1 && !d.nx21) fH = -fmaxf(fH, 0.0f);     // (nx21: defined at layer tops like the moisture fluxes, zero at the surface)
+        if (l == LC - 1 && !d.dec21) fH = -fmaxf(fH, 0.0f);     // (nx21: defined at layer tops like the moisture fluxes, zero at the surface)
         const float flux1 = hd[H_FLUX * NC] * 300000.0f;
         if (ok) {
             s_area[e] = area; s_qv[e] = qv; s_qn[e] = qn; s_fH[e] = fH; s_T[e] = T_crm;
@@ -199,7 +199,7 @@ __global__ __launch_bounds__(DT) void phys_decode_kernel(PhysDev d, int B, const
         const float *ys = d.yscale_lev + L * 5;
         const float pd = s_pd[lc], area = s_area[ec], qv = s_qv[ec], qn = s_qn[ec];
         const bool up = lc > 0, last = lc == LC - 1;
-        const float flux_t_dp = ((last && d.nx21 ? 0.0f : s_fH[ec]) - (up ? s_fH[ec - NC] : 0.0f)) / pd * (-G / CP);
+        const float flux_t_dp = ((last && d.dec21 ? 0.0f : s_fH[ec]) - (up ? s_fH[ec - NC] : 0.0f)) / pd * (-G / CP);
         const float flux_qv_dp = ((last ? 0.0f : s_fqv[ec]) - (up ? s_fqv[ec - NC] : 0.0f)) / pd * (-G);
         const float flux_qn_dp = ((last ? 0.0f : s_fqn[ec]) - (up ? s_fqn[ec - NC] : 0.0f)) / pd * (-G);
         const float sed_qn_dp = (s_sed[ec] - (up ? s_sed[ec - NC] : 0.0f)) / pd * (-G);
@@ -214,14 +214,14 @@ __global__ __launch_bounds__(DT) void phys_decode_kernel(PhysDev d, int B, const
         const float *xd = x_denorm + ((size_t)b * PH_L + L) * nxd;
         // physRad graphs: one temperature per level (flux_t_dp is the same in every region) and latent heating from the
         // area-summed rates; otherwise per sub-column
-        const float temp = xd[0] + ((d.physrad ? flux_t_dp : ph_sum<NC>(area * flux_t_dp)) / ys[0]) * 1200.0f;
+        const float temp = xd[0] + ((d.gridT ? flux_t_dp : ph_sum<NC>(area * flux_t_dp)) / ys[0]) * 1200.0f;
         float liq = fminf(fmaxf((temp - 253.16f) * 0.05f, 0.0f), 1.0f);
-        if (RAD && d.nx21) {   // per region: the ramp on the region's own temperature after the flux divergence, or the learned head
+        if (RAD && d.dec21) {  // per region: the ramp on the region's own temperature after the flux divergence, or the learned head
             liq = d.liq_off >= 0 ? 1.0f / (1.0f + expf(-HD[((size_t)(L - d.ltop) * B + b) * HDW + d.liq_off + c]))
                                  : fminf(fmaxf(((s_T[ec] + (flux_t_dp / ys[0]) * 1200.0f) - 253.16f) * 0.05f, 0.0f), 1.0f);
             if (ok) s_liq[e] = liq;
         }
-        const float cond_h = d.physrad ? ph_sum<NC>(area * cond) : cond, evap_h = d.physrad ? ph_sum<NC>(area * evap) : evap;
+        const float cond_h = d.gridT ? ph_sum<NC>(area * cond) : cond, evap_h = d.gridT ? ph_sum<NC>(area * evap) : evap;
         const float net = ((liq * LV + (1.0f - liq) * LS) * cond_h - evap_h * LV) * (1.0f / CP);
         const float dT_crm = flux_t_dp + net / ys[1] * ys[0];
         const float sT = ph_sum<NC>(area * dT_crm), sqv = ph_sum<NC>(area * dqv), sqn = ph_sum<NC>(area * dqn);
@@ -229,7 +229,7 @@ __global__ __launch_bounds__(DT) void phys_decode_kernel(PhysDev d, int B, const
         const float ssed = ph_sum<NC>(area * s_sed[ec]);
         if (RAD && ok) {                              // sub-column state after the step, as the radiation scheme sees it
             s_T[e] = fmaxf(s_T[e] + dT_crm * 1200.0f / ys[0], 0.0f);
-            s_qn[e] = fmaxf(qn + dqn * 1200.0f / ys[2], 0.0f);
+            if (!d.cld_qn_old) s_qn[e] = fmaxf(qn + dqn * 1200.0f / ys[2], 0.0f);
             s_qv[e] = fmaxf(qv + dqv * 1200.0f / ys[1], 0.0f);
         }
         if (ok && c == 0) {
@@ -395,7 +395,7 @@ __global__ __launch_bounds__(DT) void phys_decode_kernel(PhysDev d, int B, const
                                                                                       //  un-shifted, as the serialised graph gathers it)
             float liq = fminf(fmaxf((T_g - 253.16f) * 0.05f, 0.0f), 1.0f);
             if (d.liq_off >= 0) liq = 1.0f / (1.0f + expf(-HD[((size_t)(L - d.ltop) * B + b) * HDW + d.liq_off + sub]));
-            if (d.nx21 && !d.cld_liq_upd) liq = s_liq[l * NC + sub];
+            if (d.dec21 && !d.cld_liq_upd) liq = s_liq[l * NC + sub];
             const float cwp = s_pd[l] / G * qn_g * 1000.0f, cwp_ice = (1.0f - liq) * cwp;
             const float ifr = cwp_ice / fmaxf(cwp, 1e-8f);
             const float *xd = x_denorm + ((size_t)b * PH_L + L) * nxd;
@@ -525,7 +525,7 @@ static int phys_build(int nx, int nfeat, int naux, int nx_sfc, int sfc_cut, int 
     d.nx = nx; d.nfeat = nfeat; d.naux = naux; d.nx_sfc = nx_sfc; d.sfc_cut = sfc_cut; d.sfc_skip = naux - nx_sfc;
     d.nh = nh; d.ilev = ilev_crm; d.nm0 = nh_mem0; d.Lc = PH_L - ilev_crm;
     d.ltop = rad ? ilev_crm : 0; d.Lr = PH_L - d.ltop;
-    d.ncol = mp_ncol; d.rad = rad; d.physrad = physrad; d.memlm = physrad;
+    d.ncol = mp_ncol; d.rad = rad; d.physrad = physrad; d.memlm = physrad; d.gridT = d.clear0 = physrad;
     d.liq_off = w.liq_w ? PH_NHEAD * mp_ncol + 16 : -1;
     d.hdw = rad ? ((PH_NHEAD * mp_ncol + nh_mem0 + (w.liq_w ? 1 + mp_ncol : 0) + 3) / 4) * 4 : PH_NHEAD * mp_ncol + nh_mem0 + 1;
     d.hyam = up(w.hyam, 60); d.hybm = up(w.hybm, 60); d.hyai = up(w.hyai, 61); d.hybi = up(w.hybi, 61);
@@ -625,8 +625,11 @@ static int phys_build(int nx, int nfeat, int naux, int nx_sfc, int sfc_cut, int 
             const int bits = (int)w.misc[7];
             d.sw_ngk = (int)w.misc[4]; d.ice_re = (int)w.misc[5]; d.cld_band = (int)w.misc[6];
             d.sfc_sw_down = bits & 1; d.cld_liq_upd = (bits >> 1) & 1; d.rad_qn_upd = (bits >> 2) & 1;
-            if (w.swx) {      // SW gas-optics MLPs + Slingo / Ebert-Curry cloud optics
-                d.swg = up(w.swx, SWX_FLOATS); d.cldtab = up(w.cldtab, d.cld_band ? 12 * 4 + 4 * PH_NG : 12 * PH_NG);
+            d.gridT = (bits >> 3) & 1; d.clear0 = (bits >> 4) & 1; d.cld_qn_old = (bits >> 5) & 1; d.dec21 = !d.gridT;
+            if (w.swx || w.swg) {      // SW gas-optics MLPs + Slingo / Ebert-Curry cloud optics
+                d.sw_e3sm = w.swg != nullptr;             // (the unfrozen physics_rad_e3sm form of the gas optics under the wrapper)
+                d.swg = d.sw_e3sm ? up(w.swg, SWG_FLOATS) : up(w.swx, SWX_FLOATS);
+                d.cldtab = up(w.cldtab, d.cld_band ? 12 * 4 + 4 * PH_NG : 12 * PH_NG);
                 h->CS = up(nullptr, (size_t)d.Lc * max_batch * 48);
             } else {          // earlier sub-generation: the SW head MLP (24 -> 32 -> 3 x 16) of the unfrozen num4050 family
                 h->s1_w = up(w.sw1_w, 32 * PH_XR_K); h->s1_b = up(w.sw1_b, 32);
@@ -803,7 +806,7 @@ __global__ __launch_bounds__(256) void phys_wrap_pre_kernel(PhysDev d, int B, co
 // pointer order: see include/climsim_amd.h (csa_phys_wrapped_create)
 extern "C" int csa_phys_wrapped_create(int nh, int ng, int flags, const float *const *w, int max_batch, csa_phys **out)
 {
-    if (!w || !out || max_batch <= 0 || (flags & ~(CSA_PHYS_LIQ_FRAC_HEAD | CSA_PHYS_STOCHASTIC | CSA_PHYS_RAD_UPDATED_QV | CSA_PHYS_SW_HEAD))) {
+    if (!w || !out || max_batch <= 0 || (flags & ~(CSA_PHYS_LIQ_FRAC_HEAD | CSA_PHYS_STOCHASTIC | CSA_PHYS_RAD_UPDATED_QV | CSA_PHYS_SW_HEAD | CSA_PHYS_SW_GAS))) {
         csa_set_error_msg("csa_phys_wrapped_create: bad argument");
         return CSA_ERR_ARG;
     }
@@ -823,6 +826,7 @@ extern "C" int csa_phys_wrapped_create(int nh, int ng, int flags, const float *c
     v.r1_w = *p++; v.r1_b = *p++; v.r2_w = *p++; v.r2_b = *p++;
     v.nx21 = 1;
     if (flags & CSA_PHYS_SW_HEAD) { v.sw1_w = *p++; v.sw1_b = *p++; v.sw2_w = *p++; v.sw2_b = *p++; v.lbd_qn = *p++; }
+    else if (flags & CSA_PHYS_SW_GAS) { v.swg = *p++; v.cldtab = *p++; }
     else { v.swx = *p++; v.cldtab = *p++; }
     v.misc = *p++;
     const float *xmean_lev = *p++, *xdiv_lev = *p++, *lqc = *p++, *lqi = *p++;

@@ -722,7 +722,7 @@ int launch_phys_radiation(csa_phys *h, int B, const float *x_sfc, float *out_lev
     // grid y: 0 = LW gas optics, 1 = SW head (absent in the SW gas-optics generation, which has its own kernel)
     hipLaunchKernelGGL(rad_optics_kernel, dim3((M + 32 * RO_WAVES - 1) / (32 * RO_WAVES), d.swg ? 1 : 2), dim3(64 * RO_WAVES), 0, s, a);
     CSA_HIP_CHECK(hipGetLastError());
-    if (d.nx21 && d.swg) {
+    if (d.nx21 && d.swg && !d.sw_e3sm) {
         if (!mask_u) { csa_set_error_msg("physRNN (frozen export): the SW humidity coin needs its uniform draws"); return CSA_ERR_ARG; }
         hipLaunchKernelGGL(rad_sw_gas16_kernel, dim3((M + SX_ROWS - 1) / SX_ROWS), dim3(256), 0, s, h->XR, d.swg, h->CS, mask_u, h->S2, M, B, d.ilev, h->ng, d.sw_ngk);
         CSA_HIP_CHECK(hipGetLastError());

@@ -364,27 +364,45 @@ class physical_RNN_wrapped(torch.nn.Module):
             out[:a.shape[0]] = a
             return out
         arrs = [f(k) for k in _W_ORDER]
+        # decoder sub-generation without a sub-grid temperature (num27378 / num45826 / num74834: the physRad decoder): no mlp_t_crm
+        # (zero head), ONE eddy diffusivity per level (its row for every region), and -- with the clear-sky region -- a zero first row
+        # in front of the nreg - 1 rows of the condensate heads
+        grid_T = "mlp_t_crm.weight" not in state_dict
+        clear0 = grid_T and f("mlp_qn_crm.weight").shape[0] == nreg - 1
         for m in _HEADS:
-            arrs += [pad_rows(f(m + ".weight")), pad_rows(f(m + ".bias"), -1.0e30 if m == "mlp_subgrid_area_frac" else 0.0)]
+            if grid_T and m == "mlp_t_crm":
+                arrs += [np.zeros((16, self.nh), np.float32), np.zeros(16, np.float32)]
+                continue
+            w_, b_ = f(m + ".weight"), f(m + ".bias")
+            if grid_T and m == "mlp_eddy_diff":
+                w_, b_ = np.repeat(w_, nreg, 0), np.repeat(b_, nreg, 0)
+            if clear0 and m in ("mlp_qn_crm", "mlp_evap_cond_vapor_crm"):
+                w_, b_ = np.concatenate([np.zeros((1, self.nh), np.float32), w_]), np.concatenate([np.zeros(1, np.float32), b_])
+            arrs += [pad_rows(w_), pad_rows(b_, -1.0e30 if m == "mlp_subgrid_area_frac" else 0.0)]
         arrs += [f("yscale_sca_rad"), pad_rows(f("solar_weights").reshape(-1))] + [f(k) for k in _W_LW]
         arrs += [pad_rows(f("gas_optics_lw_reduce1.weight")), pad_rows(f("gas_optics_lw_reduce1.bias")),
                  pad_rows(f("gas_optics_lw_reduce2.weight")), pad_rows(f("gas_optics_lw_reduce2.bias"), -1.0e30)]
         sw_head = "mlp_sw_optprops1.weight" in state_dict      # earlier sub-generation: SW optical properties from one two-layer MLP
+        sw_e3sm = "gas_optics_model_sw1.ystd" in state_dict
         self.ngk = 0
         if sw_head:
             if nreg != 16 or f("mlp_sw_optprops1.weight").shape != (32, 24) or f("mlp_sw_optprops2.weight").shape != (48, 32):
                 raise RuntimeError("physRNN (frozen export): the SW head is built for 24 -> 32 -> 3 x 16")
             arrs += [f("mlp_sw_optprops1.weight"), f("mlp_sw_optprops1.bias"), f("mlp_sw_optprops2.weight"), f("mlp_sw_optprops2.bias"),
                      np.ascontiguousarray(f("lbd_qn").reshape(-1))]
+        elif sw_e3sm:      # the unfrozen physics_rad_e3sm form of the SW gas optics (112 k-points, mean of the two humidity variants)
+            arrs.append(_sw_gas_block(state_dict, nreg))
+            self._cloud_table(arrs, f, state_dict, cfg, nreg, pad_rows)
         else:
             self._sw_gas_arrays(arrs, f, state_dict, cfg, nreg, pad_rows)
         band_matrix = "cloud_band_to_gpt" in state_dict
         mix = (float(f("mix_near").reshape(-1)[0]), float(f("mix_vis").reshape(-1)[0])) if "mix_near" in state_dict else (0.5, 0.5)
-        bits = (1 if cfg.get("sfc_sw_down") else 0) | (2 if cfg.get("cld_liq_from_updated_T") else 0) | (4 if cfg.get("rad_updated_qn") else 0)
+        bits = (1 if cfg.get("sfc_sw_down") else 0) | (2 if cfg.get("cld_liq_from_updated_T") else 0) | (4 if cfg.get("rad_updated_qn") else 0) | \
+            (8 if grid_T else 0) | (16 if clear0 else 0) | (0 if cfg.get("cld_qn_updated", True) else 32)
         arrs.append(np.asarray([cfg["n_ir"], cfg["n_mix_end"], mix[0], mix[1], self.ngk, int(bool(cfg.get("ice_optics_on_ice_radius"))),
                                 int(band_matrix), bits], np.float32))
         arrs += [f("xmean_lev"), f("xdiv_lev"), f("lbd_qc"), f("lbd_qi")]
-        flags = (2 if liq_head else 0) | (4 if self.stochastic else 0) | (256 if cfg.get("rad_updated_qv") else 0) | (512 if sw_head else 0)
+        flags = (2 if liq_head else 0) | (4 if self.stochastic else 0) | (256 if cfg.get("rad_updated_qv") else 0) | (512 if sw_head else 0) | (64 if sw_e3sm else 0)
         if liq_head:
             arrs += [pad_rows(f("mlp_liq_frac_crm.weight")), pad_rows(f("mlp_liq_frac_crm.bias"))]
         if self.stochastic:
@@ -421,6 +439,9 @@ class physical_RNN_wrapped(torch.nn.Module):
                 wr[:, :self.ngk], br[:] = w0, f(r + ".bias")
             blk += [wr.ravel(), br]
         arrs.append(np.ascontiguousarray(np.concatenate(blk), np.float32))
+        self._cloud_table(arrs, f, state_dict, cfg, nreg, pad_rows)
+
+    def _cloud_table(self, arrs, f, state_dict, cfg, nreg, pad_rows):
         tab = np.asarray(_SLINGO + _EBERT_CURRY, np.float32)
         band_matrix = "cloud_band_to_gpt" in state_dict
         if band_matrix:           # four-band tables + the learned (4, ng) band -> g-point matrix

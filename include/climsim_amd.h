@@ -503,7 +503,10 @@ int csa_phys_debug_rnn3(csa_phys *h, int T, int B, const float *x, const float *
  *   visible and the weights of the mixed ones; ngk: k-points behind the SW coin that the reduction maps to the g-points, 0 = none;
  *   1 = the ice SW optics read the ice effective radius (0: the liquid one, as first serialised); 1 = band matrix; bit mask: 1 the
  *   first surface output is the downward (not net) shortwave, 2 cloud LW optics on the liquid fraction of the updated sub-grid
- *   temperature, 4 the SW head sees the updated cloud water].  With CSA_PHYS_SW_HEAD (earlier exports: num8701, num75599, num82174)
+ *   temperature, 4 the SW head sees the updated cloud water, 8 decoder without a sub-grid temperature (the physRad decoder: zero
+ *   mlp_t_crm head, the one eddy-diffusivity row repeated), 16 region 0 holds no condensate, 32 cloud water paths of the radiation
+ *   scheme from the sub-grid cloud water before the step].  With CSA_PHYS_SW_GAS (num27378, num45826, num74834) the SW block is the
+ *   unfrozen generation's (csa_phys_rad_create's CSA_PHYS_SW_GAS block: 112 k-points, mean of the two humidity variants).  With CSA_PHYS_SW_HEAD (earlier exports: num8701, num75599, num82174)
  *   the SW block and the cloud table are replaced by mlp_sw_optprops1.{w (32,24), b}, mlp_sw_optprops2.{w (48,32), b}, lbd_qn (60).  Then the
  *   wrapper's xmean_lev (60,21), xdiv_lev (60,21),
  *   lbd_qc (60), lbd_qi (60)   (71 pointers); with CSA_PHYS_LIQ_FRAC_HEAD mlp_liq_frac_crm.{w (16,nh), b}, with CSA_PHYS_STOCHASTIC

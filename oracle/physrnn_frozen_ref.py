@@ -185,10 +185,16 @@ def radiation(P, FL, aux, xd, play, plev, delta_plev, dec, T_new, qv_rad, mask_u
         col = (delta_plev * 6.02214076e24 * f) / ((v + 0.04698) * f * 980665)
         x = torch.cat([T_new, torch.log(play), v.sqrt().sqrt(), o3, co2, xd[:, :, 14:15], xd[:, :, 13:14]], 2)
         x = (x - xmin) / xdiv
-        taus.append((col * pow8(gas_mlp(P, "gas_optics_model_sw1", x)) * 1e-17, col * pow8(gas_mlp(P, "gas_optics_model_sw2", x)) * 1e-17))
-    pick = mask_u < 0.5                                                 # (B,60,k-points of the gas models: ng, or 14 / 12 with the reduction)
-    tau_abs = torch.where(pick, taus[0][0], taus[1][0])
-    tau_sca = torch.where(pick, taus[0][1], taus[1][1])
+        if "gas_optics_model_sw1.ystd" in P:       # num27378 / num45826 / num74834: the unfrozen physics_rad_e3sm form, 112 k-points
+            taus.append(tuple(col * pow8(P[m + ".ystd"] * gas_mlp(P, m, x) + P[m + ".ymean"]) for m in ("gas_optics_model_sw1", "gas_optics_model_sw2")))
+        else:
+            taus.append((col * pow8(gas_mlp(P, "gas_optics_model_sw1", x)) * 1e-17, col * pow8(gas_mlp(P, "gas_optics_model_sw2", x)) * 1e-17))
+    if FL.get("sw_random_mask", True):
+        pick = mask_u < 0.5                                             # (B,60,k-points of the gas models: ng, or 14 / 12 with the reduction)
+        tau_abs = torch.where(pick, taus[0][0], taus[1][0])
+        tau_sca = torch.where(pick, taus[0][1], taus[1][1])
+    else:                                          # no coin: the mean of the two humidity variants
+        tau_abs, tau_sca = (taus[0][0] + taus[1][0]) * 0.5, (taus[0][1] + taus[1][1]) * 0.5
     if "gas_optics_sw_reduce1.weight" in P:      # sub-generation with k-point -> g-point reductions behind the coin (num11916, num87824)
         tau_abs = F.softplus(_jit(_lin(P, "gas_optics_sw_reduce1", tau_abs))) * 0.01 + 1e-9
         tau_sca = F.softplus(_jit(_lin(P, "gas_optics_sw_reduce2", tau_sca))) * 0.01
@@ -213,7 +219,9 @@ def radiation(P, FL, aux, xd, play, plev, delta_plev, dec, T_new, qv_rad, mask_u
     c_asy = pad((cwp_liq * sgl + cwp_ice * sgi) / (c_sca0 + 1e-7))
     c_sca = pad(c_sca0)
     tau_sw = (tau_abs + tau_sca) + c_tau
-    sca = (tau_sca + c_sca).clamp(min=1e-9)
+    sca = tau_sca + c_sca
+    if FL.get("sw_scat_clamp", True):
+        sca = sca.clamp(min=1e-9)
     asy = c_asy * c_sca / sca
     ssa = sca / tau_sw
     return _sw_solve_and_finish(P, FL, aux, delta_plev, tau_sw, ssa, asy, lw_dn, lw_up, taps,
@@ -284,8 +292,13 @@ def forward(P, FL, x_main0, x_sfc0, rnn1_mem, hx2, mask_u, hx1=None, eps3=None, 
         rnn2out = rnn2out * srnn.transpose(0, 1)
     mem_new = _lin(P, "mlp_latent", rnn2out)
     out = _lin(P, "mlp_output", mem_new)
-    dec = microphysics_decode(P, out, mem_new, rnn2out, last_h, x_main00, delta_plev, play, P_old, ilev_crm, mp_ncol,
-                              copy_dT=False, clear_sky=False, nx21=True)
+    grid_T = "mlp_t_crm.weight" not in P           # num27378 / num45826 / num74834: the physRad decoder (no sub-grid temperature, heat flux at
+    dec = microphysics_decode(P, out, mem_new, rnn2out, last_h, x_main00, delta_plev, play, P_old, ilev_crm, mp_ncol,    # layer bottoms)
+                              copy_dT=False, clear_sky=bool(FL.get("clear_sky")), nx21=not grid_T, grid_T=grid_T)
+    if grid_T:                                     # the cloud water paths take the learned liquid fraction, the latent heating the grid ramp
+        dec["liq_frac"] = torch.sigmoid(_lin(P, "mlp_liq_frac_crm", rnn2out))
+    if not FL.get("cld_qn_updated", True):
+        dec["qn_crm"] = dec["qn_crm_old"]
     out_new = dec["out_new"]
     ys = P["yscale_lev"]
     T_new = torch.relu(x_main00[:, :, 0:1] + out_new[:, :, 0:1] / ys[:, 0:1] * 1200)

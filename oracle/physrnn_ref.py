@@ -77,7 +77,7 @@ def forward(P, inputs_main, inputs_aux, rnn_mem, inputs_denorm, hx2, ilev_crm=10
 
 
 def microphysics_decode(P, out, mem_new, r2, last_h, inputs_denorm, delta_plev, play, P_old, ilev_crm, mp_ncol, copy_dT=True,
-                        clear_sky=False, nx21=False):
+                        clear_sky=False, nx21=False, grid_T=None):
     """rnn/models/models_phys.py:414-748.  copy_dT: the nx = 21 graphs also pass the decoder's raw column-0 output of the
     levels below ilev_crm + 2 through to out_new; the radiation graphs (oracle/physrnn_rad_ref.py) do not.
     clear_sky (the physRNN_physRad-* graphs, `use_clear_sky_region`, no sub-grid temperature): region 0 holds no condensate
@@ -90,6 +90,9 @@ def microphysics_decode(P, out, mem_new, r2, last_h, inputs_denorm, delta_plev, 
     -- both in the latent heating and, returned as `liq_frac`, in the radiation scheme's cloud water paths.
     -> dict with out_new, precc, precsc, mem_out and the updated sub-column state (T_crm, qv_crm, qn_crm, area_frac)."""
     B, nlev = inputs_denorm.shape[0], inputs_denorm.shape[1]
+    # grid_T: no sub-grid temperature (grid temperature in the eddy flux and the liquid ramp, latent heating from the area-summed
+    # rates); it comes with the clear-sky region in the physRad graphs, and WITHOUT it in the frozen exports num45826 / num74834
+    grid_T = clear_sky if grid_T is None else grid_T
     x = out
     ys = P["yscale_lev"][ilev_crm:]                                                           # (50,5)
     out_new = x.new_zeros(B, nlev, 5)
@@ -110,7 +113,7 @@ def microphysics_decode(P, out, mem_new, r2, last_h, inputs_denorm, delta_plev, 
         mean = (q * area_frac).sum(-1, keepdim=True)
         return q * torch.where(mean == 0, torch.ones_like(mean), gcm / mean)
     qv_crm, qn_crm = rescale(qv_crm, qv_gcm), rescale(qn_crm, qn_gcm)
-    if clear_sky:
+    if grid_T:
         T_crm = T_gcm                                                                         # (B,50,1)
     else:
         deltaT = _lin(P, "mlp_t_crm", r2)
@@ -154,7 +157,7 @@ def microphysics_decode(P, out, mem_new, r2, last_h, inputs_denorm, delta_plev, 
     #  the positive ones, and the radiation scheme takes the FOURTH ROOT of the vapour residue: _jit lets a test realise that rounding)
     dqv_crm = _jit(flux_qv_dp - cond + evap_prec)
     dqn_crm = _jit(flux_qn_dp + cond - dqn_aa + sed_qn_dp)
-    if clear_sky:
+    if grid_T:
         temp = T_gcm.squeeze(2) + (flux_t_dp.squeeze(2) / ys[:, 0]) * 1200
         liq = F.hardtanh((temp - 253.16) * 0.05, 0.0, 1.0).unsqueeze(2)
         cond_s, evap_s = (area_frac * cond).sum(2, keepdim=True), (area_frac * evap_prec).sum(2, keepdim=True)
@@ -190,4 +193,4 @@ def microphysics_decode(P, out, mem_new, r2, last_h, inputs_denorm, delta_plev, 
     ys_ = lambda k: ys[:, k:k + 1]
     return dict(out_new=out_new, precc=precc, precsc=precsc, mem_out=mem_out, area_frac=area_frac, liq_frac=liq,
                 T_crm=torch.relu(T_crm + dT_crm * 1200 / ys_(0)), qv_crm=torch.relu(qv_crm + dqv_crm * 1200 / ys_(1)),
-                qn_crm=torch.relu(qn_crm + dqn_crm * 1200 / ys_(2)))
+                qn_crm=torch.relu(qn_crm + dqn_crm * 1200 / ys_(2)), qn_crm_old=qn_crm)

@@ -159,6 +159,7 @@ class Extractor:
             self.const("ys_qn50", r"dqn_aa", rf"torch\.mul\(torch\.mul\(alpha, qn_crm\d*\), {C}\)")
         self.const("ys_T50", r"temp\d*", rf"torch\.div\(flux_t_dp\w*, {C}\)", required=False) or \
             self.const("ys_T50", r"net_condensation_crm\d*", rf"\), {C}\)$")
+        self.const("ys_T50_sq", r"temp\d*", rf"torch\.div\(torch\.squeeze\(flux_t_dp\w*\), {C}\)", required=False)     # (the grid-temperature decoder's copy)
         self.const("pmax_coef", r"Pmax", rf"torch\.mul\({C}, ")
         self.const("yscale_lev_3d", r"out_denorm", rf"torch\.div\(out_new, {C}\)")
         # ---- LW gas optics + reductions (models_phys.py:816-1270, rnn/layers.py gasopt_mlp) -------------------------------
@@ -198,6 +199,14 @@ class Extractor:
         for i, (l, r) in enumerate(taus[:2]):
             mm = re.search(LIN, r)
             P[f"gas_optics_model_sw{i + 1}.mlp3.weight"], P[f"gas_optics_model_sw{i + 1}.mlp3.bias"] = self.lin_wb(mm.groups()[1:5])
+        F["sw_gas_ystd"] = not taus
+        if not taus:      # another sub-generation (num27378, num45826, num74834): tau = N (ystd y + ymean)^8 as in the LW model, no 1e-17
+            pat = rf"torch\.mul\(col_dry_crm_1\d*, torch\.pow\(torch\.add\(torch\.mul\({C}, " + LIN + rf"\), {C}\), 8\)\)"
+            taus = [re.search(pat, r) for l, r in self.named if re.fullmatch(r"tau_sw(_scat)?\d*", l) and re.search(pat, r)]
+            for i, mm in enumerate(taus[:2]):
+                g = mm.groups()
+                P[f"gas_optics_model_sw{i + 1}.ystd"], P[f"gas_optics_model_sw{i + 1}.ymean"] = self.c(g[0]), self.c(g[-1])
+                P[f"gas_optics_model_sw{i + 1}.mlp3.weight"], P[f"gas_optics_model_sw{i + 1}.mlp3.bias"] = self.lin_wb(g[2:6])
         F["sw_gas_reduce"] = self.linear("gas_optics_sw_reduce1", r"tau_sw\w*", r"torch\.softplus\({LIN}, 1\., 20\.\)", required=False)
         if F["sw_gas_reduce"]:
             self.linear("gas_optics_sw_reduce2", r"tau_sw_scat\w*", r"torch\.softplus\({LIN}, 1\., 20\.\)")
@@ -206,6 +215,8 @@ class Extractor:
         return self._tail(P, F, code)
 
     def _tail(self, P, F, code):
+        F["sw_scat_clamp"] = bool(re.search(r"tau_sw_scat_tot\d* = torch\.clamp\(tau_sw_scat_tot\d*, 1", code))
+        F["cld_qn_updated"] = bool(re.search(r"qn_crm\d* = torch\.relu\(torch\.add\(qn_crm\d*, ", code))     # cloud water paths of the radiation scheme
         F["sfc_sw_down"] = "flux_sw_dn_sfc" in code              # first surface output: downward (num82174) instead of net shortwave
         F["cld_liq_from_updated_T"] = bool(re.search(r"torch\.sub\(torch\.squeeze\(T_crm\d*\), 253\.16", code))   # cloud LW optics: ramp on the UPDATED T_crm
         F["rad_updated_qv"] = bool(re.search(r"qv0 = torch\.relu\(torch\.add\(qv, dqv0\)\)", code))

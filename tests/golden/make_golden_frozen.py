@@ -67,7 +67,7 @@ def draws(Fl, B, seed):
     if Fl["rnn3"]:
         d["hx1"] = torch.randn(B, nh)
         d["eps3"] = torch.randn(50, B, nh)
-    d["mask_u"] = torch.rand(60, B, Fl["sw_ng_gas"] if Fl.get("sw_gas_reduce") else ng)     # rand_like(tau_sw1): the gas models' k-points
+    d["mask_u"] = torch.rand(60, B, Fl["sw_ng_gas"] if Fl.get("sw_gas_reduce") and Fl.get("sw_random_mask") else ng)     # rand_like(tau_sw1): the gas models' k-points
     return d
 
 

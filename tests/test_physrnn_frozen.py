@@ -120,22 +120,34 @@ def test_hip_frozen_export_matches_the_artefact(fixture):
         got64 = _f64(P, FL, x, s, mem, dr)
         # Rounding level of a block: the export and the float32 restatement share torch's matmul, so their roundings of the gas-optics
         # MLPs coincide and the pair under-estimates the level of blocks that amplify those (tau = N y^8, then exp(-tau / mu0): one
-        # SOLL reached 10 x the pair's level).  Two more float32 realisations re-round every MLP layer output in its last bit.
-        jit = []
-        for sd in (1, 2):
+        # SOLL reached 10 x the pair's level).  Six more float32 realisations re-round every MLP layer output and the decoder's
+        # sub-grid tendencies in their last bit (frozen_034c6081, column 13: the updated q_v of one of the two largest regions is a clamp
+        # residue -- exactly 0 in some realisations, 1e-10 in others and on the GPU -- whose FOURTH ROOT feeds the SW gas optics).
+        def realisation(sd):
             R._JITTER = D._JITTER = torch.Generator().manual_seed(sd)
             try:
-                jit.append(_blocks(*R.forward(P, FL, x, s, mem, dr["hx2"], dr["mask_u"], **kw)))
+                return _blocks(*R.forward(P, FL, x, s, mem, dr["hx2"], dr["mask_u"], **kw))
             finally:
                 R._JITTER = D._JITTER = None
+        jit = [realisation(sd) for sd in (1, 2)]
         b_ref, bh, b32, b64 = _blocks(*ref), _blocks(*got), _blocks(*got32), _blocks(*got64)
-        for key in b_ref:
-            scale = b_ref[key].abs().max().item()
-            noise = max((r[key].double() - b64[key]).abs().max().item() for r in (b_ref, b32, jit[0], jit[1]))
-            tol = max(1e-5 * scale, 6 * noise) + 1e-30
-            assert (bh[key].double() - b64[key]).abs().max().item() <= tol, (fixture, i, key, "vs float64 restatement")
-            assert (bh[key] - b_ref[key]).abs().max().item() <= tol + noise, (fixture, i, key, "vs the export")
 
+        def bad_blocks():
+            out = []
+            for key in b_ref:
+                scale = b_ref[key].abs().max().item()
+                noise = max((r[key].double() - b64[key]).abs().max().item() for r in [b_ref, b32] + jit)
+                tol = max(1e-5 * scale, 6 * noise) + 1e-30
+                if (bh[key].double() - b64[key]).abs().max().item() > tol:
+                    out.append((fixture, i, key, "vs float64 restatement"))
+                if (bh[key] - b_ref[key]).abs().max().item() > tol + noise:
+                    out.append((fixture, i, key, "vs the export"))
+            return out
+        bad = bad_blocks()
+        if bad:       # a per-cell event (clamp residue under the fourth root) that the first two realisations did not have: four more
+            jit += [realisation(sd) for sd in (3, 4, 5, 6)]
+            bad = bad_blocks()
+        assert not bad, bad
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("fixture", [f for f in FIX if "case0.srnn" in np.load(os.path.join(GOLDEN, f + ".npz")).files])
@@ -168,4 +180,4 @@ def test_index_of_the_frozen_exports_is_consistent_with_the_fixtures():
     assert {idx[k]["code"] for k in cpu_built} == built
     twins = [k for k, v in idx.items() if v["status"].startswith("twin of a built variant")]
     assert all(idx[k]["cpu_twin_code"] in built for k in twins)
-    assert len(cpu_built) == 44 and len(twins) == 23
+    assert len(cpu_built) == 47 and len(twins) == 24
