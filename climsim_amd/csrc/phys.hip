@@ -810,8 +810,8 @@ extern "C" int csa_phys_wrapped_create(int nh, int ng, int flags, const float *c
         csa_set_error_msg("csa_phys_wrapped_create: bad argument");
         return CSA_ERR_ARG;
     }
-    if (nh != 128 || !(ng == 12 || ng == 14 || ng == 16)) {
-        csa_set_error_msg("csa_phys_wrapped_create: built for the shipped exports (GRU 128/128; 12, 14 or 16 regions = g-points)");
+    if ((nh != 128 && nh != 112 && nh != 96) || !(ng == 12 || ng == 14 || ng == 16)) {
+        csa_set_error_msg("csa_phys_wrapped_create: built for the shipped exports (GRU 128 / 112 / 96; 12, 14 or 16 regions = g-points)");
         return CSA_ERR_UNSUPPORTED;
     }
     PhysHostW v{};

@@ -385,11 +385,16 @@ class physical_RNN_wrapped(torch.nn.Module):
         sw_head = "mlp_sw_optprops1.weight" in state_dict      # earlier sub-generation: SW optical properties from one two-layer MLP
         sw_e3sm = "gas_optics_model_sw1.ystd" in state_dict
         self.ngk = 0
-        if sw_head:
-            if nreg != 16 or f("mlp_sw_optprops1.weight").shape != (32, 24) or f("mlp_sw_optprops2.weight").shape != (48, 32):
-                raise RuntimeError("physRNN (frozen export): the SW head is built for 24 -> 32 -> 3 x 16")
-            arrs += [f("mlp_sw_optprops1.weight"), f("mlp_sw_optprops1.bias"), f("mlp_sw_optprops2.weight"), f("mlp_sw_optprops2.bias"),
-                     np.ascontiguousarray(f("lbd_qn").reshape(-1))]
+        if sw_head:       # 24 -> nhid <= 32 -> 3 x nreg; hidden units and g-points zero-padded to 32 / 16
+            w1, b1, w2, b2 = (f("mlp_sw_optprops" + k) for k in ("1.weight", "1.bias", "2.weight", "2.bias"))
+            nhid = w1.shape[0]
+            if w1.shape[1] != 24 or nhid > 32 or w2.shape != (3 * nreg, nhid):
+                raise RuntimeError("physRNN (frozen export): the SW head is built for 24 -> (<= 32) -> 3 x nreg")
+            W1, B1, W2, B2 = np.zeros((32, 24), np.float32), np.zeros(32, np.float32), np.zeros((48, 32), np.float32), np.zeros(48, np.float32)
+            W1[:nhid], B1[:nhid] = w1, b1
+            for c in range(3):
+                W2[16 * c:16 * c + nreg, :nhid], B2[16 * c:16 * c + nreg] = w2[nreg * c:nreg * (c + 1)], b2[nreg * c:nreg * (c + 1)]
+            arrs += [W1, B1, W2, B2, np.ascontiguousarray(f("lbd_qn").reshape(-1))]
         elif sw_e3sm:      # the unfrozen physics_rad_e3sm form of the SW gas optics (112 k-points, mean of the two humidity variants)
             arrs.append(_sw_gas_block(state_dict, nreg))
             self._cloud_table(arrs, f, state_dict, cfg, nreg, pad_rows)
