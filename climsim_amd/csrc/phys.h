@@ -53,6 +53,7 @@ struct PhysDev {
     int cld_qn_old;         // 1: the radiation scheme's cloud water paths take the sub-grid cloud water BEFORE the step (num45826 / num74834)
     int sw_e3sm;            // nx21 wrapper + solver around the unfrozen physics_rad_e3sm SW gas optics (112 k-points, mean of the two humidity
                             // variants, reductions): swg = the SWG_* block, cldtab = the cloud table / band matrix
+    int rad_T_old;          // nx21: 1 = the radiation scheme reads the temperature BEFORE the step (num36398)
     int rad_qn_upd;         // SW head MLP of the earlier nx21 exports: 1 = it sees the UPDATED grid-mean cloud water
     int sfc_sw_down;        // nx21: 1 = the first surface output is the DOWNWARD shortwave (num82174), 0 = the net one
     int cld_liq_upd;        // nx21: 1 = cloud LW optics take the liquid fraction of the UPDATED sub-grid temperature (num82174)
@@ -111,6 +112,7 @@ struct csa_phys {
     // add_stochastic_layer graphs: rnn3 (MyStochasticGRULayer5 over rnn2's output), its output and the perturbed sequence
     struct csa_stoch *rnn3 = nullptr;
     float *H3 = nullptr, *H2p = nullptr;
+    int rnn3_last_mul = 0;  // the release / surface heads read rnn2's last state TIMES the third RNN's (num36398) instead of the latter alone
     // frozen `*_wrapped` exports: the wrapper's constants (rnn/utils.py:182-217) and the buffers between its two passes and the model
     int ng = PH_NG;         // g-points of the export (= nreg: 12 / 14 / 16; the kernels run 16 with zero-weight padding)
     float *wr_xmean = nullptr, *wr_xdiv = nullptr, *wr_lqc = nullptr, *wr_lqi = nullptr;

@@ -292,7 +292,7 @@ __global__ __launch_bounds__(DT) void phys_decode_kernel(PhysDev d, int B, const
             const size_t row = (size_t)L * B + b;
             const float *xd = x_denorm + ((size_t)b * PH_L + L) * nxd;
             const float *ys = d.yscale_lev + L * 5;
-            const float T_new = fmaxf(xd[0] + s_o01[L][0] / ys[0] * 1200.0f, 0.0f);
+            const float T_new = d.rad_T_old ? xd[0] : fmaxf(xd[0] + s_o01[L][0] / ys[0] * 1200.0f, 0.0f);
             const float qv_new = d.nx21 && !d.rad_qv_upd ? xd[nxd - 1] : fmaxf(xd[nxd - 1] + s_o01[L][1] / ys[1] * 1200.0f, 0.0f);
             const float vmr = (d.physrad || d.nx21 ? qv_new / (1.0f - qv_new) : qv_new) * 1.608079364f, fact = 1.0f / (1.0f + vmr), m_air = (vmr + 0.04698f) * fact;
             const float pd = sp * (d.hybi[L + 1] - d.hybi[L]) + (d.hyai[L + 1] - d.hyai[L]) * 100000.0f;
@@ -400,7 +400,7 @@ __global__ __launch_bounds__(DT) void phys_decode_kernel(PhysDev d, int B, const
             const float ifr = cwp_ice / fmaxf(cwp, 1e-8f);
             const float *xd = x_denorm + ((size_t)b * PH_L + L) * nxd;
             const float *ys = d.yscale_lev + L * 5;
-            const float T_new = fmaxf(xd[0] + s_o01[L][0] / ys[0] * 1200.0f, 0.0f);
+            const float T_new = d.rad_T_old ? xd[0] : fmaxf(xd[0] + s_o01[L][0] / ys[0] * 1200.0f, 0.0f);
             const float rei = fminf(fmaxf(ph_reitab(d.retab, T_new), 13.0f), 130.0f);
             float tau_cld = cwp * 0.090361f * (1.0f - ifr) + cwp * ifr * (1.0f / rei + 0.005f);
             if (d.cld_w) {          // learned optics: ReLU(Linear([(T_crm - 160) / 180, r_ice / 125, r_liq / 13.5, new memory (15 + stored water)]))
@@ -626,6 +626,7 @@ static int phys_build(int nx, int nfeat, int naux, int nx_sfc, int sfc_cut, int 
             d.sw_ngk = (int)w.misc[4]; d.ice_re = (int)w.misc[5]; d.cld_band = (int)w.misc[6];
             d.sfc_sw_down = bits & 1; d.cld_liq_upd = (bits >> 1) & 1; d.rad_qn_upd = (bits >> 2) & 1;
             d.gridT = (bits >> 3) & 1; d.clear0 = (bits >> 4) & 1; d.cld_qn_old = (bits >> 5) & 1; d.dec21 = !d.gridT;
+            d.rad_T_old = (bits >> 6) & 1; h->rnn3_last_mul = (bits >> 7) & 1;
             if (w.swx || w.swg) {      // SW gas-optics MLPs + Slingo / Ebert-Curry cloud optics
                 d.sw_e3sm = w.swg != nullptr;             // (the unfrozen physics_rad_e3sm form of the gas optics under the wrapper)
                 d.swg = d.sw_e3sm ? up(w.swg, SWG_FLOATS) : up(w.swx, SWX_FLOATS);
@@ -931,7 +932,7 @@ static int phys_forward_impl(csa_phys *h, int B, const float *x_main, const floa
         hipLaunchKernelGGL(phys_mul_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, (const f32x4 *)h->H2, (const f32x4 *)h->H3,
                            (f32x4 *)h->H2p, n4);
         CSA_HIP_CHECK(hipGetLastError());
-        Hhead = h->H2p; Hlast = h->H3;
+        Hhead = h->H2p; Hlast = h->rnn3_last_mul ? h->H2p : h->H3;
     }
     if ((rc = launch_proj_gemm(Hhead, h->whead, h->bhead, h->HD, M, d.hdw, nh, s, 0))) return rc;
     if (d.rad) {

@@ -403,7 +403,8 @@ class physical_RNN_wrapped(torch.nn.Module):
         band_matrix = "cloud_band_to_gpt" in state_dict
         mix = (float(f("mix_near").reshape(-1)[0]), float(f("mix_vis").reshape(-1)[0])) if "mix_near" in state_dict else (0.5, 0.5)
         bits = (1 if cfg.get("sfc_sw_down") else 0) | (2 if cfg.get("cld_liq_from_updated_T") else 0) | (4 if cfg.get("rad_updated_qn") else 0) | \
-            (8 if grid_T else 0) | (16 if clear0 else 0) | (0 if cfg.get("cld_qn_updated", True) else 32)
+            (8 if grid_T else 0) | (16 if clear0 else 0) | (0 if cfg.get("cld_qn_updated", True) else 32) | \
+            (0 if cfg.get("rad_updated_T", True) else 64) | (128 if cfg.get("rnn3_last_mul") else 0)
         arrs.append(np.asarray([cfg["n_ir"], cfg["n_mix_end"], mix[0], mix[1], self.ngk, int(bool(cfg.get("ice_optics_on_ice_radius"))),
                                 int(band_matrix), bits], np.float32))
         arrs += [f("xmean_lev"), f("xdiv_lev"), f("lbd_qc"), f("lbd_qi")]

@@ -505,7 +505,8 @@ int csa_phys_debug_rnn3(csa_phys *h, int T, int B, const float *x, const float *
  *   first surface output is the downward (not net) shortwave, 2 cloud LW optics on the liquid fraction of the updated sub-grid
  *   temperature, 4 the SW head sees the updated cloud water, 8 decoder without a sub-grid temperature (the physRad decoder: zero
  *   mlp_t_crm head, the one eddy-diffusivity row repeated), 16 region 0 holds no condensate, 32 cloud water paths of the radiation
- *   scheme from the sub-grid cloud water before the step].  With CSA_PHYS_SW_GAS (num27378, num45826, num74834) the SW block is the
+ *   scheme from the sub-grid cloud water before the step, 64 radiation on the temperature before the step, 128 the release / surface
+ *   heads read rnn2's last state times the third RNN's (num36398)].  With CSA_PHYS_SW_GAS (num27378, num45826, num74834) the SW block is the
  *   unfrozen generation's (csa_phys_rad_create's CSA_PHYS_SW_GAS block: 112 k-points, mean of the two humidity variants).  With CSA_PHYS_SW_HEAD (earlier exports: num8701, num75599, num82174)
  *   the SW block and the cloud table are replaced by mlp_sw_optprops1.{w (32,24), b}, mlp_sw_optprops2.{w (48,32), b}, lbd_qn (60).  Then the
  *   wrapper's xmean_lev (60,21), xdiv_lev (60,21),

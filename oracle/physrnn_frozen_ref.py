@@ -288,7 +288,7 @@ def forward(P, FL, x_main0, x_sfc0, rnn1_mem, hx2, mask_u, hx1=None, eps3=None, 
             srnn = stochastic_gru(rnn2out.transpose(0, 1), hx1, eps3, P["rnn3.weight_ih"], P["rnn3.weight_zh"], P["rnn3.weight_encoder"])
         if taps is not None:
             taps["srnn"] = srnn
-        last_h = srnn[-1]
+        last_h = last_h * srnn[-1] if FL.get("rnn3_last_mul") else srnn[-1]
         rnn2out = rnn2out * srnn.transpose(0, 1)
     mem_new = _lin(P, "mlp_latent", rnn2out)
     out = _lin(P, "mlp_output", mem_new)
@@ -301,7 +301,7 @@ def forward(P, FL, x_main0, x_sfc0, rnn1_mem, hx2, mask_u, hx1=None, eps3=None, 
         dec["qn_crm"] = dec["qn_crm_old"]
     out_new = dec["out_new"]
     ys = P["yscale_lev"]
-    T_new = torch.relu(x_main00[:, :, 0:1] + out_new[:, :, 0:1] / ys[:, 0:1] * 1200)
+    T_new = torch.relu(x_main00[:, :, 0:1] + out_new[:, :, 0:1] / ys[:, 0:1] * 1200) if FL.get("rad_updated_T", True) else x_main00[:, :, 0:1]
     qv = x_main00[:, :, -1:]
     if FL["rad_updated_qv"]:
         qv = torch.relu(qv + out_new[:, :, 1:2] / ys[:, 1:2] * 1200)

@@ -161,7 +161,7 @@ class Extractor:
             self.const("ys_T50", r"net_condensation_crm\d*", rf"\), {C}\)$")
         self.const("ys_T50_sq", r"temp\d*", rf"torch\.div\(torch\.squeeze\(flux_t_dp\w*\), {C}\)", required=False)     # (the grid-temperature decoder's copy)
         self.const("pmax_coef", r"Pmax", rf"torch\.mul\({C}, ")
-        self.const("yscale_lev_3d", r"out_denorm", rf"torch\.div\(out_new, {C}\)")
+        self.const("yscale_lev_3d", r"out_denorm", rf"torch\.div\(out_new, {C}\)", required=False)     # (absent where radiation reads the state before the step)
         # ---- LW gas optics + reductions (models_phys.py:816-1270, rnn/layers.py gasopt_mlp) -------------------------------
         m = self.find(r"x_gas\d+", rf"torch\.div\(torch\.sub\(x_gas, {C}\), {C}\)")
         P["gas_optics_model_lw.xmin"], P["gas_optics_model_lw.xdiv"] = self.c(m.group(1)), self.c(m.group(2))
@@ -215,6 +215,8 @@ class Extractor:
         return self._tail(P, F, code)
 
     def _tail(self, P, F, code):
+        F["rad_updated_T"] = bool(re.search(r"T\d* = torch\.relu\(torch\.add\(T, dT\d*\)\)", code))    # radiation on the updated temperature (all but num36398)
+        F["rnn3_last_mul"] = "last_h = torch.mul(hidden" in code      # release / surface heads read rnn2's last state TIMES the third RNN's (num36398)
         F["sw_scat_clamp"] = bool(re.search(r"tau_sw_scat_tot\d* = torch\.clamp\(tau_sw_scat_tot\d*, 1", code))
         F["cld_qn_updated"] = bool(re.search(r"qn_crm\d* = torch\.relu\(torch\.add\(qn_crm\d*, ", code))     # cloud water paths of the radiation scheme
         F["sfc_sw_down"] = "flux_sw_dn_sfc" in code              # first surface output: downward (num82174) instead of net shortwave
@@ -228,7 +230,8 @@ class Extractor:
             P["mix_near"], P["mix_vis"] = self.c(a.group(1)).reshape(-1), self.c(b.group(1)).reshape(-1)
         self.const("yscale_T60", r"dT_rad\d+", rf"torch\.mul\(dT_rad\d*, {C}\)")
         self.const("yscale_sca_rad", r"out_sfc_rad\d+", rf"torch\.mul\(out_sfc_rad\d*, {C}\)")
-        self.const("yscale_lev", r"out_denorm\d+", rf"torch\.div\(out_new\d+, {C}\)")
+        self.const("yscale_lev", r"out_denorm\d+", rf"torch\.div\(out_new\d+, {C}\)", required=False) or \
+            self.const("yscale_lev", r"out_denorm", rf"torch\.div\(out_new\d+, {C}\)")
         self.const("yscale_sca", r"out_sfc_denorm", rf"torch\.div\(out_sfc\d*, {C}\)")
         m = re.search(r"repeats = torch\.tensor\(\[([\d, ]+)\]", code)
         F["band_repeats"] = [int(v) for v in m.group(1).split(",")] if m else None

@@ -180,4 +180,4 @@ def test_index_of_the_frozen_exports_is_consistent_with_the_fixtures():
     assert {idx[k]["code"] for k in cpu_built} == built
     twins = [k for k, v in idx.items() if v["status"].startswith("twin of a built variant")]
     assert all(idx[k]["cpu_twin_code"] in built for k in twins)
-    assert len(cpu_built) == 49 and len(twins) == 24
+    assert len(cpu_built) == 50 and len(twins) == 24
