@@ -371,19 +371,21 @@ def aux_workload(a, rank, world, dist):
         tr = physical_RNN_trainer(m)
         xs_ = [t.cuda() for t in phys_inputs(Pw, B, 300 + rank)]
         hx2 = torch.randn(B, 128, generator=g).cuda()
-        tgt = [torch.randn(B, 60, 5, generator=g).cuda() * 0.1, torch.randn(B, 8, generator=g).cuda() * 0.1]
+        tgt = [torch.randn(B, 60, 5, generator=g).cuda() * 0.1, torch.randn(B, 8, generator=g).abs().cuda() * 0.1]
+        yto = [torch.randn(B, 60, 6, generator=g).cuda() * 1e-6, torch.randn(B, 8, generator=g).abs().cuda() * 1e-6]
         d_mem = torch.zeros(B, 50, 16, device="cuda")
-        n_out = float(world * B * (60 * 5 + 8))
 
-        def step():   # forward, MSE gradient (two elementwise torch ops: the loss is not part of this path), backward, all-reduce, Adam
+        def step():   # forward, the reference trainer's loss (huber + energy + water) with its gradient, backward, all-reduce, Adam
             tr.zero_grad()
             o, osfc, _ = tr.forward(xs_, hx2=hx2)
-            tr.backward((o - tgt[0]) * (2.0 / n_out), (osfc - tgt[1]) * (2.0 / n_out), d_mem)
+            sc, d_o, d_s = tr.loss(o, osfc, tgt[0], tgt[1], yto[0], yto[1], xs_[3], xs_[1], scalars=False)
+            tr.backward(d_o, d_s, d_mem)
             if world > 1:
                 dist.all_reduce(tr.grads)
+                tr.grads.mul_(1.0 / world)
             tr.adam_step(1e-5)
         flop_col = 3 * (60 * (2.0 * 22 * 128 + 2.0 * 384 * (143 + 128) + 2.0 * 384 * 256 + 2.0 * 192 * 128) + 50 * 16 * 150.0)
-        what = ("physRNN-Hidden training step: forward with saved activations, MSE gradient, hand-written backward (decoder, BPTT through both GRUs, "
+        what = ("physRNN-Hidden training step: forward with saved activations, huber + energy + water loss with its gradient, hand-written backward (decoder, BPTT through both GRUs, "
                 "weight-gradient GEMMs), Adam + re-pack; fwd+bwd = 3x forward FLOP")
     elif a.workload.startswith("physrnn_") and not a.workload.startswith("physrnn_rad_"):
         import numpy as np

@@ -47,7 +47,7 @@ SYMBOLS = ["csa_create", "csa_destroy", "csa_set_params", "csa_packed_width", "c
            "csa_eval_scratch_bytes", "csa_eval_metrics", "csa_eval_crps", "csa_derive_inputs",
            "csa_phys_create", "csa_phys_destroy", "csa_phys_forward", "csa_phys_tap", "csa_phys_rad_create", "csa_phys_postprocess", "csa_phys_forward_noise", "csa_phys_debug_forward_srnn", "csa_phys_debug_rnn3", "csa_phys_wrapped_create", "csa_phys_wrapped_forward",
            "csa_phys_train_enable", "csa_phys_train_num_params", "csa_phys_train_param_info", "csa_phys_train_get_params", "csa_phys_train_set_params",
-           "csa_phys_train_forward", "csa_phys_train_backward", "csa_phys_train_adam_step",
+           "csa_phys_train_forward", "csa_phys_train_backward", "csa_phys_train_adam_step", "csa_phys_train_loss",
            "csa_online_create", "csa_online_destroy", "csa_online_dims", "csa_online_forward",
            "csa_stoch_gru5_create", "csa_stoch_lstm4_create", "csa_stoch_destroy", "csa_stoch_gru5_forward",
            "csa_stoch_lstm4_forward", "csa_stoch_enable_training", "csa_stoch_num_params", "csa_stoch_gru5_forward_train",
@@ -205,6 +205,7 @@ def lib():
     L.csa_phys_train_forward.argtypes = [H, i, i, _F, _F, _F, _F, i, _F, _F, _F, _F, ctypes.c_void_p]
     L.csa_phys_train_backward.argtypes = [H, i, i, _F, _F, _F, _F, i, _F, _F, _F, _F, _F, ctypes.c_void_p]
     L.csa_phys_train_adam_step.argtypes = [H, _F] + [ctypes.c_float] * 5 + [ctypes.c_void_p]
+    L.csa_phys_train_loss.argtypes = [H, i, i, i, ctypes.c_float, ctypes.c_float] + [_F] * 11 + [ctypes.c_void_p]
     L.csa_phys_postprocess.argtypes = [H, i, _F, _F, _F, i, _F, _F, ctypes.c_void_p]
     L.csa_online_destroy.argtypes = [H]
     L.csa_online_dims.argtypes = [H, ctypes.POINTER(i), ctypes.POINTER(i)]

@@ -393,6 +393,7 @@ struct PhysTrain {
     struct Slot { float *X1, *H1, *hx, *HD, *GP1, *GP2, *Hs1, *Hs2; int B = 0; };      // what one pending forward keeps
     std::vector<Slot> slots;
     float *dHD, *dH2, *dH1, *dX1, *dlast, *dhx1, *dhx2, *dpold, *XIN, *XS, *DHX, *part, *part_b, *rtmp;
+    float *samp, *ecoef, *sp;          // loss scratch (train_misc.hip::launch_loss), for nslots * max_batch samples
     int *m_whead, *m_bhead, *m_wih1, *m_whh1, *m_b1a, *m_b1b, *m_wih2, *m_whh2, *m_b2a, *m_b2b, *m_dec, *m_init, *m_initb, *m_s1, *m_s1b;
     std::vector<GatherEntry> gathers;
     GatherEntry *gtab = nullptr;
@@ -567,6 +568,7 @@ extern "C" int csa_phys_train_enable(csa_phys *h, int nslots)
     pf = std::max(pf, MB * (size_t)pb_part_floats(nh));
     t->part = pt_alloc<float>(t, pf, rc); t->part_b = pt_alloc<float>(t, (size_t)t->nsplit * 4 * nh, rc);
     t->rtmp = pt_alloc<float>(t, (size_t)32 * pb_part_floats(nh), rc);
+    t->samp = pt_alloc<float>(t, (size_t)nslots * MB * 9, rc); t->ecoef = pt_alloc<float>(t, MB, rc); t->sp = pt_alloc<float>(t, (size_t)nslots * MB, rc);
     if (rc == CSA_OK) rc = pt_repack(t, nullptr);
     if (rc == CSA_OK && hipDeviceSynchronize() != hipSuccess) rc = CSA_ERR_HIP;
     if (rc != CSA_OK) { phys_train_free(t); return rc; }
@@ -692,6 +694,36 @@ extern "C" int csa_phys_train_backward(csa_phys *h, int slot, int B, const float
     if ((rc = launch_reduce_partials(t->part_b, ns, nh, t->m_s1b, nullptr, grads, s))) return rc;
     S.B = 0;
     return CSA_OK;
+}
+
+__global__ void phys_sp_kernel(const float *__restrict__ xs, int nxs, float a, float bconst, float *__restrict__ sp, int n)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) sp[i] = xs[(size_t)i * nxs] * a + bconst;
+}
+
+// The reference trainer's loss on the physRNN outputs (rnn/utils.py:1203-1366 with rnn/metrics.py:142-163, 193-315: huber + energy +
+// water closures, mp_mode 1 post-processing of the 5 -> 6 variables) and its analytic gradient: the loss kernels of the TBPTT trainer
+// (train_misc.hip) on this model's scale factors.  Arguments as csa_train_loss; x_raw (Tw*B, 60, nxd) = inputs_denorm.
+extern "C" int csa_phys_train_loss(csa_phys *h, int B, int Tw, int nxd, float w_energy, float w_water, const float *pred, const float *pred_sfc,
+                                   const float *tgt, const float *tgt_sfc, const float *yto, const float *yto_sfc, const float *x_raw,
+                                   const float *x_sfc_n, float *scalars, float *d_pred, float *d_pred_sfc, void *stream)
+{
+    if (!h || !h->tr || B <= 0 || B > h->max_batch || Tw <= 0 || Tw > (int)h->tr->slots.size() || nxd < 5 || !pred || !pred_sfc || !tgt || !tgt_sfc ||
+        !yto || !yto_sfc || !x_raw || !x_sfc_n || !scalars) {
+        csa_set_error_msg("csa_phys_train_loss: bad argument (the window may hold as many steps as the trainer has slots)");
+        return CSA_ERR_ARG;
+    }
+    PhysTrain *t = h->tr;
+    hipStream_t s = (hipStream_t)stream;
+    const int N = B * Tw;
+    DevModel m{};
+    m.cfg.nlev = PH_L; m.cfg.nx = nxd; m.cfg.ny = 5; m.cfg.ny_sfc = 8; m.cfg.mp_mode = 1; m.cfg.nx_sfc = h->d.naux;
+    m.yscale_lev = h->d.yscale_lev; m.yscale_sca = h->d.yscale_sca;
+    hipLaunchKernelGGL(phys_sp_kernel, dim3((N + 255) / 256), dim3(256), 0, s, x_sfc_n, h->d.naux, h->d.xdiv_sca0, h->d.xmean_sca0, t->sp, N);
+    CSA_HIP_CHECK(hipGetLastError());
+    return launch_loss(m, h->d.hyai, h->d.hybi, B, Tw, w_energy, w_water, pred, pred_sfc, tgt, tgt_sfc, yto, yto_sfc, x_raw, t->sp, t->samp, t->ecoef,
+                       scalars, d_pred, d_pred_sfc, s);
 }
 
 // Adam step on the flat parameter vector (torch.optim.Adam semantics, as csa_train_adam), then the kernel layouts re-packed

@@ -320,6 +320,26 @@ class physical_RNN_trainer:
             d_mem = self.backward(d_o, d_sfc, d_mem, slot=t)
         return outs, mem, d_mem
 
+    def loss(self, preds, preds_sfc, tgt, tgt_sfc, yto, yto_sfc, x_raw, x_sfc_n, Tw=1, w_energy=6.0e-6, w_water=6.0e7, grad=True, scalars=True):
+        """The reference trainer's loss over a window of Tw steps stacked on the leading axis (rnn/utils.py:1203-1366) -> (dict of the
+        seven scalars, d loss / d preds, d loss / d preds_sfc)."""
+        N = preds.shape[0]
+        B, m = N // Tw, self.model
+        preds, preds_sfc = _check(preds, (N, m.nlev, 5), "preds"), _check(preds_sfc, (N, 8), "preds_sfc")
+        tgt, tgt_sfc = _check(tgt, (N, m.nlev, 5), "tgt"), _check(tgt_sfc, (N, 8), "tgt_sfc")
+        yto, yto_sfc = _check(yto, (N, m.nlev, 6), "yto"), _check(yto_sfc, (N, 8), "yto_sfc")
+        x_raw = _check(x_raw, (N, m.nlev, x_raw.shape[-1]), "x_raw")
+        x_sfc_n = _check(x_sfc_n, (N, m.nx_sfc), "x_sfc_n")
+        sc = torch.empty(7, device=self.device)
+        d_p, d_s = (torch.empty_like(preds), torch.empty_like(preds_sfc)) if grad else (None, None)
+        rc = _lib.lib().csa_phys_train_loss(self._h, B, int(Tw), int(x_raw.shape[-1]), float(w_energy), float(w_water), _ptr(preds), _ptr(preds_sfc),
+                                            _ptr(tgt), _ptr(tgt_sfc), _ptr(yto), _ptr(yto_sfc), _ptr(x_raw), _ptr(x_sfc_n), _ptr(sc),
+                                            _ptr(d_p), _ptr(d_s), self._stream())
+        if rc != 0:
+            raise RuntimeError(f"csa_phys_train_loss failed ({rc}): {_lib.last_error()}")
+        names = ("loss", "huber", "mse", "mae", "energy", "water", "precip_sum_mse")
+        return (dict(zip(names, sc.tolist())) if scalars else sc), d_p, d_s       # (scalars=False: the device tensor, no host sync)
+
     def adam_step(self, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
         """torch.optim.Adam (the reference's default, train_rnn_rollout_torchscript_hydra.py:678); weight_decay is its L2 term."""
         rc = _lib.lib().csa_phys_train_adam_step(self._h, _ptr(self.grads), float(lr), float(betas[0]), float(betas[1]), float(eps),

@@ -547,6 +547,12 @@ int csa_phys_train_forward(csa_phys *h, int slot, int B, const float *x_main, co
 int csa_phys_train_backward(csa_phys *h, int slot, int B, const float *x_main, const float *x_sfc, const float *rnn_mem, const float *x_denorm,
                             int nxd, const float *d_out, const float *d_out_sfc, const float *d_mem_out, float *d_mem_in,
                             float *grads, void *stream);
+/* the reference trainer's loss on this model's outputs (huber + energy + water closures, rnn/utils.py:1203-1366, rnn/metrics.py:142-315)
+ * with its analytic gradient: arguments as csa_train_loss (pred (Tw*B,60,5) / tgt normalised, yto (Tw*B,60,6) / yto_sfc physical
+ * targets, x_raw (Tw*B,60,nxd) = inputs_denorm, x_sfc_n (Tw*B,naux) normalised; scalars: 7 device floats); Tw <= nslots */
+int csa_phys_train_loss(csa_phys *h, int B, int Tw, int nxd, float w_energy, float w_water, const float *pred, const float *pred_sfc,
+                        const float *tgt, const float *tgt_sfc, const float *yto, const float *yto_sfc, const float *x_raw,
+                        const float *x_sfc_n, float *scalars, float *d_pred, float *d_pred_sfc, void *stream);
 int csa_phys_train_adam_step(csa_phys *h, const float *grads, float lr, float beta1, float beta2, float eps, float weight_decay,
                              void *stream);
 

@@ -270,3 +270,41 @@ def test_training_entry_points_are_declared_and_exported():
     for s in ("csa_phys_train_enable", "csa_phys_train_forward", "csa_phys_train_backward", "csa_phys_train_adam_step",
               "csa_phys_train_param_info", "csa_phys_train_get_params", "csa_phys_train_set_params", "csa_phys_train_num_params"):
         assert s in _lib.SYMBOLS and ("int " + s + "(") in hdr
+
+
+@pytest.mark.gpu
+def test_hip_physrnn_loss_and_gradient_match_the_restated_reference_loss():
+    """csa_phys_train_loss = the reference trainer's loss (rnn/utils.py:1203-1366; rnn/metrics.py energy / water closures; mp_mode 1
+    post-processing, models.py:273-339) on this model's outputs.  Oracle: oracle/torch_ref.py::window_loss -- pinned to rnn/metrics.py
+    by tests/test_train_golden.py -- with this model's scale factors, float64, and torch autograd for the gradient."""
+    import types
+    from oracle import torch_ref
+    g, P = _load()
+    grid = np.load(os.path.join(GOLDEN, "grid_consts.npz"))
+    B, Tw = 21, 2
+    N = B * Tw
+    gen = torch.Generator().manual_seed(31)
+    xd = torch.cat([inputs(P, B, 60 + t)[3] for t in range(Tw)], 0)
+    xs = torch.cat([inputs(P, B, 60 + t)[1] for t in range(Tw)], 0)
+    ys_l, ys_s = P["yscale_lev"], P["yscale_sca"]
+    preds = 0.3 * torch.randn(N, 60, 5, generator=gen)
+    preds_sfc = 0.3 * torch.randn(N, 8, generator=gen).abs()
+    tgt, tgt_sfc = 0.3 * torch.randn(N, 60, 5, generator=gen), 0.3 * torch.randn(N, 8, generator=gen).abs()
+    ns = types.SimpleNamespace(mp_mode=1, yscale_lev=ys_l.double(), yscale_sca=ys_s.double(), xdiv_sca=P["xdiv_sca"].double(),
+                               xmean_sca=P["xmean_sca"].double())
+    ns.postprocess = lambda o, s_, x: torch_ref.EmulatorRef.postprocess(ns, o, s_, x)
+    yto, yto_sfc = ns.postprocess(tgt.double(), tgt_sfc.double(), xd.double())            # physical targets of the same shape family
+    p64, s64 = preds.double().requires_grad_(True), preds_sfc.double().requires_grad_(True)
+    loss, sc = torch_ref.window_loss(ns, p64, s64, tgt.double(), tgt_sfc.double(), yto, yto_sfc, xd.double(), xs.double(),
+                                     grid["hyai"], grid["hybi"], Tw)
+    loss.backward()
+    m, tr = _trainer(P, B, slots=Tw)
+    d = lambda t: t.float().contiguous().cuda()
+    got, d_p, d_s = tr.loss(d(preds), d(preds_sfc), d(tgt), d(tgt_sfc), d(yto), d(yto_sfc), d(xd), d(xs), Tw=Tw)
+    for k, v in sc.items():
+        assert abs(got[k] - float(v)) <= 2e-5 * abs(float(v)) + 1e-12, (k, got[k], float(v))
+    for a, r in ((d_p, p64.grad), (d_s, s64.grad)):
+        assert (a.cpu().double() - r).abs().max().item() <= 2e-5 * r.abs().max().item()
+    with pytest.raises(RuntimeError, match="csa_phys_train_loss failed"):
+        tr.loss(d(torch.cat([preds] * 2)), d(torch.cat([preds_sfc] * 2)), d(torch.cat([tgt] * 2)), d(torch.cat([tgt_sfc] * 2)), d(torch.cat([yto] * 2)),
+                d(torch.cat([yto_sfc] * 2)), d(torch.cat([xd] * 2)), d(torch.cat([xs] * 2)), Tw=2 * Tw)        # more steps than slots

@@ -147,3 +147,56 @@ def test_ensemble_window_step_two_ranks_equals_the_single_process_step_and_the_r
         assert float((a - ref).abs().max()) <= 2e-5 * float(ref.abs().max()) + 1e-30, name      # the reference's own autograd
     for k in ("loss", "skill", "spread"):
         assert abs(sc2[k] - sc1[k]) <= 2e-6 * abs(sc1[k]) + 1e-30, k
+
+
+def _phys_case():
+    from test_physrnn import _load
+    from make_golden_physrnn import inputs
+    from test_physrnn_train import _upstream
+    g, P = _load()
+    B = 13
+    xm, xs, mem, xd = inputs(P, B, 77)
+    hx2 = torch.randn(B, 128, generator=torch.Generator().manual_seed(5))
+    return P, B, (xm, xs, mem, xd), hx2, _upstream(B, 3)
+
+
+def _phys_step(P, B, lo, hi, inp, hx2, ups):
+    from climsim_amd.physrnn import physical_RNN_autoreg, physical_RNN_trainer
+    tr = physical_RNN_trainer(physical_RNN_autoreg(P, max_batch=B))
+    c = lambda t: t[lo:hi].contiguous().cuda()
+    tr.forward([c(t) for t in inp], hx2=c(hx2))
+    tr.backward(*(c(u) for u in ups))
+    return tr
+
+
+def _phys_worker(rank, world, port, q):
+    _init(rank, world, port)
+    try:
+        P, B, inp, hx2, ups = _phys_case()
+        lo, hi = sharding.shard_bounds(B, world, rank)          # 7 + 6 columns
+        tr = _phys_step(P, B, lo, hi, inp, hx2, ups)
+        dist.all_reduce(tr.grads)                               # the ONE collective of the step: flat gradient, sum over the column shards
+        tr.adam_step(1e-3)
+        torch.cuda.synchronize()
+        if rank == 0:
+            q.put((tr.grads.cpu(), tr.params().cpu()))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_physrnn_trainer_two_ranks_equal_the_single_process_step():
+    """physRNN training shards by columns like the rest of the path: the loss is a sum over columns, so the flat gradients of ragged
+    shards add up to the single-process gradient, and the Adam step taken from the all-reduced gradient is the same step."""
+    g2, p2 = _run(_phys_worker)
+    P, B, inp, hx2, ups = _phys_case()
+    tr = _phys_step(P, B, 0, B, inp, hx2, ups)
+    g1 = tr.grads.cpu()
+    for name, off, r, c in tr.info:
+        a, b = g2[off:off + r * c], g1[off:off + r * c]
+        assert float((a - b).abs().max()) <= 5e-6 * float(b.abs().max()) + 1e-30, name
+    tr.adam_step(1e-3)
+    p1 = tr.params().cpu()
+    big = g1.abs() > 1e-3 * g1.abs().max()
+    assert float((p2 - p1)[big].abs().max()) <= 1e-5 * 1e-3 + 1.2e-7
