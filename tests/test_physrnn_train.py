@@ -302,7 +302,7 @@ def test_hip_physrnn_loss_and_gradient_match_the_restated_reference_loss():
     d = lambda t: t.float().contiguous().cuda()
     got, d_p, d_s = tr.loss(d(preds), d(preds_sfc), d(tgt), d(tgt_sfc), d(yto), d(yto_sfc), d(xd), d(xs), Tw=Tw)
     for k, v in sc.items():
-        assert abs(got[k] - float(v)) <= 2e-5 * abs(float(v)) + 1e-12, (k, got[k], float(v))
+        assert abs(got[k] - float(v.detach())) <= 2e-5 * abs(float(v.detach())) + 1e-12, (k, got[k], float(v.detach()))
     for a, r in ((d_p, p64.grad), (d_s, s64.grad)):
         assert (a.cpu().double() - r).abs().max().item() <= 2e-5 * r.abs().max().item()
     with pytest.raises(RuntimeError, match="csa_phys_train_loss failed"):
