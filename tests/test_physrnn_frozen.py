@@ -151,6 +151,36 @@ def test_hip_frozen_export_matches_the_artefact(fixture):
         assert not bad, bad
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("fixture,B", [("frozen_a153783c", 384), ("frozen_a153783c", 600), ("frozen_4e616858", 384), ("frozen_cc399fc7", 545)])
+def test_hip_frozen_export_at_the_benchmarked_batch_sizes(fixture, B):
+    """The fixtures hold B = 8 / 37 (one column per workgroup in the GRU kernels); the bench runs 384 (two columns per workgroup) and
+    2,700 (four on the matrix pipe, from 544).  Here one variant of each radiation sub-generation runs at those kernel classes against the
+    float64 restatement (pinned by the export at the fixture sizes), tolerance as above."""
+    from climsim_amd.physrnn import physical_RNN_wrapped
+    from make_golden_frozen import inputs_wrapped, draws
+    g, P, FL = _load(fixture)
+    m = physical_RNN_wrapped(P, FL, max_batch=B)
+    x, s, mem = inputs_wrapped(P, B, 500 + B)
+    dr = draws(FL, B, 6000 + B)
+    d = lambda t: None if t is None else t.cuda()
+    got = [t.cpu() for t in m(d(x), d(s), d(mem), hx2=d(dr["hx2"]), mask_u=d(dr["mask_u"]))]
+    assert all(torch.isfinite(t).all() for t in got)
+    b64 = _blocks(*_f64(P, FL, x, s, mem, dr))
+    real = [_blocks(*R.forward(P, FL, x, s, mem, dr["hx2"], dr["mask_u"]))]
+    for sd in range(1, 5):
+        R._JITTER = D._JITTER = torch.Generator().manual_seed(sd)
+        try:
+            real.append(_blocks(*R.forward(P, FL, x, s, mem, dr["hx2"], dr["mask_u"])))
+        finally:
+            R._JITTER = D._JITTER = None
+    bh = _blocks(*got)
+    for key in b64:
+        scale = b64[key].abs().max().item()
+        noise = max((r[key].double() - b64[key]).abs().max().item() for r in real)
+        assert (bh[key].double() - b64[key]).abs().max().item() <= max(1e-5 * scale, 6 * noise) + 1e-30, (fixture, B, key)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("fixture", GPU_ONLY)
 def test_hip_gpu_only_exports_match_the_restatement(fixture):
     """The eight `_gpu_wrapped.pt` files with weights of their own (tests/golden/make_golden_frozen_gpuonly.py): they carry CUDA device

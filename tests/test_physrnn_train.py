@@ -111,7 +111,7 @@ def _trainer(P, max_batch, slots=1):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("B", [3, 64, 385])
+@pytest.mark.parametrize("B", [3, 64, 385, 2700])      # (385: odd, two columns per workgroup; 2,700: the benchmarked shard, matrix-pipe GRU forward)
 def test_hip_physrnn_gradients_match_autograd_of_the_restatement(B):
     g, P = _load()
     xm, xs, mem, xd = inputs(P, B, 70 + B)
