@@ -20,7 +20,7 @@ for fx in T.FIX:
         got32 = R.forward(P, FL, x, s, mem, dr["hx2"], dr["mask_u"], **{k: dr[k] for k in ("hx1", "eps3", "srnn") if k in dr})
         got64 = T._f64(P, FL, x, s, mem, dr)
         jit = []
-        for sd in (1, 2):
+        for sd in range(1, 7):
             R._JITTER = D._JITTER = torch.Generator().manual_seed(sd)
             jit.append(T._blocks(*R.forward(P, FL, x, s, mem, dr["hx2"], dr["mask_u"], **{k: dr[k] for k in ("hx1", "eps3", "srnn") if k in dr})))
             R._JITTER = D._JITTER = None
@@ -28,7 +28,7 @@ for fx in T.FIX:
         out = []
         for key in b_ref:
             scale = b_ref[key].abs().max().item() + 1e-300
-            noise = max((r[key].double() - b64[key]).abs().max().item() for r in (b_ref, b32, jit[0], jit[1]))
+            noise = max((r[key].double() - b64[key]).abs().max().item() for r in [b_ref, b32] + jit)
             e = (bh[key].double() - b64[key]).abs().max().item()
             out.append(f"{key[0][4:]}{key[1] if key[1] is not None else ''}{'t' if len(key) > 2 else ''}: {e / scale:.1e} ({e / max(noise, 1e-5 * scale):.1f})")
         print(fx, "nreg", FL["nreg"], "rnn3", FL["rnn3"], "liq", FL["pred_subgrid_liq_frac"], "case", i, "| error / block max (error / max(noise, 1e-5 max)):", "  ".join(out), flush=True)
