@@ -1,6 +1,8 @@
+"""GPU diagnostic: where (column, level, g-point) the HIP frozen-export path departs most from the float64 restatement, with the work-array
+taps of the radiation scheme next to the restatement's (python tests/reports/frozen_diag.py <fixture> <case>).  Test infrastructure."""
 import sys, os, numpy as np, torch
-sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "..", "tests"))
-sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "..", "tests", "golden"))
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "golden"))
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", ".."))
 from test_physrnn_frozen import _load, _case, _f64, R
 from climsim_amd.physrnn import physical_RNN_wrapped
