@@ -111,33 +111,34 @@ __global__ __launch_bounds__(PB_T) void phys_decode_bwd_kernel(PhysDev d, int B,
     if (tid < LC) { s_dpv[tid] = 0.0f; s_dliq[tid] = 0.0f; s_dS[tid] = 0.0f; }
     __syncthreads();
 
+    // forward values the water budget needs: precipitation production of every level (phase C's clamps, cell-parallel, summed over the
+    // regions with the forward kernel's own shuffle tree) and the sedimentation reaching the surface
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const int e = it * PB_T + tid, l = e >> 4, c = e & 15;
+        const bool ok = l < LC;
+        const int lc = ok ? l : 0, ec = ok ? e : c, L = lc + ilev;
+        const float *hd = HD + ((size_t)L * B + b) * HDW + c;
+        const float *ys = d.yscale_lev + L * 5;
+        const float pd = s_pd[lc], qv = s_qv[ec], qn = s_qn[ec];
+        const bool up = lc > 0, last = lc == LC - 1;
+        const float fqv_dp = ((last ? 0.0f : s_fqv[ec]) - (up ? s_fqv[ec - NC] : 0.0f)) / pd * (-G);
+        const float fqn_dp = ((last ? 0.0f : s_fqn[ec]) - (up ? s_fqn[ec - NC] : 0.0f)) / pd * (-G);
+        const float sed_dp = (s_sed[ec] - (up ? s_sed[ec - NC] : 0.0f)) / pd * (-G);
+        float evap = (fmaxf(hd[H_EVAP * NC], 0.0f) + 1e-6f) * s_pv[lc];
+        float cond = hd[H_COND * NC];
+        float aa = fmaxf(hd[H_AA * NC], 0.0f) * qn * ys[2];
+        cond = fmaxf(cond, ((-(ys[2] * qn / 1200.0f) - fqn_dp) + aa) - sed_dp);
+        evap = fmaxf(evap, (-(ys[1] * qv / 1200.0f) - fqv_dp) + cond);
+        aa = fmaxf(aa, ((fqn_dp + cond) + sed_dp) - ys[2] * (-qn + 0.0006f) / 1200.0f);
+        const float sprec = ph_sum<NC>(s_area[ec] * (aa - evap)), ssed = ph_sum<NC>(s_area[ec] * s_sed[ec]);
+        if (ok && c == 0) { s_dS[lc] = pd * OOG * sprec; if (last) s_dliq[0] = ssed; }
+    }
+    __syncthreads();
+
     // ---------------- phase D': column water budget, surface heads ----------------
     if (tid < 64) {
-        // forward: dprec per level needs phase C values -> recompute the level sums here (lane = level)
-        float w = 0.0f, ssed_last = 0.0f;
-        if (tid < LC) {
-            const int l = tid;
-            float sprec = 0.0f;
-            for (int c = 0; c < NC; ++c) {
-                const int ec = l * NC + c;
-                const float *hd = HD + ((size_t)(l + ilev) * B + b) * HDW + c;
-                const float *ys = d.yscale_lev + (l + ilev) * 5;
-                const float pd = s_pd[l], qv = s_qv[ec], qn = s_qn[ec];
-                const bool up = l > 0, last = l == LC - 1;
-                const float fqv_dp = ((last ? 0.0f : s_fqv[ec]) - (up ? s_fqv[ec - NC] : 0.0f)) / pd * (-G);
-                const float fqn_dp = ((last ? 0.0f : s_fqn[ec]) - (up ? s_fqn[ec - NC] : 0.0f)) / pd * (-G);
-                const float sed_dp = (s_sed[ec] - (up ? s_sed[ec - NC] : 0.0f)) / pd * (-G);
-                float evap = (fmaxf(hd[H_EVAP * NC], 0.0f) + 1e-6f) * s_pv[l];
-                float cond = hd[H_COND * NC];
-                float aa = fmaxf(hd[H_AA * NC], 0.0f) * qn * ys[2];
-                cond = fmaxf(cond, ((-(ys[2] * qn / 1200.0f) - fqn_dp) + aa) - sed_dp);
-                evap = fmaxf(evap, (-(ys[1] * qv / 1200.0f) - fqv_dp) + cond);
-                aa = fmaxf(aa, ((fqn_dp + cond) + sed_dp) - ys[2] * (-qn + 0.0006f) / 1200.0f);
-                sprec += s_area[ec] * (aa - evap);
-                if (last) ssed_last += s_area[ec] * s_sed[ec];
-            }
-            w = s_pd[l] * OOG * sprec;
-        }
+        float w = tid < LC ? s_dS[tid] : 0.0f, ssed_last = tid == 0 ? s_dliq[0] : 0.0f;
         for (int o = 32; o > 0; o >>= 1) { w += __shfl_xor(w, o); ssed_last += __shfl_xor(ssed_last, o); }
         if (tid == 0) {
             const float *dos = d_out_sfc + (size_t)b * 8;
