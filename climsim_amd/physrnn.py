@@ -364,7 +364,7 @@ class physical_RNN_wrapped(torch.nn.Module):
         forward(x_main0 (B,60,20), x_sfc0 (B,19), rnn1_mem (50,B,16)) -> (out_lev (B,60,6), out_sfc (B,8), rnn1_mem (50,B,16))
 
     `state_dict`: the export's constants under the names they had before freezing; `cfg`: the variant's switches and maps
-    (`rad_updated_qv`, `n_ir`, `n_mix_end`, `band_idx`) -- tests/golden/frozen_extract.py recovers both from an export's serialised
+    (`rad_updated_qv`, `n_ir`, `n_mix_end`, `band_idx`) -- climsim_amd/frozen_extract.py recovers both from an export's serialised
     code.  The export draws rnn2's initial state, the stochastic third RNN's state and noise and the SW humidity coin inside forward;
     pass `hx2=`, `hx1=`, `eps3=`, `mask_u=` to make a call reproducible (whatever is omitted is drawn here on the device)."""
 
@@ -440,6 +440,14 @@ class physical_RNN_wrapped(torch.nn.Module):
         if rc != 0:
             raise RuntimeError(f"csa_phys_wrapped_create failed ({rc}): {_lib.last_error()}")
         self._h, self.max_batch = h, max_batch
+
+    @classmethod
+    def from_export(cls, path, *, max_batch=4096):
+        """Drop-in for `torch.jit.load(path)` of a frozen `*_wrapped.pt` export: reads the graph constants and the switches of the
+        export's code variant (climsim_amd/frozen_extract.py) and builds the HIP model with them."""
+        from .frozen_extract import load_export
+        state_dict, cfg = load_export(path)
+        return cls(state_dict, cfg, max_batch=max_batch)
 
     def _sw_gas_arrays(self, arrs, f, state_dict, cfg, nreg, pad_rows):
         """SW gas-optics block (csrc/phys.h SWX_*) and the cloud-optics table of the later sub-generations"""

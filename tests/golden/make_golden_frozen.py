@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Golden vectors for the FROZEN physRNN exports (rnn/saved_models/*_wrapped.pt, what an E3SM host loads), from the artefacts
 themselves: one export per serialised-code variant is loaded with torch.jit.load on the CPU (executes only TorchScript), its graph
-constants are named by tests/golden/frozen_extract.py, it is run on seeded RAW inputs, and its internal random draws (rnn2's initial
+constants are named by climsim_amd/frozen_extract.py, it is run on seeded RAW inputs, and its internal random draws (rnn2's initial
 state, the stochastic third RNN's state and noise, the fair coin of the SW humidity variants) are reproduced by re-seeding and
 stored.  Output: tests/golden/frozen_<tag>.npz -- named weights ("w."), switches ("flag."), inputs, draws, outputs.  Data only."""
 import glob

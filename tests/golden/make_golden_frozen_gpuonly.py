@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Weights-only fixtures for the eight `_gpu_wrapped.pt` exports that hold weights of their OWN (no `_cpu` twin, or another checkpoint
 than their twin).  They carry CUDA device literals and do not execute in the build container, so they have no reference outputs;
-what CAN be taken from them is data: the graph constants, named by tests/golden/frozen_extract.py, and the switches of their
+what CAN be taken from them is data: the graph constants, named by climsim_amd/frozen_extract.py, and the switches of their
 serialised code -- every one of which lies inside a code variant whose `_cpu` files pin the restatement (tests/golden/frozen_index.json).
 tests/test_physrnn_frozen.py then holds the HIP path to the float64 restatement with THESE weights: parity of these eight files is
 pinned through the restatement only (no output of the file itself) -- said so where the test is documented.

@@ -1,6 +1,6 @@
 """The FROZEN physRNN exports (rnn/saved_models/*_wrapped.pt -- 82 of the 114 shipped artefacts, the modules an E3SM host loads):
 restatement (CPU) and HIP path (GPU) against the artefacts' own outputs on seeded raw inputs, one fixture per serialised-code
-variant (tests/golden/make_golden_frozen.py; constants named by tests/golden/frozen_extract.py).
+variant (tests/golden/make_golden_frozen.py; constants named by climsim_amd/frozen_extract.py).
 Tolerance: as tests/test_physrnn_rad.py -- per output block max(1e-5 x max|ref|, 6 x the float32 rounding level of the block),
 the level measured as the distance of the artefact from the float64 restatement, which must itself sit within 5e-3."""
 import glob
@@ -253,3 +253,19 @@ def test_index_of_the_frozen_exports_is_consistent_with_the_fixtures():
     assert len(cpu_built) == 50 and len(twins) == 24
     own = {k for k, v in idx.items() if v["status"].startswith(("another checkpoint", "no _cpu twin"))}
     assert own == {str(np.load(os.path.join(GOLDEN, f + ".npz"))["artefact"]) for f in GPU_ONLY} and len(own) == 8     # all 82 files covered
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/rnn/saved_models"), reason="the shipped exports exist in the build container only")
+@pytest.mark.parametrize("fixture", ["frozen_a153783c", "frozen_cc399fc7", "frozen_4e616858"])
+def test_load_export_names_the_constants_of_a_shipped_export(fixture):
+    """climsim_amd.frozen_extract.load_export (what physical_RNN_wrapped.from_export uses) on the very file a fixture was made from:
+    the same named constants and switches as the fixture stores."""
+    from climsim_amd.frozen_extract import load_export
+    g, P, FL = _load(fixture)
+    sd, cfg = load_export(os.path.join("/root/reference/rnn/saved_models", str(g["artefact"])))
+    for k, v in P.items():
+        assert torch.equal(sd[k].reshape(v.shape), v), k
+    for k, v in FL.items():
+        if k != "band_idx":
+            assert int(cfg[k]) == v, k
+    assert list(cfg["band_idx"]) == FL["band_idx"]
