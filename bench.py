@@ -287,7 +287,7 @@ def train_leg(a, rank, world, dist, steps, warmup, with_cpu, B=384, tag="cur_lst
     return out
 
 
-def aux_workload(a, rank, world, dist):
+def aux_workload(a, rank, world, dist, ret=False):
     """Secondary workloads (parity-test configurations, reported for DESIGN.md's tables; not the headline):
     cur_lstm144_384   current-generation tuple wrapper at the reference's default width nh = 144
     mlp_384 / cnn_384 offline Keras baselines (random weights of the reference architectures), forward."""
@@ -470,15 +470,18 @@ def aux_workload(a, rank, world, dist):
     el, _ = _timed(step, a.steps, a.warmup, dist)
     if rank == 0:
         tf = B * flop_col * a.steps / el / 1e12
-        print(json.dumps({
+        out = ({
             "metric": "train-step columns/sec" if "train" in a.workload else "grid-columns/sec emulator fwd",
             "value": world * B * a.steps / el, "unit": "grid-columns/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * el / a.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": a.workload, "columns_per_gpu": B, "what": what,
                        "parallelism": f"columns sharded x{world}, " + ("one flat-gradient all-reduce per step" if "train" in a.workload else "no collective")},
-            "whole_path": {"flop_per_column": flop_col, "achieved_tflops": tf, "frac_fp32_peak": tf / PEAK_FP32_TFLOPS}}),
-            flush=True)
+            "whole_path": {"flop_per_column": flop_col, "achieved_tflops": tf, "frac_fp32_peak": tf / PEAK_FP32_TFLOPS}})
+        if ret:
+            return out
+        print(json.dumps(out), flush=True)
+    return None
 
 
 AUX = ["cur_lstm144_384", "cur_lstm128_384", "cur_gru128_384", "mlp_384", "online_mlp_384", "physrnn_384", "physrnn_rad_384", "physrnn_2700", "physrnn_rad_2700", "physrnn_e3sm_384", "physrnn_e3sm_2700", "physrnn_wrapped_384", "physrnn_wrapped_2700", "physrnn_train_384", "physrnn_train_2700", "cur_gru128_2700", "cnn_384", "cnn_train_384",
@@ -640,6 +643,15 @@ def main():
                 line["shard_2700"] = {"forward": {"metric": "grid-columns/sec emulator fwd", **sf},
                                       "train": st}
                 line["strong_scaled"] = strong
+            # the physRNN side of the path: the deployed frozen export and the training step, 384 columns per GPU
+            phys = {}
+            for w in ("physrnn_wrapped_384", "physrnn_train_384"):
+                aa = argparse.Namespace(**{**vars(a), "workload": w, "steps": max(10, min(a.steps, 100)), "warmup": max(3, min(a.warmup, 10))})
+                o = aux_workload(aa, rank, world, dist, ret=True)
+                if rank == 0:
+                    phys[w] = {k: o[k] for k in ("metric", "value", "unit", "ms_per_step", "steps", "warmup", "config", "whole_path")}
+            if rank == 0:
+                line["physrnn"] = phys
     if rank == 0:
         print(json.dumps(line), flush=True)
     finish()
