@@ -131,6 +131,8 @@ void gru4m_pack_weights(int nh, const float *w_hh, float *packed);
 int launch_rec4m_gru(int nh, const float *whh_m, const float *bhn, const float *P, const float *h0, float *Hout, int B, int L,
                      int reverse_out, hipStream_t s);
 bool gru4m_selected(int nh, int B);
+int launch_rec4m_train_gru(int nh, const float *whh_m, const float *bhn, float *P, const float *h0, float *Hout, int B, int L,
+                           int reverse_out, float *Hseq, hipStream_t s);
 bool rec4m_selected(int use_lstm, int nh, int B);
 int launch_rec4m(int nh, const float *whh_m, const float *P, const float *h0, const float *c0, float *Hout, int B, int L,
                  int reverse_out, hipStream_t s);

@@ -390,6 +390,7 @@ struct PhysTrain {
     PhysDev d;
     float *params = nullptr, *adam_m = nullptr, *adam_v = nullptr;
     float *wih1, *bias1, *bhn1, *whh1g, *wih2, *bias2, *bhn2, *whh2g, *whead, *bhead;      // forward layouts (gate rows u*4 + [r, z, n, pad])
+    float *whh1m, *whh2m;                                                                   // matrix-pipe GRU kernel (from 544 columns)
     float *wih1T, *wih2T, *whh1Tp, *whh2Tp, *wheadT;                                       // backward layouts
     struct Slot { float *X1, *H1, *hx, *HD, *GP1, *GP2, *Hs1, *Hs2; int B = 0; };      // what one pending forward keeps
     std::vector<Slot> slots;
@@ -502,7 +503,7 @@ extern "C" int csa_phys_train_enable(csa_phys *h, int nslots)
     // GRU layers: gate rows u*4 + [r, z, n, pad]; K of rnn1 padded from nh + 15 to nh + 16 (zero column).  After BPTT the saved-gate
     // buffer holds [dr~, dz~, dn~, g_hn] per unit: W_ih / b_ih gradients take columns 0, 1, 2; W_hh / b_hh take 0, 1 and 3 (as gate n).
     auto gru = [&](int Ksrc, int K, int o_wih, int o_whh, int o_bih, int o_bhh, float *&wih, float *&bias, float *&bhn, float *&whhg,
-                   float *&whhTp, float *&wihT, int *&m_wih, int *&m_whh, int *&m_ba, int *&m_bb) {
+                   float *&whhTp, float *&wihT, int *&m_wih, int *&m_whh, int *&m_ba, int *&m_bb, float *&whhm) {
         std::vector<int> iw((size_t)4 * nh * K, -1), b1(4 * nh, -1), b2(4 * nh, -1), ibhn(nh), tt((size_t)K * 4 * nh, -1);
         std::vector<int> gw((size_t)4 * nh * nh, -1), gbb(4 * nh, -1);
         for (int u = 0; u < nh; ++u) {
@@ -528,9 +529,17 @@ extern "C" int csa_phys_train_enable(csa_phys *h, int nslots)
         whhg = pt_gather(t, pt_to_int(pk, o_whh), nullptr, rc);
         bwd_rec_pack_weights_gru(nh, ih.data(), pkT.data());
         whhTp = pt_gather(t, pt_to_int(pkT, o_whh), nullptr, rc);
+        {   // gru4m_pack_weights: zero fourth row of every block -> index -1
+            std::vector<float> pm((size_t)4 * nh * nh);
+            for (size_t i = 0; i < ih.size(); ++i) ih[i] = (float)(i + 1);
+            gru4m_pack_weights(nh, ih.data(), pm.data());
+            std::vector<int> im(pm.size());
+            for (size_t i = 0; i < pm.size(); ++i) im[i] = pm[i] == 0.0f ? -1 : o_whh + (int)pm[i] - 1;
+            whhm = pt_gather(t, im, nullptr, rc);
+        }
     };
-    gru(Kin, K1, O(4), O(5), O(6), O(7), t->wih1, t->bias1, t->bhn1, t->whh1g, t->whh1Tp, t->wih1T, t->m_wih1, t->m_whh1, t->m_b1a, t->m_b1b);
-    gru(nh, nh, O(8), O(9), O(10), O(11), t->wih2, t->bias2, t->bhn2, t->whh2g, t->whh2Tp, t->wih2T, t->m_wih2, t->m_whh2, t->m_b2a, t->m_b2b);
+    gru(Kin, K1, O(4), O(5), O(6), O(7), t->wih1, t->bias1, t->bhn1, t->whh1g, t->whh1Tp, t->wih1T, t->m_wih1, t->m_whh1, t->m_b1a, t->m_b1b, t->whh1m);
+    gru(nh, nh, O(8), O(9), O(10), O(11), t->wih2, t->bias2, t->bhn2, t->whh2g, t->whh2Tp, t->wih2T, t->m_wih2, t->m_whh2, t->m_b2a, t->m_b2b, t->whh2m);
     {   // head GEMM rows: 11 decoder heads x 16 regions, mlp_latent (15), mlp_output_rad (1)
         std::vector<int> mw((size_t)HDW * nh, -1), mb(HDW, -1), mt((size_t)nh * HDW, -1);
         for (int r = 0; r < HDW; ++r) {
@@ -627,10 +636,13 @@ extern "C" int csa_phys_train_forward(csa_phys *h, int slot, int B, const float 
     S.B = 0;
     if ((rc = launch_phys_prep(d, B, x_main, x_sfc, rnn_mem, S.X1, S.hx, s))) return rc;
     if ((rc = launch_proj_gemm(S.X1, t->wih1, t->bias1, S.GP1, M, 4 * nh, nh + 16, s))) return rc;
-    if ((rc = launch_rec_train_gru(nh, t->whh1g, t->bhn1, S.GP1, S.hx, S.H1, B, L, 1, S.Hs1, s))) return rc;
+    const bool four = gru4m_selected(nh, B);      // four columns per workgroup on the matrix pipe from 544 columns (as inference)
+    if ((rc = four ? launch_rec4m_train_gru(nh, t->whh1m, t->bhn1, S.GP1, S.hx, S.H1, B, L, 1, S.Hs1, s)
+                   : launch_rec_train_gru(nh, t->whh1g, t->bhn1, S.GP1, S.hx, S.H1, B, L, 1, S.Hs1, s))) return rc;
     if ((rc = launch_proj_gemm(S.H1, t->wih2, t->bias2, S.GP2, M, 4 * nh, nh, s))) return rc;
     float *H2 = S.Hs2 + (size_t)B * nh;
-    if ((rc = launch_rec_train_gru(nh, t->whh2g, t->bhn2, S.GP2, hx2, H2, B, L, 0, S.Hs2, s))) return rc;
+    if ((rc = four ? launch_rec4m_train_gru(nh, t->whh2m, t->bhn2, S.GP2, hx2, H2, B, L, 0, S.Hs2, s)
+                   : launch_rec_train_gru(nh, t->whh2g, t->bhn2, S.GP2, hx2, H2, B, L, 0, S.Hs2, s))) return rc;
     if ((rc = launch_proj_gemm(H2, t->whead, t->bhead, S.HD, M, d.hdw, nh, s))) return rc;
     if ((rc = launch_phys_decode_hidden(d, B, S.HD, H2, x_sfc, rnn_mem, x_denorm, nxd, out_lev, out_sfc, mem_out, s))) return rc;
     S.B = B;

@@ -17,6 +17,7 @@
 // (packed FMA) -- MFMA would need >=4 (4x4x1) or 16 (16x16x4) columns per CU and leaves most of
 // the chip idle at the 384-column batch of BASELINE.json configs[1]; see DESIGN.md.
 #include "common.h"
+#include <type_traits>
 #include <cstring>
 
 #ifndef CSA_FAST_GATES
@@ -682,11 +683,15 @@ __global__ __launch_bounds__(NH * 4, (NH / 16 + 3) / 4) void lstm_rec4m_kernel(
 //   r = sigma(x_r + D.x), z = sigma(x_z + D.y), n = tanh(x_n + r (D.z + b_hn)), h = (1 - z) n + z h
 // happen in the lane, no cross-lane traffic.  P rows are [r, z, n] per unit, unpadded: one 12-byte load per step.
 // Same arithmetic as gru_rec2_kernel up to the order of the k-sum.
-template <int NH, bool BLGP>
+// TRAIN (round 3): the training forward of the GRU models at shard size -- P rows are the 4-padded rows of the training buffers, the
+// lane ends a step with [r, z, n, W_hn h + b_hn] of its (unit, column) and writes them IN PLACE over the row it consumed, h_t also to
+// Hseq (L+1 slots, slot 0 = the initial state): what gru_rec2_kernel<NH, true> saves and gru_bwd_rec_kernel reads.
+template <int NH, bool BLGP, bool TRAIN = false>
 __global__ __launch_bounds__(NH * 4, (NH / 16 + 3) / 4) void gru_rec4m_kernel(
-    const float *__restrict__ Wk, const float *__restrict__ bhn, const float *__restrict__ P,
-    const float *__restrict__ h0, float *__restrict__ Hout, int B, int L, int reverse_out)
+    const float *__restrict__ Wk, const float *__restrict__ bhn, const float *P,
+    const float *__restrict__ h0, float *__restrict__ Hout, int B, int L, int reverse_out, float *Pw = nullptr, float *__restrict__ Hseq = nullptr)
 {
+    constexpr int PS = TRAIN ? 4 : 3;
     constexpr int NT = NH * 4;
     static_assert(NH % 16 == 0, "nh must be a multiple of 16");
     __shared__ __attribute__((aligned(16))) float hbuf[2][4 * NH];      // layout: see lstm_rec4m_kernel
@@ -704,9 +709,13 @@ __global__ __launch_bounds__(NH * 4, (NH / 16 + 3) / 4) void gru_rec4m_kernel(
     float h = h0[(size_t)b * NH + u];
     const int hslot = (u >> 4) * 64 + ((((u & 15) >> 2) * 4 + x) << 2) + (u & 3);
     hbuf[0][hslot] = h;
-    const float *Pb = P + (size_t)b * (3 * NH) + u * 3;
-    const size_t Pstep = (size_t)B * (3 * NH);
-    f32x3 preA = f32x3{Pb[0], Pb[1], Pb[2]}, preB = preA;
+    if (TRAIN && valid) Hseq[(size_t)b * NH + u] = h;
+    const float *Pb = P + (size_t)b * (PS * NH) + u * PS;
+    const size_t Pstep = (size_t)B * (PS * NH);
+    typedef typename std::conditional<TRAIN, f32x4, f32x3>::type prow;
+    prow preA, preB;
+    preA.x = Pb[0]; preA.y = Pb[1]; preA.z = Pb[2];
+    preB = preA;
     const int hoff = BLGP ? (((lane >> 4) * 4 + x) << 2) : (x << 2);
     __syncthreads();
 
@@ -720,7 +729,8 @@ __global__ __launch_bounds__(NH * 4, (NH / 16 + 3) / 4) void gru_rec4m_kernel(
         const int t_ = (T);                                                                            \
         {   /* unconditional prefetch + unconditional wait: see lstm_rec2_kernel */                     \
             const float *pn = Pb + (size_t)(t_ + 1 < L ? t_ + 1 : L - 1) * Pstep;                      \
-            asm volatile("global_load_dwordx3 %0, %1, off" : "=&v"(NXT) : "v"(pn) : "memory");         \
+            if (TRAIN) asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(NXT) : "v"(pn) : "memory"); \
+            else asm volatile("global_load_dwordx3 %0, %1, off" : "=&v"(NXT) : "v"(pn) : "memory");    \
         }                                                                                              \
         const float *hb = &hbuf[t_ & 1][0] + hoff;                                                     \
         f32x4 acc = {0.f, 0.f, 0.f, 0.f}, accb = acc, accc = acc, accd = acc;                          \
@@ -747,6 +757,10 @@ __global__ __launch_bounds__(NH * 4, (NH / 16 + 3) / 4) void gru_rec4m_kernel(
         h = (1.0f - zg) * n + zg * h;                                                                  \
         hbuf[(t_ & 1) ^ 1][hslot] = h;                                                                 \
         if (valid) Hout[((size_t)(reverse_out ? L - 1 - t_ : t_) * B + b) * NH + u] = h;               \
+        if (TRAIN && valid) {                                                                          \
+            Hseq[((size_t)(t_ + 1) * B + b) * NH + u] = h;                                             \
+            *(f32x4 *)(Pw + ((size_t)t_ * B + b) * (4 * NH) + u * 4) = f32x4{rg, zg, n, acc.z + bn};   \
+        }                                                                                              \
         LDS_BARRIER();                                                                                 \
     }
     for (int t = 0; t < L; t += 2) {
@@ -1229,6 +1243,23 @@ int launch_rec4m_gru(int nh, const float *whh_m, const float *bhn, const float *
         return CSA_ERR_UNSUPPORTED;
     }
 #undef G4M
+    CSA_HIP_CHECK(hipGetLastError());
+    return CSA_OK;
+}
+// training forward on the matrix pipe (gates saved in place over the 4-padded rows, h sequence into Hseq)
+int launch_rec4m_train_gru(int nh, const float *whh_m, const float *bhn, float *P, const float *h0, float *Hout, int B, int L,
+                           int reverse_out, float *Hseq, hipStream_t s)
+{
+    const dim3 grid((B + 3) / 4), block(nh * 4);
+    switch (nh) {
+    case 64:  hipLaunchKernelGGL((gru_rec4m_kernel<64, true, true>), grid, block, 0, s, whh_m, bhn, P, h0, Hout, B, L, reverse_out, P, Hseq); break;
+    case 96:  hipLaunchKernelGGL((gru_rec4m_kernel<96, true, true>), grid, block, 0, s, whh_m, bhn, P, h0, Hout, B, L, reverse_out, P, Hseq); break;
+    case 112: hipLaunchKernelGGL((gru_rec4m_kernel<112, true, true>), grid, block, 0, s, whh_m, bhn, P, h0, Hout, B, L, reverse_out, P, Hseq); break;
+    case 128: hipLaunchKernelGGL((gru_rec4m_kernel<128, true, true>), grid, block, 0, s, whh_m, bhn, P, h0, Hout, B, L, reverse_out, P, Hseq); break;
+    default:
+        csa_set_error_msg("gru_rec4m(train): hidden size not supported (64, 96, 112, 128)");
+        return CSA_ERR_UNSUPPORTED;
+    }
     CSA_HIP_CHECK(hipGetLastError());
     return CSA_OK;
 }

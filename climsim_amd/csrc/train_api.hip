@@ -306,7 +306,7 @@ extern "C" int csa_train_create(const csa_config *cfg, const csa_params *p, cons
     // columns 0,1,2, W_hh / b_hh gradients take columns 0,1 and 3 (as gate row n).
     struct GruMaps { std::vector<int> wih, whh, ba, bb; } gm1, gm2;
     auto gru_pack = [&](int nh, int K, int o_wih, int o_whh, int o_bih, int o_bhh, const float *&wih, const float *&bias,
-                        const float *&bhn, const float *&whhp, float *&whhTp, float *&wihT, GruMaps &gm) {
+                        const float *&bhn, const float *&whhp, float *&whhTp, float *&wihT, GruMaps &gm, const float *&whhm) {
         std::vector<int> iw((size_t)4 * nh * K, -1), b1(4 * nh, -1), b2(4 * nh, -1), ibhn(nh), t((size_t)K * 4 * nh, -1);
         gm.wih.assign((size_t)4 * nh * K, -1); gm.whh.assign((size_t)4 * nh * nh, -1); gm.ba.assign(4 * nh, -1); gm.bb.assign(4 * nh, -1);
         for (int u = 0; u < nh; ++u) {
@@ -339,6 +339,15 @@ extern "C" int csa_train_create(const csa_config *cfg, const csa_params *p, cons
         bwd_rec_pack_weights_gru(nh, ih.data(), pkT.data());
         whhTp = (float *)add_gather(h, to_int(pkT, o_whh), nullptr, rc);
         wihT = (float *)add_gather(h, t, nullptr, rc);
+        whhm = nullptr;
+        if (nh <= 128 && nh % 16 == 0) {      // matrix-pipe kernel at shard size (gru_rec4m_kernel<NH, true, TRAIN>): zero fourth rows -> index -1
+            std::vector<float> i1((size_t)3 * nh * nh), pm((size_t)4 * nh * nh);
+            for (size_t i = 0; i < i1.size(); ++i) i1[i] = (float)(i + 1);
+            gru4m_pack_weights(nh, i1.data(), pm.data());
+            std::vector<int> im(pm.size());
+            for (size_t i = 0; i < pm.size(); ++i) im[i] = pm[i] == 0.0f ? -1 : o_whh + (int)pm[i] - 1;
+            whhm = add_gather(h, im, nullptr, rc);
+        }
     };
     // the two deterministic layers in execution order: (rnn1, rnn2), or (rnn0, rnn1) for the stochastic variant
     const std::string la = st ? "rnn0" : "rnn1", lb = st ? "rnn1" : "rnn2";
@@ -350,9 +359,9 @@ extern "C" int csa_train_create(const csa_config *cfg, const csa_params *p, cons
                   d.wih2, d.bias2, d.whh2p, h->whh2Tp, h->wih2T, rowmap2, d.whh2m);
     } else {
         gru_pack(nh1, nin1, O("rnn1.weight_ih_l0"), O("rnn1.weight_hh_l0"), O("rnn1.bias_ih_l0"), O("rnn1.bias_hh_l0"),
-                 d.wih1, d.bias1, d.bhn1, d.whh1p, h->whh1Tp, h->wih1T, gm1);
+                 d.wih1, d.bias1, d.bhn1, d.whh1p, h->whh1Tp, h->wih1T, gm1, d.whh1m);
         gru_pack(nh2, nh1, O("rnn2.weight_ih_l0"), O("rnn2.weight_hh_l0"), O("rnn2.bias_ih_l0"), O("rnn2.bias_hh_l0"),
-                 d.wih2, d.bias2, d.bhn2, d.whh2p, h->whh2Tp, h->wih2T, gm2);
+                 d.wih2, d.bias2, d.bhn2, d.whh2p, h->whh2Tp, h->wih2T, gm2, d.whh2m);
     }
     d.lat_wt = add_gather(h, transposed_idx(O("mlp_latent.weight"), nm, nh2), nullptr, rc);
     d.lat_b = add_gather(h, iota_off(O("mlp_latent.bias"), nm), nullptr, rc);
@@ -536,7 +545,8 @@ extern "C" int csa_train_forward(csa_trainer *h, int slot, int B, const float *x
     {
         StageTimer tm(h, 0, s);
         if (c.use_lstm) rc = rec_train_lstm(nh1, h->dm.whh1p, h->dm.whh1m, S.GP1, S.hc0, S.hc0 + (size_t)B * nhm, S.H1lev, B, L, 1, S.H1seq, S.C1, s);
-        else rc = launch_rec_train_gru(nh1, h->dm.whh1p, h->dm.bhn1, S.GP1, S.hc0, S.H1lev, B, L, 1, S.H1seq, s);
+        else rc = h->dm.whh1m && gru4m_selected(nh1, B) ? launch_rec4m_train_gru(nh1, h->dm.whh1m, h->dm.bhn1, S.GP1, S.hc0, S.H1lev, B, L, 1, S.H1seq, s)
+                                                        : launch_rec_train_gru(nh1, h->dm.whh1p, h->dm.bhn1, S.GP1, S.hc0, S.H1lev, B, L, 1, S.H1seq, s);
         if (rc) return rc;
     }
     {
@@ -547,8 +557,9 @@ extern "C" int csa_train_forward(csa_trainer *h, int slot, int B, const float *x
         StageTimer tm(h, 0, s);
         if (c.use_lstm) rc = rec_train_lstm(nh2, h->dm.whh2p, h->dm.whh2m, S.GP2, S.hc0 + (size_t)2 * B * nhm, S.hc0 + (size_t)3 * B * nhm,
                                             S.H2 + (size_t)B * nh2, B, L, 0, S.H2, S.C2, s);
-        else rc = launch_rec_train_gru(nh2, h->dm.whh2p, h->dm.bhn2, S.GP2, S.hc0 + (size_t)2 * B * nhm, S.H2 + (size_t)B * nh2, B, L, 0,
-                                       S.H2, s);
+        else rc = h->dm.whh2m && gru4m_selected(nh2, B)
+                      ? launch_rec4m_train_gru(nh2, h->dm.whh2m, h->dm.bhn2, S.GP2, S.hc0 + (size_t)2 * B * nhm, S.H2 + (size_t)B * nh2, B, L, 0, S.H2, s)
+                      : launch_rec_train_gru(nh2, h->dm.whh2p, h->dm.bhn2, S.GP2, S.hc0 + (size_t)2 * B * nhm, S.H2 + (size_t)B * nh2, B, L, 0, S.H2, s);
         if (rc) return rc;
     }
     if ((rc = launch_head(h->dm, B, HEAD_RAW, S.H2 + (size_t)B * nh2, x_main_n, nullptr, out, out_sfc, S.Z, s))) return rc;
