@@ -230,3 +230,46 @@ def test_two_rank_cnn_and_crps_shard_gradients_sum_to_the_unsharded_gradient():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert res["cnn"] <= 1e-5 and res["crps_grad"] <= 1e-5 and res["crps_val"] <= 1e-6, res
+
+
+def _phys_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.set_num_threads(2)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from test_physrnn import _load
+        from test_physrnn_train import _autograd, _upstream
+        from make_golden_physrnn import inputs
+        g, P = _load()
+        B = 9                                                   # ragged split: 5 + 4
+        xm, xs, mem, xd = inputs(P, B, 21)
+        hx2 = torch.randn(B, 128, generator=torch.Generator().manual_seed(4))
+        ups = _upstream(B, 6)
+        lo, hi = sharding.shard_bounds(B, world, rank)
+        _, gl = _autograd(P, xm[lo:hi], xs[lo:hi], mem[lo:hi], xd[lo:hi], hx2[lo:hi], [u[lo:hi] for u in ups], torch.float64)
+        names = sorted(k for k in gl if k != "rnn_mem")
+        flat = torch.cat([gl[k].reshape(-1) for k in names])
+        sharding.allreduce_flat_(flat, world, average=False)    # the ONE collective of a physRNN training step (sum: the loss is a sum over columns)
+        if rank == 0:
+            _, gw = _autograd(P, xm, xs, mem, xd, hx2, ups, torch.float64)
+            ref = torch.cat([gw[k].reshape(-1) for k in names])
+            q.put((float((flat - ref).abs().max()), float(ref.abs().max())))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_physrnn_shard_gradients_sum_to_the_unsharded_gradient():
+    """The physRNN training loss is a sum over columns: the flat gradients of two ragged column shards, all-reduced, are the gradient
+    of the whole batch (CPU twin, through the restatement, of tests/test_sharding_gpu.py::test_physrnn_trainer_two_ranks_...)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_phys_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    err, scale = q.get(timeout=600)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert err <= 1e-10 * scale
