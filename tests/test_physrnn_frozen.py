@@ -269,3 +269,33 @@ def test_load_export_names_the_constants_of_a_shipped_export(fixture):
         if k != "band_idx":
             assert int(cfg[k]) == v, k
     assert list(cfg["band_idx"]) == FL["band_idx"]
+
+
+@pytest.mark.gpu
+def test_frozen_export_call_can_be_captured_into_a_hip_graph_by_the_host():
+    """csa_phys_wrapped_forward allocates nothing and launches only on the caller's stream: an online host may capture the nine launches
+    of a step into a hipGraph (here torch.cuda.CUDAGraph around the ctypes call) and replay them over persistent buffers; replays are
+    bit-identical to eager calls and see new buffer contents."""
+    from climsim_amd.physrnn import physical_RNN_wrapped
+    from make_golden_frozen import inputs_wrapped, draws
+    g, P, FL = _load("frozen_a153783c")
+    B = 48
+    m = physical_RNN_wrapped(P, FL, max_batch=B)
+    x, s, mem = (t.cuda() for t in inputs_wrapped(P, B, 77))
+    dr = {k: v.cuda() for k, v in draws(FL, B, 78).items()}
+    ref = [t.clone() for t in m(x, s, mem, hx2=dr["hx2"], mask_u=dr["mask_u"])]
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        out = m(x, s, mem, hx2=dr["hx2"], mask_u=dr["mask_u"])
+    for _ in range(3):
+        for t in out:
+            t.zero_()
+        graph.replay()
+        torch.cuda.synchronize()
+        assert all(torch.equal(a, b) for a, b in zip(out, ref))
+    mem.mul_(0.5)                                   # same pointers, new contents
+    graph.replay()
+    torch.cuda.synchronize()
+    eager = m(x, s, mem, hx2=dr["hx2"], mask_u=dr["mask_u"])
+    assert all(torch.equal(a, b) for a, b in zip(out, eager)) and not torch.equal(out[2], ref[2])
