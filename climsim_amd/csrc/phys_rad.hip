@@ -426,19 +426,53 @@ __global__ __launch_bounds__(64 * SG_WAVES) void rad_sw_gas_kernel(const float *
 // Two models (absorption, Rayleigh) 7 -> 32 -> 32 -> ng, Softsign, tau = N_dry y^8 1e-17, each evaluated for the humidity of the two
 // largest regions of the level (XR row: [T, ln p, h2o_1^(1/4), o3^(1/4), co2, n2o, ch4, h2o_2^(1/4), N_dry_1, N_dry_2], normalised by the
 // decoder); per (row, g-point) ONE of the two humidity variants is taken by the coin mask_u < 0.5.  14 kFLOP per row -- 0.33 GFLOP per
-// 384-column call, a fiftieth of the GRU work -- so this is a plain vector kernel: lane 4 r + c evaluates combination c = 2 variant +
-// model of row r with the weights broadcast from LDS, the four lanes of a row exchange their ng optical depths by shuffles and each
-// finishes a quarter of the g-points (gas + cloud -> tau, ssa, g).  Padded g-points (ng < 16) get tau 1, ssa 0, g 0: they carry no flux.
-#define SX_ROWS 64
-__global__ __launch_bounds__(256) void rad_sw_gas16_kernel(const float *__restrict__ XR, const float *__restrict__ swx, const float *__restrict__ CS,
-                                                          const float *__restrict__ mask_u, float *__restrict__ S2, int M, int B, int ilev, int ng, int ngk)
+// 384-column call, a fiftieth of the GRU work -- so this is a vector kernel, and what it costs is the LENGTH of a lane's dependent
+// chain, not throughput (22 us at 48 columns, 24 us at 384 with one lane per (row, combination) evaluating a whole MLP: 1,792 FMAs).
+// Round 3: SIXTEEN lanes per row -- lane 16 r + 4 c + q evaluates, for combination c = 2 variant + model of row r, the hidden units
+// n = 4 j + q (j = 0..7) of both layers and the outputs g = 4 j + q (j = 0..3): 440 FMAs; the four q-lanes of a quad exchange their
+// activations by DPP quad broadcasts, the four combinations of a row their optical depths through LDS (all sixteen lanes sit in one
+// wave), and lane (c, q) finishes g-point 4 c + q (coin, clamps, gas + cloud -> tau, ssa, g).  Weights in LDS with row strides of
+// 36 floats (W2, W3) so that the four adjacent rows a quad reads as float4 fall into different banks.
+// Padded g-points (ng < 16) get tau 1, ssa 0, g 0: they carry no flux.
+#define SX_ROWS 16
+#define SX_LD 36
+#define SX_W1 0                                 // per model in LDS: W1 (32, 8), b1 (32), W2 (32, 36), b2 (32), W3 (16, 36), b3 (16)
+#define SX_B1 (SX_W1 + 32 * 8)
+#define SX_W2 (SX_B1 + 32)
+#define SX_B2 (SX_W2 + 32 * SX_LD)
+#define SX_W3 (SX_B2 + 32)
+#define SX_B3 (SX_W3 + 16 * SX_LD)
+#define SX_MODEL (SX_B3 + 16)
+template <int Q> __device__ __forceinline__ float sx_quad(float v)      // the value lane Q of this lane's quad holds
 {
-    __shared__ __attribute__((aligned(16))) float sw[SWX_FLOATS];
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), Q * 0x55, 0xF, 0xF, true));
+}
+__global__ __launch_bounds__(256) void rad_sw_gas16_kernel(const float *__restrict__ XR, const float *__restrict__ swx, const float *__restrict__ CS,
+                                                          const float *__restrict__ mask_u, float *__restrict__ S2, int M, int B, int ilev, int ng, int ngk,
+                                                          int npass)
+{
+    __shared__ __attribute__((aligned(16))) float sw[2 * SX_MODEL];
+    __shared__ __attribute__((aligned(16))) float sred[2 * SWX_RED_FLOATS];
+    __shared__ float st[SX_ROWS][4][16];
     const int tid = threadIdx.x;
-    for (int i = tid; i < SWX_FLOATS / 4; i += 256) *(f32x4 *)(sw + 4 * i) = *(const f32x4 *)(swx + 4 * i);
+    for (int i = tid; i < 2 * SWX_MODEL_FLOATS; i += 256) {        // global block (row stride 32) -> LDS (row stride 36 for W2, W3)
+        const int mdl = i / SWX_MODEL_FLOATS, o = i - mdl * SWX_MODEL_FLOATS;
+        int dst;
+        if (o < SWX_B1) dst = SX_W1 + o;
+        else if (o < SWX_W2) dst = SX_B1 + (o - SWX_B1);
+        else if (o < SWX_B2) { const int e = o - SWX_W2; dst = SX_W2 + (e >> 5) * SX_LD + (e & 31); }
+        else if (o < SWX_W3) dst = SX_B2 + (o - SWX_B2);
+        else if (o < SWX_B3) { const int e = o - SWX_W3; dst = SX_W3 + (e >> 5) * SX_LD + (e & 31); }
+        else dst = SX_B3 + (o - SWX_B3);
+        sw[mdl * SX_MODEL + dst] = swx[SWX_MODEL0 + i];
+    }
+    if (ngk > 0) for (int i = tid; i < 2 * SWX_RED_FLOATS; i += 256) sred[i] = swx[SWX_RED + i];
     __syncthreads();
-    const int r = tid >> 2, c = tid & 3, variant = c >> 1, model = c & 1;
-    const int row = blockIdx.x * SX_ROWS + r, rowc = min(row, M - 1);
+    const int r = tid >> 4, c = (tid >> 2) & 3, q = tid & 3, variant = c >> 1, model = c & 1;
+    // npass row groups per workgroup: 1 where the chain length decides (a few hundred columns), 4 at shard size, where the weight
+    // block's trip to LDS per workgroup does (1.412 against 1.397 ms per 2,700-column call with one pass)
+    for (int pass = 0; pass < npass; ++pass) {
+    const int row = (blockIdx.x * npass + pass) * SX_ROWS + r, rowc = min(row, M - 1);
     const float *xr = XR + (size_t)rowc * PH_XR_K;
     float x[8];
 #pragma unroll
@@ -446,98 +480,76 @@ __global__ __launch_bounds__(256) void rad_sw_gas16_kernel(const float *__restri
     if (variant) x[2] = xr[7];
     x[7] = 0.0f;
     const float col = xr[8 + variant];
-    const float *W = sw + SWX_MODEL0 + model * SWX_MODEL_FLOATS;
-    float h1[32], h2[32];
+    const float *W = sw + model * SX_MODEL;
+    float h1[8], h2[8], hf[32];
 #pragma unroll
-    for (int n = 0; n < 32; ++n) {
-        float a = W[SWX_B1 + n];
-        const f32x4 w0 = *(const f32x4 *)(W + SWX_W1 + n * 8), w1 = *(const f32x4 *)(W + SWX_W1 + n * 8 + 4);
+    for (int j = 0; j < 8; ++j) {
+        const int n = 4 * j + q;
+        float a = W[SX_B1 + n];
+        const f32x4 w0 = *(const f32x4 *)(W + SX_W1 + n * 8), w1 = *(const f32x4 *)(W + SX_W1 + n * 8 + 4);
         a = fmaf(x[0], w0.x, a); a = fmaf(x[1], w0.y, a); a = fmaf(x[2], w0.z, a); a = fmaf(x[3], w0.w, a);
         a = fmaf(x[4], w1.x, a); a = fmaf(x[5], w1.y, a); a = fmaf(x[6], w1.z, a);
-        h1[n] = a / (fabsf(a) + 1.0f);
+        h1[j] = a / (fabsf(a) + 1.0f);
     }
 #pragma unroll
-    for (int n = 0; n < 32; ++n) {
-        float a = W[SWX_B2 + n];
+    for (int j = 0; j < 8; ++j) { hf[4 * j] = sx_quad<0>(h1[j]); hf[4 * j + 1] = sx_quad<1>(h1[j]); hf[4 * j + 2] = sx_quad<2>(h1[j]); hf[4 * j + 3] = sx_quad<3>(h1[j]); }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int n = 4 * j + q;
+        float a = W[SX_B2 + n];
 #pragma unroll
         for (int k = 0; k < 32; k += 4) {
-            const f32x4 w = *(const f32x4 *)(W + SWX_W2 + n * 32 + k);
-            a = fmaf(h1[k], w.x, a); a = fmaf(h1[k + 1], w.y, a); a = fmaf(h1[k + 2], w.z, a); a = fmaf(h1[k + 3], w.w, a);
+            const f32x4 w = *(const f32x4 *)(W + SX_W2 + n * SX_LD + k);
+            a = fmaf(hf[k], w.x, a); a = fmaf(hf[k + 1], w.y, a); a = fmaf(hf[k + 2], w.z, a); a = fmaf(hf[k + 3], w.w, a);
         }
-        h2[n] = a / (fabsf(a) + 1.0f);
+        h2[j] = a / (fabsf(a) + 1.0f);
     }
-    float tau[16];
 #pragma unroll
-    for (int n = 0; n < 16; ++n) {
-        float a = W[SWX_B3 + n];
-#pragma unroll
-        for (int k = 0; k < 32; k += 4) {
-            const f32x4 w = *(const f32x4 *)(W + SWX_W3 + n * 32 + k);
-            a = fmaf(h2[k], w.x, a); a = fmaf(h2[k + 1], w.y, a); a = fmaf(h2[k + 2], w.z, a); a = fmaf(h2[k + 3], w.w, a);
-        }
-        tau[n] = (col * pr_pow8(a)) * 1.0000000000000001e-17f;
-    }
-    // lane c of the row finishes g-points 4c .. 4c+3: absorption / Rayleigh of both variants from lanes 0..3 of the quad
-    const int L = rowc / B, b = rowc - L * B;
-    if (ngk > 0) {
-        // sub-generation with k-point reductions (num11916, num87824): the coin picks the humidity variant per K-POINT (mask_u is
-        // (60, B, ngk)), then tau_g = softplus(W tau_k + b) * 0.01 (+ 1e-9 for the absorption); every lane gathers the ngk selected
-        // absorption / Rayleigh depths of its row from the quad and reduces them for its four g-points
-        float asel[16], ssel[16];
-#pragma unroll
-        for (int k = 0; k < 16; ++k) {
-            const float mine = tau[k];
-            const float v0 = __shfl(mine, (tid & ~3) + 0, 64), v1 = __shfl(mine, (tid & ~3) + 1, 64);
-            const float v2 = __shfl(mine, (tid & ~3) + 2, 64), v3 = __shfl(mine, (tid & ~3) + 3, 64);
-            const bool first = k < ngk ? mask_u[(size_t)rowc * ngk + k] < 0.5f : true;
-            asel[k] = k < ngk ? (first ? v0 : v2) : 0.0f;
-            ssel[k] = k < ngk ? (first ? v1 : v3) : 0.0f;
-        }
-        const float *R1 = sw + SWX_RED, *R2 = sw + SWX_RED + SWX_RED_FLOATS;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int g = 4 * c + j;
-            float a = R1[256 + g], sc = R2[256 + g];
-#pragma unroll
-            for (int k = 0; k < 16; ++k) { a = fmaf(asel[k], R1[g * 16 + k], a); sc = fmaf(ssel[k], R2[g * 16 + k], sc); }
-            if (row >= M) continue;
-            float *o = S2 + (size_t)row * 48;
-            const float t_abs = (a > 20.0f ? a : log1pf(expf(a))) * 0.01f + 1.0000000000000001e-09f;
-            const float t_sca = (sc > 20.0f ? sc : log1pf(expf(sc))) * 0.01f;
-            float c_tau = 0.0f, c_sca = 0.0f, c_asy = 0.0f;
-            if (L >= ilev) {
-                const float *cs = CS + ((size_t)(L - ilev) * B + b) * 48;
-                c_tau = cs[g]; c_sca = cs[16 + g]; c_asy = cs[32 + g];
-            }
-            const float tot = (t_abs + t_sca) + c_tau, sca = fmaxf(t_sca + c_sca, 1.0000000000000001e-09f);
-            o[g] = tot; o[16 + g] = sca / tot; o[32 + g] = (c_asy * c_sca) / sca;
-        }
-        return;
-    }
+    for (int j = 0; j < 8; ++j) { hf[4 * j] = sx_quad<0>(h2[j]); hf[4 * j + 1] = sx_quad<1>(h2[j]); hf[4 * j + 2] = sx_quad<2>(h2[j]); hf[4 * j + 3] = sx_quad<3>(h2[j]); }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        float a0 = 0.f, s0 = 0.f, a1 = 0.f, s1 = 0.f;
+        const int g = 4 * j + q;
+        float a = W[SX_B3 + g];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {          // g = 4 q + j is finished by lane q: every lane publishes tau[4 q + j] in turn
-            const float mine = tau[4 * q + j];
-            const float v0 = __shfl(mine, (tid & ~3) + 0, 64), v1 = __shfl(mine, (tid & ~3) + 1, 64);
-            const float v2 = __shfl(mine, (tid & ~3) + 2, 64), v3 = __shfl(mine, (tid & ~3) + 3, 64);
-            if (q == c) { a0 = v0; s0 = v1; a1 = v2; s1 = v3; }
+        for (int k = 0; k < 32; k += 4) {
+            const f32x4 w = *(const f32x4 *)(W + SX_W3 + g * SX_LD + k);
+            a = fmaf(hf[k], w.x, a); a = fmaf(hf[k + 1], w.y, a); a = fmaf(hf[k + 2], w.z, a); a = fmaf(hf[k + 3], w.w, a);
         }
-        const int g = 4 * c + j;
-        if (row >= M) continue;
-        float *o = S2 + (size_t)row * 48;
+        st[r][c][g] = (col * pr_pow8(a)) * 1.0000000000000001e-17f;
+    }
+    ro_fence();                     // the sixteen lanes of a row are in one wave: LDS writes above are visible to the reads below
+    if (row >= M) continue;
+    // lane (c, q) finishes g-point g = 4 c + q: absorption / Rayleigh depths of both humidity variants from the row's four combinations
+    const int L = rowc / B, b = rowc - L * B, g = 4 * c + q;
+    float *o = S2 + (size_t)row * 48;
+    float t_abs, t_sca;
+    if (ngk > 0) {
+        // sub-generation with k-point reductions (num11916, num87824): the coin picks the humidity variant per K-POINT (mask_u is
+        // (60, B, ngk)), then tau_g = softplus(W tau_k + b) * 0.01 (+ 1e-9 for the absorption)
+        const float *R1 = sred, *R2 = sred + SWX_RED_FLOATS;
+        float a = R1[256 + g], sc = R2[256 + g];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const bool first = k < ngk ? mask_u[(size_t)rowc * ngk + k] < 0.5f : true;
+            const float ak = k < ngk ? (first ? st[r][0][k] : st[r][2][k]) : 0.0f, sk = k < ngk ? (first ? st[r][1][k] : st[r][3][k]) : 0.0f;
+            a = fmaf(ak, R1[g * 16 + k], a); sc = fmaf(sk, R2[g * 16 + k], sc);
+        }
+        t_abs = pr_softplus(a) * 0.01f + 1.0000000000000001e-09f;
+        t_sca = pr_softplus(sc) * 0.01f;
+    } else {
         if (g >= ng) { o[g] = 1.0f; o[16 + g] = 0.0f; o[32 + g] = 0.0f; continue; }
         const bool first = mask_u[(size_t)row * ng + g] < 0.5f;
-        const float t_abs = fmaxf(first ? a0 : a1, 1.0000000000000001e-09f), t_sca = first ? s0 : s1;
-        float c_tau = 0.0f, c_sca = 0.0f, c_asy = 0.0f;
-        if (L >= ilev) {
-            const float *cs = CS + ((size_t)(L - ilev) * B + b) * 48;
-            c_tau = cs[g]; c_sca = cs[16 + g]; c_asy = cs[32 + g];
-        }
-        const float tot = (t_abs + t_sca) + c_tau, sca = fmaxf(t_sca + c_sca, 1.0000000000000001e-09f);
-        o[g] = tot; o[16 + g] = sca / tot; o[32 + g] = (c_asy * c_sca) / sca;
+        t_abs = fmaxf(first ? st[r][0][g] : st[r][2][g], 1.0000000000000001e-09f);
+        t_sca = first ? st[r][1][g] : st[r][3][g];
     }
+    float c_tau = 0.0f, c_sca = 0.0f, c_asy = 0.0f;
+    if (L >= ilev) {
+        const float *cs = CS + ((size_t)(L - ilev) * B + b) * 48;
+        c_tau = cs[g]; c_sca = cs[16 + g]; c_asy = cs[32 + g];
+    }
+    const float tot = (t_abs + t_sca) + c_tau, sca = fmaxf(t_sca + c_sca, 1.0000000000000001e-09f);
+    o[g] = tot; o[16 + g] = sca / tot; o[32 + g] = (c_asy * c_sca) / sca;
+    }   // pass
 }
 
 #define RS_T 256
@@ -724,7 +736,9 @@ int launch_phys_radiation(csa_phys *h, int B, const float *x_sfc, float *out_lev
     CSA_HIP_CHECK(hipGetLastError());
     if (d.nx21 && d.swg && !d.sw_e3sm) {
         if (!mask_u) { csa_set_error_msg("physRNN (frozen export): the SW humidity coin needs its uniform draws"); return CSA_ERR_ARG; }
-        hipLaunchKernelGGL(rad_sw_gas16_kernel, dim3((M + SX_ROWS - 1) / SX_ROWS), dim3(256), 0, s, h->XR, d.swg, h->CS, mask_u, h->S2, M, B, d.ilev, h->ng, d.sw_ngk);
+        const int npass = M >= 60 * 1024 ? 4 : 1;
+        hipLaunchKernelGGL(rad_sw_gas16_kernel, dim3((M + SX_ROWS * npass - 1) / (SX_ROWS * npass)), dim3(256), 0, s, h->XR, d.swg, h->CS, mask_u, h->S2, M, B,
+                           d.ilev, h->ng, d.sw_ngk, npass);
         CSA_HIP_CHECK(hipGetLastError());
     } else if (d.swg) {
         hipLaunchKernelGGL(rad_sw_gas_kernel, dim3((M + 32 * SG_WAVES - 1) / (32 * SG_WAVES)), dim3(64 * SG_WAVES), 0, s, h->XR, d.swg, h->CS, h->S2, M, B, d.ilev);

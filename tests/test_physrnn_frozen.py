@@ -130,7 +130,7 @@ def test_hip_frozen_export_matches_the_artefact(fixture):
                 return _blocks(*R.forward(P, FL, x, s, mem, dr["hx2"], dr["mask_u"], **kw))
             finally:
                 R._JITTER = D._JITTER = None
-        jit = [realisation(sd) for sd in (1, 2)]
+        jit = []
         b_ref, bh, b32, b64 = _blocks(*ref), _blocks(*got), _blocks(*got32), _blocks(*got64)
 
         def bad_blocks():
@@ -144,14 +144,45 @@ def test_hip_frozen_export_matches_the_artefact(fixture):
                 if (bh[key] - b_ref[key]).abs().max().item() > tol + noise:
                     out.append((fixture, i, key, "vs the export"))
             return out
-        bad = bad_blocks()
-        if bad:       # a per-cell event (clamp residue under the fourth root) that the first two realisations did not have: four more
-            jit += [realisation(sd) for sd in (3, 4, 5, 6)]
-            bad = bad_blocks()
+        bad = bad_blocks()            # first against the level of the pair (export, float32 restatement) alone
+        for more in ((1, 2), (3, 4, 5, 6)):      # then with re-rounded realisations: a per-cell event the pair / the first two did not have
+            if bad:
+                jit += [realisation(sd) for sd in more]
+                bad = bad_blocks()
         assert not bad, bad
 
+def _assert_within_rounding(bh, b64, real, more, what):
+    """Every block of the HIP result within max(1e-5 x block maximum, 6 x rounding level) of the float64 restatement; the level from the
+    float32 realisations `real`, extended by `more()` (a generator of further realisations) only when a block fails: a clamp residue
+    under a fourth root is a per-cell event that a couple of realisations may not have."""
+    def bad():
+        out = []
+        for key in b64:
+            scale = b64[key].abs().max().item()
+            noise = max((r[key].double() - b64[key]).abs().max().item() for r in real)
+            if (bh[key].double() - b64[key]).abs().max().item() > max(1e-5 * scale, 6 * noise) + 1e-30:
+                out.append(what + (key,))
+        return out
+    b = bad()
+    if b:
+        real.extend(more())
+        b = bad()
+    assert not b, b
+
+
+def _realisations(P, FL, x, s, mem, dr, kw, seeds):
+    out = []
+    for sd in seeds:
+        R._JITTER = D._JITTER = torch.Generator().manual_seed(sd)
+        try:
+            out.append(_blocks(*R.forward(P, FL, x, s, mem, dr["hx2"], dr["mask_u"], **kw)))
+        finally:
+            R._JITTER = D._JITTER = None
+    return out
+
+
 @pytest.mark.gpu
-@pytest.mark.parametrize("fixture,B", [("frozen_a153783c", 384), ("frozen_a153783c", 600), ("frozen_4e616858", 384), ("frozen_cc399fc7", 545)])
+@pytest.mark.parametrize("fixture,B", [("frozen_a153783c", 384), ("frozen_4e616858", 384), ("frozen_cc399fc7", 545)])
 def test_hip_frozen_export_at_the_benchmarked_batch_sizes(fixture, B):
     """The fixtures hold B = 8 / 37 (one column per workgroup in the GRU kernels); the bench runs 384 (two columns per workgroup) and
     2,700 (four on the matrix pipe, from 544).  Here one variant of each radiation sub-generation runs at those kernel classes against the
@@ -167,17 +198,7 @@ def test_hip_frozen_export_at_the_benchmarked_batch_sizes(fixture, B):
     assert all(torch.isfinite(t).all() for t in got)
     b64 = _blocks(*_f64(P, FL, x, s, mem, dr))
     real = [_blocks(*R.forward(P, FL, x, s, mem, dr["hx2"], dr["mask_u"]))]
-    for sd in range(1, 5):
-        R._JITTER = D._JITTER = torch.Generator().manual_seed(sd)
-        try:
-            real.append(_blocks(*R.forward(P, FL, x, s, mem, dr["hx2"], dr["mask_u"])))
-        finally:
-            R._JITTER = D._JITTER = None
-    bh = _blocks(*got)
-    for key in b64:
-        scale = b64[key].abs().max().item()
-        noise = max((r[key].double() - b64[key]).abs().max().item() for r in real)
-        assert (bh[key].double() - b64[key]).abs().max().item() <= max(1e-5 * scale, 6 * noise) + 1e-30, (fixture, B, key)
+    _assert_within_rounding(_blocks(*got), b64, real, lambda: _realisations(P, FL, x, s, mem, dr, {}, (1, 2, 3, 4, 5)), (fixture, B))
 
 
 @pytest.mark.gpu
@@ -206,17 +227,7 @@ def test_hip_gpu_only_exports_match_the_restatement(fixture):
     kw = {k: dr[k] for k in ("hx1", "eps3", "srnn") if k in dr}
     b64 = _blocks(*_f64(P, FL, x, s, mem, dr))
     real = [_blocks(*R.forward(P, FL, x, s, mem, dr["hx2"], dr["mask_u"], **kw))]
-    for sd in range(1, 9):
-        R._JITTER = D._JITTER = torch.Generator().manual_seed(sd)
-        try:
-            real.append(_blocks(*R.forward(P, FL, x, s, mem, dr["hx2"], dr["mask_u"], **kw)))
-        finally:
-            R._JITTER = D._JITTER = None
-    bh = _blocks(*got)
-    for key in b64:
-        scale = b64[key].abs().max().item()
-        noise = max((r[key].double() - b64[key]).abs().max().item() for r in real)
-        assert (bh[key].double() - b64[key]).abs().max().item() <= max(1e-5 * scale, 6 * noise) + 1e-30, (fixture, key)
+    _assert_within_rounding(_blocks(*got), b64, real, lambda: _realisations(P, FL, x, s, mem, dr, kw, (1, 2, 3, 4, 5, 6, 7, 8)), (fixture,))
 
 
 @pytest.mark.gpu
