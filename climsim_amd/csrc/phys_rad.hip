@@ -552,7 +552,7 @@ __global__ __launch_bounds__(256) void rad_sw_gas16_kernel(const float *__restri
     }   // pass
 }
 
-#define RS_T 256
+#define RS_T 512
 __global__ __launch_bounds__(RS_T) void phys_rad_solve_kernel(PhysDev d, int B, const float *__restrict__ x_sfc, const float *__restrict__ TP,
                                                             const float *__restrict__ CL, const float *__restrict__ S2,
                                                             const float *__restrict__ RS, float *__restrict__ out_lev, float *__restrict__ out_sfc)

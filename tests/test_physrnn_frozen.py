@@ -110,7 +110,10 @@ def test_hip_frozen_export_matches_the_artefact(fixture):
     from climsim_amd.physrnn import physical_RNN_wrapped
     g, P, FL = _load(fixture)
     m = physical_RNN_wrapped(P, FL, max_batch=64)
-    for i in range(2):
+    # both stored cases (B = 8, 37) for one variant of each sub-generation, the B = 37 case for the others (the CPU tests above hold the
+    # restatement to both cases of every variant; the GPU box spends most of this test in the float64 / float32 restatement runs)
+    both = fixture in ("frozen_a153783c", "frozen_21cd615c", "frozen_268bd379", "frozen_4e616858", "frozen_cc399fc7", "frozen_f8c86018")
+    for i in ((0, 1) if both else (1,)):
         x, s, mem, dr, ref = _case(g, P, i)
         d = lambda t: None if t is None else t.cuda()
         got = m(d(x), d(s), d(mem), hx2=d(dr["hx2"]), hx1=d(dr.get("hx1")), eps3=d(dr.get("eps3")), mask_u=d(dr["mask_u"]), _srnn=d(dr.get("srnn")))
