@@ -37,6 +37,8 @@ struct PhysDev {
     const float *cld_sw_w, *cld_sw_b;   // learned SW cloud optics (48, 19), (48): cloud_optics_sw2 o cloud_optics_sw composed (num88741), or null
     // the "nx21" generation of the frozen `*_wrapped` exports (csa_phys_wrapped_create):
     int memlm;              // rnn_mem level-major (50, B, 16) in and out (physrad graphs and nx21)
+    int mem_B, mem_off;     // level-major caller tensors (rnn_mem, mem_out, mask_u) of a column SUB-RANGE of the call: row (l, b) sits at
+                            // l * mem_B + mem_off + b; mem_B == 0: the call's own B, no offset (csa_phys_wrapped_forward's column halves)
     int nx21;               // decoder: eddy heat flux zero at the surface, per-region liquid fraction shared with the cloud optics; radiation:
                             // vapour mixing ratio q / (1 - q), 7-32-32-16 SW gas optics with the humidity coin (swg = the SWX_* block), ice SW
                             // optics on the LIQUID radius (as serialised), no relu on the SW fluxes, NET shortwave as first surface output
@@ -118,6 +120,9 @@ struct csa_phys {
     float *wr_xmean = nullptr, *wr_xdiv = nullptr, *wr_lqc = nullptr, *wr_lqi = nullptr;
     float *XM = nullptr, *XS = nullptr, *XD = nullptr, *O5 = nullptr, *OS = nullptr;
     // training (phys_train.hip; non-radiative graph): the trainable tensors as given at create, and the state csa_phys_train_enable builds
+    // column halves of csa_phys_wrapped_forward (from CSA_PHYS_HALVES_MIN columns): second half on a side stream, one fork + one join
+    hipStream_t side = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     std::vector<float> host_params;
     struct PhysTrain *tr = nullptr;
     std::vector<void *> owned;
@@ -147,7 +152,7 @@ template <int N> __device__ __forceinline__ float ph_max(float v)
 // row of (column b, CRM level l) in rnn_mem / mem_out: (B, 50, 16), or level-major (50, B, 16) for the physRad graphs
 __device__ __forceinline__ size_t ph_mem_row(const PhysDev &d, int B, int b, int l)
 {
-    return d.memlm ? (size_t)l * B + b : (size_t)b * d.Lc + l;
+    return d.memlm ? (size_t)l * (d.mem_B ? d.mem_B : B) + d.mem_off + b : (size_t)b * d.Lc + l;
 }
 
 #endif

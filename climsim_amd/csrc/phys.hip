@@ -877,6 +877,9 @@ extern "C" int csa_phys_destroy(csa_phys *h)
 {
     if (!h) return CSA_ERR_ARG;
     if (h->tr) phys_train_free(h->tr);
+    if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
+    if (h->ev_join) (void)hipEventDestroy(h->ev_join);
+    if (h->side) (void)hipStreamDestroy(h->side);
     if (h->rnn3) csa_stoch_destroy(h->rnn3);
     for (void *p : h->owned) (void)hipFree(p);
     delete h;
@@ -889,10 +892,55 @@ __global__ __launch_bounds__(256) void phys_mul_kernel(const f32x4 *__restrict__
     if (i < n4) o[i] = a[i] * b[i];
 }
 
+// From CSA_PHYS_HALVES_MIN columns (default 640, the LSTM path's threshold: the deployed export measured 0.428 -> 0.380 ms at 640 columns,
+// 0.776 -> 0.674 ms at 1,280, 1.391 -> 1.264 ms at 2,700; 0.297 -> 0.340 ms at 512) a physRNN call runs as two column halves on two
+// streams, as the LSTM path does (api.hip::run_forward_halves): the decoder / optics / solver launches are chains of dependent work per
+// workgroup, and two such chains overlap.  The second half works in the upper part of every work array (the handle's pointers are
+// shifted for the duration of ITS launches: kernels take them by value) and addresses the caller's level-major tensors (rnn_mem,
+// mem_out, mask_u) with the call's row stride (PhysDev::mem_B / mem_off).  Not with the stochastic third RNN (one layer handle with
+// buffers of its own).  part(columns, first column, stream) launches one part.
+static bool phys_halves_eligible(const csa_phys *h, int B)
+{
+    static const int halves_min = getenv("CSA_PHYS_HALVES_MIN") ? atoi(getenv("CSA_PHYS_HALVES_MIN")) : 640;
+    return !h->rnn3 && halves_min > 0 && B >= halves_min;
+}
+template <typename F> static int phys_halves(csa_phys *h, int B, hipStream_t s, F part)
+{
+    if (!h->side) {
+        CSA_HIP_CHECK(hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking));
+        CSA_HIP_CHECK(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+        CSA_HIP_CHECK(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
+    }
+    const int B1 = (B + 1) / 2, B2 = B - B1;
+    CSA_HIP_CHECK(hipEventRecord(h->ev_fork, s));
+    CSA_HIP_CHECK(hipStreamWaitEvent(h->side, h->ev_fork, 0));
+    h->d.mem_B = B; h->d.mem_off = 0;
+    int rc = part(B1, 0, s);
+    if (rc == CSA_OK) {
+        // per-column floats of every work array a call touches; the second half lives B1 columns further up
+        const PhysDev &d = h->d;
+        struct Shift { float **p; size_t per; } sh[] = {
+            {&h->X1, (size_t)d.Lr * (d.nh + 16)}, {&h->P, (size_t)d.Lr * 4 * d.nh}, {&h->H1, (size_t)d.Lr * d.nh}, {&h->H2, (size_t)d.Lr * d.nh},
+            {&h->hx, (size_t)d.nh}, {&h->HD, (size_t)d.Lr * d.hdw}, {&h->XG, (size_t)PH_L * PH_XG_K}, {&h->XR, (size_t)PH_L * PH_XR_K},
+            {&h->RS, (size_t)PH_L * 2}, {&h->CL, (size_t)d.Lc * PH_NG}, {&h->TP, (size_t)PH_L * 32}, {&h->S2, (size_t)PH_L * 48},
+            {&h->CS, (size_t)d.Lc * 48}, {&h->XM, (size_t)PH_L * 21}, {&h->XS, (size_t)19}, {&h->XD, (size_t)PH_L * 21}, {&h->O5, (size_t)PH_L * 5},
+            {&h->OS, (size_t)8}};
+        for (Shift &x : sh) if (*x.p) *x.p += x.per * B1;
+        h->d.mem_off = B1;
+        rc = part(B2, B1, h->side);
+        for (Shift &x : sh) if (*x.p) *x.p -= x.per * B1;
+    }
+    h->d.mem_B = 0; h->d.mem_off = 0;
+    if (rc) return rc;
+    CSA_HIP_CHECK(hipEventRecord(h->ev_join, h->side));
+    CSA_HIP_CHECK(hipStreamWaitEvent(s, h->ev_join, 0));
+    return CSA_OK;
+}
+
 // x_main (B,60,nx) normalised, x_sfc (B,naux) normalised, rnn_mem (B,50,16), x_denorm (B,60,nxd) raw (T, ., qliq, qice, ..., qv last),
 // hx2 (B,nh): the N(0,1) draw the reference makes for rnn2's initial state; add_stochastic_layer graphs also draw hx1 (B,nh), rnn3's
 // initial state, and eps3 (Lr,B,nh), the layer's noise.  -> out_lev (B,60,5), out_sfc (B,8), mem_out (B,50,16)
-static int phys_forward_impl(csa_phys *h, int B, const float *x_main, const float *x_sfc, const float *rnn_mem,
+static int phys_forward_part(csa_phys *h, int B, const float *x_main, const float *x_sfc, const float *rnn_mem,
                              const float *x_denorm, int nxd, const float *hx2, const float *hx1, const float *eps3, const float *srnn,
                              float *out_lev, float *out_sfc, float *mem_out, void *stream, const float *mask_u = nullptr)
 {
@@ -950,6 +998,24 @@ static int phys_forward_impl(csa_phys *h, int B, const float *x_main, const floa
                        out_lev, out_sfc, mem_out, PhysRadOut{});
     CSA_HIP_CHECK(hipGetLastError());
     return CSA_OK;
+}
+
+// the unfrozen graphs' entry points: one part, or two column halves (phys_halves)
+static int phys_forward_impl(csa_phys *h, int B, const float *x_main, const float *x_sfc, const float *rnn_mem,
+                             const float *x_denorm, int nxd, const float *hx2, const float *hx1, const float *eps3, const float *srnn,
+                             float *out_lev, float *out_sfc, float *mem_out, void *stream)
+{
+    if (!h || B <= 0 || !phys_halves_eligible(h, B) || !x_main || !x_sfc || !rnn_mem || !x_denorm || !hx2 || !out_lev || !out_sfc || !mem_out)
+        return phys_forward_part(h, B, x_main, x_sfc, rnn_mem, x_denorm, nxd, hx2, hx1, eps3, srnn, out_lev, out_sfc, mem_out, stream);
+    const PhysDev &d = h->d;
+    const int nx = d.nx, naux = d.naux, nh = d.nh, lm = d.memlm, Lc = d.Lc;
+    return phys_halves(h, B, (hipStream_t)stream, [&](int Bp, int off, hipStream_t sp) {
+        // batch-first tensors move by pointer; level-major rnn_mem / mem_out keep their base and take the call's row stride
+        const size_t moff = lm ? 0 : (size_t)off * Lc * 16;
+        return phys_forward_part(h, Bp, x_main + (size_t)off * PH_L * nx, x_sfc + (size_t)off * naux, rnn_mem + moff,
+                                 x_denorm + (size_t)off * PH_L * nxd, nxd, hx2 + (size_t)off * nh, hx1, eps3, srnn,
+                                 out_lev + (size_t)off * PH_L * 5, out_sfc + (size_t)off * 8, mem_out + moff, sp);
+    });
 }
 
 extern "C" int csa_phys_forward_noise(csa_phys *h, int B, const float *x_main, const float *x_sfc, const float *rnn_mem,
@@ -1040,14 +1106,19 @@ extern "C" int csa_phys_wrapped_forward(csa_phys *h, int B, const float *x_main0
         return CSA_ERR_ARG;
     }
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(phys_wrap_pre_kernel, dim3((B * PH_L + 255) / 256), dim3(256), 0, s, h->d, B, x_main0, x_sfc0, h->wr_xmean, h->wr_xdiv,
-                       h->wr_lqc, h->wr_lqi, h->XM, h->XS, h->XD);
-    CSA_HIP_CHECK(hipGetLastError());
-    int rc = phys_forward_impl(h, B, h->XM, h->XS, rnn1_mem, h->XD, 21, hx2, hx1, eps3, srnn, h->O5, h->OS, mem_out, stream, mask_u);
-    if (rc) return rc;
-    hipLaunchKernelGGL(phys_post_kernel, dim3((B * PH_L + 255) / 256), dim3(256), 0, s, h->d, B, h->O5, h->OS, h->XD, 21, out_lev, out_sfc, 1);
-    CSA_HIP_CHECK(hipGetLastError());
-    return CSA_OK;
+    auto part = [&](int Bp, int off, hipStream_t sp) -> int {      // columns [off, off + Bp) of the call on stream sp
+        const PhysDev &d = h->d;
+        hipLaunchKernelGGL(phys_wrap_pre_kernel, dim3((Bp * PH_L + 255) / 256), dim3(256), 0, sp, d, Bp, x_main0 + (size_t)off * PH_L * 20,
+                           x_sfc0 + (size_t)off * 19, h->wr_xmean, h->wr_xdiv, h->wr_lqc, h->wr_lqi, h->XM, h->XS, h->XD);
+        CSA_HIP_CHECK(hipGetLastError());
+        int rc = phys_forward_part(h, Bp, h->XM, h->XS, rnn1_mem, h->XD, 21, hx2 + (size_t)off * d.nh, hx1, eps3, srnn, h->O5, h->OS, mem_out, sp, mask_u);
+        if (rc) return rc;
+        hipLaunchKernelGGL(phys_post_kernel, dim3((Bp * PH_L + 255) / 256), dim3(256), 0, sp, d, Bp, h->O5, h->OS, h->XD, 21,
+                           out_lev + (size_t)off * PH_L * 6, out_sfc + (size_t)off * 8, 1);
+        CSA_HIP_CHECK(hipGetLastError());
+        return CSA_OK;
+    };
+    return phys_halves_eligible(h, B) ? phys_halves(h, B, s, part) : part(B, 0, s);
 }
 
 // taps for tests: level-major (Lr, B, nh) outputs of rnn1 (level order) and rnn2 of the last call

@@ -449,7 +449,7 @@ template <int Q> __device__ __forceinline__ float sx_quad(float v)      // the v
 }
 __global__ __launch_bounds__(256) void rad_sw_gas16_kernel(const float *__restrict__ XR, const float *__restrict__ swx, const float *__restrict__ CS,
                                                           const float *__restrict__ mask_u, float *__restrict__ S2, int M, int B, int ilev, int ng, int ngk,
-                                                          int npass)
+                                                          int npass, int mem_B, int mem_off)
 {
     __shared__ __attribute__((aligned(16))) float sw[2 * SX_MODEL];
     __shared__ __attribute__((aligned(16))) float sred[2 * SWX_RED_FLOATS];
@@ -521,6 +521,7 @@ __global__ __launch_bounds__(256) void rad_sw_gas16_kernel(const float *__restri
     if (row >= M) continue;
     // lane (c, q) finishes g-point g = 4 c + q: absorption / Rayleigh depths of both humidity variants from the row's four combinations
     const int L = rowc / B, b = rowc - L * B, g = 4 * c + q;
+    const size_t mrow = (size_t)L * (mem_B ? mem_B : B) + mem_off + b;        // row of the caller's (60, B_call, .) coin field
     float *o = S2 + (size_t)row * 48;
     float t_abs, t_sca;
     if (ngk > 0) {
@@ -530,7 +531,7 @@ __global__ __launch_bounds__(256) void rad_sw_gas16_kernel(const float *__restri
         float a = R1[256 + g], sc = R2[256 + g];
 #pragma unroll
         for (int k = 0; k < 16; ++k) {
-            const bool first = k < ngk ? mask_u[(size_t)rowc * ngk + k] < 0.5f : true;
+            const bool first = k < ngk ? mask_u[mrow * ngk + k] < 0.5f : true;
             const float ak = k < ngk ? (first ? st[r][0][k] : st[r][2][k]) : 0.0f, sk = k < ngk ? (first ? st[r][1][k] : st[r][3][k]) : 0.0f;
             a = fmaf(ak, R1[g * 16 + k], a); sc = fmaf(sk, R2[g * 16 + k], sc);
         }
@@ -538,7 +539,7 @@ __global__ __launch_bounds__(256) void rad_sw_gas16_kernel(const float *__restri
         t_sca = pr_softplus(sc) * 0.01f;
     } else {
         if (g >= ng) { o[g] = 1.0f; o[16 + g] = 0.0f; o[32 + g] = 0.0f; continue; }
-        const bool first = mask_u[(size_t)row * ng + g] < 0.5f;
+        const bool first = mask_u[mrow * ng + g] < 0.5f;
         t_abs = fmaxf(first ? st[r][0][g] : st[r][2][g], 1.0000000000000001e-09f);
         t_sca = first ? st[r][1][g] : st[r][3][g];
     }
@@ -738,7 +739,7 @@ int launch_phys_radiation(csa_phys *h, int B, const float *x_sfc, float *out_lev
         if (!mask_u) { csa_set_error_msg("physRNN (frozen export): the SW humidity coin needs its uniform draws"); return CSA_ERR_ARG; }
         const int npass = M >= 60 * 1024 ? 4 : 1;
         hipLaunchKernelGGL(rad_sw_gas16_kernel, dim3((M + SX_ROWS * npass - 1) / (SX_ROWS * npass)), dim3(256), 0, s, h->XR, d.swg, h->CS, mask_u, h->S2, M, B,
-                           d.ilev, h->ng, d.sw_ngk, npass);
+                           d.ilev, h->ng, d.sw_ngk, npass, d.mem_B, d.mem_off);
         CSA_HIP_CHECK(hipGetLastError());
     } else if (d.swg) {
         hipLaunchKernelGGL(rad_sw_gas_kernel, dim3((M + 32 * SG_WAVES - 1) / (32 * SG_WAVES)), dim3(64 * SG_WAVES), 0, s, h->XR, d.swg, h->CS, h->S2, M, B, d.ilev);

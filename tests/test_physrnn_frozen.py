@@ -313,3 +313,25 @@ def test_frozen_export_call_can_be_captured_into_a_hip_graph_by_the_host():
     torch.cuda.synchronize()
     eager = m(x, s, mem, hx2=dr["hx2"], mask_u=dr["mask_u"])
     assert all(torch.equal(a, b) for a, b in zip(out, eager)) and not torch.equal(out[2], ref[2])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fixture", ["frozen_a153783c", "frozen_4e616858", "frozen_cc399fc7"])
+def test_frozen_export_column_halves_reproduce_the_sub_batch_calls(fixture):
+    """From 640 columns csa_phys_wrapped_forward runs two column halves on two streams (upper half of every work array, the caller's
+    level-major rnn1_mem / mem_out / mask_u addressed with the call's row stride).  Columns are independent and both routes use the same
+    kernel classes (1,201 = 601 + 600 columns: both halves and both sub-batch calls sit between 544, where the GRUs move to the matrix
+    pipe, and 640), so the call must equal, bit for bit, the two calls a caller would make for its halves."""
+    from climsim_amd.physrnn import physical_RNN_wrapped
+    from make_golden_frozen import inputs_wrapped, draws
+    g, P, FL = _load(fixture)
+    B, B1 = 1201, 601
+    m = physical_RNN_wrapped(P, FL, max_batch=B)
+    x, s, mem = (t.cuda() for t in inputs_wrapped(P, B, 91))
+    dr = {k: v.cuda() for k, v in draws(FL, B, 92).items()}
+    whole = m(x, s, mem, hx2=dr["hx2"], mask_u=dr["mask_u"])
+    parts = [m(x[a:b].contiguous(), s[a:b].contiguous(), mem[:, a:b].contiguous(), hx2=dr["hx2"][a:b].contiguous(),
+               mask_u=dr["mask_u"][:, a:b].contiguous()) for a, b in ((0, B1), (B1, B))]
+    assert torch.equal(whole[0], torch.cat([p[0] for p in parts], 0)) and torch.equal(whole[1], torch.cat([p[1] for p in parts], 0))
+    assert torch.equal(whole[2], torch.cat([p[2] for p in parts], 1))
+    assert all(torch.isfinite(t).all() for t in whole)

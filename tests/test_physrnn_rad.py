@@ -365,8 +365,9 @@ def test_hip_stochastic_graph_noise_handling():
 @pytest.mark.parametrize("fixture", ["physrnn_rad", "physrad16_b", "physrad16_e3sm"])
 def test_hip_radiation_graph_properties_at_shard_size(fixture):
     """2,700 columns (the per-GPU shard of the high-resolution grid): deterministic, finite, and a column's result does not
-    depend on which other columns share the call (rows of a 640-column call = the same rows of the 2,700-column call, bit for
-    bit: same kernel classes -- two-column GRU recurrence, 128 / 64-row GEMM tiles with identical k order)."""
+    depend on which other columns share the call (rows of a 1,200-column call = the same rows of the 2,700-column call, bit for
+    bit: from 640 columns a call runs as two column halves on two streams, and the halves of both calls -- 600 and 1,350 columns --
+    are in the same kernel classes: matrix-pipe GRU recurrence from 544 columns, 128 / 64-row GEMM tiles with identical k order)."""
     g, P = _load(fixture)
     m = _hip_model(P, 2700)
     B = 2700
@@ -379,7 +380,7 @@ def test_hip_radiation_graph_properties_at_shard_size(fixture):
     a = _run(m, xm, xs, mem, xd, **kw)
     b = _run(m, xm, xs, mem, xd, **kw)
     assert all(torch.equal(u, v) for u, v in zip(a, b)) and all(torch.isfinite(u).all() for u in a)
-    n = 640
+    n = 1200
     sub = {k: (v[:, :n] if k == "eps3" else v[:n]).contiguous() for k, v in kw.items()}
     c = _run(m, xm[:n].contiguous(), xs[:n].contiguous(), mem[:n].contiguous(), xd[:n].contiguous(), **sub)
     for u, v in zip(a, c):
