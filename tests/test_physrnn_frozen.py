@@ -293,7 +293,11 @@ def test_frozen_export_call_can_be_captured_into_a_hip_graph_by_the_host():
     from climsim_amd.physrnn import physical_RNN_wrapped
     from make_golden_frozen import inputs_wrapped, draws
     g, P, FL = _load("frozen_a153783c")
-    B = 48
+    _graph_case(physical_RNN_wrapped, P, FL, inputs_wrapped, draws, 48)
+    _graph_case(physical_RNN_wrapped, P, FL, inputs_wrapped, draws, 700)        # two column halves: the side stream joins the capture
+
+
+def _graph_case(physical_RNN_wrapped, P, FL, inputs_wrapped, draws, B):
     m = physical_RNN_wrapped(P, FL, max_batch=B)
     x, s, mem = (t.cuda() for t in inputs_wrapped(P, B, 77))
     dr = {k: v.cuda() for k, v in draws(FL, B, 78).items()}
