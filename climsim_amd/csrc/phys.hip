@@ -1101,7 +1101,8 @@ extern "C" int csa_phys_wrapped_forward(csa_phys *h, int B, const float *x_main0
                                         const float *hx1, const float *eps3, const float *mask_u, const float *srnn, float *out_lev,
                                         float *out_sfc, float *mem_out, void *stream)
 {
-    if (!h || !h->XM || !x_main0 || !x_sfc0 || !rnn1_mem || !hx2 || !mask_u || !out_lev || !out_sfc || !mem_out || B <= 0 || B > h->max_batch) {
+    const bool coin = h && h->d.swg && !h->d.sw_e3sm;      // only the 7-32-32-ng SW gas-optics sub-generations flip the humidity coin
+    if (!h || !h->XM || !x_main0 || !x_sfc0 || !rnn1_mem || !hx2 || (coin && !mask_u) || !out_lev || !out_sfc || !mem_out || B <= 0 || B > h->max_batch) {
         csa_set_error_msg("csa_phys_wrapped_forward: bad argument (or not a csa_phys_wrapped_create handle)");
         return CSA_ERR_ARG;
     }

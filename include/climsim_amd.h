@@ -514,7 +514,8 @@ int csa_phys_debug_rnn3(csa_phys *h, int T, int B, const float *x, const float *
  *   rnn3.{weight_ih, weight_zh, weight_encoder}.  CSA_PHYS_RAD_UPDATED_QV: radiation reads the updated grid-mean q_v.
  * csa_phys_wrapped_forward: the random draws the export makes inside forward are ARGUMENTS (device pointers): hx2 (B,nh) rnn2's initial
  * state; hx1 (B,nh), eps3 (50,B,nh) the stochastic third RNN's state and noise (CSA_PHYS_STOCHASTIC, else null); mask_u (60,B,ngk or ng) the
- * uniform field of the SW humidity coin (`torch.rand_like(tau) < 0.5` picks the largest region's humidity).  srnn: test hook, null in
+ * uniform field of the SW humidity coin (`torch.rand_like(tau) < 0.5` picks the largest region's humidity; exports without the coin --
+ * CSA_PHYS_SW_HEAD, CSA_PHYS_SW_GAS -- take null).  srnn: test hook, null in
  * production (the third RNN's output supplied: that layer is chaotic on synthetic inputs, see tests/test_physrnn_frozen.py). */
 int csa_phys_wrapped_create(int nh, int ng, int flags, const float *const *w, int max_batch, csa_phys **out);
 int csa_phys_wrapped_forward(csa_phys *h, int B, const float *x_main0, const float *x_sfc0, const float *rnn1_mem, const float *hx2,
