@@ -288,7 +288,13 @@ __global__ __launch_bounds__(DT) void phys_decode_kernel(PhysDev d, int B, const
     // ---- phase E (RAD): inputs of the radiation scheme -- the artefact's radiative_transfer up to its three MLPs ----
     if constexpr (RAD) {
         const float *aux = x_sfc + (size_t)b * d.naux;
-        for (int L = tid; L < PH_L; L += DT) {
+        // One level per lane, THREE waves each doing a third of a level's row (the rows cost ~30 IEEE divisions, two fourth roots and a
+        // logarithm each: 19 k cycles when one lane did a whole row -- a third of this kernel at a few hundred columns, measured with
+        // cycle stamps -- while seven waves idled): wave 0 writes RS and XG[0:12], wave 1 XG[12:24], wave 2 the SW inputs XR; the
+        // level's scalars are recomputed by each.  The other waves go straight to the cloud optics below.
+        const int role = tid >> 6, L_e = tid & 63;
+        if (role < 3 && L_e < PH_L) {
+            const int L = L_e;
             const size_t row = (size_t)L * B + b;
             const float *xd = x_denorm + ((size_t)b * PH_L + L) * nxd;
             const float *ys = d.yscale_lev + L * 5;
@@ -298,15 +304,19 @@ __global__ __launch_bounds__(DT) void phys_decode_kernel(PhysDev d, int B, const
             const float pd = sp * (d.hybi[L + 1] - d.hybi[L]) + (d.hyai[L + 1] - d.hyai[L]) * 100000.0f;
             const float col_dry = (pd * 10.0f * 6.02214076e23f * fact) / (m_air * 1000.0f * 100.0f * 9.80665f);
             const float play = d.hyam[L] * 100000.0f + sp * d.hybm[L], lp = logf(play), v4 = sqrtf(sqrtf(vmr));
-            ro.RS[row * 2] = col_dry; ro.RS[row * 2 + 1] = T_new;
-            float f[PH_XG_K];
+            if (role < 2) {
+                if (role == 0) { ro.RS[row * 2] = col_dry; ro.RS[row * 2 + 1] = T_new; }
+                float f[PH_XG_K];
 #pragma unroll
-            for (int k = 0; k < PH_XG_K; ++k) f[k] = 0.0f;
-            f[0] = T_new; f[1] = lp; f[2] = v4; f[3] = sqrtf(sqrtf(xd[12])); f[4] = 0.0003887f; f[5] = xd[13]; f[6] = xd[14];
-            float *xg = ro.XG + row * PH_XG_K;
+                for (int k = 0; k < PH_XG_K; ++k) f[k] = 0.0f;
+                f[0] = T_new; f[1] = lp; f[2] = v4; f[3] = sqrtf(sqrtf(xd[12])); f[4] = 0.0003887f; f[5] = xd[13]; f[6] = xd[14];
+                float *xg = ro.XG + row * PH_XG_K;
 #pragma unroll
-            for (int k = 0; k < PH_XG_K; ++k)
-                xg[k] = k < 18 ? fmaxf((f[k] - d.g_xmin[k]) / d.g_range[k], 0.0f) : 0.0f;
+                for (int k = 0; k < PH_XG_K / 2; ++k) {
+                    const int kk = k + (role ? PH_XG_K / 2 : 0);
+                    xg[kk] = kk < 18 ? fmaxf(((role ? f[k + PH_XG_K / 2] : f[k]) - d.g_xmin[kk]) / d.g_range[kk], 0.0f) : 0.0f;
+                }
+            } else {
             float *xr = ro.XR + row * PH_XR_K;
             if (d.swg) {
                 // physics_rad_e3sm generation: inputs of the SW gas-optics MLPs for the humidity of the two largest regions of the
@@ -332,8 +342,7 @@ __global__ __launch_bounds__(DT) void phys_decode_kernel(PhysDev d, int B, const
                     xr[j ? 7 : 2] = (sqrtf(sqrtf(v[j])) - xmin[2]) / xdiv[2];
                     xr[8 + j] = ((pd * 6.02214076e24f) * fj) / (((v[j] + 0.04698f) * fj) * 980665.0f);
                 }
-                continue;
-            }
+            } else {
             const float *xm = ro.x_main + ((size_t)b * PH_L + L) * d.nx;
             xr[0] = (lp - 0.00515f) / 11.59485f;
             xr[1] = (T_new - 160.0f) / 180.0f;
@@ -351,6 +360,8 @@ __global__ __launch_bounds__(DT) void phys_decode_kernel(PhysDev d, int B, const
             const float *lat = HD + ((size_t)(L - d.ltop) * B + b) * HDW + PH_NHEAD * NC;
 #pragma unroll
             for (int k = 0; k < nm0; ++k) xr[9 + k] = L >= ilev ? lat[k] : 0.0f;
+            }   // SW head inputs
+            }   // role 2
         }
         // cloud optical depth per (CRM level, g-point).  use_mcica graphs (mp_ncol 4): every g-point sees one sub-column,
         // sub-column j owning round-to-largest-remainder(area_j * 16) consecutive g-points (physics_rad.py:533); the
