@@ -162,30 +162,43 @@ __global__ __launch_bounds__(DT) void phys_decode_kernel(PhysDev d, int B, const
     }
 
     // ---- phase B: sub-grid state and the fluxes at each level ----
-    for (int e0 = 0; e0 < LC * NC; e0 += DT) {
-        const int e = e0 + tid, l = e >> SH, c = e & (NC - 1);
-        const bool ok = l < LC;
-        const int L = (ok ? l : 0) + ilev;
+    // (the head-GEMM and input values of ALL passes are requested before the first is used: the shuffles below are convergent
+    //  operations the compiler does not move loads across, and a pass otherwise starts with a full memory round trip)
+    constexpr int NPASS = (LC * NC + DT - 1) / DT;
+    float hB[NPASS][8], xB[NPASS][4];
+#pragma unroll
+    for (int ip = 0; ip < NPASS; ++ip) {
+        const int e = ip * DT + tid, l = e >> SH, c = e & (NC - 1);
+        const int L = (l < LC ? l : 0) + ilev;
         const float *hd = HD + ((size_t)(L - d.ltop) * B + b) * HDW + c;
         const float *xd = x_denorm + ((size_t)b * PH_L + L) * nxd;
-        const float a_raw = hd[H_AREA * NC];
+        hB[ip][0] = hd[H_AREA * NC]; hB[ip][1] = hd[H_QV * NC]; hB[ip][2] = hd[H_QN * NC]; hB[ip][3] = hd[H_QICE * NC];
+        hB[ip][4] = hd[H_T * NC]; hB[ip][5] = hd[H_EDDY * NC]; hB[ip][6] = hd[H_FLUX * NC]; hB[ip][7] = hd[H_SED * NC];
+        xB[ip][0] = xd[0]; xB[ip][1] = xd[2]; xB[ip][2] = xd[3]; xB[ip][3] = xd[nxd - 1];
+    }
+#pragma unroll
+    for (int ip = 0; ip < NPASS; ++ip) {
+        const int e = ip * DT + tid, l = e >> SH, c = e & (NC - 1);
+        const bool ok = l < LC;
+        const int L = (ok ? l : 0) + ilev;
+        const float a_raw = hB[ip][0];
         const float am = ph_max<NC>(a_raw), ae = expf(a_raw - am), area = ae / ph_sum<NC>(ae);
-        float qv = ph_softplus(hd[H_QV * NC]), qn = ph_softplus(hd[H_QN * NC]), qi = ph_softplus(hd[H_QICE * NC]);
+        float qv = ph_softplus(hB[ip][1]), qn = ph_softplus(hB[ip][2]), qi = ph_softplus(hB[ip][3]);
         if (d.clear0 && c == 0) qn = 0.0f;           // clear-sky region (its condensation head row is zero too: see phys_build)
         const float mqv = ph_sum<NC>(qv * area), mqn = ph_sum<NC>(qn * area), mqi = ph_sum<NC>(qi * area);
-        qv *= mqv == 0.0f ? 1.0f : xd[nxd - 1] / mqv;
-        qn *= mqn == 0.0f ? 1.0f : (xd[2] + xd[3]) / mqn;
-        qi *= mqi == 0.0f ? 1.0f : xd[3] / mqi;
-        const float dT = hd[H_T * NC];
-        const float T_crm = xd[0] + (dT - ph_sum<NC>(dT * area));
+        qv *= mqv == 0.0f ? 1.0f : xB[ip][3] / mqv;
+        qn *= mqn == 0.0f ? 1.0f : (xB[ip][1] + xB[ip][2]) / mqn;
+        qi *= mqi == 0.0f ? 1.0f : xB[ip][2] / mqi;
+        const float dT = hB[ip][4];
+        const float T_crm = xB[ip][0] + (dT - ph_sum<NC>(dT * area));
         const float play = d.hyam[L] * 100000.0f + sp * d.hybm[L], play_up = d.hyam[L - 1] * 100000.0f + sp * d.hybm[L - 1];
-        float fH = hd[H_EDDY * NC] * (CP / G) * T_crm * (play - play_up);
+        float fH = hB[ip][5] * (CP / G) * T_crm * (play - play_up);
         if (l == LC - 1 && !d.dec21) fH = -fmaxf(fH, 0.0f);     // (nx21: defined at layer tops like the moisture fluxes, zero at the surface)
-        const float flux1 = hd[H_FLUX * NC] * 300000.0f;
+        const float flux1 = hB[ip][6] * 300000.0f;
         if (ok) {
             s_area[e] = area; s_qv[e] = qv; s_qn[e] = qn; s_fH[e] = fH; s_T[e] = T_crm;
             s_fqv[e] = flux1 * qv; s_fqn[e] = flux1 * qn;
-            s_sed[e] = fmaxf(hd[H_SED * NC], 0.0f) * G * qi * d.yscale_lev[L * 5 + 2];
+            s_sed[e] = fmaxf(hB[ip][7], 0.0f) * G * qi * d.yscale_lev[L * 5 + 2];
         }
     }
     __syncthreads();
