@@ -165,7 +165,7 @@ __global__ __launch_bounds__(DT) void phys_decode_kernel(PhysDev d, int B, const
     // (the head-GEMM and input values of ALL passes are requested before the first is used: the shuffles below are convergent
     //  operations the compiler does not move loads across, and a pass otherwise starts with a full memory round trip)
     constexpr int NPASS = (LC * NC + DT - 1) / DT;
-    float hB[NPASS][8], xB[NPASS][4];
+    float hB[NPASS][8], xB[NPASS][4], hC[NPASS][3];      // (hC: the three heads phase C reads, same rows)
 #pragma unroll
     for (int ip = 0; ip < NPASS; ++ip) {
         const int e = ip * DT + tid, l = e >> SH, c = e & (NC - 1);
@@ -175,6 +175,7 @@ __global__ __launch_bounds__(DT) void phys_decode_kernel(PhysDev d, int B, const
         hB[ip][0] = hd[H_AREA * NC]; hB[ip][1] = hd[H_QV * NC]; hB[ip][2] = hd[H_QN * NC]; hB[ip][3] = hd[H_QICE * NC];
         hB[ip][4] = hd[H_T * NC]; hB[ip][5] = hd[H_EDDY * NC]; hB[ip][6] = hd[H_FLUX * NC]; hB[ip][7] = hd[H_SED * NC];
         xB[ip][0] = xd[0]; xB[ip][1] = xd[2]; xB[ip][2] = xd[3]; xB[ip][3] = xd[nxd - 1];
+        hC[ip][0] = hd[H_EVAP * NC]; hC[ip][1] = hd[H_COND * NC]; hC[ip][2] = hd[H_AA * NC];
     }
 #pragma unroll
     for (int ip = 0; ip < NPASS; ++ip) {
@@ -204,11 +205,11 @@ __global__ __launch_bounds__(DT) void phys_decode_kernel(PhysDev d, int B, const
     __syncthreads();
 
     // ---- phase C: flux divergences, clamps, tendencies, area-weighted means ----
-    for (int e0 = 0; e0 < LC * NC; e0 += DT) {
-        const int e = e0 + tid, l = e >> SH, c = e & (NC - 1);
+#pragma unroll
+    for (int ip = 0; ip < NPASS; ++ip) {
+        const int e = ip * DT + tid, l = e >> SH, c = e & (NC - 1);
         const bool ok = l < LC;
         const int lc = ok ? l : 0, ec = ok ? e : c, L = lc + ilev;
-        const float *hd = HD + ((size_t)(L - d.ltop) * B + b) * HDW + c;
         const float *ys = d.yscale_lev + L * 5;
         const float pd = s_pd[lc], area = s_area[ec], qv = s_qv[ec], qn = s_qn[ec];
         const bool up = lc > 0, last = lc == LC - 1;
@@ -216,9 +217,9 @@ __global__ __launch_bounds__(DT) void phys_decode_kernel(PhysDev d, int B, const
         const float flux_qv_dp = ((last ? 0.0f : s_fqv[ec]) - (up ? s_fqv[ec - NC] : 0.0f)) / pd * (-G);
         const float flux_qn_dp = ((last ? 0.0f : s_fqn[ec]) - (up ? s_fqn[ec - NC] : 0.0f)) / pd * (-G);
         const float sed_qn_dp = (s_sed[ec] - (up ? s_sed[ec - NC] : 0.0f)) / pd * (-G);
-        float evap = (fmaxf(hd[H_EVAP * NC], 0.0f) + 1e-6f) * s_pv[lc];
-        float cond = hd[H_COND * NC];
-        float aa = fmaxf(hd[H_AA * NC], 0.0f) * qn * ys[2];
+        float evap = (fmaxf(hC[ip][0], 0.0f) + 1e-6f) * s_pv[lc];
+        float cond = hC[ip][1];
+        float aa = fmaxf(hC[ip][2], 0.0f) * qn * ys[2];
         cond = fmaxf(cond, ((-(ys[2] * qn / 1200.0f) - flux_qn_dp) + aa) - sed_qn_dp);
         evap = fmaxf(evap, (-(ys[1] * qv / 1200.0f) - flux_qv_dp) + cond);
         aa = fmaxf(aa, ((flux_qn_dp + cond) + sed_qn_dp) - ys[2] * (-qn + 0.0006f) / 1200.0f);
