@@ -670,9 +670,10 @@ __global__ __launch_bounds__(RS_T) void phys_rad_solve_kernel(PhysDev d, int B, 
 #pragma unroll 4
         for (int j = L - 1; j >= 0; --j) {
             const int e = j * NG + g;
-            const float inv = 1.0f / (1.0f - A * s_R[e]);
-            Ad = s_Rd[e] + (s_Tdir[e] * Ad + s_Td[e] * A) * s_T[e] * inv;
-            A = s_R[e] + s_T[e] * s_T[e] * A * inv;
+            // (the division is the dependent chain of this sweep: v_rcp_f32, 1 ulp, instead of the ten-instruction IEEE sequence)
+            const float Tj = s_T[e], inv = __builtin_amdgcn_rcpf(1.0f - A * s_R[e]);
+            Ad = s_Rd[e] + (s_Tdir[e] * Ad + s_Td[e] * A) * Tj * inv;
+            A = s_R[e] + (Tj * Tj) * A * inv;
             s_A[e] = A; s_Ad[e] = Ad;
         }
         float dif = 0.0f, dr = toa;
@@ -681,7 +682,7 @@ __global__ __launch_bounds__(RS_T) void phys_rad_solve_kernel(PhysDev d, int B, 
         for (int j = 0; j < L; ++j) {
             const int e = j * NG + g;
             const float Ab = s_A[e + NG], Adb = s_Ad[e + NG];
-            const float inv = 1.0f / (1.0f - s_R[e] * Ab);
+            const float inv = __builtin_amdgcn_rcpf(1.0f - s_R[e] * Ab);      // (off the chain: known once the upward sweep is done)
             dif = (s_T[e] * dif + dr * (s_T[e] * Adb * s_R[e] + s_Td[e])) * inv;
             dr = dr * s_Tdir[e];
             s_sup[e + NG] = fmaxf(dr * Adb + dif * Ab, lo);
