@@ -395,6 +395,13 @@ struct PhysTrain {
     struct Slot { float *X1, *H1, *hx, *HD, *GP1, *GP2, *Hs1, *Hs2; int B = 0; };      // what one pending forward keeps
     std::vector<Slot> slots;
     float *dHD, *dH2, *dH1, *dX1, *dlast, *dhx1, *dhx2, *dpold, *XIN, *XS, *DHX, *part, *part_b, *rtmp;
+    // weight-gradient GEMMs: every one keeps its partials in a region of its own (arena) until ONE queued reduction at the end of the
+    // backward call; they run on a side stream beside the dependent chain (BPTT kernels, dX GEMMs), which never reads them
+    float *arena = nullptr;
+    size_t arena_floats = 0;
+    ReduceJobs rq;
+    hipStream_t side = nullptr;
+    hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     float *samp, *ecoef, *sp;          // loss scratch (train_misc.hip::launch_loss), for nslots * max_batch samples
     int *m_whead, *m_bhead, *m_wih1, *m_whh1, *m_b1a, *m_b1b, *m_wih2, *m_whh2, *m_b2a, *m_b2b, *m_dec, *m_init, *m_initb, *m_s1, *m_s1b;
     std::vector<GatherEntry> gathers;
@@ -407,6 +414,8 @@ void phys_train_free(PhysTrain *t)
 {
     if (!t) return;
     for (void *p : t->owned) (void)hipFree(p);
+    for (hipEvent_t e : t->ev) if (e) (void)hipEventDestroy(e);
+    if (t->side) (void)hipStreamDestroy(t->side);
     delete t;
 }
 
@@ -578,6 +587,8 @@ extern "C" int csa_phys_train_enable(csa_phys *h, int nslots)
     pf = std::max(pf, MB * (size_t)pb_part_floats(nh));
     t->part = pt_alloc<float>(t, pf, rc); t->part_b = pt_alloc<float>(t, (size_t)t->nsplit * 4 * nh, rc);
     t->rtmp = pt_alloc<float>(t, (size_t)32 * pb_part_floats(nh), rc);
+    t->arena_floats = (size_t)t->nsplit * ((size_t)HDW * nh + HDW + 3 * (size_t)4 * nh * nh + (size_t)4 * nh * K1 + 2 * 4 * nh + 2 * ((size_t)nh * 32 + nh));
+    t->arena = pt_alloc<float>(t, t->arena_floats, rc);
     t->samp = pt_alloc<float>(t, (size_t)nslots * MB * 9, rc); t->ecoef = pt_alloc<float>(t, MB, rc); t->sp = pt_alloc<float>(t, (size_t)nslots * MB, rc);
     if (rc == CSA_OK) rc = pt_repack(t, nullptr);
     if (rc == CSA_OK && hipDeviceSynchronize() != hipSuccess) rc = CSA_ERR_HIP;
@@ -671,40 +682,70 @@ extern "C" int csa_phys_train_backward(csa_phys *h, int slot, int B, const float
     hipLaunchKernelGGL(phys_decode_bwd_kernel, dim3(B), dim3(PB_T), 0, s, d, B, S.HD, H2, x_sfc, rnn_mem, x_denorm, nxd, d_out, d_out_sfc, d_mem_out,
                        t->dHD, t->dlast, t->dpold, t->part);
     CSA_HIP_CHECK(hipGetLastError());
-    if ((rc = launch_reduce_partials_2stage(t->part, B, npart, t->m_dec, nullptr, grads, t->rtmp, 32, s))) return rc;
+    // every reduction of this call is queued and runs as one launch at its end
+    ReduceJobs &rq = t->rq;
+    rq.n = 0; rq.nblk = 0;
+    if ((rc = reduce_queue_add_2stage(rq, t->part, B, npart, t->m_dec, nullptr, t->rtmp, 32, s))) return rc;
+    static const bool side_on = !getenv("CSA_PHYS_TRAIN_SIDE") || atoi(getenv("CSA_PHYS_TRAIN_SIDE")) != 0;
+    hipStream_t sw = s;                                   // the stream of the weight-gradient GEMMs
+    int nev = 0;
+    if (side_on) {
+        if (!t->side) {
+            CSA_HIP_CHECK(hipStreamCreateWithFlags(&t->side, hipStreamNonBlocking));
+            for (hipEvent_t &e : t->ev) CSA_HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        }
+        sw = t->side;
+    }
+    // the side stream picks up what the main stream has produced so far
+    auto handoff = [&]() -> int {
+        if (!side_on) return CSA_OK;
+        CSA_HIP_CHECK(hipEventRecord(t->ev[nev], s));
+        CSA_HIP_CHECK(hipStreamWaitEvent(sw, t->ev[nev], 0));
+        ++nev;
+        return CSA_OK;
+    };
+    float *pa = t->arena;
+    // dW = A^T Bm as split-M partials (+ the column sums of A for the bias when ba is given), reduction queued
+    auto wgrad = [&](const float *A, int lda, const float *Bm, int ldb, int Mr, int N1, int N2, const int *map, const int *ba,
+                     const int *bb) -> int {
+        float *cp = pa, *cb = nullptr;
+        pa += (size_t)ns * N1 * N2;
+        if (ba) { cb = pa; pa += (size_t)ns * N1; }
+        if ((size_t)(pa - t->arena) > t->arena_floats) { csa_set_error_msg("csa_phys_train_backward: partial arena too small"); return CSA_ERR_ARG; }
+        int r = ba ? launch_gemm_tn_partial_cs(A, lda, Bm, ldb, cp, cb, Mr, N1, N2, ns, sw) : launch_gemm_tn_partial(A, lda, Bm, ldb, cp, Mr, N1, N2, ns, sw);
+        if (r) return r;
+        if ((r = reduce_queue_add(rq, cp, ns, N1 * N2, map, nullptr))) return r;
+        return ba ? reduce_queue_add(rq, cb, ns, N1, ba, bb) : CSA_OK;
+    };
     // head GEMM
     if ((rc = launch_proj_gemm(t->dHD, t->wheadT, nullptr, t->dH2, M, nh, HDW, s))) return rc;
     hipLaunchKernelGGL(phys_add_last_kernel, dim3((B * nh + 255) / 256), dim3(256), 0, s, t->dH2 + (size_t)(L - 1) * B * nh, t->dlast, B * nh);
     CSA_HIP_CHECK(hipGetLastError());
-    if ((rc = launch_gemm_tn_partial_cs(t->dHD, HDW, H2, nh, t->part, t->part_b, M, HDW, nh, ns, s))) return rc;
-    if ((rc = launch_reduce_partials(t->part, ns, HDW * nh, t->m_whead, nullptr, grads, s))) return rc;
-    if ((rc = launch_reduce_partials(t->part_b, ns, HDW, t->m_bhead, nullptr, grads, s))) return rc;
     // rnn2 (downward)
     if ((rc = launch_bwd_rec_gru(nh, t->whh2Tp, S.GP2, S.Hs2, t->dH2, t->dhx2, B, L, 0, s))) return rc;
+    if ((rc = handoff())) return rc;                      // dHD, GP2
+    if ((rc = wgrad(t->dHD, HDW, H2, nh, M, HDW, nh, t->m_whead, t->m_bhead, nullptr))) return rc;
+    if ((rc = wgrad(S.GP2, 4 * nh, S.H1, nh, M, 4 * nh, nh, t->m_wih2, t->m_b2a, t->m_b2b))) return rc;
+    if ((rc = wgrad(S.GP2, 4 * nh, S.Hs2, nh, M, 4 * nh, nh, t->m_whh2, nullptr, nullptr))) return rc;
     if ((rc = launch_proj_gemm(S.GP2, t->wih2T, nullptr, t->dH1, M, nh, 4 * nh, s))) return rc;
-    if ((rc = launch_gemm_tn_partial_cs(S.GP2, 4 * nh, S.H1, nh, t->part, t->part_b, M, 4 * nh, nh, ns, s))) return rc;
-    if ((rc = launch_reduce_partials(t->part, ns, 4 * nh * nh, t->m_wih2, nullptr, grads, s))) return rc;
-    if ((rc = launch_reduce_partials(t->part_b, ns, 4 * nh, t->m_b2a, t->m_b2b, grads, s))) return rc;
-    if ((rc = launch_gemm_tn_partial(S.GP2, 4 * nh, S.Hs2, nh, t->part, M, 4 * nh, nh, ns, s))) return rc;
-    if ((rc = launch_reduce_partials(t->part, ns, 4 * nh * nh, t->m_whh2, nullptr, grads, s))) return rc;
     // rnn1 (upward): dH1 is in level order, the recurrence ran over the flipped axis
     if ((rc = launch_bwd_rec_gru(nh, t->whh1Tp, S.GP1, S.Hs1, t->dH1, t->dhx1, B, L, 1, s))) return rc;
+    if ((rc = handoff())) return rc;                      // GP1
+    if ((rc = wgrad(S.GP1, 4 * nh, S.X1, K1, M, 4 * nh, K1, t->m_wih1, t->m_b1a, t->m_b1b))) return rc;
+    if ((rc = wgrad(S.GP1, 4 * nh, S.Hs1, nh, M, 4 * nh, nh, t->m_whh1, nullptr, nullptr))) return rc;
     if ((rc = launch_proj_gemm(S.GP1, t->wih1T, nullptr, t->dX1, M, K1, 4 * nh, s))) return rc;
-    if ((rc = launch_gemm_tn_partial_cs(S.GP1, 4 * nh, S.X1, K1, t->part, t->part_b, M, 4 * nh, K1, ns, s))) return rc;
-    if ((rc = launch_reduce_partials(t->part, ns, 4 * nh * K1, t->m_wih1, nullptr, grads, s))) return rc;
-    if ((rc = launch_reduce_partials(t->part_b, ns, 4 * nh, t->m_b1a, t->m_b1b, grads, s))) return rc;
-    if ((rc = launch_gemm_tn_partial(S.GP1, 4 * nh, S.Hs1, nh, t->part, M, 4 * nh, nh, ns, s))) return rc;
-    if ((rc = launch_reduce_partials(t->part, ns, 4 * nh * nh, t->m_whh1, nullptr, grads, s))) return rc;
     // mlp_initial, mlp_surface1, incoming memory (DPRE reuses dH1: rnn1's BPTT has consumed it)
     hipLaunchKernelGGL(phys_prep_bwd_kernel, dim3(B), dim3(128), 0, s, d, B, x_main, x_sfc, S.X1, S.hx, t->dX1, t->dhx1, t->dpold, t->dH1, t->XIN,
                        t->DHX, t->XS, d_mem_in);
     CSA_HIP_CHECK(hipGetLastError());
-    if ((rc = launch_gemm_tn_partial_cs(t->dH1, nh, t->XIN, 32, t->part, t->part_b, M, nh, 32, ns, s))) return rc;
-    if ((rc = launch_reduce_partials(t->part, ns, nh * 32, t->m_init, nullptr, grads, s))) return rc;
-    if ((rc = launch_reduce_partials(t->part_b, ns, nh, t->m_initb, nullptr, grads, s))) return rc;
-    if ((rc = launch_gemm_tn_partial_cs(t->DHX, nh, t->XS, 32, t->part, t->part_b, B, nh, 32, ns, s))) return rc;
-    if ((rc = launch_reduce_partials(t->part, ns, nh * 32, t->m_s1, nullptr, grads, s))) return rc;
-    if ((rc = launch_reduce_partials(t->part_b, ns, nh, t->m_s1b, nullptr, grads, s))) return rc;
+    if ((rc = handoff())) return rc;                      // DPRE, XIN, DHX, XS
+    if ((rc = wgrad(t->dH1, nh, t->XIN, 32, M, nh, 32, t->m_init, t->m_initb, nullptr))) return rc;
+    if ((rc = wgrad(t->DHX, nh, t->XS, 32, B, nh, 32, t->m_s1, t->m_s1b, nullptr))) return rc;
+    if ((rc = launch_reduce_queue(rq, grads, sw))) return rc;
+    if (side_on) {
+        CSA_HIP_CHECK(hipEventRecord(t->ev[nev], sw));
+        CSA_HIP_CHECK(hipStreamWaitEvent(s, t->ev[nev], 0));
+    }
     S.B = 0;
     return CSA_OK;
 }

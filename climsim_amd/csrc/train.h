@@ -24,6 +24,14 @@ int launch_gemm_tn_conv(const float *A, int lda, const float *Bm, int ldb, float
                         int nsplit, int conv_L, int conv_cin, hipStream_t s);
 int launch_colsum_partial(const float *A, float *part, int M, int N, int nsplit, hipStream_t s);
 int launch_reduce_partials(const float *part, int nsplit, int n, const int *map, const int *map2, float *grad, hipStream_t s);
+// several reductions in one launch (train_misc.hip): queue jobs whose targets do not overlap, each with its own partial buffer
+#define REDUCE_MAX_JOBS 16
+struct ReduceJob { const float *part; const int *map, *map2; int nsplit, n, blk0, small; };
+struct ReduceJobs { int n = 0, nblk = 0; ReduceJob j[REDUCE_MAX_JOBS]; };
+int reduce_queue_add(ReduceJobs &J, const float *part, int nsplit, int n, const int *map, const int *map2);
+int launch_reduce_queue(ReduceJobs &J, float *grad, hipStream_t s);
+int reduce_queue_add_2stage(ReduceJobs &J, const float *part, int nsplit, int n, const int *map, const int *map2, float *tmp, int chunks,
+                            hipStream_t s);
 int launch_reduce_partials_2stage(const float *part, int nsplit, int n, const int *map, const int *map2, float *grad, float *tmp,
                                   int chunks, hipStream_t s);
 

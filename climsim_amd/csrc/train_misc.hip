@@ -212,11 +212,9 @@ int launch_colsum_partial(const float *A, float *part, int M, int N, int nsplit,
 
 // grad[map ? map[i] : i] += sum_s part[s][i]   (map may send two sources to different targets only;
 // idx2, when given, receives the same sum as well: b_ih and b_hh share one gradient)
-__global__ void reduce_partials_kernel(const float *__restrict__ part, int nsplit, int n,
-                                       const int *__restrict__ map, const int *__restrict__ map2,
-                                       float *__restrict__ grad)
+__device__ __forceinline__ void reduce_partials_body(int i, const float *__restrict__ part, int nsplit, int n,
+                                                     const int *__restrict__ map, const int *__restrict__ map2, float *__restrict__ grad)
 {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     // fixed summation order (s ascending within each of eight interleaved chains, chains combined pairwise):
     // deterministic, and the eight loads per trip are independent (a single dependent chain costs nsplit memory latencies;
@@ -232,6 +230,12 @@ __global__ void reduce_partials_kernel(const float *__restrict__ part, int nspli
     const int d = map ? map[i] : i;
     if (d >= 0) grad[d] += a_;
     if (map2) { const int d2 = map2[i]; if (d2 >= 0) grad[d2] += a_; }
+}
+__global__ void reduce_partials_kernel(const float *__restrict__ part, int nsplit, int n,
+                                       const int *__restrict__ map, const int *__restrict__ map2,
+                                       float *__restrict__ grad)
+{
+    reduce_partials_body(blockIdx.x * blockDim.x + threadIdx.x, part, nsplit, n, map, map2, grad);
 }
 // first stage for MANY partials (one per column: head / prep backward): chunk c of `chunks` sums its contiguous run of
 // partials into tmp[c][i]; the ordinary reduction then finishes over `chunks`.  Fixed order -> deterministic.
@@ -255,15 +259,25 @@ int launch_reduce_partials_2stage(const float *part, int nsplit, int n, const in
     return launch_reduce_partials(tmp, chunks, n, map, map2, grad, s);
 }
 
+// the two-stage form for the queue: the first stage runs now on s, the final reduction over `chunks` joins the queue
+int reduce_queue_add_2stage(ReduceJobs &J, const float *part, int nsplit, int n, const int *map, const int *map2, float *tmp, int chunks,
+                            hipStream_t s)
+{
+    if (nsplit <= chunks || !tmp) return reduce_queue_add(J, part, nsplit, n, map, map2);
+    const int per = (nsplit + chunks - 1) / chunks;
+    hipLaunchKernelGGL(reduce_stage1_kernel, dim3((n + 255) / 256, chunks), dim3(256), 0, s, part, nsplit, n, per, tmp);
+    CSA_HIP_CHECK(hipGetLastError());
+    return reduce_queue_add(J, tmp, chunks, n, map, map2);
+}
+
 // the same reduction for SHORT vectors (biases, head / prep partials: n <= 16 K): with one thread per element the launch is
 // a handful of workgroups walking nsplit dependent-latency loads (6 us for 512 elements x 64 partials).  Here eight lanes
 // share an element: lane q sums partials q, q+8, ... (two interleaved chains), then three xor-shuffles combine the eight
 // sums in a fixed tree -> deterministic, ~3x shorter.
-__global__ __launch_bounds__(256) void reduce_partials_small_kernel(const float *__restrict__ part, int nsplit, int n,
-                                                                    const int *__restrict__ map, const int *__restrict__ map2,
-                                                                    float *__restrict__ grad)
+__device__ __forceinline__ void reduce_partials_small_body(int gid, const float *__restrict__ part, int nsplit, int n,
+                                                           const int *__restrict__ map, const int *__restrict__ map2, float *__restrict__ grad)
 {
-    const int gid = blockIdx.x * 256 + threadIdx.x, i = gid >> 3, q = gid & 7;
+    const int i = gid >> 3, q = gid & 7;
     const int ic = i < n ? i : n - 1;                       // all lanes take part in the shuffles
     float a0 = 0.0f, a1 = 0.0f;
     int s = q;
@@ -278,6 +292,44 @@ __global__ __launch_bounds__(256) void reduce_partials_small_kernel(const float 
     const int d = map ? map[i] : i;
     if (d >= 0) grad[d] += a;
     if (map2) { const int d2 = map2[i]; if (d2 >= 0) grad[d2] += a; }
+}
+__global__ __launch_bounds__(256) void reduce_partials_small_kernel(const float *__restrict__ part, int nsplit, int n,
+                                                                    const int *__restrict__ map, const int *__restrict__ map2,
+                                                                    float *__restrict__ grad)
+{
+    reduce_partials_small_body(blockIdx.x * 256 + threadIdx.x, part, nsplit, n, map, map2, grad);
+}
+
+// Several reductions in ONE launch (a backward step queues the reduction of every weight-gradient GEMM and runs them together at
+// its end: thirteen launches of 5-11 us, most of them a handful of workgroups, become one).  Each job keeps the scheme
+// launch_reduce_partials would have chosen for it, so the sums are bit-identical to separate launches.  The jobs' targets must
+// not overlap (different parameter tensors), and every job needs its own partial buffer until the launch.
+__global__ __launch_bounds__(256) void reduce_partials_multi_kernel(ReduceJobs J, float *__restrict__ grad)
+{
+    int j = 0;
+    while (j + 1 < J.n && (int)blockIdx.x >= J.j[j + 1].blk0) ++j;
+    const ReduceJob &r = J.j[j];
+    const int gid = ((int)blockIdx.x - r.blk0) * 256 + threadIdx.x;
+    if (r.small) reduce_partials_small_body(gid, r.part, r.nsplit, r.n, r.map, r.map2, grad);
+    else reduce_partials_body(gid, r.part, r.nsplit, r.n, r.map, r.map2, grad);
+}
+int reduce_queue_add(ReduceJobs &J, const float *part, int nsplit, int n, const int *map, const int *map2)
+{
+    if (J.n >= REDUCE_MAX_JOBS) { csa_set_error_msg("reduce_queue_add: queue full"); return CSA_ERR_ARG; }
+    ReduceJob &r = J.j[J.n++];
+    r.part = part; r.nsplit = nsplit; r.n = n; r.map = map; r.map2 = map2;
+    r.small = n <= 16384 && nsplit >= 16;
+    r.blk0 = J.nblk;
+    J.nblk += r.small ? (8 * n + 255) / 256 : (n + 255) / 256;
+    return CSA_OK;
+}
+int launch_reduce_queue(ReduceJobs &J, float *grad, hipStream_t s)
+{
+    if (J.n == 0) return CSA_OK;
+    hipLaunchKernelGGL(reduce_partials_multi_kernel, dim3(J.nblk), dim3(256), 0, s, J, grad);
+    CSA_HIP_CHECK(hipGetLastError());
+    J.n = 0; J.nblk = 0;
+    return CSA_OK;
 }
 
 int launch_reduce_partials(const float *part, int nsplit, int n, const int *map, const int *map2, float *grad, hipStream_t s)
