@@ -52,6 +52,10 @@ struct csa_trainer {
     float *dH2, *dH1, *dX1, *dhc1, *dhc2, *part, *samp, *ecoef, *sp;
     float *part_b = nullptr;         // partial bias gradients (column sums of dP), a side output of the W_ih GEMM
     float *rtmp = nullptr;           // first-stage sums of the per-column partial reductions
+    // one queued reduction per backward call / flush (train_misc.hip::reduce_partials_multi_kernel): every weight-gradient GEMM keeps
+    // its partials in a region of the arena, the prep partials have a buffer (and first-stage sums) of their own
+    float *arena = nullptr, *part2 = nullptr, *rtmp2 = nullptr;
+    size_t arena_floats = 0;
     size_t part_floats;
     int nsplit;
     // deferred weight gradients (csa_train_set_deferred): the W_ih / W_hh gradient GEMMs of the backward calls are
@@ -465,6 +469,10 @@ extern "C" int csa_train_create(const csa_config *cfg, const csa_params *p, cons
     h->part = dalloc<float>(h, h->part_floats, rc);
     h->part_b = dalloc<float>(h, (size_t)h->nsplit * 4 * std::max(c.nh1, c.nh2), rc);
     h->rtmp = dalloc<float>(h, (size_t)32 * std::max(head_bwd_partial_floats(c), prep_bwd_partial_floats(c)), rc);
+    h->rtmp2 = dalloc<float>(h, (size_t)32 * prep_bwd_partial_floats(c), rc);
+    h->part2 = dalloc<float>(h, Bm * (size_t)prep_bwd_partial_floats(c), rc);
+    h->arena_floats = (size_t)h->nsplit * 4 * ((size_t)c.nh2 * c.nh1 + c.nh2 + (size_t)c.nh2 * c.nh2 + (size_t)c.nh1 * nin1 + c.nh1 + (size_t)c.nh1 * c.nh1);
+    h->arena = dalloc<float>(h, h->arena_floats, rc);
     h->samp = dalloc<float>(h, (size_t)max_window * Bm * 9, rc);
     h->ecoef = dalloc<float>(h, Bm, rc);
     h->sp = dalloc<float>(h, (size_t)max_window * Bm, rc);
@@ -652,7 +660,19 @@ extern "C" int csa_train_backward(csa_trainer *h, int slot, int B, const float *
     int rc;
     // head
     if ((rc = launch_head_bwd(h->dm, B, d_out, d_out_sfc, d_mem_out, S.Z, S.H2 + (size_t)B * nh2, h->dH2, h->part, s))) return rc;
-    if ((rc = launch_reduce_partials_2stage(h->part, B, head_bwd_partial_floats(c), h->map_head, nullptr, grads, h->rtmp, 32, s))) return rc;
+    // every reduction of this call is queued (distinct targets, a partial buffer each) and runs as one launch at its end
+    ReduceJobs rq;
+    if ((rc = reduce_queue_add_2stage(rq, h->part, B, head_bwd_partial_floats(c), h->map_head, nullptr, h->rtmp, 32, s))) return rc;
+    float *pa = h->arena;
+    auto wgrad = [&](const float *A, int lda, const float *Bm, int ldb, int N1, int N2, const int *map, const int *ba, const int *bb) -> int {
+        float *cp = pa, *cb = nullptr;
+        pa += (size_t)ns * N1 * N2;
+        if (ba) { cb = pa; pa += (size_t)ns * N1; }
+        int r = ba ? launch_gemm_tn_partial_cs(A, lda, Bm, ldb, cp, cb, M, N1, N2, ns, s) : launch_gemm_tn_partial(A, lda, Bm, ldb, cp, M, N1, N2, ns, s);
+        if (r) return r;
+        if ((r = reduce_queue_add(rq, cp, ns, N1 * N2, map, nullptr))) return r;
+        return ba ? reduce_queue_add(rq, cb, ns, N1, ba, bb) : CSA_OK;
+    };
     // rnn2 (downward): BPTT, then input / weight gradients from dP2 (stored in place in GP2)
     { StageTimer tm(h, 1, s);
     if (c.use_lstm) {
@@ -663,11 +683,8 @@ extern "C" int csa_train_backward(csa_trainer *h, int slot, int B, const float *
     { StageTimer tm(h, 3, s);
     if ((rc = launch_proj_gemm(S.GP2, h->wih2T, nullptr, h->dH1, M, nh1, 4 * nh2, s))) return rc; }
     if (!h->defer) {
-        if ((rc = launch_gemm_tn_partial_cs(S.GP2, 4 * nh2, S.H1lev, nh1, h->part, h->part_b, M, 4 * nh2, nh1, ns, s))) return rc;
-        if ((rc = launch_reduce_partials(h->part, ns, 4 * nh2 * nh1, h->map_wih2, nullptr, grads, s))) return rc;
-        if ((rc = launch_reduce_partials(h->part_b, ns, 4 * nh2, h->map_b2a, h->map_b2b, grads, s))) return rc;
-        if ((rc = launch_gemm_tn_partial(S.GP2, 4 * nh2, S.H2, nh2, h->part, M, 4 * nh2, nh2, ns, s))) return rc;
-        if ((rc = launch_reduce_partials(h->part, ns, 4 * nh2 * nh2, h->map_whh2, nullptr, grads, s))) return rc;
+        if ((rc = wgrad(S.GP2, 4 * nh2, S.H1lev, nh1, 4 * nh2, nh1, h->map_wih2, h->map_b2a, h->map_b2b))) return rc;
+        if ((rc = wgrad(S.GP2, 4 * nh2, S.H2, nh2, 4 * nh2, nh2, h->map_whh2, nullptr, nullptr))) return rc;
     }
     // rnn1 (upward): dH1 is in level order, the recurrence runs in sequence order
     { StageTimer tm(h, 1, s);
@@ -679,11 +696,8 @@ extern "C" int csa_train_backward(csa_trainer *h, int slot, int B, const float *
     { StageTimer tm(h, 3, s);
     if ((rc = launch_proj_gemm(S.GP1, h->wih1T, nullptr, h->dX1, M, nin1, 4 * nh1, s))) return rc; }
     if (!h->defer) {
-        if ((rc = launch_gemm_tn_partial_cs(S.GP1, 4 * nh1, S.X1, nin1, h->part, h->part_b, M, 4 * nh1, nin1, ns, s))) return rc;
-        if ((rc = launch_reduce_partials(h->part, ns, 4 * nh1 * nin1, h->map_wih1, nullptr, grads, s))) return rc;
-        if ((rc = launch_reduce_partials(h->part_b, ns, 4 * nh1, h->map_b1a, h->map_b1b, grads, s))) return rc;
-        if ((rc = launch_gemm_tn_partial(S.GP1, 4 * nh1, S.H1seq, nh1, h->part, M, 4 * nh1, nh1, ns, s))) return rc;
-        if ((rc = launch_reduce_partials(h->part, ns, 4 * nh1 * nh1, h->map_whh1, nullptr, grads, s))) return rc;
+        if ((rc = wgrad(S.GP1, 4 * nh1, S.X1, nin1, 4 * nh1, nin1, h->map_wih1, h->map_b1a, h->map_b1b))) return rc;
+        if ((rc = wgrad(S.GP1, 4 * nh1, S.H1seq, nh1, 4 * nh1, nh1, h->map_whh1, nullptr, nullptr))) return rc;
     } else {
         if (!h->pending.empty() && h->pending_B != B) { csa_set_error_msg("csa_train_backward(deferred): batch size changed inside a window"); return CSA_ERR_ARG; }
         if ((int)h->pending.size() >= TN_MAX_SEGS) { csa_set_error_msg("csa_train_backward(deferred): flush before more than 8 pending steps"); return CSA_ERR_ARG; }
@@ -691,8 +705,9 @@ extern "C" int csa_train_backward(csa_trainer *h, int slot, int B, const float *
         h->pending_B = B;
     }
     // mlp_initial / surface / TOA MLPs, gradient w.r.t. the incoming memory
-    if ((rc = launch_prep_bwd(h->dm, B, h->dX1, S.X1, S.X16, S.xs, S.hc0, h->dhc1, h->dhc2, d_mem_in, h->part, s))) return rc;
-    return launch_reduce_partials_2stage(h->part, B, prep_bwd_partial_floats(c), h->map_prep, nullptr, grads, h->rtmp, 32, s);
+    if ((rc = launch_prep_bwd(h->dm, B, h->dX1, S.X1, S.X16, S.xs, S.hc0, h->dhc1, h->dhc2, d_mem_in, h->part2, s))) return rc;
+    if ((rc = reduce_queue_add_2stage(rq, h->part2, B, prep_bwd_partial_floats(c), h->map_prep, nullptr, h->rtmp2, 32, s))) return rc;
+    return launch_reduce_queue(rq, grads, s);
 }
 
 extern "C" int csa_train_set_deferred(csa_trainer *h, int enable)
@@ -716,19 +731,26 @@ extern "C" int csa_train_flush_wgrad(csa_trainer *h, float *grads, void *stream)
     const int ns = (h->nsplit / nseg) * nseg;      // same number of partials as one per-step call, shared by the segments
     int rc;
     StageTimer tm(h, 4, s);
+    // the four GEMMs keep their partials in regions of the arena; ONE queued reduction at the end
+    ReduceJobs rq;
+    float *pa = h->arena;
     // ba / bb: the bias gradient (column sums of dP over all pending steps) comes out of the W_ih GEMM of each RNN
     auto run = [&](float *Slot::*a, float *Slot::*b, int N1, int N2, const int *map, const int *ba, const int *bb) {
         TnSegs g{};
         g.n = nseg;
         for (int i = 0; i < nseg; ++i) { g.A[i] = h->slots[h->pending[i]].*a; g.B[i] = h->slots[h->pending[i]].*b; }
-        if ((rc = launch_gemm_tn_segs(g, N1, N2, h->part, M, N1, N2, ns, 0, 0, s, ba ? h->part_b : nullptr))) return rc;
-        if ((rc = launch_reduce_partials(h->part, ns, N1 * N2, map, nullptr, grads, s))) return rc;
-        return ba ? launch_reduce_partials(h->part_b, ns, N1, ba, bb, grads, s) : CSA_OK;
+        float *cp = pa, *cb = nullptr;
+        pa += (size_t)ns * N1 * N2;
+        if (ba) { cb = pa; pa += (size_t)ns * N1; }
+        if ((rc = launch_gemm_tn_segs(g, N1, N2, cp, M, N1, N2, ns, 0, 0, s, cb))) return rc;
+        if ((rc = reduce_queue_add(rq, cp, ns, N1 * N2, map, nullptr))) return rc;
+        return ba ? reduce_queue_add(rq, cb, ns, N1, ba, bb) : CSA_OK;
     };
     if ((rc = run(&Slot::GP2, &Slot::H1lev, 4 * nh2, nh1, h->map_wih2, h->map_b2a, h->map_b2b))) return rc;
     if ((rc = run(&Slot::GP2, &Slot::H2, 4 * nh2, nh2, h->map_whh2, nullptr, nullptr))) return rc;
     if ((rc = run(&Slot::GP1, &Slot::X1, 4 * nh1, nin1, h->map_wih1, h->map_b1a, h->map_b1b))) return rc;
     if ((rc = run(&Slot::GP1, &Slot::H1seq, 4 * nh1, nh1, h->map_whh1, nullptr, nullptr))) return rc;
+    if ((rc = launch_reduce_queue(rq, grads, s))) return rc;
     h->pending.clear();
     return CSA_OK;
 }
