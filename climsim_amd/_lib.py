@@ -30,7 +30,7 @@ SYMBOLS = ["csa_create", "csa_destroy", "csa_set_params", "csa_packed_width", "c
            "csa_forward_packed", "csa_forward_tuple", "csa_model_forward", "csa_forward_tuple_noise",
            "csa_model_forward_noise", "csa_forward_packed_noise", "csa_postprocess", "csa_tap_rnn1",
            "csa_tap_rnn2", "csa_last_error", "csa_version", "csa_set_profiling", "csa_reset_profile",
-           "csa_get_profile", "csa_stage_name", "csa_set_halves", "csa_set_rec1_max_batch", "csa_set_small_gemm_rows", "csa_debug_stage",
+           "csa_get_profile", "csa_stage_name", "csa_set_halves", "csa_set_rec1_max_batch", "csa_set_small_gemm_rows", "csa_set_gemm_split", "csa_debug_stage",
            "csa_train_create", "csa_train_destroy", "csa_train_num_params", "csa_train_num_tensors",
            "csa_train_param_info", "csa_train_params", "csa_train_sync_params", "csa_train_copy_state", "csa_train_forward", "csa_train_forward_noise",
            "csa_train_backward", "csa_train_set_deferred", "csa_train_flush_wgrad", "csa_train_loss", "csa_train_adam",
@@ -116,6 +116,7 @@ def lib():
     L.csa_set_rec1_max_batch.argtypes = [H, i]
     L.csa_debug_stage.argtypes = [H, i, i, _F, _F, _F, _F, _F, _F, _F, ctypes.c_void_p]
     L.csa_set_small_gemm_rows.argtypes = [i]
+    L.csa_set_gemm_split.argtypes = [i]
     L.csa_stage_name.argtypes = [i]
     L.csa_stage_name.restype = ctypes.c_char_p
     Fp = ctypes.POINTER(ctypes.c_float)

@@ -202,6 +202,171 @@ __global__ __launch_bounds__(GB_THREADS) void proj_gemm_kernel(
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Split-operand variant of the plain projection (opt-in: csa_set_gemm_split / CSA_GEMM_SPLIT_BF16=1; the default stays
+// the fp32 MFMA chain above).  Every fp32 operand is written as hi + mid + lo, three bf16 values (v_cvt_pk_bf16_f32,
+// round-to-nearest: the split is EXACT, 3 x 8 significand bits), and the product a*b is accumulated in fp32 from the six
+// partial products hi*hi, hi*mid, mid*hi, hi*lo, lo*hi, mid*mid on v_mfma_f32_32x32x16_bf16 (bf16 x bf16 is exact in
+// fp32).  Dropped: mid*lo, lo*mid, lo*lo <= 2^-24 |a||b| each -- the size of ONE fp32 rounding, of which the fp32 chain
+// makes K.  Six bf16 MFMAs of 32 cycles replace eight fp32 MFMAs of 64 cycles per 16-deep K step (2.7x fewer matrix-pipe
+// cycles).  Same 128x128 tile / 2x2 waves / LDS double buffer; operands are split ONCE, while staging, into three bf16
+// planes per operand (rows of 16 + 8 bf16: the 16-byte operand reads of 16 consecutive rows touch distinct banks).
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+#define B3_LD 24
+__device__ __forceinline__ void b3_split(const f32x4 v, bf16x4 &h, bf16x4 &m, bf16x4 &l)
+{
+    h = __builtin_convertvector(v, bf16x4);
+    const f32x4 r1 = v - __builtin_convertvector(h, f32x4);
+    m = __builtin_convertvector(r1, bf16x4);
+    const f32x4 r2 = r1 - __builtin_convertvector(m, f32x4);
+    l = __builtin_convertvector(r2, bf16x4);
+}
+__global__ __launch_bounds__(GB_THREADS) void proj_gemm_b3_kernel(
+    const float *__restrict__ A, const float *__restrict__ W, const float *__restrict__ bias,
+    float *__restrict__ C, int M, int N, int K, int tiles_m, int tiles_n)
+{
+    __shared__ __attribute__((aligned(16))) __bf16 As[2][3][GB_M * B3_LD];
+    __shared__ __attribute__((aligned(16))) __bf16 Ws[2][3][GB_N * B3_LD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    int bid = blockIdx.x;
+    {
+        const int nwg = tiles_m * tiles_n;
+        if (nwg % 8 == 0) bid = (bid & 7) * (nwg >> 3) + (bid >> 3);
+    }
+    const int m0 = (bid / tiles_n) * GB_M, n0 = (bid % tiles_n) * GB_N;
+    const int lr = tid >> 2, kq = (tid & 3) * 4;
+    // three-stage pipeline: the global loads of chunk c+2 are in flight (asm-issued, counted s_waitcnt) while chunk c is multiplied
+    // and chunk c+1 (loaded one iteration earlier) is split and written to the other LDS buffer between the MFMAs of chunk c
+    f32x4 ra[2][2], rw[2][2];
+    const float *pa[2], *pw[2];
+    bool rok[2], cok[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int row = m0 + lr + 64 * i, col = n0 + lr + 64 * i;
+        rok[i] = row < M; cok[i] = col < N;
+        pa[i] = A + (size_t)min(row, M - 1) * K;
+        pw[i] = W + (size_t)min(col, N - 1) * K;
+    }
+#define B3_GLOAD(k0, SET)                                                                                             \
+    {                                                                                                                 \
+        const int kc = min((k0) + kq, K - 4);          /* clamped address; values past K are zeroed when they are split */ \
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(ra[SET][0]) : "v"(pa[0] + kc));                        \
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(ra[SET][1]) : "v"(pa[1] + kc));                        \
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(rw[SET][0]) : "v"(pw[0] + kc));                        \
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(rw[SET][1]) : "v"(pw[1] + kc));                        \
+    }
+    // split one float4 of chunk k0 (register R, valid flag OK) into the three planes of operand buffer P at offset o
+#define B3_PUT(P, R, OK, k0, o)                                                                                       \
+    {                                                                                                                 \
+        f32x4 v_ = R;                                                                                                 \
+        if (!((OK) && (k0) + kq < K)) v_ = f32x4{0, 0, 0, 0};                                                         \
+        bf16x4 h_, m_, l_;                                                                                            \
+        b3_split(v_, h_, m_, l_);                                                                                     \
+        *(bf16x4 *)(P[0] + (o)) = h_; *(bf16x4 *)(P[1] + (o)) = m_; *(bf16x4 *)(P[2] + (o)) = l_;                     \
+    }
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+    // operand element e of lane (row = lane & 31, group g = lane >> 5) is k = 8 g + e, for A and W alike
+    const int arow = (wm * 64 + (lane & 31)) * B3_LD + 8 * (lane >> 5);
+    const int wrow = (wn * 64 + (lane & 31)) * B3_LD + 8 * (lane >> 5);
+    const int o0 = lr * B3_LD + kq, o1 = (lr + 64) * B3_LD + kq;
+    const int nchunk = (K + GB_K - 1) / GB_K;
+    B3_GLOAD(0, 0)
+    B3_GLOAD(GB_K, 1)
+    asm volatile("s_waitcnt vmcnt(4)" : "+v"(ra[0][0]), "+v"(ra[0][1]), "+v"(rw[0][0]), "+v"(rw[0][1]));
+    B3_PUT(As[0], ra[0][0], rok[0], 0, o0) B3_PUT(As[0], ra[0][1], rok[1], 0, o1)
+    B3_PUT(Ws[0], rw[0][0], cok[0], 0, o0) B3_PUT(Ws[0], rw[0][1], cok[1], 0, o1)
+    __syncthreads();
+#define B3_MMA(i, j)                                                                                                  \
+    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[j][1], acc[i][j], 0, 0, 0);                        \
+    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][2], acc[i][j], 0, 0, 0);                        \
+    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][2], b[j][0], acc[i][j], 0, 0, 0);                        \
+    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][1], acc[i][j], 0, 0, 0);                        \
+    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[j][0], acc[i][j], 0, 0, 0);                        \
+    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][0], acc[i][j], 0, 0, 0);
+    // chunk c from LDS buffer c & 1; SET holds chunk c+1; chunk c+2 goes into the other set (consumed one iteration ago).
+    // Six partial products per tile, smallest first; the split of one float4 follows each tile's MFMAs in program order.
+#define B3_CHUNK(c, SET)                                                                                              \
+    {                                                                                                                 \
+        const int cur = (c) & 1, k1 = ((c) + 1) * GB_K;                                                               \
+        B3_GLOAD(((c) + 2) * GB_K, (SET) ^ 1)                                                                         \
+        bf16x8 a[2][3], b[2][3];                                                                                      \
+        _Pragma("unroll") for (int p = 0; p < 3; ++p)                                                                 \
+            _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                           \
+                a[i][p] = *(const bf16x8 *)(As[cur][p] + arow + i * 32 * B3_LD);                                      \
+                b[i][p] = *(const bf16x8 *)(Ws[cur][p] + wrow + i * 32 * B3_LD);                                      \
+            }                                                                                                         \
+        B3_MMA(0, 0)                                                                                                  \
+        asm volatile("s_waitcnt vmcnt(4)" : "+v"(ra[SET][0]), "+v"(ra[SET][1]), "+v"(rw[SET][0]), "+v"(rw[SET][1])); \
+        B3_PUT(As[cur ^ 1], ra[SET][0], rok[0], k1, o0)                                                               \
+        B3_MMA(0, 1)                                                                                                  \
+        B3_PUT(As[cur ^ 1], ra[SET][1], rok[1], k1, o1)                                                               \
+        B3_MMA(1, 0)                                                                                                  \
+        B3_PUT(Ws[cur ^ 1], rw[SET][0], cok[0], k1, o0)                                                               \
+        B3_MMA(1, 1)                                                                                                  \
+        B3_PUT(Ws[cur ^ 1], rw[SET][1], cok[1], k1, o1)                                                               \
+        __syncthreads();                                                                                              \
+    }
+    for (int c = 0; c < nchunk; c += 2) {      // (an odd chunk count runs one more chunk of zeros)
+        B3_CHUNK(c, 1)
+        B3_CHUNK(c + 1, 0)
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the last two (unused) prefetches
+#undef B3_CHUNK
+#undef B3_MMA
+#undef B3_PUT
+#undef B3_GLOAD
+    float bv[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int col = n0 + wn * 64 + j * 32 + (lane & 31);
+        bv[j] = (bias && col < N) ? bias[col] : 0.0f;
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] += bv[j];
+    if ((m0 + GB_M <= M) && (n0 + GB_N <= N)) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            float *cp = C + (size_t)(m0 + wm * 64 + 4 * (lane >> 5)) * N + n0 + wn * 64 + j * 32 + (lane & 31);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    cp[(size_t)(i * 32 + (r & 3) + 8 * (r >> 2)) * N] = acc[i][j][r];
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = n0 + wn * 64 + j * 32 + (lane & 31);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    if (row < M && col < N) C[(size_t)row * N + col] = acc[i][j][r];
+                }
+        }
+    }
+}
+
+static int g_gemm_split = -1;      // 1: the plain projection runs on the split-bf16 kernel (csa_set_gemm_split)
+extern "C" int csa_set_gemm_split(int on)
+{
+    g_gemm_split = on != 0;
+    return CSA_OK;
+}
+
 static int g_small_rows = -1;      // rows up to which the projection uses the small-M kernel (csa_set_small_gemm_rows)
 extern "C" int csa_set_small_gemm_rows(int rows)
 {
@@ -219,6 +384,13 @@ int launch_proj_gemm(const float *A, const float *W, const float *bias, float *C
         g_small_rows = e ? atoi(e) : CSA_SMALL_GEMM_ROWS_DEFAULT;
     }
     if ((class_rows > 0 ? class_rows : M) <= g_small_rows) return launch_gemm_small(A, W, bias, C, M, N, K, 0, 0.0f, 0, s);
+    if (g_gemm_split < 0) g_gemm_split = getenv("CSA_GEMM_SPLIT_BF16") ? atoi(getenv("CSA_GEMM_SPLIT_BF16")) != 0 : 0;
+    if (g_gemm_split && K % 4 == 0) {
+        const int tiles_m = (M + GB_M - 1) / GB_M, tiles_n = (N + GB_N - 1) / GB_N;
+        hipLaunchKernelGGL(proj_gemm_b3_kernel, dim3(tiles_m * tiles_n), dim3(GB_THREADS), 0, s, A, W, bias, C, M, N, K, tiles_m, tiles_n);
+        CSA_HIP_CHECK(hipGetLastError());
+        return CSA_OK;
+    }
     return launch_gemm_act(A, W, bias, C, M, N, K, 0, 0.0f, 0, s);
 }
 

@@ -156,6 +156,11 @@ int csa_set_halves(csa_emulator *h, int enable);
 /* Process-wide: projections with at most `rows` rows (= nlev * B) use the small-M split-K GEMM (32x32 tiles; default
  * 11,520 = 192 columns, the measured crossover; also settable with CSA_SMALL_GEMM_ROWS before the first call). */
 int csa_set_small_gemm_rows(int rows);
+/* Opt-in: the plain input projections (launch_proj_gemm above the small-GEMM threshold) run with every fp32 operand split
+ * exactly into three bf16 values and six partial products per term on the bf16 matrix pipe, fp32 accumulation (gemm.hip;
+ * the dropped cross terms are <= 2^-24 |a||b|, one fp32 rounding).  Default off (environment: CSA_GEMM_SPLIT_BF16=1): the
+ * default is the fp32 MFMA chain. */
+int csa_set_gemm_split(int on);
 /* Largest batch that runs the recurrence with one column per workgroup (latency variant, LSTM nh <= 128; default 256 =
  * one column per CU).  0 forces the two-column kernel everywhere. */
 int csa_set_rec1_max_batch(csa_emulator *h, int max_batch);
