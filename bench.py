@@ -652,6 +652,18 @@ def main():
                     phys[w] = {k: o[k] for k in ("metric", "value", "unit", "ms_per_step", "steps", "warmup", "config", "whole_path")}
             if rank == 0:
                 line["physrnn"] = phys
+            # opt-in projection GEMM (csa_set_gemm_split: fp32 operands split exactly into three bf16 values, six partial products on the
+            # bf16 matrix pipe, fp32 accumulation -- DESIGN.md 4.10): the headline workload and the memory wrapper once more with it on.
+            # NOT the headline value: the default library path (fp32 MFMA chain) is what `value` above measures.
+            from climsim_amd import _lib
+            _lib.lib().csa_set_gemm_split(1)
+            try:
+                sg = {w: forward_leg(a, w, rank, world, dist, a.steps, a.warmup, False) for w in ("v4_stateless_384", "v4_memory_384")}
+            finally:
+                _lib.lib().csa_set_gemm_split(0)
+            if rank == 0:
+                line["gemm_split_optin"] = {w: {k: o[k] for k in ("value", "unit", "ms_per_step", "steps", "warmup", "kernel_ms", "whole_path")}
+                                            for w, o in sg.items()}
     if rank == 0:
         print(json.dumps(line), flush=True)
     finish()

@@ -210,10 +210,14 @@ __global__ __launch_bounds__(GB_THREADS) void proj_gemm_kernel(
 // fp32).  Dropped: mid*lo, lo*mid, lo*lo <= 2^-24 |a||b| each -- the size of ONE fp32 rounding, of which the fp32 chain
 // makes K.  Six bf16 MFMAs of 32 cycles replace eight fp32 MFMAs of 64 cycles per 16-deep K step (2.7x fewer matrix-pipe
 // cycles).  Same 128x128 tile / 2x2 waves / LDS double buffer; operands are split ONCE, while staging, into three bf16
-// planes per operand (rows of 16 + 8 bf16: the 16-byte operand reads of 16 consecutive rows touch distinct banks).
+// planes per operand.
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-#define B3_LD 24
+#define B3_LD 16
+// LDS rows are 16 bf16 = 32 bytes, unpadded (49 KB per workgroup: THREE workgroups per CU, so the 720 tiles of the headline shape
+// run in one round); the two 16-byte halves of rows 8..15 (mod 16) are swapped, which keeps the 16-byte operand reads of 16
+// consecutive rows on distinct banks
+__device__ __forceinline__ int b3_swz(int row) { return (row >> 3) & 1; }
 __device__ __forceinline__ void b3_split(const f32x4 v, bf16x4 &h, bf16x4 &m, bf16x4 &l)
 {
     h = __builtin_convertvector(v, bf16x4);
@@ -222,7 +226,7 @@ __device__ __forceinline__ void b3_split(const f32x4 v, bf16x4 &h, bf16x4 &m, bf
     const f32x4 r2 = r1 - __builtin_convertvector(m, f32x4);
     l = __builtin_convertvector(r2, bf16x4);
 }
-__global__ __launch_bounds__(GB_THREADS) void proj_gemm_b3_kernel(
+__global__ __launch_bounds__(GB_THREADS, 3) void proj_gemm_b3_kernel(
     const float *__restrict__ A, const float *__restrict__ W, const float *__restrict__ bias,
     float *__restrict__ C, int M, int N, int K, int tiles_m, int tiles_n)
 {
@@ -274,9 +278,9 @@ __global__ __launch_bounds__(GB_THREADS) void proj_gemm_b3_kernel(
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
     // operand element e of lane (row = lane & 31, group g = lane >> 5) is k = 8 g + e, for A and W alike
-    const int arow = (wm * 64 + (lane & 31)) * B3_LD + 8 * (lane >> 5);
-    const int wrow = (wn * 64 + (lane & 31)) * B3_LD + 8 * (lane >> 5);
-    const int o0 = lr * B3_LD + kq, o1 = (lr + 64) * B3_LD + kq;
+    const int arow = (wm * 64 + (lane & 31)) * B3_LD + 8 * ((lane >> 5) ^ b3_swz(lane & 31));
+    const int wrow = (wn * 64 + (lane & 31)) * B3_LD + 8 * ((lane >> 5) ^ b3_swz(lane & 31));
+    const int o0 = lr * B3_LD + 8 * ((kq >> 3) ^ b3_swz(lr)) + (kq & 7), o1 = o0 + 64 * B3_LD;
     const int nchunk = (K + GB_K - 1) / GB_K;
     B3_GLOAD(0, 0)
     B3_GLOAD(GB_K, 1)
@@ -318,7 +322,10 @@ __global__ __launch_bounds__(GB_THREADS) void proj_gemm_b3_kernel(
         B3_CHUNK(c, 1)
         B3_CHUNK(c + 1, 0)
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the last two (unused) prefetches
+    // the last two (unused) prefetches: their target registers stay allocated until the loads have landed -- tied to the wait, or
+    // the epilogue could be given a register that an in-flight load still writes
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(ra[0][0]), "+v"(ra[0][1]), "+v"(rw[0][0]), "+v"(rw[0][1]),
+                                        "+v"(ra[1][0]), "+v"(ra[1][1]), "+v"(rw[1][0]), "+v"(rw[1][1]) :: "memory");
 #undef B3_CHUNK
 #undef B3_MMA
 #undef B3_PUT

@@ -8,3 +8,5 @@ if "shard_2700" in d:
     print("shard fwd", round(d["shard_2700"]["forward"]["ms_per_step"], 4), "train", round(d["shard_2700"]["train"]["ms_per_step"], 3))
 for k, v in d.get("physrnn", {}).items():
     print(k, round(v["ms_per_step"], 4), "ms", round(v["value"]), v["unit"])
+for k, v in d.get("gemm_split_optin", {}).items():
+    print("gemm_split_optin", k, round(v["ms_per_step"], 4), "ms", round(v["value"]), v["unit"])
