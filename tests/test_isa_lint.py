@@ -74,3 +74,6 @@ def test_no_compiler_instruction_touches_an_in_flight_prefetch():
         assert len(seen) >= 3 and all(l.rstrip().endswith("OK") for l in seen), (fam, seen)
     assert sum("lstm_rec2_kernel" in l and "Lb1E" in l for l in r.stdout.splitlines()) == 4      # the TRAIN variants too
     assert sum("gru_bwd_rec_kernel" in l and l.rstrip().endswith("OK") for l in r.stdout.splitlines()) == 2   # BPTT of the GRU (round 3)
+    # the split-bf16 projection GEMM: its two trailing prefetches stay tied to the final wait (an untied diagnostic build let the
+    # epilogue write v81 of an in-flight load and faulted on the GPU; this lint reports exactly that instruction for that build)
+    assert sum("proj_gemm_b3_kernel" in l and l.rstrip().endswith("OK") for l in r.stdout.splitlines()) == 1

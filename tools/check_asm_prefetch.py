@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""ISA lint for the asm-pipelined recurrent kernels (rec.hip, train_rec.hip).
+"""ISA lint for the asm-pipelined kernels (rec.hip, train_rec.hip; gemm.hip::proj_gemm_b3_kernel).
 
 The projections of step t+1 are fetched with `asm volatile("global_load_dword{,x2,x4} ...")` at the top of step t and
 become valid behind an `asm("s_waitcnt vmcnt(N)" : "+v"(reg))` in step t+1 (double buffering: the registers of a prefetch
@@ -24,7 +24,7 @@ import sys
 import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-DEFAULT = [os.path.join(ROOT, "climsim_amd", "csrc", "rec.hip"), os.path.join(ROOT, "climsim_amd", "csrc", "train_rec.hip")]
+DEFAULT = [os.path.join(ROOT, "climsim_amd", "csrc", f) for f in ("rec.hip", "train_rec.hip", "gemm.hip")]      # gemm.hip: proj_gemm_b3_kernel
 LOAD = re.compile(r"^\s*global_load_dword(?:x([234]))?\s+(v\[(\d+):(\d+)\]|v(\d+)),")
 REG = re.compile(r"\bv\[(\d+):(\d+)\]|\bv(\d+)\b")
 
