@@ -244,6 +244,13 @@ class Emulator:
         True / False force it, None restores the default (automatic from 640 columns)."""
         return _lib.lib().csa_set_halves(self._h, 2 if enable is None else int(bool(enable)))
 
+    @staticmethod
+    def set_gemm_split(enable):
+        """Process-wide opt-in (csa_set_gemm_split): the input projections of calls above the small-GEMM threshold run with every fp32
+        operand split exactly into three bf16 values, six partial products on the bf16 matrix pipe and fp32 accumulation.
+        Default off: the fp32 MFMA chain."""
+        return _lib.lib().csa_set_gemm_split(int(bool(enable)))
+
     def set_rec1_max_batch(self, max_batch):
         """Largest batch that uses the one-column-per-workgroup recurrent kernel (default 256); 0 disables it."""
         self._rc(_lib.lib().csa_set_rec1_max_batch(self._h, int(max_batch)), "csa_set_rec1_max_batch")
