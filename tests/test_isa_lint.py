@@ -77,3 +77,32 @@ def test_no_compiler_instruction_touches_an_in_flight_prefetch():
     # the split-bf16 projection GEMM: its two trailing prefetches stay tied to the final wait (an untied diagnostic build let the
     # epilogue write v81 of an in-flight load and faulted on the GPU; this lint reports exactly that instruction for that build)
     assert sum("proj_gemm_b3_kernel" in l and l.rstrip().endswith("OK") for l in r.stdout.splitlines()) == 1
+
+
+@pytest.mark.skipif(not (shutil.which("hipcc") or os.path.exists("/opt/rocm/bin/hipcc")), reason="hipcc not available")
+def test_split_gemm_main_loop_keeps_its_software_pipeline(tmp_path):
+    """proj_gemm_b3_kernel: two 16-deep chunks per loop trip = 48 bf16 MFMAs, and the ONLY vector-memory waits in
+    the loop are the two counted `s_waitcnt vmcnt(4)` that leave the prefetch of chunk c+2 in flight -- a compiler-placed
+    `vmcnt(0)` there is what made the first pipelined version slower than the unpipelined one."""
+    import re
+    out = tmp_path / "gemm.s"
+    subprocess.check_call([os.environ.get("HIPCC", "/opt/rocm/bin/hipcc"), "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=fast",
+                           "-I" + os.path.join(ROOT, "include"), "-S", "--cuda-device-only",
+                           os.path.join(ROOT, "climsim_amd", "csrc", "gemm.hip"), "-o", str(out)], stderr=subprocess.DEVNULL)
+    lines = out.read_text().splitlines()
+    a = next(i for i, l in enumerate(lines) if l.startswith("_Z19proj_gemm_b3_kernel"))
+    b = next(i for i, l in enumerate(lines) if i > a and l.strip().startswith("s_endpgm"))
+    body = lines[a:b]
+    labels = {l.split(":")[0]: i for i, l in enumerate(body) if re.match(r"^\.LBB\d+_\d+:", l)}
+    loops = []
+    for i, l in enumerate(body):
+        m = re.match(r"\s*s_cbranch_\w+\s+(\.LBB\d+_\d+)", l)
+        if m and m.group(1) in labels and labels[m.group(1)] < i:
+            loops.append(body[labels[m.group(1)]:i])
+    main = [seg for seg in loops if any("v_mfma_f32_32x32x16_bf16" in x for x in seg)]
+    assert len(main) == 1
+    seg = main[0]
+    assert sum("v_mfma_f32_32x32x16_bf16" in x for x in seg) == 48
+    assert [x.strip() for x in seg if "vmcnt" in x] == ["s_waitcnt vmcnt(4)", "s_waitcnt vmcnt(4)"]
+    assert sum(x.strip().startswith("global_load_dwordx4") for x in seg) == 8
+    assert not any("scratch_" in x for x in body)      # no spills at three workgroups per CU
